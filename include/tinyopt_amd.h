@@ -1,0 +1,179 @@
+/* tinyopt_amd.h — C-ABI of the MI355X-native Levenberg-Marquardt / Gauss-Newton hot path.
+ *
+ * This is the drop-in boundary beneath tinyopt's `Optimize(x, cost, options)` /
+ * Accumulate-callback API (reference: include/tinyopt/optimize.h:16-77,
+ * include/tinyopt/optimizers/optimizer.h:145-539).  The reference has NO FFI layer (it is a
+ * header-only template library), so every entry point below cites the C++ interface it
+ * replaces.  Plain pointers and sizes only; no torch / Eigen / HIP types in any signature.
+ *
+ * Conventions
+ *  - Every `*_dev` pointer is a DEVICE pointer valid on the handle's GPU; `*_host` is host memory.
+ *  - All functions return 0 on success, <0 on error (see TOA_E_*); `toa_last_error()` describes it.
+ *    Numeric outcomes are never errors: they are per-problem `StopReason` integers with the SAME
+ *    values as the reference enum (include/tinyopt/stop_reasons.h:14-43).
+ *  - A handle is NOT thread-safe: one handle per host thread per GPU (reference: one stateful
+ *    `Optimizer_` per thread, optimizers/optimizer.h:544-548).  All kernels are launched on the
+ *    `stream` given at creation (a hipStream_t cast to void*, NULL = default stream) and are
+ *    asynchronous w.r.t. the host unless stated.
+ *  - Problems are independent; a "batch" is P problems of identical (n, m, dtype, model).
+ */
+#ifndef TINYOPT_AMD_H_
+#define TINYOPT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOA_VERSION 1
+
+/* error codes */
+#define TOA_OK 0
+#define TOA_E_ARG (-1)     /* invalid argument (reference: std::invalid_argument, optimize.h:47,55,75) */
+#define TOA_E_HIP (-2)     /* HIP runtime error */
+#define TOA_E_NOMEM (-3)   /* device allocation failed (reference: bad_alloc -> kOutOfMemory) */
+#define TOA_E_UNSUPPORTED (-4)
+
+/* scalar type of x / H / g (the solver `Scalar`, solvers/lm.h:27) */
+#define TOA_F32 0
+#define TOA_F64 1
+
+/* residual-model families compiled into the library (device functors).  Arbitrary host lambdas
+ * cannot run on the GPU; see INTEGRATION.md for the "bring your own functor" template entry. */
+#define TOA_MODEL_DENSE_ROW 1       /* r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1+0.1cos(a_i.x)) a_i    */
+#define TOA_MODEL_GAUSSIAN_PRIOR 2  /* r = (x-y)/sigma, m = n  (benchmarks/dense.cpp:53-66, losses/mahalanobis.h:124-136) */
+#define TOA_MODEL_SQRT2 3           /* r = x*x - 2, n = m = 1   (tests/sqrt2.cpp:30-70) */
+#define TOA_MODEL_SE3_REPROJ 4      /* pinhole reprojection of 3-D points, SE3 right-perturbation */
+
+/* StopReason — identical values to include/tinyopt/stop_reasons.h:14-43 */
+#define TOA_STOP_OUT_OF_MEMORY (-4)
+#define TOA_STOP_SOLVER_FAILED (-3)
+#define TOA_STOP_NAN_OR_INF (-2)
+#define TOA_STOP_SKIPPED (-1)
+#define TOA_STOP_NONE 0
+#define TOA_STOP_MIN_ERROR 1
+#define TOA_STOP_MIN_REL_ERROR 2
+#define TOA_STOP_MIN_DELTA_NORM 3
+#define TOA_STOP_MIN_GRAD_NORM 4
+#define TOA_STOP_MAX_ITERS 5
+#define TOA_STOP_MAX_NO_DECR 6
+#define TOA_STOP_MAX_CONSEC_NO_DECR 7
+#define TOA_STOP_TIMED_OUT 8
+#define TOA_STOP_USER_STOPPED 9
+
+/* POD mirror of tinyopt::Options (include/tinyopt/optimizers/options.h:18-156), numeric knobs only.
+ * Not mirrored (host-side concerns, evaluated by the header adaptor between launches or unsupported
+ * on the device path): log.*, stop_callback, stop_callback2, max_duration_ms. */
+typedef struct toa_options {
+  int32_t solver_type;          /* 0 LevenbergMarquardt, 1 GaussNewton            options.h:24-30 */
+  int32_t max_iters;            /* uint16 in the reference, default 50           options.h:89   */
+  float min_error;              /* 1e-12f                                        options.h:90   */
+  float min_rerr_dec;           /* 1e-10f                                        options.h:91   */
+  float min_step_norm2;         /* 1e-14f                                        options.h:92   */
+  float min_grad_norm2;         /* 1e-18f                                        options.h:93   */
+  int32_t max_total_failures;   /* uint8, 0 = unlimited                          options.h:94   */
+  int32_t max_consec_failures;  /* uint8, default 5, 0 = unlimited               options.h:95   */
+  float damping_init;           /* 1e-4f; 0 disables damping                     options.h:133  */
+  float damping_min;            /* 1e-9f                                         options.h:136  */
+  float damping_max;            /* 1e9f                                          options.h:136  */
+  float good_factor;            /* 1/3                                           options.h:138  */
+  float bad_factor;             /* 2                                             options.h:139  */
+  float grad_clipping;          /* 0 = off                                       options.h:49   */
+  float check_min_H_diag;       /* 0 = off                                       options.h:63   */
+  uint8_t check_final_cost;     /* false                                         options.h:43   */
+  uint8_t use_step_quality_approx; /* false                                      options.h:46   */
+  uint8_t use_ldlt;             /* true                                          options.h:59   */
+  uint8_t H_is_full;            /* true (device H is always symmetric-full)      options.h:61   */
+  uint8_t save_last;            /* true: export final undamped H                 options.h:66   */
+  uint8_t use_squared_norm;     /* true                                          options.h:76   */
+  uint8_t downscale_by_2;       /* false                                         options.h:77   */
+  uint8_t normalize;            /* false                                         options.h:79   */
+} toa_options;
+
+/* `Options{}` defaults (options.h:43-148). */
+void toa_options_default(toa_options* o);
+/* benchmarks/options.h:10-27 `CreateOptions()`. */
+void toa_options_benchmark(toa_options* o);
+
+/* Per-problem results of a batched solve — POD mirror of tinyopt::Output (include/tinyopt/output.h:26-145).
+ * Every pointer is a DEVICE pointer to an array of P entries (or NULL to skip that output, except
+ * stop_reason / num_iters / final_cost which are required). */
+typedef struct toa_results {
+  int32_t* stop_reason;        /* [P]  Output::stop_reason                     output.h:108 */
+  int32_t* num_iters;          /* [P]  Output::num_iters (failed iters count)  output.h:115, optimizer.h:307 */
+  int32_t* num_failures;       /* [P]  Output::num_failures                    output.h:116 */
+  int32_t* num_consec_failures;/* [P]  Output::num_consec_failures             output.h:117 */
+  double* final_cost;          /* [P]  Output::final_cost.cost                 output.h:104 */
+  int32_t* final_num_residuals;/* [P]  Output::final_cost.num_resisuals                      */
+  double* final_rerr_dec;      /* [P]  Output::final_rerr_dec                  output.h:105 */
+  double* final_hessian;       /* [P][n*n] undamped final H as double (optimizer.h:313-316), col-major; NULL or !save_last: skipped */
+  double* errs;                /* [P][hist_stride] Output::errs                output.h:140 */
+  double* deltas2;             /* [P][hist_stride] Output::deltas2             output.h:141 */
+  uint8_t* successes;          /* [P][hist_stride] Output::successes           output.h:142 */
+  int32_t hist_stride;         /* >= max_iters+2 when history pointers are given */
+  int32_t _pad;
+} toa_results;
+
+typedef struct toa_context* toa_handle;
+
+/* ---- lifetime (replaces: `lm::Optimizer<H_t> optimizer(options)` construction, optimize.h:50-53) ---- */
+int toa_create(toa_handle* out, int device, void* stream);
+int toa_destroy(toa_handle h);
+const char* toa_last_error(void);
+/* Device properties the measurement needs (CU count, clock, name). */
+int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size_t name_len);
+
+/* ---- device memory conveniences for non-torch callers (the C++ header adaptor) ---- */
+int toa_malloc(toa_handle h, void** dev_ptr, size_t bytes);
+int toa_free(toa_handle h, void* dev_ptr);
+int toa_memcpy_h2d(toa_handle h, void* dst_dev, const void* src_host, size_t bytes);  /* synchronous */
+int toa_memcpy_d2h(toa_handle h, void* dst_host, const void* src_dev, size_t bytes);  /* synchronous */
+int toa_memset(toa_handle h, void* dst_dev, int value, size_t bytes);                 /* stream-ordered */
+int toa_synchronize(toa_handle h);
+
+/* ---- DenseRow problem data --------------------------------------------------------------------
+ * HBM layout ("packed"): per problem a [m4][RS] array of T, m4 = round_up(m,4), RS = NB*ceil((n+1)/NB),
+ * NB = ceil((n+1)/16); row i = [a_i0 .. a_i,n-1, b_i, 0...]; padding rows/cols are zero.  A wavefront
+ * then reads 4 consecutive rows with one coalesced NB*sizeof(T)-byte load per lane, already in MFMA
+ * operand order.  n <= 63. */
+int toa_dense_row_layout(int dtype, int n, int m, int* nb, int* row_stride, int* rows_padded, size_t* bytes_per_problem);
+/* Pack natural arrays (A: [P][m][n] row-major, b: [P][m], device pointers) into the layout above. */
+int toa_dense_row_pack(toa_handle h, int dtype, int n, int m, int64_t P,
+                       const void* A_dev, const void* b_dev, void* packed_dev);
+/* Generate the synthetic DenseRow batch of SURVEY §8(d) directly in HBM (counter-based RNG keyed by
+ * (seed, problem id, element); identical to oracle/synth.hpp).  problem0 = id of the first problem
+ * (rank offset for sharded runs).  x0_dev / xstar_dev: [P][n] of T (either may be NULL). */
+int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64_t seed, int64_t problem0,
+                        void* packed_dev, void* x0_dev, void* xstar_dev);
+
+/* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
+ *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).
+ * want_grad = 0  <=>  grad == nullptr (cost only).  g_dev: [P][n] T; H_dev: [P][n*n] T full symmetric
+ * (assigned, not accumulated); cost_dev: [P] double (= ||r||^2, un-normalised); nres_dev: [P] int32. */
+int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
+                   const void* data_dev, const void* x_dev, int want_grad,
+                   void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);
+
+/* ---- K3: damped solve (replaces SolverLM::Build's damping lm.h:108-117 + SolverGN::Solve gn.h:150-171
+ *      -> SolveLDLT math.h:232-240).  H_ii <- H_ii * scale (double, Marquardt multiplicative), then
+ *      dx = -H^-1 g by pivoted LDL^T with Eigen's acceptance rule (info()==Success && isPositive()).
+ *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure). */
+int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
+                     double scale, void* dx_dev, int32_t* ok_dev);
+
+/* ---- fused batched solve (replaces Optimizer_::OptimizeAcc optimizer.h:242-327 + Step :331-539 +
+ *      SolverLM lm.h:46-171 for P independent problems).  x_dev: [P][n] T, updated in place
+ *      (reference: `x` by non-const ref).  One launch; no host round trips; each wavefront runs whole
+ *      problems to their StopReason.  counters_dev (optional, [4] uint64): {accumulate passes,
+ *      evaluate-only passes, linear solves, problems} summed over the batch — the units the roofline
+ *      accounting in bench.py multiplies by the algorithmic bytes per pass. */
+int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
+               const void* data_dev, void* x_dev, const toa_options* options,
+               const toa_results* results, uint64_t* counters_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYOPT_AMD_H_ */

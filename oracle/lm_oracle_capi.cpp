@@ -1,0 +1,299 @@
+// TEST INFRASTRUCTURE ONLY.  C entry points (ctypes) over oracle/lm_oracle.hpp for tests/,
+// bench.py's cpu_baseline leg and __graft_entry__.smoke().  Never linked into the product.
+// Uses the POD `toa_options` from include/tinyopt_amd.h purely as a data contract.
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "../include/tinyopt_amd.h"
+#include "lm_oracle.hpp"
+#include "synth.hpp"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace oracle;
+
+static Options from_pod(const toa_options& p) {
+  Options o;
+  o.solver_type = p.solver_type;
+  o.max_iters = uint16_t(p.max_iters);
+  o.min_error = p.min_error;
+  o.min_rerr_dec = p.min_rerr_dec;
+  o.min_step_norm2 = p.min_step_norm2;
+  o.min_grad_norm2 = p.min_grad_norm2;
+  o.max_total_failures = uint8_t(p.max_total_failures);
+  o.max_consec_failures = uint8_t(p.max_consec_failures);
+  o.damping_init = p.damping_init;
+  o.damping_range = {{p.damping_min, p.damping_max}};
+  o.good_factor = p.good_factor;
+  o.bad_factor = p.bad_factor;
+  o.grad_clipping = p.grad_clipping;
+  o.check_min_H_diag = p.check_min_H_diag;
+  o.check_final_cost = p.check_final_cost;
+  o.use_step_quality_approx = p.use_step_quality_approx;
+  o.use_ldlt = p.use_ldlt;
+  o.H_is_full = p.H_is_full;
+  o.save_last = p.save_last;
+  o.use_squared_norm = p.use_squared_norm;
+  o.downscale_by_2 = p.downscale_by_2;
+  o.normalize = p.normalize;
+  return o;
+}
+
+// ---- DenseRow model: r_i = a_i.x + 0.1 sin(a_i.x) - b_i, J_i = (1 + 0.1 cos(a_i.x)) a_i.
+// Folded exactly like the AD bridge folds a residual VECTOR (diff/optimize_autodiff.h:123-164):
+// grad = J^T r, H = J^T J (full), cost = (||r||^2, m); all arithmetic in T.
+// Loop order is i-outer (rank-1 updates) — same per-entry summation order as a naive
+// triple loop, but vectorisable, so the timed CPU baseline is not artificially slow.
+template <typename T>
+struct DenseRowAcc {
+  int n, m;
+  const T* A;  // m×n row-major
+  const T* b;  // m
+  mutable std::vector<T> Jrow;
+  DenseRowAcc(int n_, int m_, const T* A_, const T* b_) : n(n_), m(m_), A(A_), b(b_), Jrow(n_) {}
+  Cost operator()(const std::vector<T>& x, T* g, T* H) const {
+    T c = 0;
+    for (int i = 0; i < m; ++i) {
+      const T* a = A + size_t(i) * n;
+      T t = 0;
+      for (int j = 0; j < n; ++j) t += a[j] * x[j];
+      const T r = t + T(0.1) * std::sin(t) - b[i];
+      c += r * r;
+      if (g) {
+        const T s = T(1) + T(0.1) * std::cos(t);
+        T* J = Jrow.data();
+        for (int j = 0; j < n; ++j) J[j] = s * a[j];
+        for (int j = 0; j < n; ++j) g[j] += J[j] * r;
+        if (H) {
+          for (int q = 0; q < n; ++q) {  // column q of col-major H: H[q*n + p] += J[p]*J[q]
+            const T Jq = J[q];
+            T* Hq = H + size_t(q) * n;
+            for (int p = 0; p < n; ++p) Hq[p] += J[p] * Jq;
+          }
+        }
+      }
+    }
+    return Cost(double(c), m);
+  }
+};
+
+// ---- GaussianPrior, the manual callback of benchmarks/dense.cpp:57-66 / :90-99:
+// res = (x-y)/sigma; grad = J*res with J = diag(1/sigma); H.diagonal() = sigma^-2;
+// returns res.squaredNorm() as a SCALAR => Cost(v, 1) (cost.h:22).
+template <typename T>
+struct GaussianPriorAcc {
+  int n;
+  const T* y;
+  const T* sigma;
+  Cost operator()(const std::vector<T>& x, T* g, T* H) const {
+    T c = 0;
+    for (int j = 0; j < n; ++j) {
+      const T res = (x[j] - y[j]) / sigma[j];
+      c += res * res;
+      if (g) {
+        g[j] = (T(1) / sigma[j]) * res;
+        const T is = T(1) / sigma[j];
+        H[size_t(j) * n + j] = is * is;
+      }
+    }
+    return Cost(double(c));
+  }
+};
+
+template <typename T>
+static void run_batch_dense_row(int64_t P, int n, int m, const T* A, const T* b, T* x, const Options& o,
+                                int32_t* stop, int32_t* iters, int32_t* fails, double* cost, double* rerr,
+                                double* finalH, double* errs, double* deltas2, uint8_t* succ, int hist_stride,
+                                int nthreads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t p = 0; p < P; ++p) {
+    DenseRowAcc<T> acc(n, m, A + size_t(p) * m * n, b + size_t(p) * m);
+    std::vector<T> xv(x + p * n, x + (p + 1) * n);
+    Optimizer<T> opt(o, n);
+    Output out = opt.OptimizeAcc(xv, acc, EuclidPlus<T>());
+    std::memcpy(x + p * n, xv.data(), sizeof(T) * n);
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (fails) fails[p] = out.num_failures;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (rerr) rerr[p] = out.final_rerr_dec;
+    if (finalH && !out.final_hessian.empty())
+      std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
+    if (errs) {
+      for (size_t k = 0; k < out.errs.size() && int(k) < hist_stride; ++k) {
+        errs[size_t(p) * hist_stride + k] = out.errs[k];
+        if (deltas2) deltas2[size_t(p) * hist_stride + k] = out.deltas2[k];
+        if (succ) succ[size_t(p) * hist_stride + k] = out.successes[k];
+      }
+    }
+  }
+  (void)nthreads;
+}
+
+extern "C" {
+
+int oracle_num_threads_max() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// Synthetic DenseRow batch (natural layout): A [P][m][n], b [P][m], x0 [P][n] of T; xstar [P][n] double.
+void oracle_synth_dense_row(int dtype, uint64_t seed, int64_t problem0, int64_t P, int n, int m,
+                            void* A, void* b, void* x0, double* xstar) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32)
+      synth::dense_row_problem<float>(seed, uint64_t(problem0 + p), n, m,
+                                      A ? (float*)A + size_t(p) * m * n : nullptr, b ? (float*)b + size_t(p) * m : nullptr,
+                                      x0 ? (float*)x0 + size_t(p) * n : nullptr, xstar ? xstar + size_t(p) * n : nullptr);
+    else
+      synth::dense_row_problem<double>(seed, uint64_t(problem0 + p), n, m,
+                                       A ? (double*)A + size_t(p) * m * n : nullptr, b ? (double*)b + size_t(p) * m : nullptr,
+                                       x0 ? (double*)x0 + size_t(p) * n : nullptr, xstar ? xstar + size_t(p) * n : nullptr);
+  }
+}
+
+void oracle_synth_gaussian_prior(int dtype, uint64_t seed, int64_t problem0, int64_t P, int n,
+                                 void* y, void* sigma, void* x0) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32)
+      synth::gaussian_prior_problem<float>(seed, uint64_t(problem0 + p), n, (float*)y + p * n, (float*)sigma + p * n, (float*)x0 + p * n);
+    else
+      synth::gaussian_prior_problem<double>(seed, uint64_t(problem0 + p), n, (double*)y + p * n, (double*)sigma + p * n, (double*)x0 + p * n);
+  }
+}
+
+// One Accumulate call per problem: g [P][n], H [P][n*n] col-major full, cost [P], nres [P].
+void oracle_dense_row_accumulate(int dtype, int64_t P, int n, int m, const void* A, const void* b, const void* x,
+                                 int want_grad, void* g, void* H, double* cost, int32_t* nres) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32) {
+      DenseRowAcc<float> acc(n, m, (const float*)A + size_t(p) * m * n, (const float*)b + size_t(p) * m);
+      std::vector<float> xv((const float*)x + p * n, (const float*)x + (p + 1) * n);
+      float* gp = want_grad ? (float*)g + p * n : nullptr;
+      float* Hp = want_grad ? (float*)H + size_t(p) * n * n : nullptr;
+      if (gp) { std::fill(gp, gp + n, 0.f); std::fill(Hp, Hp + size_t(n) * n, 0.f); }
+      Cost c = acc(xv, gp, Hp);
+      cost[p] = c.cost; if (nres) nres[p] = c.num_residuals;
+    } else {
+      DenseRowAcc<double> acc(n, m, (const double*)A + size_t(p) * m * n, (const double*)b + size_t(p) * m);
+      std::vector<double> xv((const double*)x + p * n, (const double*)x + (p + 1) * n);
+      double* gp = want_grad ? (double*)g + p * n : nullptr;
+      double* Hp = want_grad ? (double*)H + size_t(p) * n * n : nullptr;
+      if (gp) { std::fill(gp, gp + n, 0.0); std::fill(Hp, Hp + size_t(n) * n, 0.0); }
+      Cost c = acc(xv, gp, Hp);
+      cost[p] = c.cost; if (nres) nres[p] = c.num_residuals;
+    }
+  }
+}
+
+// Damped solve per problem, exactly lm.h:108-117 (H_ii *= scale, in double) + gn.h:150-171.
+void oracle_solve_damped(int dtype, int64_t P, int n, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32) {
+      std::vector<float> Hp((const float*)H + size_t(p) * n * n, (const float*)H + size_t(p + 1) * n * n), mg(n);
+      for (int i = 0; i < n; ++i) { Hp[size_t(i) * n + i] = float(Hp[size_t(i) * n + i] * scale); mg[i] = -((const float*)g)[p * n + i]; }
+      ok[p] = SolveLDLT<float>(n, Hp.data(), mg.data(), (float*)dx + p * n) ? 1 : 0;
+    } else {
+      std::vector<double> Hp((const double*)H + size_t(p) * n * n, (const double*)H + size_t(p + 1) * n * n), mg(n);
+      for (int i = 0; i < n; ++i) { Hp[size_t(i) * n + i] = Hp[size_t(i) * n + i] * scale; mg[i] = -((const double*)g)[p * n + i]; }
+      ok[p] = SolveLDLT<double>(n, Hp.data(), mg.data(), (double*)dx + p * n) ? 1 : 0;
+    }
+  }
+}
+
+// Batched LM on DenseRow problems; returns wall seconds.  x [P][n] updated in place.
+double oracle_dense_row_lm(int dtype, int64_t P, int n, int m, const void* A, const void* b, void* x,
+                           const toa_options* opts, int32_t* stop, int32_t* iters, int32_t* fails, double* cost,
+                           double* rerr, double* finalH, double* errs, double* deltas2, uint8_t* succ,
+                           int hist_stride, int nthreads) {
+  const Options o = from_pod(*opts);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (dtype == TOA_F32)
+    run_batch_dense_row<float>(P, n, m, (const float*)A, (const float*)b, (float*)x, o, stop, iters, fails, cost, rerr,
+                               finalH, errs, deltas2, succ, hist_stride, nthreads);
+  else
+    run_batch_dense_row<double>(P, n, m, (const double*)A, (const double*)b, (double*)x, o, stop, iters, fails, cost,
+                                rerr, finalH, errs, deltas2, succ, hist_stride, nthreads);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Batched LM on GaussianPrior problems (benchmarks/dense.cpp manual-callback semantics).
+double oracle_gaussian_prior_lm(int dtype, int64_t P, int n, const void* y, const void* sigma, void* x,
+                                const toa_options* opts, int32_t* stop, int32_t* iters, int32_t* fails,
+                                double* cost, double* finalH) {
+  const Options o = from_pod(*opts);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t p = 0; p < P; ++p) {
+    Output out;
+    if (dtype == TOA_F32) {
+      GaussianPriorAcc<float> acc{n, (const float*)y + p * n, (const float*)sigma + p * n};
+      std::vector<float> xv((float*)x + p * n, (float*)x + (p + 1) * n);
+      Optimizer<float> opt(o, n);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<float>());
+      std::memcpy((float*)x + p * n, xv.data(), sizeof(float) * n);
+    } else {
+      GaussianPriorAcc<double> acc{n, (const double*)y + p * n, (const double*)sigma + p * n};
+      std::vector<double> xv((double*)x + p * n, (double*)x + (p + 1) * n);
+      Optimizer<double> opt(o, n);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<double>());
+      std::memcpy((double*)x + p * n, xv.data(), sizeof(double) * n);
+    }
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (fails) fails[p] = out.num_failures;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (finalH && !out.final_hessian.empty())
+      std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Scalar sqrt2 problems (tests/sqrt2.cpp:30-56 manual float / :58-70 AD double): r = x*x-2,
+// grad = J r, H = J^2, cost = r^2 (1 residual).
+void oracle_sqrt2_lm(int dtype, int64_t P, void* x, const toa_options* opts, int32_t* stop, int32_t* iters,
+                     double* cost, double* errs, double* deltas2, uint8_t* succ, int hist_stride) {
+  const Options o = from_pod(*opts);
+  for (int64_t p = 0; p < P; ++p) {
+    Output out;
+    if (dtype == TOA_F32) {
+      std::vector<float> xv{((float*)x)[p]};
+      auto acc = [](const std::vector<float>& x, float* g, float* H) {
+        float r = x[0] * x[0] - 2, J = 2 * x[0];
+        if (g) { g[0] = J * r; H[0] = J * J; }
+        return Cost(double(r * r));
+      };
+      Optimizer<float> opt(o, 1);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<float>());
+      ((float*)x)[p] = xv[0];
+    } else {
+      std::vector<double> xv{((double*)x)[p]};
+      auto acc = [](const std::vector<double>& x, double* g, double* H) {
+        double r = x[0] * x[0] - 2, J = 2 * x[0];
+        if (g) { g[0] = J * r; H[0] = J * J; }
+        return Cost(r * r);
+      };
+      Optimizer<double> opt(o, 1);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<double>());
+      ((double*)x)[p] = xv[0];
+    }
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (errs)
+      for (size_t k = 0; k < out.errs.size() && int(k) < hist_stride; ++k) {
+        errs[size_t(p) * hist_stride + k] = out.errs[k];
+        if (deltas2) deltas2[size_t(p) * hist_stride + k] = out.deltas2[k];
+        if (succ) succ[size_t(p) * hist_stride + k] = out.successes[k];
+      }
+  }
+}
+
+}  // extern "C"
