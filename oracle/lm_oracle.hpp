@@ -206,10 +206,13 @@ struct LDLT {
       const T realAkk = at(k, k);
       const bool pivot_is_valid = std::abs(realAkk) > T(0);
       if (k == 0 && !pivot_is_valid) {
-        // entire diagonal is zero: nothing more to do (LDLT.h "the entire diagonal is zero")
+        // LDLT.h "The entire diagonal is zero, there is nothing more to do except filling the
+        // transpositions, and checking that the other entries are zero."
         sign = 0;
-        for (int j = 0; j < n; ++j) transp[j] = j;
-        ok = true;
+        for (int j = 0; j < n; ++j) {
+          transp[j] = j;
+          for (int r = j + 1; r < n; ++r) ok = ok && (at(r, j) == T(0));
+        }
         return;
       }
       if (rs > 0 && pivot_is_valid) {

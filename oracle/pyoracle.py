@@ -1,0 +1,143 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes wrapper over oracle/_build/liblm_oracle.so (numpy in/out).
+
+May be imported only by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke().
+Nothing under tinyopt_amd/ imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_build", "liblm_oracle.so")
+PIN = os.path.join(_HERE, "_build", "pin_reference_tests")
+
+sys.path.insert(0, os.path.dirname(_HERE))
+from tinyopt_amd._capi import ToaOptions  # POD data contract only (no library load)  # noqa: E402
+
+F32, F64 = 0, 1
+_lib = None
+
+
+def build(march: str | None = None, out_dir: str | None = None) -> str:
+    """make -C oracle (g++).  `march`/`out_dir` let bench.py build a host-tuned copy elsewhere."""
+    if march is None and out_dir is None:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        return LIB
+    out_dir = out_dir or os.path.join(_HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "liblm_oracle_native.so")
+    subprocess.run(["g++", "-std=c++17", "-O3", f"-march={march or 'native'}", "-fopenmp", "-fPIC", "-shared",
+                    "-o", out, os.path.join(_HERE, "lm_oracle_capi.cpp")], check=True)
+    return out
+
+
+def load(path: str | None = None):
+    global _lib
+    if path is None and _lib is not None:
+        return _lib
+    p = path or LIB
+    if not os.path.exists(p):
+        build()
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.oracle_num_threads_max.restype = C.c_int
+    lib.oracle_synth_dense_row.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.oracle_synth_gaussian_prior.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, vp, vp, vp]
+    lib.oracle_dense_row_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.oracle_solve_damped.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.c_double, vp, vp]
+    lib.oracle_dense_row_lm.restype = C.c_double
+    lib.oracle_dense_row_lm.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.POINTER(ToaOptions),
+                                        vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
+    lib.oracle_gaussian_prior_lm.restype = C.c_double
+    lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _code(dtype) -> int:
+    return F32 if np.dtype(dtype) == np.float32 else F64
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def synth_dense_row(P, n, m, dtype, seed=0x71940917, problem0=0):
+    lib = load()
+    A = np.empty((P, m, n), dtype)
+    b = np.empty((P, m), dtype)
+    x0 = np.empty((P, n), dtype)
+    xs = np.empty((P, n), np.float64)
+    lib.oracle_synth_dense_row(_code(dtype), seed, problem0, P, n, m, _p(A), _p(b), _p(x0), _p(xs))
+    return A, b, x0, xs
+
+
+def dense_row_accumulate(A, b, x, want_grad=True):
+    lib = load()
+    P, m, n = A.shape
+    g = np.zeros((P, n), A.dtype)
+    H = np.zeros((P, n, n), A.dtype)
+    cost = np.zeros(P, np.float64)
+    nres = np.zeros(P, np.int32)
+    lib.oracle_dense_row_accumulate(_code(A.dtype), P, n, m, _p(A), _p(b), _p(np.ascontiguousarray(x)), int(want_grad),
+                                    _p(g), _p(H), _p(cost), _p(nres))
+    return g, H, cost, nres
+
+
+def solve_damped(H, g, scale=1.0):
+    lib = load()
+    P, n = g.shape
+    dx = np.zeros_like(g)
+    ok = np.zeros(P, np.int32)
+    lib.oracle_solve_damped(_code(g.dtype), P, n, _p(np.ascontiguousarray(H)), _p(np.ascontiguousarray(g)), float(scale),
+                            _p(dx), _p(ok))
+    return dx, ok
+
+
+def dense_row_lm(A, b, x0, pod: ToaOptions, history=False, nthreads=1, lib=None):
+    """Returns dict(x, stop, iters, fails, cost, rerr, H, errs, deltas2, succ, seconds)."""
+    lib = lib or load()
+    P, m, n = A.shape
+    x = np.array(x0, copy=True)
+    stop = np.zeros(P, np.int32)
+    iters = np.zeros(P, np.int32)
+    fails = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    rerr = np.zeros(P, np.float64)
+    Hf = np.zeros((P, n, n), np.float64) if pod.save_last else None
+    hs = pod.max_iters + 2
+    errs = np.zeros((P, hs), np.float64) if history else None
+    d2 = np.zeros((P, hs), np.float64) if history else None
+    succ = np.zeros((P, hs), np.uint8) if history else None
+    secs = lib.oracle_dense_row_lm(_code(A.dtype), P, n, m, _p(A), _p(b), _p(x), C.byref(pod), _p(stop), _p(iters),
+                                   _p(fails), _p(cost), _p(rerr), _p(Hf), _p(errs), _p(d2), _p(succ), hs, nthreads)
+    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, rerr=rerr, H=Hf, errs=errs, deltas2=d2, succ=succ,
+                seconds=secs)
+
+
+def sqrt2_lm(x0, pod: ToaOptions, history=True):
+    lib = load()
+    x = np.array(x0, copy=True)
+    P = x.shape[0]
+    stop = np.zeros(P, np.int32)
+    iters = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    hs = pod.max_iters + 2
+    errs = np.zeros((P, hs), np.float64)
+    d2 = np.zeros((P, hs), np.float64)
+    succ = np.zeros((P, hs), np.uint8)
+    lib.oracle_sqrt2_lm(_code(x.dtype), P, _p(x), C.byref(pod), _p(stop), _p(iters), _p(cost), _p(errs), _p(d2), _p(succ), hs)
+    return dict(x=x, stop=stop, iters=iters, cost=cost, errs=errs, deltas2=d2, succ=succ)
+
+
+def run_pin_tests() -> subprocess.CompletedProcess:
+    if not os.path.exists(PIN):
+        build()
+    return subprocess.run([PIN], capture_output=True, text=True)

@@ -1,0 +1,229 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) vs the CPU oracle on the same seeded
+inputs.  Tolerances: fp64 rel 1e-10 on g/H/cost, 1e-8 on final x, identical
+StopReason / iteration counts; fp32 rel 1e-4 on g/H/cost (math.h:297-301 FloatEpsilon class)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+ACC_CASES = [
+    # dtype, n, m, P          (BASELINE configs C2, C3, C4 shapes + ragged / edge shapes)
+    (np.float64, 6, 1000, 3),
+    (np.float64, 12, 500, 9),
+    (np.float32, 50, 2000, 5),
+    (np.float64, 1, 1, 4),
+    (np.float64, 1, 7, 4),
+    (np.float32, 3, 10, 6),
+    (np.float64, 15, 33, 5),   # n+1 == 16: exactly one block
+    (np.float64, 16, 35, 5),   # NB = 2
+    (np.float32, 31, 101, 5),  # NB = 2 full
+    (np.float32, 33, 64, 5),   # NB = 3
+    (np.float64, 47, 97, 3),   # NB = 3 full
+    (np.float64, 50, 203, 3),  # NB = 4, m % 4 != 0
+    (np.float32, 63, 130, 3),  # largest n
+]
+
+
+@pytest.mark.parametrize("dtype,n,m,P", ACC_CASES)
+def test_accumulate_matches_oracle(ta, oracle, dtype, n, m, P):
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, dtype, seed=1234)
+    g_ref, H_ref, c_ref, nres_ref = oracle.dense_row_accumulate(A, b, x0)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0).cuda()
+    g, H, c, nres = ta.accumulate(model, x, want_grad=True)
+    torch.cuda.synchronize()
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    for p in range(P):
+        assert _rel(g[p].cpu().numpy(), g_ref[p]) < tol
+        Hg = H[p].cpu().numpy()
+        assert _rel(Hg, H_ref[p]) < tol
+        assert np.array_equal(Hg, Hg.T), "device H must be exactly symmetric"
+    assert _rel(c.cpu().numpy(), c_ref) < tol
+    assert (nres.cpu().numpy() == nres_ref).all()
+    # cost-only call (grad == nullptr)
+    _, _, c2, nres2 = ta.accumulate(model, x, want_grad=False)
+    assert _rel(c2.cpu().numpy(), c_ref) < tol
+    assert (nres2.cpu().numpy() == nres_ref).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [1, 2, 5, 12, 33, 50, 63])
+def test_solve_damped_spd(ta, oracle, dtype, n):
+    rng = np.random.default_rng(n)
+    P = 7
+    J = rng.uniform(-1, 1, (P, 3 * n + 2, n))
+    H = np.einsum("pij,pik->pjk", J, J).astype(dtype)
+    g = rng.uniform(-1, 1, (P, n)).astype(dtype)
+    for scale in (1.0, 1.0001, 3.0):
+        dx_ref, ok_ref = oracle.solve_damped(H, g, scale)
+        dx, ok = ta.solve_damped(torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda(), scale)
+        torch.cuda.synchronize()
+        assert (ok.cpu().numpy() == ok_ref).all() and ok_ref.all()
+        tol = 1e-9 if dtype == np.float64 else 2e-3   # conditioning-dependent
+        assert _rel(dx.cpu().numpy(), dx_ref) < tol
+        # residual check independent of the oracle: (H_damped) dx = -g
+        Hd = H.astype(np.float64).copy()
+        idx = np.arange(n)
+        Hd[:, idx, idx] = (Hd[:, idx, idx] * scale).astype(dtype)
+        r = np.einsum("pij,pj->pi", Hd, dx.cpu().numpy().astype(np.float64)) + g
+        assert np.abs(r).max() < (1e-9 if dtype == np.float64 else 2e-3)
+
+
+def test_solve_damped_acceptance_rule(ta, oracle):
+    """math.h:236: fail iff info()!=Success || !isPositive(); semi-definite passes (pseudo-inverse)."""
+    mats = [
+        np.diag([-1.0, -2.0, -3.0]),            # negative definite -> fail
+        np.diag([1.0, -2.0, 3.0]),              # indefinite -> fail
+        np.diag([2.0, 0.0, 5.0]),               # zero pivot, semi-definite -> ok, that component 0
+        np.zeros((3, 3)),                       # all zero -> ok, dx = 0
+        np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0.0]]),  # zero diagonal, non-zero off-diagonal -> fail
+        np.array([[4, 2, 0.6], [2, 2, 0.5], [0.6, 0.5, 3.0]]),  # SPD
+        np.array([[1, 2, 0], [2, 1, 0], [0, 0, 1.0]]),  # indefinite via off-diagonals -> fail
+        np.array([[1e-30, 0, 0], [0, 1, 0], [0, 0, 1e30]]),  # badly scaled SPD -> pivoting
+    ]
+    H = np.stack(mats)
+    g = np.tile(np.array([1.0, -2.0, 0.5]), (len(mats), 1))
+    dx_ref, ok_ref = oracle.solve_damped(H, g, 1.0)
+    dx, ok = ta.solve_damped(torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda(), 1.0)
+    torch.cuda.synchronize()
+    assert list(ok_ref) == [0, 0, 1, 1, 0, 1, 0, 1]
+    assert (ok.cpu().numpy() == ok_ref).all()
+    good = ok_ref == 1
+    assert np.allclose(dx.cpu().numpy()[good], dx_ref[good], rtol=1e-12, atol=1e-300)
+
+
+LM_CASES = [
+    (np.float64, 12, 500, 40),
+    (np.float64, 6, 1000, 8),
+    (np.float64, 1, 5, 8),
+    (np.float64, 16, 60, 16),
+    (np.float64, 50, 300, 6),
+    (np.float32, 50, 2000, 12),
+    (np.float32, 12, 500, 16),
+]
+
+
+@pytest.mark.parametrize("dtype,n,m,P", LM_CASES)
+@pytest.mark.parametrize("which", ["benchmark", "default"])
+def test_lm_run_matches_oracle(ta, oracle, dtype, n, m, P, which):
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=99)
+    opts = ta.Options.benchmark() if which == "benchmark" else ta.Options()
+    opts.hessian.save_last = True
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy()
+    stop = out.stop_reason.cpu().numpy()
+    iters = out.num_iters.cpu().numpy()
+    assert (stop >= 0).all() and (ref["stop"] >= 0).all()
+    if dtype == np.float64:
+        assert np.abs(xg - ref["x"]).max() < 1e-8
+        # the first iterations (before round-off decides good/bad at the noise floor) must be identical
+        errs = out.errs.cpu().numpy()
+        for p in range(P):
+            k = min(3, iters[p], ref["iters"][p])
+            assert _rel(errs[p, :k], ref["errs"][p, :k]) < 1e-9
+            assert (out.successes.cpu().numpy()[p, :k] == ref["succ"][p, :k]).all()
+        assert _rel(out.final_cost.cpu().numpy(), ref["cost"]) < 1e-9
+        Hf = out.final_hessian.cpu().numpy()
+        assert _rel(Hf, ref["H"]) < 1e-9
+        # stop reason / iteration count: identical wherever the decision is not at the round-off floor
+        same = (stop == ref["stop"]) & (iters == ref["iters"])
+        assert same.mean() >= 0.9, f"stop/iters agree on only {same.mean():.2f}"
+    else:
+        assert np.abs(xg - ref["x"]).max() < 2e-3
+        assert _rel(out.final_cost.cpu().numpy(), ref["cost"]) < 1e-3
+        assert np.abs(iters - ref["iters"]).max() <= 4
+    # planted solution recovered to the noise level (independent of the oracle)
+    assert np.abs(xg - xs).max() < 5e-3
+
+
+def test_lm_counters_and_history_shapes(ta, oracle):
+    A, b, x0, _ = oracle.synth_dense_row(10, 12, 500, np.float64, seed=5)
+    opts = ta.Options.benchmark()
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    cnt = out.counters.cpu().numpy()
+    iters = out.num_iters.cpu().numpy()
+    assert cnt[3] == 10
+    assert cnt[0] + cnt[1] >= iters.sum()          # every iteration runs at least one pass
+    assert out.final_hessian is None               # benchmark options: save_last = false
+    # history entries beyond num_iters stay zero (reference: vectors have exactly num_iters entries)
+    errs = out.errs.cpu().numpy()
+    for p in range(10):
+        assert (errs[p, iters[p]:] == 0).all()
+
+
+def test_synth_device_matches_oracle(ta, oracle):
+    for dtype, tdt, n, m in ((np.float64, torch.float64, 12, 50), (np.float32, torch.float32, 50, 37)):
+        P = 6
+        A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=77, problem0=1000)
+        model, x0d, xsd = ta.DenseRow.synthetic(P, n, m, tdt, seed=77, problem0=1000)
+        ref_model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        torch.cuda.synchronize()
+        got = model.packed.cpu().numpy()
+        want = ref_model.packed.cpu().numpy()
+        lay = ta.api.dense_row_layout(tdt, n, m)
+        got = got.reshape(P, lay["rows_padded"], lay["row_stride"])
+        want = want.reshape(P, lay["rows_padded"], lay["row_stride"])
+        assert np.array_equal(got[:, :, :n], want[:, :, :n]), "A must be bit-identical (integer hash + exact conversion)"
+        assert np.allclose(got[:, :, n], want[:, :, n], rtol=0, atol=1e-6 if dtype == np.float32 else 1e-14)
+        assert np.array_equal(got[:, :, n + 1:], want[:, :, n + 1:])
+        assert np.array_equal(x0d.cpu().numpy(), x0)
+        assert np.allclose(xsd.cpu().numpy(), xs.astype(dtype))
+
+
+def test_option_variants(ta, oracle):
+    A, b, x0, xs = oracle.synth_dense_row(12, 12, 200, np.float64, seed=3)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    variants = []
+    o = ta.Options(); o.solver_type = ta.Options.GaussNewton; variants.append(o)
+    o = ta.Options(); o.cost.downscale_by_2 = True; variants.append(o)
+    o = ta.Options(); o.cost.normalize = True; variants.append(o)
+    o = ta.Options(); o.cost.use_squared_norm = False; variants.append(o)
+    o = ta.Options(); o.check_final_cost = True; o.max_iters = 3; variants.append(o)
+    o = ta.Options(); o.max_iters = 1; variants.append(o)
+    o = ta.Options(); o.lm.damping_init = 10.0; variants.append(o)
+    o = ta.Options(); o.use_step_quality_approx = True; variants.append(o)
+    o = ta.Options(); o.grad_clipping = 0.5; o.max_iters = 5; variants.append(o)
+    o = ta.Options(); o.hessian.check_min_H_diag = 1e9; variants.append(o)   # forces Build failure -> kSolverFailed
+    o = ta.Options(); o.min_error = 1e3; variants.append(o)                  # immediate kMinError
+    o = ta.Options(); o.max_total_failures = 1; o.max_consec_failures = 0; o.min_step_norm2 = 0; o.min_rerr_dec = 0
+    o.min_grad_norm2 = 0; o.min_error = 0; o.max_iters = 30; variants.append(o)
+    for i, o in enumerate(variants):
+        ref = oracle.dense_row_lm(A, b, x0, o.to_pod())
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, o)
+        torch.cuda.synchronize()
+        stop = out.stop_reason.cpu().numpy()
+        iters = out.num_iters.cpu().numpy()
+        agree = ((stop == ref["stop"]) & (iters == ref["iters"])).mean()
+        assert agree >= 0.75, f"variant {i}: stop/iters agreement {agree}: {stop} vs {ref['stop']}, {iters} vs {ref['iters']}"
+        assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6, f"variant {i}"
+        assert _rel(out.final_cost.cpu().numpy(), ref["cost"]) < 1e-8, f"variant {i}"
+
+
+def test_argument_errors(ta):
+    model, x0, _ = ta.DenseRow.synthetic(4, 12, 50, torch.float64)
+    with pytest.raises(TypeError):
+        ta.Optimize(x0, lambda x: x)            # host callable cannot run on the GPU path
+    with pytest.raises(ValueError):
+        ta.Optimize(x0[:, :5].contiguous(), model)
+    o = ta.Options(); o.solver_type = 2         # GradientDescent is not on this path (optimize.h:75 throws)
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(x0, model, o)
+    o = ta.Options(); o.hessian.use_ldlt = False
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(x0, model, o)

@@ -1,0 +1,327 @@
+"""Host-side mirror of tinyopt's Optimize / Options / Output for batched device models.
+
+Names and meanings follow the reference:
+  Options   include/tinyopt/optimizers/options.h:18-156 (nested groups hessian / cost / lm kept)
+  Output    include/tinyopt/output.h:26-145 (one entry per problem of the batch)
+  Optimize  include/tinyopt/optimize.h:16-77  ``Optimize(x, cost, options)``; x is updated in place
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import _capi
+from ._capi import F32, F64, MODEL_DENSE_ROW, ToaOptions, ToaResults, check
+
+
+class StopReason(enum.IntEnum):  # include/tinyopt/stop_reasons.h:14-43
+    kOutOfMemory = -4
+    kSolverFailed = -3
+    kSystemHasNaNOrInf = -2
+    kSkipped = -1
+    kNone = 0
+    kMinError = 1
+    kMinRelError = 2
+    kMinDeltaNorm = 3
+    kMinGradNorm = 4
+    kMaxIters = 5
+    kMaxNoDecr = 6
+    kMaxConsecNoDecr = 7
+    kTimedOut = 8
+    kUserStopped = 9
+
+
+@dataclass
+class _Hessian:  # options.h:58-67
+    use_ldlt: bool = True
+    H_is_full: bool = True
+    check_min_H_diag: float = 0.0
+    save_last: bool = True
+
+
+@dataclass
+class _CostScaling:  # options.h:75-80
+    use_squared_norm: bool = True
+    downscale_by_2: bool = False
+    normalize: bool = False
+
+
+@dataclass
+class _LM:  # options.h:127-141
+    damping_init: float = 1e-4
+    damping_range: tuple = (1e-9, 1e9)
+    good_factor: float = 1.0 / 3.0
+    bad_factor: float = 2.0
+
+
+@dataclass
+class Options:
+    """tinyopt::Options (options.h:18-156).  log.*, stop_callback*, max_duration_ms are host-side
+    features of the reference that the device path does not take."""
+    LevenbergMarquardt = 0
+    GaussNewton = 1
+    solver_type: int = 0
+    check_final_cost: bool = False
+    use_step_quality_approx: bool = False
+    grad_clipping: float = 0.0
+    hessian: _Hessian = field(default_factory=_Hessian)
+    cost: _CostScaling = field(default_factory=_CostScaling)
+    max_iters: int = 50
+    min_error: float = 1e-12
+    min_rerr_dec: float = 1e-10
+    min_step_norm2: float = 1e-14
+    min_grad_norm2: float = 1e-18
+    max_total_failures: int = 0
+    max_consec_failures: int = 5
+    lm: _LM = field(default_factory=_LM)
+
+    @staticmethod
+    def benchmark() -> "Options":
+        """benchmarks/options.h:10-27 CreateOptions()."""
+        o = Options()
+        o.max_iters = 10
+        o.min_error = 0.0
+        o.min_rerr_dec = 1e-12
+        o.min_step_norm2 = 1e-16
+        o.max_consec_failures = 3
+        o.hessian.save_last = False
+        return o
+
+    def to_pod(self) -> ToaOptions:
+        p = ToaOptions()
+        p.solver_type = int(self.solver_type)
+        p.max_iters = int(self.max_iters)
+        p.min_error = self.min_error
+        p.min_rerr_dec = self.min_rerr_dec
+        p.min_step_norm2 = self.min_step_norm2
+        p.min_grad_norm2 = self.min_grad_norm2
+        p.max_total_failures = int(self.max_total_failures)
+        p.max_consec_failures = int(self.max_consec_failures)
+        p.damping_init = self.lm.damping_init
+        p.damping_min, p.damping_max = self.lm.damping_range
+        p.good_factor = self.lm.good_factor
+        p.bad_factor = self.lm.bad_factor
+        p.grad_clipping = self.grad_clipping
+        p.check_min_H_diag = self.hessian.check_min_H_diag
+        p.check_final_cost = int(self.check_final_cost)
+        p.use_step_quality_approx = int(self.use_step_quality_approx)
+        p.use_ldlt = int(self.hessian.use_ldlt)
+        p.H_is_full = int(self.hessian.H_is_full)
+        p.save_last = int(self.hessian.save_last)
+        p.use_squared_norm = int(self.cost.use_squared_norm)
+        p.downscale_by_2 = int(self.cost.downscale_by_2)
+        p.normalize = int(self.cost.normalize)
+        return p
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.float64:
+        return F64
+    raise ValueError("dtype must be torch.float32 or torch.float64")  # reference: Scalar is float/double
+
+
+class Context:
+    """Owns a C-ABI handle bound to one GPU and torch's current stream on it."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("tinyopt_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path")
+        self.lib = _capi.load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        check(self.lib.toa_create(C.byref(h), self.device, C.c_void_p(self.stream.cuda_stream)))
+        self.h = h
+
+    def info(self):
+        cus, khz = C.c_int(), C.c_int()
+        name = C.create_string_buffer(128)
+        check(self.lib.toa_device_info(self.h, C.byref(cus), C.byref(khz), name, 128))
+        return {"num_cus": cus.value, "clock_khz": khz.value, "name": name.value.decode()}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.toa_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: Optional[int] = None) -> Context:
+    dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(dev)
+    return _default_ctx[key]
+
+
+def dense_row_layout(dtype: torch.dtype, n: int, m: int):
+    lib = _capi.load()
+    nb, rs, m4 = C.c_int(), C.c_int(), C.c_int()
+    nbytes = C.c_size_t()
+    check(lib.toa_dense_row_layout(_dtype_code(dtype), n, m, C.byref(nb), C.byref(rs), C.byref(m4), C.byref(nbytes)))
+    return {"nb": nb.value, "row_stride": rs.value, "rows_padded": m4.value, "bytes_per_problem": nbytes.value}
+
+
+class DenseRow:
+    """Device residual model  r_i(x) = a_i.x + 0.1 sin(a_i.x) - b_i  for a batch of P problems.
+
+    Plays the role of the user's cost functor in ``Optimize(x, cost)`` (a Jet-invocable residual
+    functor in the reference, e.g. benchmarks/dense.cpp:56,71-74) — here a tag object that selects
+    the pre-instantiated device functor and owns the problem data in HBM (packed layout).
+    """
+    model_id = MODEL_DENSE_ROW
+
+    def __init__(self, packed: torch.Tensor, n: int, m: int, P: int):
+        self.packed, self.n, self.m, self.P = packed, int(n), int(m), int(P)
+        self.dtype = packed.dtype
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        """bytes one Accumulate/Evaluate pass must read per problem = m(n+1)sizeof(T)."""
+        return self.m * (self.n + 1) * self.packed.element_size()
+
+    @staticmethod
+    def from_arrays(A: torch.Tensor, b: torch.Tensor, ctx: Optional[Context] = None) -> "DenseRow":
+        """A: [P, m, n], b: [P, m] on the GPU (natural layout) -> packed layout."""
+        ctx = ctx or default_context(A.device.index)
+        P, m, n = A.shape
+        assert b.shape == (P, m) and A.dtype == b.dtype and A.is_cuda and b.is_cuda
+        A, b = A.contiguous(), b.contiguous()
+        lay = dense_row_layout(A.dtype, n, m)
+        packed = torch.empty(P * lay["rows_padded"] * lay["row_stride"], dtype=A.dtype, device=A.device)
+        check(ctx.lib.toa_dense_row_pack(ctx.h, _dtype_code(A.dtype), n, m, P, A.data_ptr(), b.data_ptr(), packed.data_ptr()))
+        return DenseRow(packed, n, m, P)
+
+    @staticmethod
+    def synthetic(P: int, n: int, m: int, dtype: torch.dtype, seed: int = 0x71940917, problem0: int = 0,
+                  ctx: Optional[Context] = None):
+        """Generate the SURVEY §8(d) batch directly in HBM.  Returns (model, x0, xstar)."""
+        ctx = ctx or default_context()
+        dev = torch.device("cuda", ctx.device)
+        lay = dense_row_layout(dtype, n, m)
+        packed = torch.empty(P * lay["rows_padded"] * lay["row_stride"], dtype=dtype, device=dev)
+        x0 = torch.empty(P, n, dtype=dtype, device=dev)
+        xstar = torch.empty(P, n, dtype=dtype, device=dev)
+        check(ctx.lib.toa_dense_row_synth(ctx.h, _dtype_code(dtype), n, m, P, seed, problem0, packed.data_ptr(),
+                                          x0.data_ptr(), xstar.data_ptr()))
+        return DenseRow(packed, n, m, P), x0, xstar
+
+
+@dataclass
+class Output:
+    """tinyopt::Output (output.h:26-145), one row per problem; tensors live on the GPU."""
+    stop_reason: torch.Tensor
+    num_iters: torch.Tensor
+    num_failures: torch.Tensor
+    num_consec_failures: torch.Tensor
+    final_cost: torch.Tensor
+    final_num_residuals: torch.Tensor
+    final_rerr_dec: torch.Tensor
+    final_hessian: Optional[torch.Tensor] = None
+    errs: Optional[torch.Tensor] = None
+    deltas2: Optional[torch.Tensor] = None
+    successes: Optional[torch.Tensor] = None
+    counters: Optional[torch.Tensor] = None  # [acc passes, eval passes, solves, problems]
+
+    def Succeeded(self) -> torch.Tensor:  # output.h:30
+        return self.stop_reason >= 0
+
+    def Converged(self) -> torch.Tensor:  # output.h:33-35
+        return (self.stop_reason >= 1) & (self.stop_reason < 5)
+
+
+def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
+             ctx: Optional[Context] = None, out: Optional[Output] = None) -> Output:
+    """``tinyopt::Optimize(x, cost, options)`` (optimize.h:16-77) for a batch of independent problems.
+
+    x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
+    cost: a device model (``DenseRow``).  Returns the per-problem Output.  One kernel launch,
+    asynchronous on torch's current stream.
+    """
+    options = options or Options()
+    if not isinstance(cost, DenseRow):
+        raise TypeError("cost must be a device model (DenseRow); host callables cannot run on the GPU path")
+    if not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be a contiguous GPU tensor")
+    P, n = x.shape
+    if n != cost.n or P != cost.P or x.dtype != cost.dtype:
+        raise ValueError("x shape/dtype does not match the model")  # reference: std::invalid_argument
+    ctx = ctx or default_context(x.device.index)
+    dev = x.device
+    pod = options.to_pod()
+    if out is None:
+        i32 = dict(dtype=torch.int32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        out = Output(
+            stop_reason=torch.zeros(P, **i32), num_iters=torch.zeros(P, **i32), num_failures=torch.zeros(P, **i32),
+            num_consec_failures=torch.zeros(P, **i32), final_cost=torch.zeros(P, **f64),
+            final_num_residuals=torch.zeros(P, **i32), final_rerr_dec=torch.zeros(P, **f64),
+            counters=torch.zeros(4, dtype=torch.int64, device=dev))
+        if options.hessian.save_last:
+            out.final_hessian = torch.zeros(P, n, n, **f64)
+        if history:
+            hs = options.max_iters + 2
+            out.errs = torch.zeros(P, hs, **f64)
+            out.deltas2 = torch.zeros(P, hs, **f64)
+            out.successes = torch.zeros(P, hs, dtype=torch.uint8, device=dev)
+    else:
+        out.counters.zero_()
+    res = ToaResults()
+    res.stop_reason = out.stop_reason.data_ptr()
+    res.num_iters = out.num_iters.data_ptr()
+    res.num_failures = out.num_failures.data_ptr()
+    res.num_consec_failures = out.num_consec_failures.data_ptr()
+    res.final_cost = out.final_cost.data_ptr()
+    res.final_num_residuals = out.final_num_residuals.data_ptr()
+    res.final_rerr_dec = out.final_rerr_dec.data_ptr()
+    res.final_hessian = out.final_hessian.data_ptr() if out.final_hessian is not None else None
+    res.errs = out.errs.data_ptr() if out.errs is not None else None
+    res.deltas2 = out.deltas2.data_ptr() if out.deltas2 is not None else None
+    res.successes = out.successes.data_ptr() if out.successes is not None else None
+    res.hist_stride = out.errs.shape[1] if out.errs is not None else 0
+    check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                             x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
+    return out
+
+
+def accumulate(cost: DenseRow, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Context] = None):
+    """The Accumulate callback ``acc(x, grad, H) -> Cost`` (docs/API.md:37-57) for a batch.
+    Returns (g [P,n], H [P,n,n], cost [P] float64, nres [P]); g/H are None when want_grad is False."""
+    ctx = ctx or default_context(x.device.index)
+    P, n = x.shape
+    dev = x.device
+    g = torch.zeros(P, n, dtype=x.dtype, device=dev) if want_grad else None
+    H = torch.zeros(P, n, n, dtype=x.dtype, device=dev) if want_grad else None
+    c = torch.zeros(P, dtype=torch.float64, device=dev)
+    nres = torch.zeros(P, dtype=torch.int32, device=dev)
+    check(ctx.lib.toa_accumulate(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                                 x.data_ptr(), int(want_grad), g.data_ptr() if want_grad else None,
+                                 H.data_ptr() if want_grad else None, c.data_ptr(), nres.data_ptr()))
+    return g, H, c, nres
+
+
+def solve_damped(H: torch.Tensor, g: torch.Tensor, scale: float = 1.0, ctx: Optional[Context] = None):
+    """SolverLM damping (lm.h:108-117, H_ii *= scale) + SolverGN::Solve (gn.h:150-171) for a batch.
+    Returns (dx [P,n], ok [P] int32)."""
+    ctx = ctx or default_context(H.device.index)
+    P, n = g.shape
+    H, g = H.contiguous(), g.contiguous()
+    dx = torch.zeros_like(g)
+    ok = torch.zeros(P, dtype=torch.int32, device=g.device)
+    check(ctx.lib.toa_solve_damped(ctx.h, _dtype_code(g.dtype), n, P, H.data_ptr(), g.data_ptr(), float(scale),
+                                   dx.data_ptr(), ok.data_ptr()))
+    return dx, ok
