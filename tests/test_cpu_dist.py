@@ -1,0 +1,68 @@
+"""CPU tests of the N>1 path: world_size-2 gloo processes exercising shard_range + the single result
+gather (the only collective on the path)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions():
+    from tinyopt_amd.dist import shard_range
+    for P in (0, 1, 7, 8, 100000, 12501):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(P, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == P
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, P, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tinyopt_amd.dist import gather_output, shard_range
+    lo, hi = shard_range(P, rank, world)
+    ids = torch.arange(lo, hi, dtype=torch.float64)
+    x = (ids[:, None] * 10 + torch.arange(n, dtype=torch.float64)[None, :]).to(torch.float32)
+    fields = {"stop_reason": (ids % 5).to(torch.int32), "num_iters": (ids * 2).to(torch.int32), "final_cost": ids * 0.5}
+    out = gather_output(x, fields, P_total=P)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in out.items()})
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world2_gloo():
+    P, n, world = 11, 3, 2   # uneven shards: 6 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ids = np.arange(P, dtype=np.float64)
+    assert np.array_equal(got["x"], (ids[:, None] * 10 + np.arange(n)[None, :]).astype(np.float32))
+    assert np.array_equal(got["stop_reason"], (ids % 5).astype(np.int32))
+    assert np.array_equal(got["num_iters"], (ids * 2).astype(np.int32))
+    assert np.array_equal(got["final_cost"], ids * 0.5)
+
+
+def test_gather_single_process_passthrough():
+    from tinyopt_amd.dist import gather_output
+    x = torch.zeros(4, 2)
+    out = gather_output(x, {"stop_reason": torch.ones(4, dtype=torch.int32)}, P_total=4)
+    assert out["x"] is x and out["stop_reason"].sum() == 4

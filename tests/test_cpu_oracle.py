@@ -1,0 +1,82 @@
+"""CPU tests (`-m "not gpu"`): the oracle against the reference's known answers and against the
+committed golden fixtures."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_pinned_to_reference_known_answers(oracle):
+    """oracle/pin_reference_tests.cpp restates tests/{sqrt2,basic,solvers,optimize_easy,optimize_hard,
+    circle,cov}.cpp of the reference + the README trace and asserts what they assert."""
+    r = oracle.run_pin_tests()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout
+
+
+def test_sqrt2_golden(oracle):
+    from tinyopt_amd.api import Options
+    o = Options()
+    o.max_iters = 20
+    o.max_consec_failures = 0
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        g = np.load(os.path.join(GOLD, f"sqrt2_{tag}.npz"))
+        r = oracle.sqrt2_lm(g["x0"].astype(dt), o.to_pod())
+        assert np.array_equal(r["stop"], g["stop"]) and np.array_equal(r["iters"], g["iters"])
+        assert np.allclose(r["x"], g["x"], rtol=1e-12 if dt == np.float64 else 1e-6)
+        assert np.allclose(np.abs(r["x"]), np.sqrt(2.0), atol=1e-5)       # tests/sqrt2.cpp:55
+        assert ((r["stop"] >= 1) & (r["stop"] < 5)).all()                  # Converged()
+        assert np.allclose(r["errs"], g["errs"], rtol=1e-9 if dt == np.float64 else 1e-4, atol=1e-30)
+
+
+def test_dense_row_golden(oracle):
+    from tinyopt_amd.api import Options
+    for tag, dt in (("c2_f64", np.float64), ("c3_f64", np.float64), ("c4_f32", np.float32), ("c4_f64", np.float64)):
+        g = np.load(os.path.join(GOLD, f"dense_row_{tag}.npz"))
+        n, m, P = int(g["n"]), int(g["m"]), int(g["P"])
+        A, b, x0, xs = oracle.synth_dense_row(P, n, m, dt, seed=int(g["seed"]))
+        assert np.isclose(A.astype(np.float64).sum(), g["A_sum"], rtol=1e-12)   # inputs regenerate identically
+        assert np.isclose(b.astype(np.float64).sum(), g["b_sum"], rtol=1e-12)
+        assert np.array_equal(x0, g["x0"])
+        gg, H, c, nres = oracle.dense_row_accumulate(A, b, x0)
+        tol = 1e-12 if dt == np.float64 else 1e-5
+        assert np.allclose(gg, g["g"], rtol=tol, atol=tol) and np.allclose(H, g["H"], rtol=tol, atol=tol)
+        assert np.allclose(c, g["cost"], rtol=tol)
+        o = Options.benchmark()
+        o.hessian.save_last = True
+        r = oracle.dense_row_lm(A, b, x0, o.to_pod(), history=True)
+        assert np.array_equal(r["stop"], g["stop"]) and np.array_equal(r["iters"], g["iters"])
+        assert np.allclose(r["x"], g["x"], rtol=tol, atol=tol)
+        # independent of any fixture: the planted solution is recovered to the noise level
+        assert np.abs(r["x"] - xs).max() < 5e-3
+
+
+def test_accumulate_against_finite_differences(oracle):
+    """In the spirit of diff/gradient_check.h:96-98,201-213: g = J^T r must match a central finite
+    difference of 0.5*||r||^2, and H = J^T J must be symmetric PSD."""
+    A, b, x0, _ = oracle.synth_dense_row(2, 6, 40, np.float64, seed=11)
+    g, H, c, _ = oracle.dense_row_accumulate(A, b, x0)
+    eps = 1e-6
+    for p in range(2):
+        for j in range(6):
+            xp = x0.copy(); xp[p, j] += eps
+            xm = x0.copy(); xm[p, j] -= eps
+            cp = oracle.dense_row_accumulate(A, b, xp, want_grad=False)[2][p]
+            cm = oracle.dense_row_accumulate(A, b, xm, want_grad=False)[2][p]
+            assert abs(0.5 * (cp - cm) / (2 * eps) - g[p, j]) < 1e-6 * max(1.0, abs(g[p, j]))
+        assert np.allclose(H[p], H[p].T, atol=1e-14)
+        assert np.linalg.eigvalsh(H[p]).min() > -1e-10
+
+
+def test_ldlt_golden_and_numpy(oracle):
+    g = np.load(os.path.join(GOLD, "ldlt_spd.npz"))
+    for H, gv, n, dxg in zip(g["H"], g["g"], g["n"], g["dx"]):
+        n = int(n)
+        Hn, gn = H[:n, :n].copy(), gv[:n].copy()
+        dx, ok = oracle.solve_damped(Hn[None], gn[None], 1.0001)
+        assert ok[0] == 1
+        assert np.allclose(dx[0], dxg[:n], rtol=1e-12, atol=1e-300)
+        Hd = Hn.copy()
+        Hd[np.arange(n), np.arange(n)] *= 1.0001
+        assert np.allclose(dx[0], np.linalg.solve(Hd, -gn), rtol=1e-9)
