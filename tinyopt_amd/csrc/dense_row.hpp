@@ -46,8 +46,145 @@ struct Mfma<double> {
   static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 
-__device__ __forceinline__ void sincos_t(float t, float* s, float* c) { sincosf(t, s, c); }
-__device__ __forceinline__ void sincos_t(double t, double* s, double* c) { sincos(t, s, c); }
+// sin/cos for the DenseRow functor.  Branch-free Cody-Waite reduction by pi/2 (FMA, 3 / 2 constants)
+// + Cephes minimax polynomials on [-pi/4, pi/4]: <= ~1.5 ulp for |t| < ~1e4, which covers the
+// model's domain (|a_i.x| <= n * |x|_inf).  libm's sincos carries a Payne-Hanek path whose register
+// footprint would halve the occupancy of the whole fused kernel for arguments that never occur.
+__device__ __forceinline__ void sincos_t(float t, float* s, float* c) {
+  const float j = rintf(t * 0.636619772367581343f);
+  float y = fmaf(-j, 1.5707963705062866f, t);
+  y = fmaf(-j, -4.371138828673793e-08f, y);
+  y = fmaf(-j, -1.7151245100058819e-15f, y);
+  const float z = y * y;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * y, y);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int q = int(j) & 3;
+  const float sv = (q & 1) ? pc : ps;
+  const float cv = (q & 1) ? ps : pc;
+  *s = (q & 2) ? -sv : sv;
+  *c = ((q + 1) & 2) ? -cv : cv;
+}
+__device__ __forceinline__ void sincos_t(double t, double* s, double* c) {
+  const double j = rint(t * 0.63661977236758134308);
+  double y = fma(-j, 1.5707963267948966, t);
+  y = fma(-j, 6.123233995736766e-17, y);
+  const double z = y * y;
+  double ps = 1.58962301576546568060e-10;
+  ps = fma(ps, z, -2.50507477628578072866e-8);
+  ps = fma(ps, z, 2.75573136213857245213e-6);
+  ps = fma(ps, z, -1.98412698295895385996e-4);
+  ps = fma(ps, z, 8.33333333332211858878e-3);
+  ps = fma(ps, z, -1.66666666666666307295e-1);
+  ps = fma(ps, z * y, y);
+  double pc = -1.13585365213876817300e-11;
+  pc = fma(pc, z, 2.08757008419747316778e-9);
+  pc = fma(pc, z, -2.75573141792967388112e-7);
+  pc = fma(pc, z, 2.48015872888517045348e-5);
+  pc = fma(pc, z, -1.38888888888730564116e-3);
+  pc = fma(pc, z, 4.16666666666665929218e-2);
+  pc = fma(pc, z * z, fma(-0.5, z, 1.0));
+  const int q = int(j) & 3;
+  const double sv = (q & 1) ? pc : ps;
+  const double cv = (q & 1) ? ps : pc;
+  *s = (q & 2) ? -sv : sv;
+  *c = ((q + 1) & 2) ? -cv : cv;
+}
+
+// ---- bounds-checked buffer loads (SRSRC path), software-pipelined by hand ------------------------
+// A buffer descriptor (V#) spanning exactly one problem lets every lane issue its load
+// UNCONDITIONALLY: lanes past the row's last column and steps past the last row use an offset
+// >= num_records and the hardware returns 0 — no exec-masked branches in the hot loop.
+//
+// The loads are inline asm on purpose (cdna_hip_programming.md §5.7 form (ii)): with compiler-visible
+// loads hipcc either sinks the prefetch below the MFMAs or waits vmcnt(0) right after issuing it
+// (seen in the .s of three different formulations), which serialises HBM latency with the matrix
+// pipe.  Here the issue point is pinned at the top of the batch and the single wait sits after the
+// batch's MFMAs, naming every destination register "+v" so no consumer can be scheduled above it.
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
+using u32x3 = unsigned __attribute__((ext_vector_type(3)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+using i32x4 = int __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane(int(unsigned(a)));
+  r[1] = __builtin_amdgcn_readfirstlane(int(unsigned(a >> 32) & 0xffffu));  // stride = 0
+  r[2] = __builtin_amdgcn_readfirstlane(int(bytes));                         // num_records (bytes)
+  r[3] = 0x00020000;  // DATA_FORMAT = 32 (raw dwords), no swizzle: gfx9 / CDNA encoding
+  return r;
+}
+
+template <int kDwords>
+struct RawVec;
+template <>
+struct RawVec<1> {
+  unsigned a;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const { o[0] = a; }
+};
+template <>
+struct RawVec<2> {
+  u32x2 a;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; }
+};
+template <>
+struct RawVec<3> {
+  u32x3 a;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+};
+template <>
+struct RawVec<4> {
+  u32x4 a;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; }
+};
+template <>
+struct RawVec<6> {
+  u32x4 a;
+  u32x2 b;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1];
+  }
+};
+template <>
+struct RawVec<8> {
+  u32x4 a, b;
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  }
+  __device__ __forceinline__ void get(unsigned* o) const {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+};
+// Wait for every outstanding VMEM load of this wave; the operands make the four batch slots
+// data-dependent on the wait so that no consumer is hoisted above it.
+template <int kDwords>
+__device__ __forceinline__ void wait_batch(RawVec<kDwords>& v0, RawVec<kDwords>& v1, RawVec<kDwords>& v2, RawVec<kDwords>& v3) {
+  if constexpr (kDwords <= 4) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a) : : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a), "+v"(v0.b), "+v"(v1.b), "+v"(v2.b), "+v"(v3.b)
+                 : : "memory");
+  }
+}
 
 // Host+device layout helper.
 struct DenseRowLayout {
@@ -96,32 +233,31 @@ struct DenseRowGram {
     const bool isB_lane = (c == cB);
     if (WANT_H) clear();
     T csum = 0;
-    constexpr int kAlign = (NB * sizeof(T)) % 16 == 0 ? 16 : ((NB * sizeof(T)) % 8 == 0 ? 8 : 4);
-    const T* rowp = prob + size_t(k) * RS + (active ? c * NB : 0);
-    const size_t step_stride = size_t(4) * RS;
     const int steps = m4 >> 2;
-    constexpr int U = 4;  // register double-buffer depth (steps in flight)
-    T buf[U][NB];
-    auto load = [&](int s, T(&w)[NB]) {
-      if (active && s < steps) {
-        const T* p = (const T*)__builtin_assume_aligned(rowp + size_t(s) * step_stride, kAlign);
+    // one descriptor per problem: offsets >= num_records read as 0 (inactive lanes, tail steps)
+    const unsigned prob_bytes = unsigned(m4) * unsigned(RS) * unsigned(sizeof(T));
+    const i32x4 rsrc = make_rsrc(prob, prob_bytes);
+    const unsigned voff = active ? unsigned((k * RS + c * NB) * int(sizeof(T))) : 0x80000000u;
+    const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
+    constexpr int U = 4;  // steps per batch; the next batch's loads are in flight while this one computes
+    constexpr int kDw = NB * int(sizeof(T)) / 4;
+    RawVec<kDw> nxt[U];
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) w[cb] = p[cb];
-      } else {
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) w[cb] = T(0);
-      }
-    };
-#pragma unroll
-    for (int u = 0; u < U; ++u) load(u, buf[u]);
+    for (int u = 0; u < U; ++u) nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes);
+    wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
     for (int s0 = 0; s0 < steps; s0 += U) {
       T cur[U][NB];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
+        unsigned raw[kDw];
+        nxt[u].get(raw);
+        __builtin_memcpy(&cur[u][0], &raw[0], sizeof(raw));
+      }
+      // prefetch the next U steps (past the end: reads 0); pinned here, ahead of this batch's math
+      const unsigned soff0 = unsigned(s0 + U) * step_bytes;
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) cur[u][cb] = buf[u][cb];
-#pragma unroll
-      for (int u = 0; u < U; ++u) load(s0 + U + u, buf[u]);  // prefetch the next U steps
+      for (int u = 0; u < U; ++u) nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         T(&w)[NB] = cur[u];
@@ -150,6 +286,8 @@ struct DenseRowGram {
           csum += isB_lane ? r * r : T(0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
     }
     if (WANT_H) return T(0);
     return wave_allreduce_sum(csum);
@@ -158,7 +296,12 @@ struct DenseRowGram {
   // Scatter the Gram tiles: g[q] (q<n), undamped diagonal hd[q], cost = G[n][n].
   // Returns the cost (wave-uniform).  g / hd are LDS (or global) arrays of n.
   __device__ __forceinline__ T extract_g_diag_cost(T* __restrict__ g, T* __restrict__ hd, const int n,
-                                                   const int lane, T* __restrict__ cost_slot) const {
+                                                   const int lane_in, T* __restrict__ cost_slot) const {
+    // Opaque copy of the lane id: the ~40 per-element indices / predicates below are loop-invariant
+    // across LM iterations, and LICM would otherwise hoist them out of the problem loop and pin
+    // ~100 VGPRs + ~300 SGPRs across the hot accumulate loop.  Recomputing them per call is free.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     const int cj = lane & 15;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
@@ -181,7 +324,9 @@ struct DenseRowGram {
   // Write the full symmetric n×n matrix (off-diagonals undamped, diagonal from `diag`) with row
   // stride LD.  Used to build the LDLT workspace and to export H.
   template <typename O>
-  __device__ __forceinline__ void write_sym(O* __restrict__ M, const int LD, const int n, const int lane) const {
+  __device__ __forceinline__ void write_sym(O* __restrict__ M, const int LD, const int n, const int lane_in) const {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // see extract_g_diag_cost: keep the index math out of LICM's reach
     const int cj = lane & 15;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)

@@ -56,36 +56,61 @@ struct FusedParams {
   int lds_per_wave;
 };
 
+// Minimum resident waves per SIMD the register allocator must honour (2nd __launch_bounds__ argument
+// is waves per SIMD on CDNA).  The fused kernel alternates an MFMA-paced accumulate phase with a
+// latency-bound LDL^T phase, so >= 3 co-resident waves per SIMD are needed to keep the matrix pipe
+// and the HBM queue busy; wide fp64 Gram tiles (NB >= 3: 48-80 accumulator registers) cannot afford it.
 template <typename T, int NB>
-__global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams prm) {
+constexpr int fused_min_waves() {
+  return sizeof(T) == 4 ? (NB <= 2 ? 4 : 3) : (NB == 1 ? 4 : (NB == 2 ? 2 : 1));
+}
+
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int n = prm.n;
-  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm.lds_per_wave, n);
-  const DenseRowLayout lay = DenseRowLayout::make(n, prm.m);
+  const int n = prm_g->n;
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave, n);
+  // private per-wave copies of the option / result PODs (no inter-wave synchronisation anywhere)
+  {
+    const int* src_o = reinterpret_cast<const int*>(&prm_g->opt);
+    int* dst_o = reinterpret_cast<int*>(L.opt);
+    for (int i = lane; i < int(sizeof(toa_options) / 4); i += 64) dst_o[i] = src_o[i];
+    const int* src_r = reinterpret_cast<const int*>(&prm_g->res);
+    int* dst_r = reinterpret_cast<int*>(L.res);
+    for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+  }
+  wave_sync();
+  const int m = prm_g->m;
+  const long long P = prm_g->P;
+  const DenseRowLayout lay = DenseRowLayout::make(n, m);
   DenseRowModel<T, NB> model;
-  model.m = prm.m;
+  model.m = m;
   model.m4 = lay.m4;
   model.RS = lay.rs;
-  const T* data = static_cast<const T*>(prm.data);
-  T* X = static_cast<T*>(prm.x);
-  LmCounters cnt{0, 0, 0, 0};
+  const T* data = static_cast<const T*>(prm_g->data);
+  T* X = static_cast<T*>(prm_g->x);
+  int* queue = prm_g->queue;
   for (;;) {
     int p = 0;
-    if (lane == 0) p = atomicAdd(prm.queue, 1);
+    if (lane == 0) p = atomicAdd(queue, 1);
     p = __builtin_amdgcn_readfirstlane(p);
-    if (p >= prm.P) break;
+    if (p >= P) break;
     model.prob = data + size_t(p) * lay.elems_per_problem();
-    T x_lane = lane < n ? X[size_t(p) * n + lane] : T(0);
-    lm_solve_problem<T>(model, L, n, lane, x_lane, prm.opt, prm.res, (long long)p, cnt);
-    if (lane < n) X[size_t(p) * n + lane] = x_lane;
+    wave_sync();
+    L.xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
+    wave_sync();
+    lm_solve_problem<T>(model, L, n, lane, (long long)p);
+    if (lane < n) X[size_t(p) * n + lane] = L.xs[lane];
   }
-  if (prm.counters && lane == 0) {
-    atomicAdd(&prm.counters[0], cnt.acc_passes);
-    atomicAdd(&prm.counters[1], cnt.eval_passes);
-    atomicAdd(&prm.counters[2], cnt.solves);
-    atomicAdd(&prm.counters[3], cnt.problems);
+  unsigned long long* counters = prm_g->counters;
+  if (counters && lane == 0) {
+    atomicAdd(&counters[0], L.st->acc_passes);
+    atomicAdd(&counters[1], L.st->eval_passes);
+    atomicAdd(&counters[2], L.st->solves);
+    atomicAdd(&counters[3], L.st->problems);
   }
 }
 
@@ -236,6 +261,12 @@ struct toa_context {
   int max_lds = 0;
   char name[128] = {0};
   int* queue = nullptr;  // device work-queue head
+  void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
+  // launch-configuration cache: (kernel, dynamic LDS bytes) -> resident workgroups per CU.
+  // hipFuncSetAttribute / hipOccupancy* cost milliseconds per call; pay them once per variant.
+  struct Cfg { const void* fn; size_t lds; int wg_per_cu; };
+  Cfg cfg[32];
+  int ncfg = 0;
 };
 
 static thread_local std::string g_err;
@@ -284,15 +315,24 @@ static int launch_fused(toa_handle h, const FusedParams& prm_in) {
   prm.queue = h->queue;
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
   auto kern = lm_fused_kernel<T, NB>;
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
   int wg_per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, 256, pwg));
-  if (wg_per_cu < 1) wg_per_cu = 1;
+  for (int i = 0; i < h->ncfg; ++i)
+    if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == pwg) wg_per_cu = h->cfg[i].wg_per_cu;
+  if (wg_per_cu == 0) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, 256, pwg));
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    if (h->ncfg < 32) h->cfg[h->ncfg++] = {(const void*)kern, pwg, wg_per_cu};
+  }
   long long grid = (long long)h->num_cus * wg_per_cu;
   const long long need = (prm.P + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, prm);
+  static_assert(sizeof(FusedParams) <= 1024, "parameter block too large");
+  // stream-ordered upload of the parameter block (kept out of the kernarg segment so that its ~60
+  // scalars are loaded on demand instead of being pinned in SGPRs across the hot loop)
+  HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
@@ -358,6 +398,8 @@ int toa_create(toa_handle* out, int device, void* stream) {
   std::strncpy(c->name, prop.name, sizeof(c->name) - 1);
   hipError_t e = hipMalloc(&c->queue, 256);
   if (e != hipSuccess) { delete c; return fail(TOA_E_NOMEM, "toa_create: hipMalloc(queue) failed"); }
+  e = hipMalloc(&c->params_dev, 1024);
+  if (e != hipSuccess) { (void)hipFree(c->queue); delete c; return fail(TOA_E_NOMEM, "toa_create: hipMalloc(params) failed"); }
   *out = c;
   return TOA_OK;
 }
@@ -366,6 +408,7 @@ int toa_destroy(toa_handle h) {
   if (!h) return TOA_OK;
   (void)hipSetDevice(h->device);
   if (h->queue) (void)hipFree(h->queue);
+  if (h->params_dev) (void)hipFree(h->params_dev);
   delete h;
   return TOA_OK;
 }
