@@ -134,11 +134,15 @@ int toa_memset(toa_handle h, void* dst_dev, int value, size_t bytes);           
 int toa_synchronize(toa_handle h);
 
 /* ---- DenseRow problem data --------------------------------------------------------------------
- * HBM layout ("packed"): per problem a [m4][RS] array of T, m4 = round_up(m,4), RS = NB*ceil((n+1)/NB),
- * NB = ceil((n+1)/16); row i = [a_i0 .. a_i,n-1, b_i, 0...]; padding rows/cols are zero.  A wavefront
- * then reads 4 consecutive rows with one coalesced NB*sizeof(T)-byte load per lane, already in MFMA
- * operand order.  n <= 63. */
-int toa_dense_row_layout(int dtype, int n, int m, int* nb, int* row_stride, int* rows_padded, size_t* bytes_per_problem);
+ * HBM layout ("packed"): per problem a [m4][RS] array of T, m4 = round_up(m,4).  A row is
+ * [ main : RSM elements ][ thin : THIN elements ], RS = RSM + THIN:
+ *   main  the columns contracted on the matrix cores, NB blocks of 16; a wavefront reads 4 rows
+ *         with one coalesced NB*sizeof(T)-byte load per lane, already in MFMA operand order;
+ *   thin  when n = 16*NB + (0..3): the last n-16*NB Jacobian columns followed by b (THIN = 1..4),
+ *         contracted on the VALU; THIN = 0: b is the last main element.
+ * Padding rows/columns are zero.  n <= 63.  n = 50 fp32: RS = 48 + 3 = 51 floats = m(n+1)*4 bytes. */
+int toa_dense_row_layout(int dtype, int n, int m, int* nb, int* thin, int* row_stride, int* rows_padded,
+                         size_t* bytes_per_problem);
 /* Pack natural arrays (A: [P][m][n] row-major, b: [P][m], device pointers) into the layout above. */
 int toa_dense_row_pack(toa_handle h, int dtype, int n, int m, int64_t P,
                        const void* A_dev, const void* b_dev, void* packed_dev);

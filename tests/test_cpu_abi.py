@@ -47,19 +47,22 @@ def test_options_defaults_match_reference(built):
 def test_dense_row_layout(built):
     from tinyopt_amd import _capi
     lib = _capi.load()
-    nb, rs, m4 = C.c_int(), C.c_int(), C.c_int()
+    nb, thin, rs, m4 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     nbytes = C.c_size_t()
-    cases = {  # (dtype, n, m) -> (NB, RS, m4)
-        (0, 50, 2000): (4, 52, 2000), (1, 12, 500): (1, 13, 500), (1, 6, 1000): (1, 7, 1000),
-        (0, 15, 5): (1, 16, 8), (0, 16, 5): (2, 18, 8), (1, 63, 9): (4, 64, 12), (0, 1, 1): (1, 2, 4),
+    cases = {  # (dtype, n, m) -> (NB, THIN, RS, m4)
+        (0, 50, 2000): (3, 3, 51, 2000),   # 48 MFMA columns + thin tail {a48, a49, b}: exactly m(n+1) floats
+        (1, 12, 500): (1, 0, 13, 500), (1, 6, 1000): (1, 0, 7, 1000),
+        (0, 15, 5): (1, 0, 16, 8), (0, 16, 5): (1, 1, 17, 8), (0, 19, 5): (1, 4, 20, 8), (0, 20, 5): (2, 0, 22, 8),
+        (0, 31, 5): (2, 0, 32, 8), (0, 32, 5): (2, 1, 33, 8), (1, 48, 9): (3, 1, 49, 12), (1, 51, 9): (3, 4, 52, 12),
+        (1, 52, 9): (4, 0, 56, 12), (1, 63, 9): (4, 0, 64, 12), (0, 1, 1): (1, 0, 2, 4),
     }
     for (dt, n, m), want in cases.items():
-        assert lib.toa_dense_row_layout(dt, n, m, C.byref(nb), C.byref(rs), C.byref(m4), C.byref(nbytes)) == 0
-        assert (nb.value, rs.value, m4.value) == want
+        assert lib.toa_dense_row_layout(dt, n, m, C.byref(nb), C.byref(thin), C.byref(rs), C.byref(m4), C.byref(nbytes)) == 0
+        assert (nb.value, thin.value, rs.value, m4.value) == want, (dt, n, m)
         assert nbytes.value == rs.value * m4.value * (4 if dt == 0 else 8)
-    assert lib.toa_dense_row_layout(0, 64, 10, None, None, None, None) != 0   # n > 63: invalid argument
+    assert lib.toa_dense_row_layout(0, 64, 10, None, None, None, None, None) != 0   # n > 63: invalid argument
     assert b"n must be" in lib.toa_last_error()
-    assert lib.toa_dense_row_layout(3, 5, 10, None, None, None, None) != 0    # bad dtype
+    assert lib.toa_dense_row_layout(3, 5, 10, None, None, None, None, None) != 0    # bad dtype
 
 
 def test_stop_reason_values_match_reference():

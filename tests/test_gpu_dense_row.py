@@ -29,6 +29,12 @@ ACC_CASES = [
     (np.float64, 47, 97, 3),   # NB = 3 full
     (np.float64, 50, 203, 3),  # NB = 4, m % 4 != 0
     (np.float32, 63, 130, 3),  # largest n
+    (np.float32, 16, 40, 4),   # thin tail: b only
+    (np.float64, 17, 40, 4),   # thin tail: 1 column + b
+    (np.float32, 35, 77, 4),   # NB = 2 + thin 4
+    (np.float64, 48, 90, 3),   # NB = 3 + thin 1
+    (np.float64, 50, 90, 3),   # NB = 3 + thin 3 (fp64)
+    (np.float32, 51, 90, 3),   # NB = 3 + thin 4
 ]
 
 
@@ -108,6 +114,8 @@ LM_CASES = [
     (np.float64, 50, 300, 6),
     (np.float32, 50, 2000, 12),
     (np.float32, 12, 500, 16),
+    (np.float64, 18, 80, 8),    # thin tail
+    (np.float32, 34, 150, 8),   # thin tail
 ]
 
 
@@ -173,20 +181,28 @@ def test_lm_counters_and_history_shapes(ta, oracle):
 
 
 def test_synth_device_matches_oracle(ta, oracle):
-    for dtype, tdt, n, m in ((np.float64, torch.float64, 12, 50), (np.float32, torch.float32, 50, 37)):
+    for dtype, tdt, n, m in ((np.float64, torch.float64, 12, 50), (np.float32, torch.float32, 50, 37),
+                             (np.float32, torch.float32, 33, 9)):
         P = 6
         A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=77, problem0=1000)
         model, x0d, xsd = ta.DenseRow.synthetic(P, n, m, tdt, seed=77, problem0=1000)
         ref_model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
         torch.cuda.synchronize()
-        got = model.packed.cpu().numpy()
-        want = ref_model.packed.cpu().numpy()
         lay = ta.api.dense_row_layout(tdt, n, m)
-        got = got.reshape(P, lay["rows_padded"], lay["row_stride"])
-        want = want.reshape(P, lay["rows_padded"], lay["row_stride"])
-        assert np.array_equal(got[:, :, :n], want[:, :, :n]), "A must be bit-identical (integer hash + exact conversion)"
-        assert np.allclose(got[:, :, n], want[:, :, n], rtol=0, atol=1e-6 if dtype == np.float32 else 1e-14)
-        assert np.array_equal(got[:, :, n + 1:], want[:, :, n + 1:])
+        got = model.packed.cpu().numpy().reshape(P, lay["rows_padded"], lay["row_stride"])
+        want = ref_model.packed.cpu().numpy().reshape(P, lay["rows_padded"], lay["row_stride"])
+        # the packer itself: every A / b entry sits where the layout says, everything else is zero
+        assert np.array_equal(want[:, :m, lay["pos_cols"]], A)
+        assert np.array_equal(want[:, :m, lay["pos_b"]], b)
+        mask = np.ones(lay["row_stride"], bool)
+        mask[lay["pos_cols"]] = False
+        mask[lay["pos_b"]] = False
+        assert not want[:, :, mask].any() and not want[:, m:, :].any()
+        # device generator vs oracle generator
+        assert np.array_equal(got[:, :, lay["pos_cols"]], want[:, :, lay["pos_cols"]]), "A must be bit-identical"
+        assert np.allclose(got[:, :, lay["pos_b"]], want[:, :, lay["pos_b"]], rtol=0,
+                           atol=1e-6 if dtype == np.float32 else 1e-14)
+        assert not got[:, :, mask].any()
         assert np.array_equal(x0d.cpu().numpy(), x0)
         assert np.allclose(xsd.cpu().numpy(), xs.astype(dtype))
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyopt_amd.so")
+# TINYOPT_AMD_LIB lets experiments load an alternative build of the SAME C-ABI (never a CPU path)
+LIB_PATH = os.environ.get("TINYOPT_AMD_LIB", os.path.join(_HERE, "libtinyopt_amd.so"))
 
 F32, F64 = 0, 1
 MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SQRT2, MODEL_SE3_REPROJ = 1, 2, 3, 4
@@ -66,7 +67,7 @@ PROTOTYPES = {
     "toa_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "toa_synchronize": (C.c_int, [_P]),
     "toa_dense_row_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                       C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "toa_dense_row_pack": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "toa_dense_row_synth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int64, _P, _P, _P]),
     "toa_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),

@@ -170,10 +170,17 @@ def default_context(device: Optional[int] = None) -> Context:
 
 def dense_row_layout(dtype: torch.dtype, n: int, m: int):
     lib = _capi.load()
-    nb, rs, m4 = C.c_int(), C.c_int(), C.c_int()
+    nb, thin, rs, m4 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     nbytes = C.c_size_t()
-    check(lib.toa_dense_row_layout(_dtype_code(dtype), n, m, C.byref(nb), C.byref(rs), C.byref(m4), C.byref(nbytes)))
-    return {"nb": nb.value, "row_stride": rs.value, "rows_padded": m4.value, "bytes_per_problem": nbytes.value}
+    check(lib.toa_dense_row_layout(_dtype_code(dtype), n, m, C.byref(nb), C.byref(thin), C.byref(rs), C.byref(m4),
+                                   C.byref(nbytes)))
+    rsm = rs.value - thin.value
+    nmr = 16 * nb.value if thin.value else n
+    return {"nb": nb.value, "thin": thin.value, "row_stride": rs.value, "rows_padded": m4.value,
+            "bytes_per_problem": nbytes.value,
+            # physical positions inside a packed row (mirrors DenseRowLayout::pos_col / pos_b)
+            "pos_cols": [j if j < nmr else rsm + (j - nmr) for j in range(n)],
+            "pos_b": (rs.value - 1) if thin.value else (rsm - 1)}
 
 
 class DenseRow:

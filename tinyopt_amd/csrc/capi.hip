@@ -1,0 +1,367 @@
+// libtinyopt_amd.so — the C-ABI of include/tinyopt_amd.h: argument checking, dispatch to the
+// per-(dtype, block count) kernel instantiations (inst.hip), and the data-format callers either side
+// of the path (pack / synth kernels).  gfx950 (MI355X, CDNA4) only.
+#include "kernels.hpp"
+
+namespace toa {
+
+// Natural (A [P][m][n], b [P][m]) -> packed [P][m4][RS] (layout: DenseRowLayout).
+template <typename T>
+__global__ void dense_row_pack_kernel(const T* __restrict__ A, const T* __restrict__ b, T* __restrict__ out,
+                                      long long P, int n, int m, DenseRowLayout lay) {
+  const int RS = lay.rs, m4 = lay.m4;
+  const long long total = P * (long long)m4 * RS;
+  const int pb = lay.pos_b();
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int q = int(e % RS);
+    const long long rowg = e / RS;
+    const int i = int(rowg % m4);
+    const long long p = rowg / m4;
+    T v = 0;
+    if (i < m) {
+      if (q == pb) v = b[p * m + i];
+      else if (q < lay.nmr) v = A[(p * m + i) * n + q];
+      else if (q >= lay.rsm && lay.nmr + (q - lay.rsm) < n) v = A[(p * m + i) * n + lay.nmr + (q - lay.rsm)];
+    }
+    out[e] = v;
+  }
+}
+
+// ---- synthetic inputs (same recipe as oracle/synth.hpp) ----
+__host__ __device__ inline unsigned long long sm64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ inline unsigned long long skey(unsigned long long seed, unsigned long long p, unsigned long long s) {
+  return sm64(sm64(seed + p) ^ (s * 0xD6E8FEB86659FD93ull));
+}
+__host__ __device__ inline double u11(unsigned long long k, unsigned long long idx) {
+  return double(sm64(k + idx) >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+template <typename T>
+__global__ void dense_row_synth_kernel(T* __restrict__ out, T* __restrict__ x0, T* __restrict__ xstar,
+                                       long long P, int n, int m, DenseRowLayout lay, unsigned long long seed,
+                                       long long problem0) {
+  const int RS = lay.rs, m4 = lay.m4;
+  const long long rows = P * (long long)m4;
+  for (long long rg = (long long)blockIdx.x * blockDim.x + threadIdx.x; rg < rows; rg += (long long)gridDim.x * blockDim.x) {
+    const long long p = rg / m4;
+    const int i = int(rg % m4);
+    const unsigned long long pid = (unsigned long long)(problem0 + p);
+    T* row = out + rg * RS;
+    for (int q = 0; q < RS; ++q) row[q] = T(0);
+    if (i < m) {
+      const unsigned long long kA = skey(seed, pid, 0), kx = skey(seed, pid, 1), kn = skey(seed, pid, 2);
+      double t = 0;
+      for (int j = 0; j < n; ++j) {
+        const T a = T(u11(kA, (unsigned long long)i * n + j));
+        row[lay.pos_col(j)] = a;
+        t += double(a) * u11(kx, j);
+      }
+      row[lay.pos_b()] = T(t + 0.1 * sin(t) + 1e-3 * u11(kn, i));
+    }
+    if (i == 0) {
+      const unsigned long long kx = skey(seed, pid, 1), k0 = skey(seed, pid, 3);
+      for (int j = 0; j < n; ++j) {
+        const double xs = u11(kx, j);
+        if (xstar) xstar[p * n + j] = T(xs);
+        if (x0) x0[p * n + j] = T(xs + 0.5 * u11(k0, j));
+      }
+    }
+  }
+}
+
+}  // namespace toa
+
+using namespace toa;
+
+int toa_inst_solve_0_0(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_inst_fused_0_1(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_0_1(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_0_2(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_0_2(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_0_3(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_0_3(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_0_4(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_0_4(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_solve_1_0(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_inst_fused_1_1(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_1_1(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_1_2(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_1_2(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_1_3(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_1_3(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_fused_1_4(int thin, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_accumulate_1_4(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+
+static thread_local std::string g_err;
+int toa_fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+static int fail(int code, const std::string& msg) { return toa_fail(code, msg); }
+
+int toa_inst_fused(int dtag, int nbm, int thin, toa_handle h, const FusedParams& prm) {
+  switch (dtag * 8 + nbm) {
+    case 1: return toa_inst_fused_0_1(thin, h, prm); case 2: return toa_inst_fused_0_2(thin, h, prm);
+    case 3: return toa_inst_fused_0_3(thin, h, prm); case 4: return toa_inst_fused_0_4(thin, h, prm);
+    case 9: return toa_inst_fused_1_1(thin, h, prm); case 10: return toa_inst_fused_1_2(thin, h, prm);
+    case 11: return toa_inst_fused_1_3(thin, h, prm); case 12: return toa_inst_fused_1_4(thin, h, prm);
+  }
+  return fail(TOA_E_ARG, "bad block count");
+}
+int toa_inst_accumulate(int dtag, int nbm, int thin, toa_handle h, int n, int m, int64_t P, const void* data,
+                        const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres) {
+#define TOA_A(f) return f(thin, h, n, m, P, data, x, want_grad, g, H, cost, nres)
+  switch (dtag * 8 + nbm) {
+    case 1: TOA_A(toa_inst_accumulate_0_1); case 2: TOA_A(toa_inst_accumulate_0_2);
+    case 3: TOA_A(toa_inst_accumulate_0_3); case 4: TOA_A(toa_inst_accumulate_0_4);
+    case 9: TOA_A(toa_inst_accumulate_1_1); case 10: TOA_A(toa_inst_accumulate_1_2);
+    case 11: TOA_A(toa_inst_accumulate_1_3); case 12: TOA_A(toa_inst_accumulate_1_4);
+  }
+#undef TOA_A
+  return fail(TOA_E_ARG, "bad block count");
+}
+int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
+                   void* dx, int32_t* ok) {
+  return dtag == 0 ? toa_inst_solve_0_0(npad, h, n, P, H, g, scale, dx, ok)
+                   : toa_inst_solve_1_0(npad, h, n, P, H, g, scale, dx, ok);
+}
+
+extern "C" {
+
+const char* toa_last_error(void) { return g_err.c_str(); }
+
+void toa_options_default(toa_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->solver_type = 0;
+  o->max_iters = 50;
+  o->min_error = 1e-12f;
+  o->min_rerr_dec = 1e-10f;
+  o->min_step_norm2 = 1e-14f;
+  o->min_grad_norm2 = 1e-18f;
+  o->max_total_failures = 0;
+  o->max_consec_failures = 5;
+  o->damping_init = 1e-4f;
+  o->damping_min = 1e-9f;
+  o->damping_max = 1e9f;
+  o->good_factor = 1.0f / 3.0f;
+  o->bad_factor = 2.0f;
+  o->grad_clipping = 0;
+  o->check_min_H_diag = 0;
+  o->check_final_cost = 0;
+  o->use_step_quality_approx = 0;
+  o->use_ldlt = 1;
+  o->H_is_full = 1;
+  o->save_last = 1;
+  o->use_squared_norm = 1;
+  o->downscale_by_2 = 0;
+  o->normalize = 0;
+}
+
+void toa_options_benchmark(toa_options* o) {
+  toa_options_default(o);
+  o->max_iters = 10;
+  o->min_error = 0;
+  o->min_rerr_dec = 1e-12f;
+  o->min_step_norm2 = 1e-16f;
+  o->max_consec_failures = 3;
+  o->save_last = 0;
+}
+
+int toa_create(toa_handle* out, int device, void* stream) {
+  if (!out) return fail(TOA_E_ARG, "toa_create: out is null");
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return fail(TOA_E_ARG, "toa_create: no such device");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TOA_E_UNSUPPORTED, std::string("toa_create: this library is built for gfx950 only, device is ") + prop.gcnArchName);
+  toa_context* c = new (std::nothrow) toa_context();
+  if (!c) return fail(TOA_E_NOMEM, "toa_create: host allocation failed");
+  c->device = device;
+  c->stream = static_cast<hipStream_t>(stream);
+  c->num_cus = prop.multiProcessorCount;
+  c->clock_khz = prop.clockRate;
+  c->max_lds = int(prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock);
+  std::strncpy(c->name, prop.name, sizeof(c->name) - 1);
+  hipError_t e = hipMalloc(&c->queue, 256);
+  if (e != hipSuccess) { delete c; return fail(TOA_E_NOMEM, "toa_create: hipMalloc(queue) failed"); }
+  e = hipMalloc(&c->params_dev, 1024);
+  if (e != hipSuccess) { (void)hipFree(c->queue); delete c; return fail(TOA_E_NOMEM, "toa_create: hipMalloc(params) failed"); }
+  *out = c;
+  return TOA_OK;
+}
+
+int toa_destroy(toa_handle h) {
+  if (!h) return TOA_OK;
+  (void)hipSetDevice(h->device);
+  if (h->queue) (void)hipFree(h->queue);
+  if (h->params_dev) (void)hipFree(h->params_dev);
+  delete h;
+  return TOA_OK;
+}
+
+int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size_t name_len) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (num_cus) *num_cus = h->num_cus;
+  if (clock_khz) *clock_khz = h->clock_khz;
+  if (name && name_len) { std::strncpy(name, h->name, name_len - 1); name[name_len - 1] = 0; }
+  return TOA_OK;
+}
+
+int toa_malloc(toa_handle h, void** dev_ptr, size_t bytes) {
+  if (!h || !dev_ptr) return fail(TOA_E_ARG, "toa_malloc: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+  return TOA_OK;
+}
+int toa_free(toa_handle h, void* dev_ptr) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipFree(dev_ptr));
+  return TOA_OK;
+}
+int toa_memcpy_h2d(toa_handle h, void* dst, const void* src, size_t bytes) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TOA_OK;
+}
+int toa_memcpy_d2h(toa_handle h, void* dst, const void* src, size_t bytes) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TOA_OK;
+}
+int toa_memset(toa_handle h, void* dst, int value, size_t bytes) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(dst, value, bytes, h->stream));
+  return TOA_OK;
+}
+int toa_synchronize(toa_handle h) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TOA_OK;
+}
+
+static int check_shape(int dtype, int n, int m, int64_t P) {
+  if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+  if (n < 1 || n > 63) return fail(TOA_E_ARG, "n must be in [1, 63] on the LDS-resident path");
+  if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
+  if (P < 0 || P > 0x7fffffff) return fail(TOA_E_ARG, "P out of range");
+  return TOA_OK;
+}
+
+int toa_dense_row_layout(int dtype, int n, int m, int* nb, int* thin, int* row_stride, int* rows_padded,
+                         size_t* bytes_per_problem) {
+  if (int rc = check_shape(dtype, n, m, 0)) return rc;
+  const DenseRowLayout L = DenseRowLayout::make(n, m);
+  if (nb) *nb = L.nbm;
+  if (thin) *thin = L.thin;
+  if (row_stride) *row_stride = L.rs;
+  if (rows_padded) *rows_padded = L.m4;
+  if (bytes_per_problem) *bytes_per_problem = L.elems_per_problem() * (dtype == TOA_F32 ? 4 : 8);
+  return TOA_OK;
+}
+
+int toa_dense_row_pack(toa_handle h, int dtype, int n, int m, int64_t P, const void* A, const void* b, void* packed) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (int rc = check_shape(dtype, n, m, P)) return rc;
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const DenseRowLayout L = DenseRowLayout::make(n, m);
+  const int grid = h->num_cus * 8;
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(dense_row_pack_kernel<float>, dim3(grid), dim3(256), 0, h->stream, (const float*)A, (const float*)b,
+                       (float*)packed, (long long)P, n, m, L);
+  else
+    hipLaunchKernelGGL(dense_row_pack_kernel<double>, dim3(grid), dim3(256), 0, h->stream, (const double*)A, (const double*)b,
+                       (double*)packed, (long long)P, n, m, L);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64_t seed, int64_t problem0,
+                        void* packed, void* x0, void* xstar) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (int rc = check_shape(dtype, n, m, P)) return rc;
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const DenseRowLayout L = DenseRowLayout::make(n, m);
+  const int grid = h->num_cus * 16;
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(dense_row_synth_kernel<float>, dim3(grid), dim3(256), 0, h->stream, (float*)packed, (float*)x0,
+                       (float*)xstar, (long long)P, n, m, L, (unsigned long long)seed, (long long)problem0);
+  else
+    hipLaunchKernelGGL(dense_row_synth_kernel<double>, dim3(grid), dim3(256), 0, h->stream, (double*)packed, (double*)x0,
+                       (double*)xstar, (long long)P, n, m, L, (unsigned long long)seed, (long long)problem0);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, const void* x,
+                   int want_grad, void* g, void* H, double* cost, int32_t* nres) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (model != TOA_MODEL_DENSE_ROW) return fail(TOA_E_UNSUPPORTED, "toa_accumulate: model not available on this path");
+  if (int rc = check_shape(dtype, n, m, P)) return rc;
+  if (!data || !x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
+  return toa_inst_accumulate(dtype == TOA_F32 ? 0 : 1, lay_.nbm, lay_.thin, h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  return fail(TOA_E_ARG, "toa_accumulate: bad block count");
+}
+
+int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
+                     int32_t* ok) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (int rc = check_shape(dtype, n, 1, P)) return rc;
+  if (!H || !g || !dx || !ok) return fail(TOA_E_ARG, "toa_solve_damped: null pointer");
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  return toa_inst_solve(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, g, scale, dx, ok);
+}
+
+int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+               const toa_options* options, const toa_results* results, uint64_t* counters) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (model != TOA_MODEL_DENSE_ROW) return fail(TOA_E_UNSUPPORTED, "toa_lm_run: model not available on this path");
+  if (int rc = check_shape(dtype, n, m, P)) return rc;
+  if (!data || !x || !options || !results) return fail(TOA_E_ARG, "toa_lm_run: null pointer");
+  if (!results->stop_reason || !results->num_iters || !results->final_cost)
+    return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");
+  if (options->solver_type != 0 && options->solver_type != 1)
+    return fail(TOA_E_ARG, "toa_lm_run: solver_type must be 0 (LM) or 1 (GN) on this path");  // optimize.h:75
+  if (!options->use_ldlt && n > 1)
+    return fail(TOA_E_UNSUPPORTED, "toa_lm_run: use_ldlt=false is only implemented for n == 1 (gn.h:157-162)");
+  if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
+    return fail(TOA_E_ARG, "toa_lm_run: hist_stride must be >= max_iters + 2");
+  if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  FusedParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.data = data;
+  prm.x = x;
+  prm.P = P;
+  prm.n = n;
+  prm.m = m;
+  prm.opt = *options;
+  prm.res = *results;
+  prm.counters = reinterpret_cast<unsigned long long*>(counters);
+  const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
+  return toa_inst_fused(dtype == TOA_F32 ? 0 : 1, lay_.nbm, lay_.thin, h, prm);
+  return fail(TOA_E_ARG, "toa_lm_run: bad block count");
+}
+
+}  // extern "C"

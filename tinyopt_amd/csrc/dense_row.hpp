@@ -25,6 +25,7 @@
 
 namespace toa {
 
+#define TOA_C ,
 template <typename T>
 struct Mfma;
 template <>
@@ -35,6 +36,7 @@ struct Mfma<float> {
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = (lane>>4)*4 + reg
   static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+#define TOA_MF32(D, A, B) "v_mfma_f32_16x16x4_f32 %" #D ", %" #A ", %" #B ", %" #D "\n\t"
 };
 template <>
 struct Mfma<double> {
@@ -44,12 +46,68 @@ struct Mfma<double> {
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
   static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+#define TOA_MF64(D, A, B) "v_mfma_f64_16x16x4_f64 %" #D ", %" #A ", %" #B ", %" #D "\n\t"
 };
+
+// One Gram step = the NB(NB+1)/2 upper block-pair MFMAs of 4 residual rows, accumulating IN PLACE.
+// Inline asm with "+a" (AGPR, tied in/out) operands: with the builtin, hipcc's register allocator
+// rotates the accumulator tuples between the unrolled steps and pays ~100 v_accvgpr_mov/read/write
+// per 40 MFMAs to undo it.  `s_nop 1` covers the VALU-write -> MFMA-operand wait states that hipcc
+// does not insert inside an asm statement (cdna_hip_programming.md §5.7 item 2).
+template <typename T, int NB>
+struct GramStep;
+#define TOA_GRAM_STEP(T, TAG, NBV, BODY, ACCS, WS)                                                      \
+  template <>                                                                                           \
+  struct GramStep<T, NBV> {                                                                             \
+    using Acc = typename Mfma<T>::Acc;                                                                  \
+    static __device__ __forceinline__ void run(Acc* acc, const T* w) {                                  \
+      asm volatile("s_nop 1\n\t" BODY : ACCS : WS);                                                    \
+    }                                                                                                   \
+  };
+// tile order matches DenseRowGram::tile(i, j): (0,0),(0,1)..(0,NB-1),(1,1)...
+TOA_GRAM_STEP(float, F32, 1, TOA_MF32(0, 1, 1), "+a"(acc[0]), "v"(w[0]))
+TOA_GRAM_STEP(float, F32, 2, TOA_MF32(0, 3, 3) TOA_MF32(1, 3, 4) TOA_MF32(2, 4, 4),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
+TOA_GRAM_STEP(float, F32, 3,
+              TOA_MF32(0, 6, 6) TOA_MF32(1, 6, 7) TOA_MF32(2, 6, 8) TOA_MF32(3, 7, 7) TOA_MF32(4, 7, 8) TOA_MF32(5, 8, 8),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]),
+              "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]))
+TOA_GRAM_STEP(float, F32, 4,
+              TOA_MF32(0, 10, 10) TOA_MF32(1, 10, 11) TOA_MF32(2, 10, 12) TOA_MF32(3, 10, 13) TOA_MF32(4, 11, 11)
+              TOA_MF32(5, 11, 12) TOA_MF32(6, 11, 13) TOA_MF32(7, 12, 12) TOA_MF32(8, 12, 13) TOA_MF32(9, 13, 13),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]) TOA_C
+              "+a"(acc[6]) TOA_C "+a"(acc[7]) TOA_C "+a"(acc[8]) TOA_C "+a"(acc[9]),
+              "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]) TOA_C "v"(w[3]))
+TOA_GRAM_STEP(double, F64, 1, TOA_MF64(0, 1, 1), "+a"(acc[0]), "v"(w[0]))
+TOA_GRAM_STEP(double, F64, 2, TOA_MF64(0, 3, 3) TOA_MF64(1, 3, 4) TOA_MF64(2, 4, 4),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
+TOA_GRAM_STEP(double, F64, 3,
+              TOA_MF64(0, 6, 6) TOA_MF64(1, 6, 7) TOA_MF64(2, 6, 8) TOA_MF64(3, 7, 7) TOA_MF64(4, 7, 8) TOA_MF64(5, 8, 8),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]),
+              "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]))
+TOA_GRAM_STEP(double, F64, 4,
+              TOA_MF64(0, 10, 10) TOA_MF64(1, 10, 11) TOA_MF64(2, 10, 12) TOA_MF64(3, 10, 13) TOA_MF64(4, 11, 11)
+              TOA_MF64(5, 11, 12) TOA_MF64(6, 11, 13) TOA_MF64(7, 12, 12) TOA_MF64(8, 12, 13) TOA_MF64(9, 13, 13),
+              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]) TOA_C
+              "+a"(acc[6]) TOA_C "+a"(acc[7]) TOA_C "+a"(acc[8]) TOA_C "+a"(acc[9]),
+              "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]) TOA_C "v"(w[3]))
+#undef TOA_GRAM_STEP
 
 // sin/cos for the DenseRow functor.  Branch-free Cody-Waite reduction by pi/2 (FMA, 3 / 2 constants)
 // + Cephes minimax polynomials on [-pi/4, pi/4]: <= ~1.5 ulp for |t| < ~1e4, which covers the
 // model's domain (|a_i.x| <= n * |x|_inf).  libm's sincos carries a Payne-Hanek path whose register
 // footprint would halve the occupancy of the whole fused kernel for arguments that never occur.
+#if !defined(TOA_POLY_SINCOS)
+// fp32: v_sin_f32 / v_cos_f32 (inputs in revolutions) — 3 VALU instructions instead of ~28.  Measured on
+// MI355X against an fp64 reference (tools/accuracy_probe.py, n=50, m=2000): g / H / cost errors are
+// indistinguishable from the polynomial version and smaller than the fp32 CPU oracle's own error.
+// The accumulate pass is VALU-issue-bound (f32 MFMA shares the VALU's issue slots), so this is
+// worth ~15 % of the pass.  -DTOA_POLY_SINCOS selects the ~1.5 ulp polynomial instead.
+__device__ __forceinline__ void sincos_t(float t, float* s, float* c) {
+  *s = __sinf(t);
+  *c = __cosf(t);
+}
+#else
 __device__ __forceinline__ void sincos_t(float t, float* s, float* c) {
   const float j = rintf(t * 0.636619772367581343f);
   float y = fmaf(-j, 1.5707963705062866f, t);
@@ -65,6 +123,7 @@ __device__ __forceinline__ void sincos_t(float t, float* s, float* c) {
   *s = (q & 2) ? -sv : sv;
   *c = ((q + 1) & 2) ? -cv : cv;
 }
+#endif
 __device__ __forceinline__ void sincos_t(double t, double* s, double* c) {
   const double j = rint(t * 0.63661977236758134308);
   double y = fma(-j, 1.5707963267948966, t);
@@ -121,7 +180,8 @@ struct RawVec;
 template <>
 struct RawVec<1> {
   unsigned a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a; }
@@ -129,7 +189,8 @@ struct RawVec<1> {
 template <>
 struct RawVec<2> {
   u32x2 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; }
@@ -137,7 +198,8 @@ struct RawVec<2> {
 template <>
 struct RawVec<3> {
   u32x3 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
@@ -145,7 +207,8 @@ struct RawVec<3> {
 template <>
 struct RawVec<4> {
   u32x4 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; }
@@ -154,7 +217,8 @@ template <>
 struct RawVec<6> {
   u32x4 a;
   u32x2 b;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
                  : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
@@ -165,7 +229,8 @@ struct RawVec<6> {
 template <>
 struct RawVec<8> {
   u32x4 a, b;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
+    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
                  : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
   }
@@ -187,161 +252,291 @@ __device__ __forceinline__ void wait_batch(RawVec<kDwords>& v0, RawVec<kDwords>&
 }
 
 // Host+device layout helper.
+//
+// A packed row is  [ main : rsm elements ][ thin : `thin` elements ].
+//   main  — the columns that go through the matrix cores, NBM blocks of 16; lane c of a 16-lane row
+//           group owns the NBM contiguous elements [NBM*c, NBM*c+NBM).
+//   thin  — when n = 16*NBM + (0..3) the last <= 3 Jacobian columns plus b do not justify a whole
+//           extra block column of MFMA tiles (for n = 50 that would be 4 of 10 tiles for 3 useful
+//           columns); they are broadcast-loaded by every lane of the row group and their products are
+//           accumulated on the VALU instead (`thin` = those columns + b, 1..4).  thin == 0: b lives in
+//           the LAST main element (static position -> no per-element select in the hot loop).
+// Row stride = rsm + thin (n = 50 fp32: 48 + 3 = 51 floats = exactly the algorithmic m(n+1) bytes).
 struct DenseRowLayout {
-  int nb;    // 16-column blocks
-  int rs;    // row stride in elements = nb * ceil((n+1)/nb)
+  int nbm;   // MFMA column blocks (1..4)
+  int thin;  // VALU tail elements incl. b (0..4)
+  int nmr;   // real Jacobian columns in the main part
+  int rsm;   // physical main length
+  int rs;    // row stride in elements
   int m4;    // rows padded to a multiple of 4
   __host__ __device__ static DenseRowLayout make(int n, int m) {
     DenseRowLayout L;
-    L.nb = (n + 1 + 15) / 16;
-    L.rs = L.nb * ((n + 1 + L.nb - 1) / L.nb);
+    const int rem = n & 15;
+    if (n >= 16 && rem + 1 <= 4) {
+      L.nbm = n >> 4;
+      L.thin = rem + 1;
+      L.nmr = 16 * L.nbm;
+      L.rsm = L.nmr;
+    } else {
+      L.nbm = (n + 1 + 15) / 16;
+      L.thin = 0;
+      L.nmr = n;
+      L.rsm = L.nbm * ((n + 1 + L.nbm - 1) / L.nbm);
+    }
+    L.rs = L.rsm + L.thin;
     L.m4 = (m + 3) & ~3;
     return L;
   }
   __host__ __device__ size_t elems_per_problem() const { return size_t(m4) * rs; }
+  // physical position of Jacobian column j (0 <= j < n) and of b inside a packed row
+  __host__ __device__ int pos_col(int j) const { return j < nmr ? j : rsm + (j - nmr); }
+  __host__ __device__ int pos_b() const { return thin ? rs - 1 : rsm - 1; }
 };
 
-template <typename T, int NB>
+// all-reduce over the 4 row groups of a wave (lanes with equal lane&15)
+template <typename T>
+__device__ __forceinline__ T kgroup_allreduce_sum(T v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <typename T, int NBM, int THIN>
 struct DenseRowGram {
-  static constexpr int NT = NB * (NB + 1) / 2;  // upper block pairs
+  static constexpr int NT = NBM * (NBM + 1) / 2;                // upper block pairs on the matrix cores
+  static constexpr int NTT = THIN * (THIN + 1) / 2;             // thin x thin products
+  static constexpr int NTM = THIN ? NBM * THIN : 1;             // main x thin products per lane
   using Acc = typename Mfma<T>::Acc;
   Acc acc[NT];
+  T accT[NTM];               // accT[cb*THIN + j] = sum_rows W[row][NBM*c+cb] * thin_j   (this lane's c)
+  T accTT[NTT ? NTT : 1];    // thin_j * thin_j' (j <= j'), identical on every lane after the pass
 
-  static __device__ __forceinline__ constexpr int tile(int i, int j) {  // i <= j
-    return i * NB - i * (i - 1) / 2 + (j - i);
-  }
+  static __device__ __forceinline__ constexpr int tile(int i, int j) { return i * NBM - i * (i - 1) / 2 + (j - i); }
+  static __device__ __forceinline__ constexpr int tt(int j, int j2) { return j * THIN - j * (j - 1) / 2 + (j2 - j); }
 
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) accT[t] = T(0);
+#pragma unroll
+    for (int t = 0; t < (NTT ? NTT : 1); ++t) accTT[t] = T(0);
   }
 
   // One pass over the problem's rows.  WANT_H: full Gram (K1).  !WANT_H: cost only (K2) — returns
   // the wave-reduced sum of squares.  xs: x in LDS.  prob: packed [m4][RS].
   template <bool WANT_H>
-  __device__ __forceinline__ T pass(const T* __restrict__ prob, const int m4, const int RS, const int n,
+  __device__ __forceinline__ T pass(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
                                     const T* __restrict__ xs, const int lane) {
     const int k = lane >> 4, c = lane & 15;
-    const bool active = c * NB < RS;
-    const int cB = n / NB, cbB = n % NB;  // where b_i / r_i lives
-    T xr[NB];
+    const int RS = lay.rs, rsm = lay.rsm;
+    const bool active = c * NBM < rsm;
+    T xr[NBM];
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int q = NB * c + cb;
-      xr[cb] = (q < n) ? xs[q] : T(0);
+    for (int cb = 0; cb < NBM; ++cb) {
+      const int q = NBM * c + cb;
+      xr[cb] = (q < lay.nmr) ? xs[q] : T(0);  // b slot and padding contribute nothing to a_i.x
     }
-    const bool isB_lane = (c == cB);
+    T xt[THIN > 1 ? THIN - 1 : 1];
+#pragma unroll
+    for (int j = 0; j + 1 < THIN; ++j) xt[j] = xs[lay.nmr + j];
+    const bool isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
     if (WANT_H) clear();
     T csum = 0;
-    const int steps = m4 >> 2;
+    const int steps = lay.m4 >> 2;
     // one descriptor per problem: offsets >= num_records read as 0 (inactive lanes, tail steps)
-    const unsigned prob_bytes = unsigned(m4) * unsigned(RS) * unsigned(sizeof(T));
+    const unsigned prob_bytes = unsigned(lay.m4) * unsigned(RS) * unsigned(sizeof(T));
     const i32x4 rsrc = make_rsrc(prob, prob_bytes);
-    const unsigned voff = active ? unsigned((k * RS + c * NB) * int(sizeof(T))) : 0x80000000u;
+    const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
+    const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));  // same address for the 16 lanes of a row group
     const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
     constexpr int U = 4;  // steps per batch; the next batch's loads are in flight while this one computes
-    constexpr int kDw = NB * int(sizeof(T)) / 4;
+    constexpr int kDw = NBM * int(sizeof(T)) / 4;
+    constexpr int kDwT = THIN ? THIN * int(sizeof(T)) / 4 : 1;
     RawVec<kDw> nxt[U];
+    RawVec<kDwT> nxtT[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes);
+    for (int u = 0; u < U; ++u) {
+      nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes);
+      if (THIN) nxtT[u].issue(rsrc, vofft, unsigned(u) * step_bytes);
+    }
     wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
+    if (THIN) wait_batch<kDwT>(nxtT[0], nxtT[1], nxtT[2], nxtT[3]);
     for (int s0 = 0; s0 < steps; s0 += U) {
-      T cur[U][NB];
+      T cur[U][NBM];
+      T curT[U][THIN ? THIN : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         unsigned raw[kDw];
         nxt[u].get(raw);
         __builtin_memcpy(&cur[u][0], &raw[0], sizeof(raw));
+        if (THIN) {
+          unsigned rawT[kDwT];
+          nxtT[u].get(rawT);
+          __builtin_memcpy(&curT[u][0], &rawT[0], sizeof(T) * THIN);
+        }
       }
       // prefetch the next U steps (past the end: reads 0); pinned here, ahead of this batch's math
       const unsigned soff0 = unsigned(s0 + U) * step_bytes;
 #pragma unroll
-      for (int u = 0; u < U; ++u) nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes);
+      for (int u = 0; u < U; ++u) {
+        nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes);
+        if (THIN) nxtT[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        T(&w)[NB] = cur[u];
+        T(&w)[NBM] = cur[u];
+        T(&v)[THIN ? THIN : 1] = curT[u];
         T part = 0;
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) part += w[cb] * xr[cb];
-        const T t = row16_allreduce_sum(part);
+        for (int cb = 0; cb < NBM; ++cb) part += w[cb] * xr[cb];
+        T t = row16_allreduce_sum(part);
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; ++j) t += v[j] * xt[j];
         T sn, cs;
         sincos_t(t, &sn, &cs);
         const T sc = T(1) + T(0.1) * cs;
         const T rbase = t + T(0.1) * sn;
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-          const bool isb = isB_lane && (cb == cbB);
-          w[cb] = isb ? (rbase - w[cb]) : w[cb] * sc;
+        for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
+        if (THIN == 0) {
+          w[NBM - 1] = isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+        } else {
+          w[NBM - 1] *= sc;
+#pragma unroll
+          for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
+          v[THIN - 1] = rbase - v[THIN - 1];
         }
         if (WANT_H) {
+          GramStep<T, NBM>::run(acc, w);
 #pragma unroll
-          for (int i = 0; i < NB; ++i)
+          for (int cb = 0; cb < NBM; ++cb)
 #pragma unroll
-            for (int j = i; j < NB; ++j) acc[tile(i, j)] = Mfma<T>::fma(w[i], w[j], acc[tile(i, j)]);
+            for (int j = 0; j < THIN; ++j) accT[cb * THIN + j] += w[cb] * v[j];
+#pragma unroll
+          for (int j = 0; j < THIN; ++j)
+#pragma unroll
+            for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
         } else {
-          T r = 0;
-#pragma unroll
-          for (int cb = 0; cb < NB; ++cb) r = (cb == cbB) ? w[cb] : r;
-          csum += isB_lane ? r * r : T(0);
+          if (THIN == 0) csum += isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
+          else csum += (c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
+      if (THIN) wait_batch<kDwT>(nxtT[0], nxtT[1], nxtT[2], nxtT[3]);
     }
-    if (WANT_H) return T(0);
+    if (WANT_H) {
+      // the last MFMAs must retire before compiler-generated code reads the accumulators
+      // (XDL write -> VALU/accvgpr read needs up to 18 wait states that hipcc cannot see)
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+      if (THIN) {  // fold the 4 row groups: every lane ends with the totals for its column set
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+      }
+      return T(0);
+    }
     return wave_allreduce_sum(csum);
   }
 
-  // Scatter the Gram tiles: g[q] (q<n), undamped diagonal hd[q], cost = G[n][n].
-  // Returns the cost (wave-uniform).  g / hd are LDS (or global) arrays of n.
-  __device__ __forceinline__ T extract_g_diag_cost(T* __restrict__ g, T* __restrict__ hd, const int n,
-                                                   const int lane_in, T* __restrict__ cost_slot) const {
+  // Scatter: g[q] (q<n), undamped diagonal hd[q], and the cost.  Returns the cost (wave-uniform).
+  __device__ __forceinline__ T extract_g_diag_cost(T* __restrict__ g, T* __restrict__ hd, const DenseRowLayout& lay,
+                                                   const int n, const int lane_in, T* __restrict__ cost_slot) const {
     // Opaque copy of the lane id: the ~40 per-element indices / predicates below are loop-invariant
     // across LM iterations, and LICM would otherwise hoist them out of the problem loop and pin
     // ~100 VGPRs + ~300 SGPRs across the hot accumulate loop.  Recomputing them per call is free.
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int cj = lane & 15;
+    const int nmr = lay.nmr;
+    const int qB = lay.rsm - 1;  // THIN == 0: index of the r column inside the main Gram
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
+    for (int bi = 0; bi < NBM; ++bi)
 #pragma unroll
-      for (int bj = bi; bj < NB; ++bj)
+      for (int bj = bi; bj < NBM; ++bj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int qi = NB * Mfma<T>::out_row(lane, r) + bi;
-          const int qj = NB * cj + bj;
+          const int qi = NBM * Mfma<T>::out_row(lane, r) + bi;
+          const int qj = NBM * cj + bj;
           const T v = acc[tile(bi, bj)][r];
-          if (qi < n && qj == n) g[qi] = v;
-          if (qj < n && qi == n) g[qj] = v;
-          if (qi == qj && qi < n) hd[qi] = v;
-          if (qi == n && qj == n) *cost_slot = v;
+          if (THIN == 0) {
+            if (qi < nmr && qj == qB) g[qi] = v;
+            if (qj < nmr && qi == qB) g[qj] = v;
+            if (qi == qB && qj == qB) *cost_slot = v;
+          }
+          if (qi == qj && qi < nmr) hd[qi] = v;
         }
+    if (THIN) {
+      if (lane < 16) {
+#pragma unroll
+        for (int cb = 0; cb < NBM; ++cb) g[NBM * cj + cb] = accT[cb * THIN + (THIN - 1)];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; ++j) {
+          g[nmr + j] = accTT[tt(j, THIN - 1)];
+          hd[nmr + j] = accTT[tt(j, j)];
+        }
+        *cost_slot = accTT[tt(THIN - 1, THIN - 1)];
+      }
+    }
+    (void)n;
     wave_sync();
     return *cost_slot;
   }
 
-  // Write the full symmetric n×n matrix (off-diagonals undamped, diagonal from `diag`) with row
-  // stride LD.  Used to build the LDLT workspace and to export H.
+  // Write the full symmetric n×n matrix (undamped) with row stride LD.  Used to build the LDLT
+  // workspace and to export H.
   template <typename O>
-  __device__ __forceinline__ void write_sym(O* __restrict__ M, const int LD, const int n, const int lane_in) const {
+  __device__ __forceinline__ void write_sym(O* __restrict__ M, const int LD, const DenseRowLayout& lay, const int n,
+                                            const int lane_in) const {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));  // see extract_g_diag_cost: keep the index math out of LICM's reach
     const int cj = lane & 15;
+    const int nmr = lay.nmr;
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
+    for (int bi = 0; bi < NBM; ++bi)
 #pragma unroll
-      for (int bj = bi; bj < NB; ++bj)
+      for (int bj = bi; bj < NBM; ++bj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int qi = NB * Mfma<T>::out_row(lane, r) + bi;
-          const int qj = NB * cj + bj;
-          if (qi < n && qj < n) {
+          const int qi = NBM * Mfma<T>::out_row(lane, r) + bi;
+          const int qj = NBM * cj + bj;
+          if (qi < nmr && qj < nmr) {
             const O v = O(acc[tile(bi, bj)][r]);
             M[qi * LD + qj] = v;
             if (bi != bj) M[qj * LD + qi] = v;
           }
         }
+    if (THIN > 1) {
+      if (lane < 16) {
+#pragma unroll
+        for (int cb = 0; cb < NBM; ++cb)
+#pragma unroll
+          for (int j = 0; j + 1 < THIN; ++j) {
+            const int q = NBM * cj + cb;
+            const O v = O(accT[cb * THIN + j]);
+            M[q * LD + (nmr + j)] = v;
+            M[(nmr + j) * LD + q] = v;
+          }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; ++j)
+#pragma unroll
+          for (int j2 = j; j2 + 1 < THIN; ++j2) {
+            const O v = O(accTT[tt(j, j2)]);
+            M[(nmr + j) * LD + (nmr + j2)] = v;
+            M[(nmr + j2) * LD + (nmr + j)] = v;
+          }
+      }
+    }
+    (void)n;
   }
 };
 

@@ -1,0 +1,51 @@
+// One translation unit per (dtype, block count): compiled with -DTOA_INST_DT={0,1} -DTOA_INST_NBM={1..4},
+// or -DTOA_INST_SOLVE -DTOA_INST_DT={0,1} for the K3 seam kernels.  See __graft_entry__.build().
+#include "kernels.hpp"
+using namespace toa;
+
+#if TOA_INST_DT == 0
+using InstT = float;
+#else
+using InstT = double;
+#endif
+#define TOA_CAT2(a, b, c) a##b##_##c
+#define TOA_CAT(a, b, c) TOA_CAT2(a, b, c)
+
+#ifdef TOA_INST_SOLVE
+int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g,
+                                             double scale, void* dx, int32_t* ok) {
+  switch (npad) {
+    case 16: return launch_solve<InstT, 16>(h, n, P, H, g, scale, dx, ok);
+    case 32: return launch_solve<InstT, 32>(h, n, P, H, g, scale, dx, ok);
+    case 48: return launch_solve<InstT, 48>(h, n, P, H, g, scale, dx, ok);
+    default: return launch_solve<InstT, 64>(h, n, P, H, g, scale, dx, ok);
+  }
+}
+#else
+int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm) {
+  switch (thin) {
+    case 0: return launch_fused<InstT, TOA_INST_NBM, 0>(h, prm);
+#if TOA_INST_NBM <= 3
+    case 1: return launch_fused<InstT, TOA_INST_NBM, 1>(h, prm);
+    case 2: return launch_fused<InstT, TOA_INST_NBM, 2>(h, prm);
+    case 3: return launch_fused<InstT, TOA_INST_NBM, 3>(h, prm);
+    case 4: return launch_fused<InstT, TOA_INST_NBM, 4>(h, prm);
+#endif
+    default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
+  }
+}
+int TOA_CAT(toa_inst_accumulate_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, int n, int m, int64_t P,
+                                                             const void* data, const void* x, int want_grad, void* g,
+                                                             void* H, double* cost, int32_t* nres) {
+  switch (thin) {
+    case 0: return launch_accumulate<InstT, TOA_INST_NBM, 0>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+#if TOA_INST_NBM <= 3
+    case 1: return launch_accumulate<InstT, TOA_INST_NBM, 1>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 2: return launch_accumulate<InstT, TOA_INST_NBM, 2>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 3: return launch_accumulate<InstT, TOA_INST_NBM, 3>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 4: return launch_accumulate<InstT, TOA_INST_NBM, 4>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+#endif
+    default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
+  }
+}
+#endif

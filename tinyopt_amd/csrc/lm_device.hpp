@@ -19,6 +19,7 @@
 #pragma once
 #include "../../include/tinyopt_amd.h"
 #include "ldlt_lds.hpp"
+#include "ldlt_regs.hpp"
 #include "wave_utils.hpp"
 
 namespace toa {
@@ -180,10 +181,17 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
         model.write_sym(L.M, L.LD, n, lane);
         wave_sync();
         if (in_n) L.M[lane * L.LD + lane] = L.hd[lane];
-        ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
-        if (ok) {
-          const T d = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, in_n ? -L.g[lane] : T(0));
-          L.dx[lane] = d;
+        wave_sync();
+        const T rhs = in_n ? -L.g[lane] : T(0);
+        {  // fast path: register-resident unpivoted LDL^T (positive-definite case)
+          LdltRegs<T, Model::kNpad> F;
+          F.load(L.M, L.LD, n, lane);
+          ok = F.factor(n, lane);
+          if (ok) L.dx[lane] = F.solve(n, lane, rhs);
+        }
+        if (!ok) {  // not safely positive definite: Eigen's pivoted algorithm + acceptance rule decides
+          ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
+          if (ok) L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, rhs);
         }
       } else {  // gn.h:157-162, Dims == 1 branch only (host rejects n > 1 without LDLT)
         const T h = L.hd[0];

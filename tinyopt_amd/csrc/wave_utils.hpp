@@ -29,7 +29,9 @@ __device__ __forceinline__ int dpp_row_ror_i32(int v) {
 }
 template <int N>
 __device__ __forceinline__ float dpp_row_ror(float v) {
-  return __int_as_float(dpp_row_ror_i32<N>(__float_as_int(v)));
+  // old = 0 + bound_ctrl lets GCNDPPCombine fold the DPP move into its consumer
+  // (v_add_f32_dpp / v_max_f32_dpp: one instruction per reduction stage instead of three)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
 }
 template <int N>
 __device__ __forceinline__ double dpp_row_ror(double v) {
