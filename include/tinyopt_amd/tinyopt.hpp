@@ -1,0 +1,268 @@
+// tinyopt_amd/tinyopt.hpp — header-only C++ host adaptor over the C-ABI (include/tinyopt_amd.h).
+//
+// Mirrors the reference's user surface for the LM hot path so that a tinyopt call site changes by a
+// namespace and a cost-functor type only:
+//
+//   reference (include/tinyopt/optimize.h:16-17)          here
+//   ---------------------------------------------          ----------------------------------------
+//   tinyopt::Options options;                               tinyopt_amd::Options options;
+//   auto out = tinyopt::Optimize(x, cost, options);         auto out = tinyopt_amd::Optimize(x, cost, options);
+//     x    : one parameter block, updated in place            x    : P parameter blocks ([P][n] contiguous), in place
+//     cost : any C++ callable (residuals or Accumulate)        cost : a DEVICE model (DenseRow<Scalar>) — host
+//                                                                       lambdas cannot run on the GPU
+//     out  : tinyopt::Output                                   out  : BatchOutput (one Output row per problem)
+//
+// Option names / nesting / defaults follow include/tinyopt/optimizers/options.h:18-156; StopReason
+// values follow include/tinyopt/stop_reasons.h:14-43; Output fields follow include/tinyopt/output.h.
+// No Eigen, no HIP headers: link with -ltinyopt_amd only.  Errors of use throw std::invalid_argument
+// (as the reference does, optimize.h:47,55,75); numeric failures are StopReason values, never exceptions.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../tinyopt_amd.h"
+
+namespace tinyopt_amd {
+
+enum StopReason : int {  // include/tinyopt/stop_reasons.h:14-43
+  kOutOfMemory = -4, kSolverFailed = -3, kSystemHasNaNOrInf = -2, kSkipped = -1, kNone = 0, kMinError, kMinRelError,
+  kMinDeltaNorm, kMinGradNorm, kMaxIters, kMaxNoDecr, kMaxConsecNoDecr, kTimedOut, kUserStopped
+};
+
+struct Options {  // include/tinyopt/optimizers/options.h:18-156 (numeric knobs)
+  enum Solver { LevenbergMarquardt = 0, GaussNewton = 1 };
+  Solver solver_type = LevenbergMarquardt;
+  bool check_final_cost = false;
+  bool use_step_quality_approx = false;
+  float grad_clipping = 0;
+  struct Hessian {
+    bool use_ldlt = true;
+    bool H_is_full = true;
+    float check_min_H_diag = 0;
+    bool save_last = true;
+  } hessian;
+  struct CostScaling {
+    bool use_squared_norm = true;
+    bool downscale_by_2 = false;
+    bool normalize = false;
+  } cost;
+  uint16_t max_iters = 50;
+  float min_error = 1e-12f;
+  float min_rerr_dec = 1e-10f;
+  float min_step_norm2 = 1e-14f;
+  float min_grad_norm2 = 1e-18f;
+  uint8_t max_total_failures = 0;
+  uint8_t max_consec_failures = 5;
+  struct LM {
+    float damping_init = 1e-4f;
+    std::array<float, 2> damping_range{{1e-9f, 1e9f}};
+    float good_factor = 1.0f / 3.0f;
+    float bad_factor = 2.0f;
+  } lm;
+
+  toa_options to_pod() const {
+    toa_options p;
+    toa_options_default(&p);
+    p.solver_type = solver_type;
+    p.max_iters = max_iters;
+    p.min_error = min_error;
+    p.min_rerr_dec = min_rerr_dec;
+    p.min_step_norm2 = min_step_norm2;
+    p.min_grad_norm2 = min_grad_norm2;
+    p.max_total_failures = max_total_failures;
+    p.max_consec_failures = max_consec_failures;
+    p.damping_init = lm.damping_init;
+    p.damping_min = lm.damping_range[0];
+    p.damping_max = lm.damping_range[1];
+    p.good_factor = lm.good_factor;
+    p.bad_factor = lm.bad_factor;
+    p.grad_clipping = grad_clipping;
+    p.check_min_H_diag = hessian.check_min_H_diag;
+    p.check_final_cost = check_final_cost;
+    p.use_step_quality_approx = use_step_quality_approx;
+    p.use_ldlt = hessian.use_ldlt;
+    p.H_is_full = hessian.H_is_full;
+    p.save_last = hessian.save_last;
+    p.use_squared_norm = cost.use_squared_norm;
+    p.downscale_by_2 = cost.downscale_by_2;
+    p.normalize = cost.normalize;
+    return p;
+  }
+};
+
+// benchmarks/options.h:10-27
+inline Options CreateBenchmarkOptions() {
+  Options o;
+  o.max_iters = 10;
+  o.min_error = 0;
+  o.min_rerr_dec = 1e-12f;
+  o.min_step_norm2 = 1e-16f;
+  o.max_consec_failures = 3;
+  o.hessian.save_last = false;
+  return o;
+}
+
+inline void check(int rc) {
+  if (rc == TOA_OK) return;
+  const std::string msg = std::string("tinyopt_amd: ") + toa_last_error();
+  if (rc == TOA_E_ARG || rc == TOA_E_UNSUPPORTED) throw std::invalid_argument(msg);
+  if (rc == TOA_E_NOMEM) throw std::bad_alloc();
+  throw std::runtime_error(msg);
+}
+
+// RAII over toa_handle: one per host thread per GPU (the reference's Optimizer_ is equally stateful).
+class Context {
+ public:
+  explicit Context(int device = 0, void* stream = nullptr) { check(toa_create(&h_, device, stream)); }
+  ~Context() { toa_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  toa_handle get() const { return h_; }
+
+ private:
+  toa_handle h_ = nullptr;
+};
+
+template <typename T>
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  DeviceBuffer(const Context& c, size_t count) : c_(&c), n_(count) {
+    void* p = nullptr;
+    check(toa_malloc(c.get(), &p, count * sizeof(T)));
+    p_ = static_cast<T*>(p);
+  }
+  ~DeviceBuffer() { if (p_) toa_free(c_->get(), p_); }
+  DeviceBuffer(DeviceBuffer&& o) noexcept : c_(o.c_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) { if (p_) toa_free(c_->get(), p_); c_ = o.c_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; }
+    return *this;
+  }
+  T* data() const { return p_; }
+  size_t size() const { return n_; }
+  void upload(const T* host) { check(toa_memcpy_h2d(c_->get(), p_, host, n_ * sizeof(T))); }
+  void download(T* host) const { check(toa_memcpy_d2h(c_->get(), host, p_, n_ * sizeof(T))); }
+  void zero() { check(toa_memset(c_->get(), p_, 0, n_ * sizeof(T))); }
+
+ private:
+  const Context* c_ = nullptr;
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
+
+template <typename Scalar>
+constexpr int dtype_of() {
+  static_assert(std::is_same<Scalar, float>::value || std::is_same<Scalar, double>::value,
+                "Scalar must be float or double (the reference's solver Scalar)");
+  return std::is_same<Scalar, float>::value ? TOA_F32 : TOA_F64;
+}
+
+// Device cost model: r_i(x) = a_i.x + 0.1 sin(a_i.x) - b_i for P problems.  Takes the place of the
+// residual functor in Optimize(x, cost) (e.g. benchmarks/dense.cpp:56,71-74).
+template <typename Scalar>
+class DenseRow {
+ public:
+  // A: [P][m][n] row-major, b: [P][m] — host arrays; uploaded and packed into the HBM layout once.
+  DenseRow(const Context& ctx, int64_t P, int n, int m, const Scalar* A, const Scalar* b) : ctx_(&ctx), P_(P), n_(n), m_(m) {
+    size_t bytes = 0;
+    check(toa_dense_row_layout(dtype_of<Scalar>(), n, m, nullptr, nullptr, nullptr, nullptr, &bytes));
+    packed_ = DeviceBuffer<Scalar>(ctx, size_t(P) * bytes / sizeof(Scalar));
+    DeviceBuffer<Scalar> dA(ctx, size_t(P) * m * n), db(ctx, size_t(P) * m);
+    dA.upload(A);
+    db.upload(b);
+    check(toa_dense_row_pack(ctx.get(), dtype_of<Scalar>(), n, m, P, dA.data(), db.data(), packed_.data()));
+    check(toa_synchronize(ctx.get()));
+  }
+  static constexpr int model_id = TOA_MODEL_DENSE_ROW;
+  int64_t P() const { return P_; }
+  int n() const { return n_; }
+  int m() const { return m_; }
+  const Scalar* data() const { return packed_.data(); }
+  const Context& ctx() const { return *ctx_; }
+
+ private:
+  const Context* ctx_;
+  int64_t P_;
+  int n_, m_;
+  DeviceBuffer<Scalar> packed_;
+};
+
+// include/tinyopt/output.h:26-145, one entry per problem.
+struct BatchOutput {
+  std::vector<int32_t> stop_reason, num_iters, num_failures, num_consec_failures, final_num_residuals;
+  std::vector<double> final_cost, final_rerr_dec;
+  std::vector<double> final_hessian;          // [P][n*n], undamped; empty unless options.hessian.save_last
+  std::vector<double> errs, deltas2;          // [P][hist_stride] (only with history = true)
+  std::vector<uint8_t> successes;
+  int hist_stride = 0;
+  bool Succeeded(size_t p) const { return stop_reason[p] >= kNone; }                                  // output.h:30
+  bool Converged(size_t p) const { return stop_reason[p] >= kMinError && stop_reason[p] < kMaxIters; } // output.h:33-35
+};
+
+// tinyopt::Optimize(x, cost, options) for a batch.  x: [P][n] contiguous host scalars, updated in place.
+template <typename Scalar, typename Cost>
+BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& options = {}, bool history = false) {
+  const int64_t P = cost.P();
+  const int n = cost.n();
+  if (int64_t(x.size()) != P * n) throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P*n scalars");
+  const Context& ctx = cost.ctx();
+  DeviceBuffer<Scalar> dx(ctx, x.size());
+  dx.upload(x.data());
+  DeviceBuffer<int32_t> stop(ctx, P), iters(ctx, P), fails(ctx, P), cfails(ctx, P), nres(ctx, P);
+  DeviceBuffer<double> fc(ctx, P), fr(ctx, P);
+  DeviceBuffer<double> fH, errs, d2;
+  DeviceBuffer<uint8_t> succ;
+  toa_results r{};
+  r.stop_reason = stop.data(); r.num_iters = iters.data(); r.num_failures = fails.data();
+  r.num_consec_failures = cfails.data(); r.final_cost = fc.data(); r.final_num_residuals = nres.data();
+  r.final_rerr_dec = fr.data();
+  BatchOutput out;
+  if (options.hessian.save_last) { fH = DeviceBuffer<double>(ctx, size_t(P) * n * n); fH.zero(); r.final_hessian = fH.data(); }
+  if (history) {
+    out.hist_stride = options.max_iters + 2;
+    errs = DeviceBuffer<double>(ctx, size_t(P) * out.hist_stride); errs.zero();
+    d2 = DeviceBuffer<double>(ctx, size_t(P) * out.hist_stride); d2.zero();
+    succ = DeviceBuffer<uint8_t>(ctx, size_t(P) * out.hist_stride); succ.zero();
+    r.errs = errs.data(); r.deltas2 = d2.data(); r.successes = succ.data(); r.hist_stride = out.hist_stride;
+  }
+  const toa_options pod = options.to_pod();
+  check(toa_lm_run(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), &pod, &r, nullptr));
+  check(toa_synchronize(ctx.get()));
+  dx.download(x.data());
+  auto get = [&](auto& vec, const auto& buf) { vec.resize(buf.size()); buf.download(vec.data()); };
+  get(out.stop_reason, stop); get(out.num_iters, iters); get(out.num_failures, fails);
+  get(out.num_consec_failures, cfails); get(out.final_num_residuals, nres); get(out.final_cost, fc);
+  get(out.final_rerr_dec, fr);
+  if (options.hessian.save_last) get(out.final_hessian, fH);
+  if (history) { get(out.errs, errs); get(out.deltas2, d2); get(out.successes, succ); }
+  return out;
+}
+
+// The Accumulate-callback seam `acc(x, grad, H) -> Cost` (docs/API.md:37-57) for a batch; grad == nullptr
+// (cost only) when g / H are null.  g: [P][n], H: [P][n*n], cost: [P] (= ||r||^2), all host.
+template <typename Scalar, typename Cost>
+void Accumulate(const Cost& cost, const std::vector<Scalar>& x, std::vector<Scalar>* g, std::vector<Scalar>* H,
+                std::vector<double>& cost_out) {
+  const int64_t P = cost.P();
+  const int n = cost.n();
+  const Context& ctx = cost.ctx();
+  DeviceBuffer<Scalar> dx(ctx, x.size());
+  dx.upload(x.data());
+  DeviceBuffer<double> dc(ctx, P);
+  const bool want = g && H;
+  DeviceBuffer<Scalar> dg, dH;
+  if (want) { dg = DeviceBuffer<Scalar>(ctx, size_t(P) * n); dH = DeviceBuffer<Scalar>(ctx, size_t(P) * n * n); }
+  check(toa_accumulate(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), want ? 1 : 0,
+                       want ? dg.data() : nullptr, want ? dH.data() : nullptr, dc.data(), nullptr));
+  check(toa_synchronize(ctx.get()));
+  cost_out.resize(P);
+  dc.download(cost_out.data());
+  if (want) { g->resize(size_t(P) * n); dg.download(g->data()); H->resize(size_t(P) * n * n); dH.download(H->data()); }
+}
+
+}  // namespace tinyopt_amd
