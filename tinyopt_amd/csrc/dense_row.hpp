@@ -350,7 +350,10 @@ struct DenseRowGram {
     const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
     const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));  // same address for the 16 lanes of a row group
     const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
-    constexpr int U = 4;  // steps per batch; the next batch's loads are in flight while this one computes
+#ifndef TOA_U
+#define TOA_U 4
+#endif
+    constexpr int U = TOA_U;  // steps per batch; the next batch's loads are in flight while this one computes
     constexpr int kDw = NBM * int(sizeof(T)) / 4;
     constexpr int kDwT = THIN ? THIN * int(sizeof(T)) / 4 : 1;
     RawVec<kDw> nxt[U];
@@ -395,7 +398,11 @@ struct DenseRowGram {
 #pragma unroll
         for (int j = 0; j + 1 < THIN; ++j) t += v[j] * xt[j];
         T sn, cs;
+#ifndef TOA_ABL_NOSINCOS
         sincos_t(t, &sn, &cs);
+#else
+        sn = t; cs = t;
+#endif
         const T sc = T(1) + T(0.1) * cs;
         const T rbase = t + T(0.1) * sn;
 #pragma unroll
@@ -409,7 +416,23 @@ struct DenseRowGram {
           v[THIN - 1] = rbase - v[THIN - 1];
         }
         if (WANT_H) {
+#if defined(TOA_SPLIT_MFMA)
+#pragma unroll
+          for (int i = 0; i < NBM; ++i)
+#pragma unroll
+            for (int j = i; j < NBM; ++j) {
+              if constexpr (sizeof(T) == 4)
+                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+              else
+                asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+            }
+#elif !defined(TOA_ABL_NOMFMA)
           GramStep<T, NBM>::run(acc, w);
+#else
+#pragma unroll
+          for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
+#endif
+#ifndef TOA_ABL_NOTHIN
 #pragma unroll
           for (int cb = 0; cb < NBM; ++cb)
 #pragma unroll
@@ -418,6 +441,10 @@ struct DenseRowGram {
           for (int j = 0; j < THIN; ++j)
 #pragma unroll
             for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
+#else
+#pragma unroll
+          for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
+#endif
         } else {
           if (THIN == 0) csum += isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
           else csum += (c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);

@@ -120,7 +120,10 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
 
 // K1/K2 seam: one wave per problem (grid-stride), writes g [P][n], H [P][n*n], cost, nres.
 template <typename T, int NBM, int THIN>
-__global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, const void* x_, long long P, int n, int m,
+#ifndef TOA_ACC_WAVES
+#define TOA_ACC_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, TOA_ACC_WAVES) accumulate_kernel(const void* data_, const void* x_, long long P, int n, int m,
                                                          int want_grad, void* g_, void* H_, double* cost, int* nres) {
   __shared__ T xs_all[4][64];
   __shared__ T tmp_all[4][64 * 2 + 4];
