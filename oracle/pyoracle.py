@@ -122,6 +122,30 @@ def dense_row_lm(A, b, x0, pod: ToaOptions, history=False, nthreads=1, lib=None)
                 seconds=secs)
 
 
+def synth_gaussian_prior(P, n, dtype, seed=0x71940917, problem0=0):
+    lib = load()
+    y = np.empty((P, n), dtype)
+    sigma = np.empty((P, n), dtype)
+    x0 = np.empty((P, n), dtype)
+    lib.oracle_synth_gaussian_prior(_code(dtype), seed, problem0, P, n, _p(y), _p(sigma), _p(x0))
+    return y, sigma, x0
+
+
+def gaussian_prior_lm(y, sigma, x0, pod: ToaOptions):
+    """benchmarks/dense.cpp manual-callback semantics; returns dict(x, stop, iters, fails, cost, H, seconds)."""
+    lib = load()
+    P, n = y.shape
+    x = np.array(x0, copy=True)
+    stop = np.zeros(P, np.int32)
+    iters = np.zeros(P, np.int32)
+    fails = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    Hf = np.zeros((P, n, n), np.float64) if pod.save_last else None
+    secs = lib.oracle_gaussian_prior_lm(_code(y.dtype), P, n, _p(np.ascontiguousarray(y)), _p(np.ascontiguousarray(sigma)),
+                                        _p(x), C.byref(pod), _p(stop), _p(iters), _p(fails), _p(cost), _p(Hf))
+    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, H=Hf, seconds=secs)
+
+
 def sqrt2_lm(x0, pod: ToaOptions, history=True):
     lib = load()
     x = np.array(x0, copy=True)

@@ -1,0 +1,113 @@
+"""GPU parity for the small device models: Sqrt2 (BASELINE config 1, tests/sqrt2.cpp) and GaussianPrior
+(the reference's published dense benchmark, benchmarks/dense.cpp) against the oracle and the reference's
+known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_sqrt2_known_answers(ta, oracle, dtype, tdt):
+    """tests/sqrt2.cpp:106-112: x0 in {1, -0.3, 3.2}, max_iters 20, max_consec_failures 0 ->
+    Succeeded && Converged && |x| == sqrt(2) +- 1e-5; trajectories equal to the oracle / golden file."""
+    o = ta.Options()
+    o.max_iters = 20
+    o.max_consec_failures = 0
+    x0 = np.array([1.0, -0.3, 3.2], dtype)
+    ref = oracle.sqrt2_lm(x0, o.to_pod())
+    gold = np.load(os.path.join(GOLD, f"sqrt2_{'f64' if dtype == np.float64 else 'f32'}.npz"))
+    x = torch.from_numpy(x0.reshape(3, 1).copy()).cuda()
+    out = ta.Optimize(x, ta.Sqrt2(3, tdt), o, history=True)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy().ravel()
+    stop = out.stop_reason.cpu().numpy()
+    assert (stop >= 0).all() and ((stop >= 1) & (stop < 5)).all()
+    assert np.allclose(np.abs(xg), np.sqrt(2.0), atol=1e-5)
+    assert np.array_equal(stop, ref["stop"]) and np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+    assert np.array_equal(stop, gold["stop"])
+    # scalar arithmetic, no reductions: trajectories agree to the last bits (FMA contraction may differ)
+    rt = 1e-12 if dtype == np.float64 else 1e-5
+    assert np.allclose(xg, ref["x"], rtol=rt, atol=0)
+    assert np.allclose(out.errs.cpu().numpy(), ref["errs"], rtol=1e3 * rt, atol=1e-300)
+    assert np.allclose(out.deltas2.cpu().numpy(), ref["deltas2"], rtol=1e3 * rt, atol=1e-300)
+
+
+def test_sqrt2_readme_trace(ta):
+    """README.md:91-96: x = 1 -> 1.49995 -> 1.41667 -> 1.41422 -> 1.41421, |dx| 5.00e-1, 8.33e-2."""
+    x = torch.ones(1, 1, dtype=torch.float64, device="cuda")
+    out = ta.Optimize(x, ta.Sqrt2(1, torch.float64), ta.Options(), history=True)
+    d2 = out.deltas2.cpu().numpy()[0]
+    assert abs(np.sqrt(d2[0]) - 0.5) < 5e-4 and abs(np.sqrt(d2[1]) - 8.33e-2) < 5e-5
+    assert abs(x.item() - np.sqrt(2)) < 1e-5
+
+
+def test_sqrt2_without_ldlt(ta, oracle):
+    """benchmarks/dense.cpp:28-51 scalar cases run with use_ldlt = false (gn.h:157-162 Dims == 1 branch)."""
+    o = ta.Options.benchmark()
+    o.hessian.use_ldlt = False
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(-1, 1, 64)
+    ref = oracle.sqrt2_lm(x0, o.to_pod())
+    x = torch.from_numpy(x0.reshape(-1, 1).copy()).cuda()
+    out = ta.Optimize(x, ta.Sqrt2(64, torch.float64), o)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"])
+    assert np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+    assert np.allclose(x.cpu().numpy().ravel(), ref["x"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+@pytest.mark.parametrize("n", [3, 6, 12, 33, 50])   # the published table's sizes (docs/benchmark-ceres-table.png)
+def test_gaussian_prior_matches_oracle(ta, oracle, dtype, tdt, n):
+    P = 24
+    y, sigma, x0 = oracle.synth_gaussian_prior(P, n, dtype, seed=5)
+    o = ta.Options.benchmark()
+    o.hessian.save_last = True
+    ref = oracle.gaussian_prior_lm(y, sigma, x0, o.to_pod())
+    model = ta.GaussianPrior(torch.from_numpy(y).cuda(), torch.from_numpy(sigma).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy()
+    stop = out.stop_reason.cpu().numpy()
+    assert (stop >= 0).all()
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    assert np.abs(xg - y).max() < (1e-9 if dtype == np.float64 else 1e-4)       # known answer: x -> y
+    assert np.abs(xg - ref["x"]).max() < tol * 10
+    agree = ((stop == ref["stop"]) & (out.num_iters.cpu().numpy() == ref["iters"])).mean()
+    assert agree >= 0.8, (stop, ref["stop"], out.num_iters.cpu().numpy(), ref["iters"])
+    # tests/cov.cpp:20-47: covariance from the final UNDAMPED Hessian recovers the prior stdevs
+    Hf = out.final_hessian.cpu().numpy()
+    idx = np.arange(n)
+    assert np.allclose(np.sqrt(1.0 / Hf[:, idx, idx]), sigma, rtol=1e-7 if dtype == np.float64 else 1e-4)
+    off = Hf.copy()
+    off[:, idx, idx] = 0
+    assert not off.any()
+    assert (out.final_num_residuals.cpu().numpy() == 1).all()                 # scalar return => Cost(v, 1)
+
+
+def test_gaussian_prior_accumulate_seam(ta, oracle):
+    y, sigma, x0 = oracle.synth_gaussian_prior(5, 12, np.float64, seed=9)
+    model = ta.GaussianPrior(torch.from_numpy(y).cuda(), torch.from_numpy(sigma).cuda())
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(x0).cuda())
+    res = (x0 - y) / sigma
+    assert np.array_equal(g.cpu().numpy(), (1.0 / sigma) * res)               # same operation order: bit-identical
+    Hn = H.cpu().numpy()
+    assert np.array_equal(Hn[:, np.arange(12), np.arange(12)], (1.0 / sigma) * (1.0 / sigma))
+    assert np.allclose(c.cpu().numpy(), (res * res).sum(1), rtol=1e-14)
+    assert (nres.cpu().numpy() == 1).all()
+
+
+def test_model_shape_errors(ta):
+    y = torch.zeros(2, 3, dtype=torch.float64, device="cuda")
+    model = ta.GaussianPrior(y, y + 1)
+    with pytest.raises(ValueError):
+        ta.Optimize(torch.zeros(2, 4, dtype=torch.float64, device="cuda"), model)
+    model.m = 5                                                               # m != n -> invalid argument from the C-ABI
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(torch.zeros(2, 3, dtype=torch.float64, device="cuda"), model)

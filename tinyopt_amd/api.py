@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import F32, F64, MODEL_DENSE_ROW, ToaOptions, ToaResults, check
+from ._capi import F32, F64, MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SQRT2, ToaOptions, ToaResults, check
 
 
 class StopReason(enum.IntEnum):  # include/tinyopt/stop_reasons.h:14-43
@@ -228,6 +228,40 @@ class DenseRow:
         return DenseRow(packed, n, m, P), x0, xstar
 
 
+class GaussianPrior:
+    """Device residual model  r = (x - y) / sigma  (m = n) — the residual of the reference's published dense
+    benchmark with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66):
+    grad = J*res, H.diagonal() = sigma^-2, cost = res.squaredNorm() returned as a scalar (1 residual)."""
+    model_id = MODEL_GAUSSIAN_PRIOR
+
+    def __init__(self, y: torch.Tensor, sigma: torch.Tensor):
+        assert y.shape == sigma.shape and y.dim() == 2 and y.is_cuda and y.dtype == sigma.dtype
+        self.P, self.n = y.shape
+        self.m = self.n
+        self.dtype = y.dtype
+        self.packed = torch.stack([y, sigma], dim=1).contiguous()  # [P][2][n]
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return 2 * self.n * self.packed.element_size()
+
+
+class Sqrt2:
+    """Device residual model  r = x*x - 2  (n = m = 1), tests/sqrt2.cpp:30-70."""
+    model_id = MODEL_SQRT2
+
+    def __init__(self, P: int, dtype: torch.dtype, device=None):
+        self.P, self.n, self.m, self.dtype = int(P), 1, 1, dtype
+        self.packed = torch.zeros(1, dtype=dtype, device=device or "cuda")  # no problem data
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return 0
+
+
+_MODELS = (DenseRow, GaussianPrior, Sqrt2)
+
+
 @dataclass
 class Output:
     """tinyopt::Output (output.h:26-145), one row per problem; tensors live on the GPU."""
@@ -260,8 +294,9 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     asynchronous on torch's current stream.
     """
     options = options or Options()
-    if not isinstance(cost, DenseRow):
-        raise TypeError("cost must be a device model (DenseRow); host callables cannot run on the GPU path")
+    if not isinstance(cost, _MODELS):
+        raise TypeError("cost must be a device model (DenseRow, GaussianPrior, Sqrt2); host callables cannot run "
+                        "on the GPU path")
     if not x.is_cuda or not x.is_contiguous():
         raise ValueError("x must be a contiguous GPU tensor")
     P, n = x.shape
@@ -305,7 +340,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     return out
 
 
-def accumulate(cost: DenseRow, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Context] = None):
+def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Context] = None):
     """The Accumulate callback ``acc(x, grad, H) -> Cost`` (docs/API.md:37-57) for a batch.
     Returns (g [P,n], H [P,n,n], cost [P] float64, nres [P]); g/H are None when want_grad is False."""
     ctx = ctx or default_context(x.device.index)

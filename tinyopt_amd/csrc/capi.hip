@@ -97,6 +97,11 @@ int toa_inst_accumulate_1_3(int thin, toa_handle h, int n, int m, int64_t P, con
 int toa_inst_fused_1_4(int thin, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_accumulate_1_4(int thin, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 
+int toa_inst_misc_fused_0_0(int model, int npad, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_misc_fused_1_0(int model, int npad, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_misc_accumulate_0_0(int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_misc_accumulate_1_0(int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+
 static thread_local std::string g_err;
 int toa_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -124,6 +129,14 @@ int toa_inst_accumulate(int dtag, int nbm, int thin, toa_handle h, int n, int m,
   }
 #undef TOA_A
   return fail(TOA_E_ARG, "bad block count");
+}
+int toa_inst_misc_fused(int dtag, int model, int npad, toa_handle h, const FusedParams& prm) {
+  return dtag == 0 ? toa_inst_misc_fused_0_0(model, npad, h, prm) : toa_inst_misc_fused_1_0(model, npad, h, prm);
+}
+int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data,
+                             const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres) {
+  return dtag == 0 ? toa_inst_misc_accumulate_0_0(model, npad, h, n, m, P, data, x, want_grad, g, H, cost, nres)
+                   : toa_inst_misc_accumulate_1_0(model, npad, h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok) {
@@ -254,6 +267,24 @@ int toa_synchronize(toa_handle h) {
   return TOA_OK;
 }
 
+// per-model shape contract (reference: std::invalid_argument on dimension mismatch, gn.h:51,66)
+static int check_model(int model, int n, int m, const void* data) {
+  switch (model) {
+    case TOA_MODEL_DENSE_ROW:
+      if (!data) return fail(TOA_E_ARG, "DenseRow: data pointer is null");
+      return TOA_OK;
+    case TOA_MODEL_GAUSSIAN_PRIOR:
+      if (m != n) return fail(TOA_E_ARG, "GaussianPrior: m must equal n (one residual per parameter)");
+      if (!data) return fail(TOA_E_ARG, "GaussianPrior: data pointer ([P][2][n]: y, sigma) is null");
+      return TOA_OK;
+    case TOA_MODEL_SQRT2:
+      if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
+      return TOA_OK;
+    default:
+      return fail(TOA_E_UNSUPPORTED, "model not available on this path");
+  }
+}
+
 static int check_shape(int dtype, int n, int m, int64_t P) {
   if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
   if (n < 1 || n > 63) return fail(TOA_E_ARG, "n must be in [1, 63] on the LDS-resident path");
@@ -312,14 +343,16 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, const void* x,
                    int want_grad, void* g, void* H, double* cost, int32_t* nres) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  if (model != TOA_MODEL_DENSE_ROW) return fail(TOA_E_UNSUPPORTED, "toa_accumulate: model not available on this path");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
-  if (!data || !x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
+  if (int rc = check_model(model, n, m, data)) return rc;
+  if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
   if (P == 0) return TOA_OK;
   HIP_TRY(hipSetDevice(h->device));
+  const int dtag = dtype == TOA_F32 ? 0 : 1;
+  if (model != TOA_MODEL_DENSE_ROW)
+    return toa_inst_misc_accumulate(dtag, model, 16 * ((n + 15) / 16), h, n, m, P, data, x, want_grad, g, H, cost, nres);
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
-  return toa_inst_accumulate(dtype == TOA_F32 ? 0 : 1, lay_.nbm, lay_.thin, h, n, m, P, data, x, want_grad, g, H, cost, nres);
-  return fail(TOA_E_ARG, "toa_accumulate: bad block count");
+  return toa_inst_accumulate(dtag, lay_.nbm, lay_.thin, h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
@@ -335,9 +368,9 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                const toa_options* options, const toa_results* results, uint64_t* counters) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  if (model != TOA_MODEL_DENSE_ROW) return fail(TOA_E_UNSUPPORTED, "toa_lm_run: model not available on this path");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
-  if (!data || !x || !options || !results) return fail(TOA_E_ARG, "toa_lm_run: null pointer");
+  if (int rc = check_model(model, n, m, data)) return rc;
+  if (!x || !options || !results) return fail(TOA_E_ARG, "toa_lm_run: null pointer");
   if (!results->stop_reason || !results->num_iters || !results->final_cost)
     return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");
   if (options->solver_type != 0 && options->solver_type != 1)
@@ -359,6 +392,7 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, cons
   prm.opt = *options;
   prm.res = *results;
   prm.counters = reinterpret_cast<unsigned long long*>(counters);
+  if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtype == TOA_F32 ? 0 : 1, model, 16 * ((n + 15) / 16), h, prm);
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
   return toa_inst_fused(dtype == TOA_F32 ? 0 : 1, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");

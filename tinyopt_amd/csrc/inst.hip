@@ -11,7 +11,24 @@ using InstT = double;
 #define TOA_CAT2(a, b, c) a##b##_##c
 #define TOA_CAT(a, b, c) TOA_CAT2(a, b, c)
 
-#ifdef TOA_INST_SOLVE
+#ifdef TOA_INST_MISC
+int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, const FusedParams& prm) {
+  if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
+  switch (npad) {
+    case 16: return launch_fused<GaussianPriorModel<InstT, 16>>(h, prm);
+    case 32: return launch_fused<GaussianPriorModel<InstT, 32>>(h, prm);
+    case 48: return launch_fused<GaussianPriorModel<InstT, 48>>(h, prm);
+    default: return launch_fused<GaussianPriorModel<InstT, 64>>(h, prm);
+  }
+}
+int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, int n, int m, int64_t P,
+                                                       const void* data, const void* x, int want_grad, void* g, void* H,
+                                                       double* cost, int32_t* nres) {
+  (void)npad;
+  if (model == TOA_MODEL_SQRT2) return launch_accumulate<Sqrt2Model<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  return launch_accumulate<GaussianPriorModel<InstT, 16>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+}
+#elif defined(TOA_INST_SOLVE)
 int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g,
                                              double scale, void* dx, int32_t* ok) {
   switch (npad) {
@@ -24,12 +41,12 @@ int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int6
 #else
 int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm) {
   switch (thin) {
-    case 0: return launch_fused<InstT, TOA_INST_NBM, 0>(h, prm);
+    case 0: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 0>>(h, prm);
 #if TOA_INST_NBM <= 3
-    case 1: return launch_fused<InstT, TOA_INST_NBM, 1>(h, prm);
-    case 2: return launch_fused<InstT, TOA_INST_NBM, 2>(h, prm);
-    case 3: return launch_fused<InstT, TOA_INST_NBM, 3>(h, prm);
-    case 4: return launch_fused<InstT, TOA_INST_NBM, 4>(h, prm);
+    case 1: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 1>>(h, prm);
+    case 2: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 2>>(h, prm);
+    case 3: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 3>>(h, prm);
+    case 4: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 4>>(h, prm);
 #endif
     default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
   }
@@ -38,12 +55,12 @@ int TOA_CAT(toa_inst_accumulate_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handl
                                                              const void* data, const void* x, int want_grad, void* g,
                                                              void* H, double* cost, int32_t* nres) {
   switch (thin) {
-    case 0: return launch_accumulate<InstT, TOA_INST_NBM, 0>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 0: return launch_accumulate<DenseRowModel<InstT, TOA_INST_NBM, 0>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
 #if TOA_INST_NBM <= 3
-    case 1: return launch_accumulate<InstT, TOA_INST_NBM, 1>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
-    case 2: return launch_accumulate<InstT, TOA_INST_NBM, 2>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
-    case 3: return launch_accumulate<InstT, TOA_INST_NBM, 3>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
-    case 4: return launch_accumulate<InstT, TOA_INST_NBM, 4>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 1: return launch_accumulate<DenseRowModel<InstT, TOA_INST_NBM, 1>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 2: return launch_accumulate<DenseRowModel<InstT, TOA_INST_NBM, 2>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 3: return launch_accumulate<DenseRowModel<InstT, TOA_INST_NBM, 3>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 4: return launch_accumulate<DenseRowModel<InstT, TOA_INST_NBM, 4>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
 #endif
     default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
   }

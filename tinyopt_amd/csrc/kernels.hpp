@@ -25,15 +25,24 @@
 namespace toa {
 
 // ------------------------------------------------------------------------------------------------
-// DenseRow model adaptor for the LM state machine.
+// Device residual models.  Concept (see lm_device.hpp): Scalar, kNpad, init(n, m, data), bind(p),
+// accumulate / evaluate / write_sym.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NBM, int THIN>
 struct DenseRowModel {
+  using Scalar = T;
   static constexpr int kNpad = 16 * (NBM + (THIN > 0 ? 1 : 0));  // n <= kNpad - 1 ... see DenseRowLayout
   DenseRowGram<T, NBM, THIN> gram;
+  const T* data;
   const T* prob;
   DenseRowLayout lay;
   int m;
+  __device__ __forceinline__ void init(int n, int m_, const void* d) {
+    m = m_;
+    lay = DenseRowLayout::make(n, m_);
+    data = static_cast<const T*>(d);
+  }
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     gram.template pass<true>(prob, lay, n, L.xs, lane);
     cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
@@ -46,6 +55,75 @@ struct DenseRowModel {
   template <typename O>
   __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
     gram.write_sym(M, LD, lay, n, lane);
+  }
+};
+
+// Gaussian prior  r = (x - y) / sigma,  m = n — the residual of the reference's published dense
+// benchmark, with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66, 90-99;
+// losses/mahalanobis.h:124-136): grad = J * res with J = diag(1/sigma), H.diagonal() = sigma^-2 (H was
+// cleared: off-diagonals are 0), returns res.squaredNorm() as a SCALAR => Cost(v, 1) (cost.h:22).
+// Data per problem: [y (n) | sigma (n)].  Same operation order as the oracle => g and H bit-identical.
+template <typename T, int NPAD>
+struct GaussianPriorModel {
+  using Scalar = T;
+  static constexpr int kNpad = NPAD;
+  const T* data;
+  const T* y;
+  const T* sigma;
+  int n_;
+  __device__ __forceinline__ void init(int n, int, const void* d) { n_ = n; data = static_cast<const T*>(d); }
+  __device__ __forceinline__ void bind(long long p) { y = data + size_t(p) * 2 * n_; sigma = y + n_; }
+  __device__ __forceinline__ T residual(const WaveLds<T>& L, int n, int lane, T& inv_sigma) const {
+    if (lane >= n) { inv_sigma = T(0); return T(0); }
+    const T s = sigma[lane];
+    inv_sigma = T(1) / s;
+    return (L.xs[lane] - y[lane]) / s;
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    T is;
+    const T r = residual(L, n, lane, is);
+    if (lane < n) { L.g[lane] = is * r; L.hd[lane] = is * is; }
+    cost = wave_allreduce_sum(r * r);
+    nres = 1;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    T is;
+    const T r = residual(L, n, lane, is);  // MahaSquaredNorm(x - y, stdevs), dense.cpp:63-65
+    cost = wave_allreduce_sum(r * r);
+    nres = 1;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
+    if (lane < n)
+      for (int j = 0; j < n; ++j) M[lane * LD + j] = O(0);
+  }
+};
+
+// sqrt(2):  r = x*x - 2, n = m = 1 (tests/sqrt2.cpp:30-70): grad = J r, H = J^2, cost = r^2 (1 residual).
+template <typename T>
+struct Sqrt2Model {
+  using Scalar = T;
+  static constexpr int kNpad = 16;
+  __device__ __forceinline__ void init(int, int, const void*) {}
+  __device__ __forceinline__ void bind(long long) {}
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    const T x = L.xs[0];
+    const T r = x * x - T(2), J = T(2) * x;
+    if (lane == 0) { L.g[0] = J * r; L.hd[0] = J * J; }
+    cost = r * r;
+    nres = 1;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int, T& cost, int& nres) {
+    const T x = L.xs[0];
+    const T r = x * x - T(2);
+    cost = r * r;
+    nres = 1;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int, int, int lane) const {
+    if (lane == 0) M[0] = O(0);
   }
 };
 
@@ -70,8 +148,9 @@ constexpr int fused_min_waves() {
   return sizeof(T) == 4 ? (NB <= 2 ? 4 : 3) : (NB == 1 ? 4 : (NB == 2 ? 2 : 1));
 }
 
-template <typename T, int NBM, int THIN>
+template <typename Model>
 __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
+  using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -88,13 +167,9 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
   }
   wave_sync();
-  const int m = prm_g->m;
   const long long P = prm_g->P;
-  const DenseRowLayout lay = DenseRowLayout::make(n, m);
-  DenseRowModel<T, NBM, THIN> model;
-  model.m = m;
-  model.lay = lay;
-  const T* data = static_cast<const T*>(prm_g->data);
+  Model model;
+  model.init(n, prm_g->m, prm_g->data);
   T* X = static_cast<T*>(prm_g->x);
   int* queue = prm_g->queue;
   for (;;) {
@@ -102,7 +177,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     if (lane == 0) p = atomicAdd(queue, 1);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= P) break;
-    model.prob = data + size_t(p) * lay.elems_per_problem();
+    model.bind(p);
     wave_sync();
     L.xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
     wave_sync();
@@ -119,42 +194,36 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
 }
 
 // K1/K2 seam: one wave per problem (grid-stride), writes g [P][n], H [P][n*n], cost, nres.
-template <typename T, int NBM, int THIN>
-#ifndef TOA_ACC_WAVES
-#define TOA_ACC_WAVES 1
-#endif
-__global__ void __launch_bounds__(256, TOA_ACC_WAVES) accumulate_kernel(const void* data_, const void* x_, long long P, int n, int m,
-                                                         int want_grad, void* g_, void* H_, double* cost, int* nres) {
-  __shared__ T xs_all[4][64];
-  __shared__ T tmp_all[4][64 * 2 + 4];
+template <typename Model>
+__global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, const void* x_, long long P, int n, int m,
+                                                         int want_grad, void* g_, void* H_, double* cost, int* nres,
+                                                         int lds_per_wave) {
+  using T = typename Model::Scalar;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* xs = xs_all[wave];
-  T* gl = tmp_all[wave];
-  T* hd = gl + 64;
-  T* slot = hd + 64;
-  const DenseRowLayout lay = DenseRowLayout::make(n, m);
-  const T* data = static_cast<const T*>(data_);
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * lds_per_wave, n);
   const T* X = static_cast<const T*>(x_);
-  DenseRowGram<T, NBM, THIN> gram;
+  Model model;
+  model.init(n, m, data_);
   for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
     wave_sync();
-    xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
+    L.xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
     wave_sync();
-    const T* prob = data + size_t(p) * lay.elems_per_problem();
+    model.bind(p);
+    T c;
+    int nr;
     if (want_grad) {
-      gram.template pass<true>(prob, lay, n, xs, lane);
-      const T c = gram.extract_g_diag_cost(gl, hd, lay, n, lane, slot);
+      model.accumulate(L, n, lane, c, nr);
       T* G = static_cast<T*>(g_) + size_t(p) * n;
       T* H = static_cast<T*>(H_) + size_t(p) * n * n;
-      if (lane < n) G[lane] = gl[lane];
-      gram.write_sym(H, n, lay, n, lane);
+      if (lane < n) G[lane] = L.g[lane];
+      model.write_sym(H, n, n, lane);
       wave_sync();
-      if (lane < n) H[lane * n + lane] = hd[lane];  // thin-tail diagonal entries come from hd
-      if (lane == 0) { cost[p] = double(c); if (nres) nres[p] = m; }
+      if (lane < n) H[lane * n + lane] = L.hd[lane];  // the (undamped) diagonal always comes from hd
     } else {
-      const T c = gram.template pass<false>(prob, lay, n, xs, lane);
-      if (lane == 0) { cost[p] = double(c); if (nres) nres[p] = m; }
+      model.evaluate(L, n, lane, c, nr);
     }
+    if (lane == 0) { cost[p] = double(c); if (nres) nres[p] = nr; }
   }
 }
 
@@ -230,18 +299,6 @@ int toa_fail(int code, const std::string& msg);
   } while (0)
 
 namespace toa {
-template <typename T, int NBM, int THIN>
-inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad,
-                             void* g, void* H, double* cost, int32_t* nres) {
-  long long grid = (P + 3) / 4;
-  const long long cap = (long long)h->num_cus * 8;
-  if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((accumulate_kernel<T, NBM, THIN>), dim3((unsigned)grid), dim3(256), 0, h->stream, data, x, (long long)P, n, m,
-                     want_grad, g, H, cost, nres);
-  HIP_TRY(hipGetLastError());
-  return TOA_OK;
-}
-
 // waves per workgroup is fixed at 4 (256 threads); LDS per wave decides how many WGs fit per CU.
 template <typename T>
 inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg) {
@@ -254,15 +311,32 @@ inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg) {
   return TOA_OK;
 }
 
-template <typename T, int NBM, int THIN>
+template <typename Model>
+inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad,
+                             void* g, void* H, double* cost, int32_t* nres) {
+  using T = typename Model::Scalar;
+  long long grid = (P + 3) / 4;
+  const long long cap = (long long)h->num_cus * 8;
+  if (grid > cap) grid = cap;
+  size_t pw, pwg;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  HIP_TRY(hipFuncSetAttribute((const void*)accumulate_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  hipLaunchKernelGGL((accumulate_kernel<Model>), dim3((unsigned)grid), dim3(256), pwg, h->stream, data, x, (long long)P, n, m,
+                     want_grad, g, H, cost, nres, (int)pw);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+template <typename Model>
 inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
+  using T = typename Model::Scalar;
   FusedParams prm = prm_in;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
-  auto kern = lm_fused_kernel<T, NBM, THIN>;
+  auto kern = lm_fused_kernel<Model>;
   int wg_per_cu = 0;
   for (int i = 0; i < h->ncfg; ++i)
     if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == pwg) wg_per_cu = h->cfg[i].wg_per_cu;
@@ -304,5 +378,9 @@ inline int launch_solve(toa_handle h, int n, int64_t P, const void* H, const voi
 int toa_inst_fused(int dtag, int nbm, int thin, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_accumulate(int dtag, int nbm, int thin, toa_handle h, int n, int m, int64_t P, const void* data,
                         const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+// Gaussian-prior / sqrt2 models (inst.hip -DTOA_INST_MISC)
+int toa_inst_misc_fused(int dtag, int model, int npad, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data,
+                             const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok);
