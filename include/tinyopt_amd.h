@@ -152,6 +152,14 @@ int toa_dense_row_pack(toa_handle h, int dtype, int n, int m, int64_t P,
 int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64_t seed, int64_t problem0,
                         void* packed_dev, void* x0_dev, void* xstar_dev);
 
+/* ---- other device models (same entry points, `model` selects the functor) ----------------------------
+ * TOA_MODEL_GAUSSIAN_PRIOR  m == n; data_dev: [P][2][n] = y then sigma; x: [P][n].
+ * TOA_MODEL_SQRT2           n == m == 1; data_dev ignored; x: [P][1].
+ * TOA_MODEL_SE3_REPROJ      n == 6 (tangent, Sophus order upsilon, omega), m = 2 * points; x: [P][12] = rotation matrix
+ *                           (row-major) + translation, updated by pose <- pose * exp(delta)
+ *                           (include/tinyopt/3rdparty/traits/sophus.h:24-26); data_dev: [P][8 + 5*m/2] =
+ *                           [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point]. */
+
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).
  * want_grad = 0  <=>  grad == nullptr (cost only).  g_dev: [P][n] T; H_dev: [P][n*n] T full symmetric

@@ -7,6 +7,7 @@
 
 #include "../include/tinyopt_amd.h"
 #include "lm_oracle.hpp"
+#include "se3.hpp"
 #include "synth.hpp"
 
 #ifdef _OPENMP
@@ -135,6 +136,23 @@ static void run_batch_dense_row(int64_t P, int n, int m, const T* A, const T* b,
   (void)nthreads;
 }
 
+template <typename T>
+static void se3_lm_t(int64_t P, int npts, const T* data, T* poses, const Options& o, int32_t* stop, int32_t* iters,
+                     double* cost, double* finalH) {
+  for (int64_t p = 0; p < P; ++p) {
+    const T* d = data + size_t(p) * (8 + 5 * size_t(npts));
+    se3::ReprojAcc<T> acc{npts, d, d + 8};
+    se3::Pose<T> x;
+    for (int i = 0; i < 12; ++i) x[i] = poses[p * 12 + i];
+    Optimizer<T> opt(o, 6);
+    Output out = opt.OptimizeAcc(x, acc, se3::Plus<T>());
+    for (int i = 0; i < 12; ++i) poses[p * 12 + i] = x[i];
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * 36, out.final_hessian.data(), sizeof(double) * 36);
+  }
+}
 extern "C" {
 
 int oracle_num_threads_max() {
@@ -293,6 +311,55 @@ void oracle_sqrt2_lm(int dtype, int64_t P, void* x, const toa_options* opts, int
         if (deltas2) deltas2[size_t(p) * hist_stride + k] = out.deltas2[k];
         if (succ) succ[size_t(p) * hist_stride + k] = out.successes[k];
       }
+  }
+}
+
+
+// ---- SE3 reprojection.  poses: [P][12] (R row-major, t), data: [P][8 + 5*npts]
+//      ([f cx cy 0 0 0 0 0 | x y z u v ...]), updated in place.
+void oracle_se3_reproj_lm(int dtype, int64_t P, int npts, const void* data, void* poses, const toa_options* opts,
+                          int32_t* stop, int32_t* iters, double* cost, double* finalH) {
+  const Options o = from_pod(*opts);
+  if (dtype == TOA_F32) se3_lm_t<float>(P, npts, (const float*)data, (float*)poses, o, stop, iters, cost, finalH);
+  else se3_lm_t<double>(P, npts, (const double*)data, (double*)poses, o, stop, iters, cost, finalH);
+}
+// one Accumulate call: g [P][6], H [P][36], cost [P]
+void oracle_se3_reproj_accumulate(int dtype, int64_t P, int npts, const void* data, const void* poses, void* g, void* H,
+                                  double* cost) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32) {
+      const float* d = (const float*)data + size_t(p) * (8 + 5 * size_t(npts));
+      se3::ReprojAcc<float> acc{npts, d, d + 8};
+      se3::Pose<float> x;
+      for (int i = 0; i < 12; ++i) x[i] = ((const float*)poses)[p * 12 + i];
+      float* gp = (float*)g + p * 6; float* Hp = (float*)H + p * 36;
+      std::fill(gp, gp + 6, 0.f); std::fill(Hp, Hp + 36, 0.f);
+      cost[p] = acc(x, gp, Hp).cost;
+    } else {
+      const double* d = (const double*)data + size_t(p) * (8 + 5 * size_t(npts));
+      se3::ReprojAcc<double> acc{npts, d, d + 8};
+      se3::Pose<double> x;
+      for (int i = 0; i < 12; ++i) x[i] = ((const double*)poses)[p * 12 + i];
+      double* gp = (double*)g + p * 6; double* Hp = (double*)H + p * 36;
+      std::fill(gp, gp + 6, 0.0); std::fill(Hp, Hp + 36, 0.0);
+      cost[p] = acc(x, gp, Hp).cost;
+    }
+  }
+}
+// pose <- pose * exp(delta) for a batch (tests of the manifold update)
+void oracle_se3_plus(int dtype, int64_t P, void* poses, const void* delta) {
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32) {
+      se3::Pose<float> x; for (int i = 0; i < 12; ++i) x[i] = ((float*)poses)[p * 12 + i];
+      std::vector<float> d((const float*)delta + p * 6, (const float*)delta + p * 6 + 6);
+      se3::plus_eq(x, d, 1.f);
+      for (int i = 0; i < 12; ++i) ((float*)poses)[p * 12 + i] = x[i];
+    } else {
+      se3::Pose<double> x; for (int i = 0; i < 12; ++i) x[i] = ((double*)poses)[p * 12 + i];
+      std::vector<double> d((const double*)delta + p * 6, (const double*)delta + p * 6 + 6);
+      se3::plus_eq(x, d, 1.0);
+      for (int i = 0; i < 12; ++i) ((double*)poses)[p * 12 + i] = x[i];
+    }
   }
 }
 

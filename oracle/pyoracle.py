@@ -56,6 +56,9 @@ def load(path: str | None = None):
     lib.oracle_gaussian_prior_lm.restype = C.c_double
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp]
+    lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
+    lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -159,6 +162,58 @@ def sqrt2_lm(x0, pod: ToaOptions, history=True):
     succ = np.zeros((P, hs), np.uint8)
     lib.oracle_sqrt2_lm(_code(x.dtype), P, _p(x), C.byref(pod), _p(stop), _p(iters), _p(cost), _p(errs), _p(d2), _p(succ), hs)
     return dict(x=x, stop=stop, iters=iters, cost=cost, errs=errs, deltas2=d2, succ=succ)
+
+
+def se3_plus(poses, delta):
+    """pose * exp(delta) (sophus.h:24-26) for a batch; poses [P,12] (R row-major, t), delta [P,6] (upsilon, omega)."""
+    lib = load()
+    out = np.array(poses, copy=True)
+    lib.oracle_se3_plus(_code(out.dtype), out.shape[0], _p(out), _p(np.ascontiguousarray(delta.astype(out.dtype))))
+    return out
+
+
+def synth_se3_reproj(P, npts, dtype, seed=0x71940917):
+    """SURVEY §8(d) C5: T* = exp(xi*), xi* ~ 0.3 U(-1,1)^6; points in a 4 x 4 x [4,8] m frustum in the camera frame;
+    pinhole f=500, c=(320,240); pixel noise 0.5 U(-1,1); T0 = T* exp(0.05 U(-1,1)^6).
+    Returns (data [P, 8+5*npts], pose0 [P,12], pose_star [P,12])."""
+    rng = np.random.default_rng(seed)
+    ident = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (P, 1))
+    pstar = se3_plus(ident.astype(np.float64), 0.3 * rng.uniform(-1, 1, (P, 6)))
+    p0 = se3_plus(pstar, 0.05 * rng.uniform(-1, 1, (P, 6)))
+    R = pstar[:, :9].reshape(P, 3, 3)
+    t = pstar[:, 9:]
+    pc = np.stack([rng.uniform(-2, 2, (P, npts)), rng.uniform(-2, 2, (P, npts)), rng.uniform(4, 8, (P, npts))], -1)
+    pw = np.einsum("pji,pnj->pni", R, pc - t[:, None, :])          # p_w = R^T (p_c - t)
+    f, cx, cy = 500.0, 320.0, 240.0
+    uv = np.stack([f * pc[..., 0] / pc[..., 2] + cx, f * pc[..., 1] / pc[..., 2] + cy], -1) + 0.5 * rng.uniform(-1, 1, (P, npts, 2))
+    data = np.zeros((P, 8 + 5 * npts))
+    data[:, 0], data[:, 1], data[:, 2] = f, cx, cy
+    data[:, 8:] = np.concatenate([pw, uv], -1).reshape(P, -1)
+    return data.astype(dtype), p0.astype(dtype), pstar.astype(dtype)
+
+
+def se3_reproj_accumulate(data, poses, npts):
+    lib = load()
+    P = poses.shape[0]
+    g = np.zeros((P, 6), poses.dtype)
+    H = np.zeros((P, 6, 6), poses.dtype)
+    cost = np.zeros(P, np.float64)
+    lib.oracle_se3_reproj_accumulate(_code(poses.dtype), P, npts, _p(np.ascontiguousarray(data)), _p(np.ascontiguousarray(poses)),
+                                     _p(g), _p(H), _p(cost))
+    return g, H, cost
+
+
+def se3_reproj_lm(data, pose0, npts, pod: ToaOptions):
+    lib = load()
+    P = pose0.shape[0]
+    x = np.array(pose0, copy=True)
+    stop = np.zeros(P, np.int32)
+    iters = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    Hf = np.zeros((P, 6, 6), np.float64) if pod.save_last else None
+    lib.oracle_se3_reproj_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(data)), _p(x), C.byref(pod), _p(stop), _p(iters),
+                             _p(cost), _p(Hf))
+    return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf)
 
 
 def run_pin_tests() -> subprocess.CompletedProcess:

@@ -1,0 +1,130 @@
+// TEST INFRASTRUCTURE ONLY.  SE3 pieces of the oracle: the manifold update of
+// include/tinyopt/3rdparty/traits/sophus.h:24-26 (`pose *= SE3::exp(delta)`, right update, tangent
+// order (upsilon, omega) = translation first) and the pinhole reprojection residual of SURVEY §8(d) C5.
+//
+// Sophus is an un-vendored, unpinned dependency (cmake/ThirdParties.cmake:74-77, GIT_TAG main) absent from
+// the image; its published algorithm is restated: SO3::exp via Rodrigues with the small-angle series,
+// SE3::exp = (exp(omega), V(omega) upsilon), V = I + (1-cos t)/t^2 [w]x + (t-sin t)/t^3 [w]x^2.
+// Poses are stored as a rotation matrix (row-major 9) + translation (3) = 12 scalars.
+// The reference holds no reprojection residual (only a 6-residual pose prior, tests/sophus.cpp:26-44), so this
+// model is pinned by (i) group properties of exp, (ii) a finite-difference check of the right-perturbation
+// Jacobian in the spirit of diff/gradient_check.h, (iii) recovery of the planted pose.
+#pragma once
+#include <array>
+#include <cmath>
+#include <vector>
+
+#include "lm_oracle.hpp"
+
+namespace oracle {
+namespace se3 {
+
+template <typename T>
+using Pose = std::array<T, 12>;  // R (row-major 3x3), t
+
+template <typename T>
+inline void so3_exp(const T* w, T* R) {
+  const T t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const T t = std::sqrt(t2);
+  T A, B;  // A = sin t / t, B = (1 - cos t) / t^2
+  if (t2 < T(1e-10)) { A = T(1) - t2 / T(6); B = T(0.5) - t2 / T(24); }
+  else { A = std::sin(t) / t; B = (T(1) - std::cos(t)) / t2; }
+  const T wx = w[0], wy = w[1], wz = w[2];
+  R[0] = T(1) - B * (wy * wy + wz * wz); R[1] = -A * wz + B * wx * wy;          R[2] = A * wy + B * wx * wz;
+  R[3] = A * wz + B * wx * wy;          R[4] = T(1) - B * (wx * wx + wz * wz); R[5] = -A * wx + B * wy * wz;
+  R[6] = -A * wy + B * wx * wz;         R[7] = A * wx + B * wy * wz;          R[8] = T(1) - B * (wx * wx + wy * wy);
+}
+
+// exp of a twist delta = (upsilon, omega): returns (Rd, td)
+template <typename T>
+inline void exp(const T* d, T* Rd, T* td) {
+  const T* u = d;
+  const T* w = d + 3;
+  so3_exp(w, Rd);
+  const T t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const T t = std::sqrt(t2);
+  T B, C;  // V = I + B [w]x + C [w]x^2
+  if (t2 < T(1e-10)) { B = T(0.5) - t2 / T(24); C = T(1) / T(6) - t2 / T(120); }
+  else { B = (T(1) - std::cos(t)) / t2; C = (t - std::sin(t)) / (t2 * t); }
+  const T wx = w[0], wy = w[1], wz = w[2];
+  // [w]x u and [w]x [w]x u
+  const T c1[3] = {wy * u[2] - wz * u[1], wz * u[0] - wx * u[2], wx * u[1] - wy * u[0]};
+  const T c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
+  for (int i = 0; i < 3; ++i) td[i] = u[i] + B * c1[i] + C * c2[i];
+}
+
+// pose <- pose * exp(sign * delta)   (sophus.h:24-26)
+template <typename T>
+inline void plus_eq(Pose<T>& x, const std::vector<T>& delta, T sign) {
+  T d[6], Rd[9], td[3];
+  for (int i = 0; i < 6; ++i) d[i] = sign * delta[i];
+  exp(d, Rd, td);
+  T R[9], t[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = x[3 * i] * Rd[j] + x[3 * i + 1] * Rd[3 + j] + x[3 * i + 2] * Rd[6 + j];
+    t[i] = x[3 * i] * td[0] + x[3 * i + 1] * td[1] + x[3 * i + 2] * td[2] + x[9 + i];
+  }
+  for (int i = 0; i < 9; ++i) x[i] = R[i];
+  for (int i = 0; i < 3; ++i) x[9 + i] = t[i];
+}
+template <typename T>
+struct Plus {
+  void operator()(Pose<T>& x, const std::vector<T>& dx, T sign) const { plus_eq(x, dx, sign); }
+};
+
+// Reprojection residuals of npts points: r = (f X/Z + cx - u, f Y/Z + cy - v), p_c = R p + t;
+// Jacobian w.r.t. the right perturbation at delta = 0: d p_c/d upsilon = R, d p_c/d omega = -R [p]x.
+// data per point: [x y z u v]; folded as the AD bridge folds a residual vector (optimize_autodiff.h:123-164).
+template <typename T>
+struct ReprojAcc {
+  int npts;
+  const T* intr;  // f, cx, cy
+  const T* pts;   // [npts][5]
+  void row_pair(const Pose<T>& x, int i, T* r, T* J /*2x6 row-major*/) const {
+    const T* q = pts + size_t(i) * 5;
+    const T* R = x.data();
+    const T X = R[0] * q[0] + R[1] * q[1] + R[2] * q[2] + x[9];
+    const T Y = R[3] * q[0] + R[4] * q[1] + R[5] * q[2] + x[10];
+    const T Z = R[6] * q[0] + R[7] * q[1] + R[8] * q[2] + x[11];
+    const T f = intr[0], iz = T(1) / Z;
+    r[0] = f * X * iz + intr[1] - q[3];
+    r[1] = f * Y * iz + intr[2] - q[4];
+    if (!J) return;
+    // d(u,v)/d p_c
+    const T du[3] = {f * iz, T(0), -f * X * iz * iz};
+    const T dv[3] = {T(0), f * iz, -f * Y * iz * iz};
+    // d p_c / d delta = [ R | -R [p]x ],  [p]x = [[0,-z,y],[z,0,-x],[-y,x,0]]
+    T D[3][6];
+    for (int a = 0; a < 3; ++a) {
+      D[a][0] = R[3 * a]; D[a][1] = R[3 * a + 1]; D[a][2] = R[3 * a + 2];
+      D[a][3] = -(R[3 * a + 1] * q[2] - R[3 * a + 2] * q[1]);
+      D[a][4] = -(-R[3 * a] * q[2] + R[3 * a + 2] * q[0]);
+      D[a][5] = -(R[3 * a] * q[1] - R[3 * a + 1] * q[0]);
+    }
+    for (int c = 0; c < 6; ++c) {
+      J[c] = du[0] * D[0][c] + du[1] * D[1][c] + du[2] * D[2][c];
+      J[6 + c] = dv[0] * D[0][c] + dv[1] * D[1][c] + dv[2] * D[2][c];
+    }
+  }
+  Cost operator()(const Pose<T>& x, T* g, T* H) const {
+    T c = 0;
+    for (int i = 0; i < npts; ++i) {
+      T r[2], J[12];
+      row_pair(x, i, r, g ? J : nullptr);
+      c += r[0] * r[0] + r[1] * r[1];
+      if (g) {
+        for (int row = 0; row < 2; ++row) {
+          const T* Jr = J + 6 * row;
+          for (int a = 0; a < 6; ++a) {
+            g[a] += Jr[a] * r[row];
+            if (H) for (int b = 0; b < 6; ++b) H[size_t(b) * 6 + a] += Jr[a] * Jr[b];
+          }
+        }
+      }
+    }
+    return Cost(double(c), 2 * npts);
+  }
+};
+
+}  // namespace se3
+}  // namespace oracle

@@ -80,3 +80,37 @@ def test_ldlt_golden_and_numpy(oracle):
         Hd = Hn.copy()
         Hd[np.arange(n), np.arange(n)] *= 1.0001
         assert np.allclose(dx[0], np.linalg.solve(Hd, -gn), rtol=1e-9)
+
+
+def test_se3_manifold_and_reprojection_pins(oracle):
+    """The SE3 pieces (Sophus is absent: restated) are pinned by group properties of exp, a finite-difference
+    check of the right-perturbation Jacobian (spirit of diff/gradient_check.h:96-98) and planted-pose recovery."""
+    from tinyopt_amd.api import Options
+    rng = np.random.default_rng(0)
+    ident = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (8, 1))
+    d = rng.uniform(-1, 1, (8, 6))
+    d[0] = 0                      # exp(0) = identity
+    d[1, 3:] = 1e-7               # small-angle branch
+    T = oracle.se3_plus(ident, d)
+    assert np.array_equal(T[0], ident[0])
+    R = T[:, :9].reshape(-1, 3, 3)
+    assert np.abs(np.einsum("pij,pkj->pik", R, R) - np.eye(3)).max() < 1e-14
+    assert np.allclose(np.linalg.det(R), 1.0)
+    back = oracle.se3_plus(T, -d)                                     # exp(d) exp(-d) = I
+    assert np.abs(back - ident).max() < 1e-14
+    assert np.allclose(T[1, 9:], d[1, :3], atol=1e-7)                 # V(omega) -> I as omega -> 0
+    # pure translation / pure rotation about z by pi/2
+    Tz = oracle.se3_plus(ident[:1], np.array([[0, 0, 0, 0, 0, np.pi / 2]]))
+    assert np.allclose(Tz[0, :9].reshape(3, 3), [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    # Jacobian of the reprojection residual vs central differences over pose * exp(+-eps e_a)
+    data, p0, pstar = oracle.synth_se3_reproj(2, 150, np.float64, seed=3)
+    g, H, c = oracle.se3_reproj_accumulate(data, p0, 150)
+    eps = 1e-6
+    for a in range(6):
+        e = np.zeros((2, 6)); e[:, a] = eps
+        cp = oracle.se3_reproj_accumulate(data, oracle.se3_plus(p0, e), 150)[2]
+        cm = oracle.se3_reproj_accumulate(data, oracle.se3_plus(p0, -e), 150)[2]
+        assert np.allclose(0.5 * (cp - cm) / (2 * eps), g[:, a], rtol=1e-6)
+    r = oracle.se3_reproj_lm(data, p0, 150, Options().to_pod())
+    assert ((r["stop"] >= 1) & (r["stop"] < 5)).all()                 # Succeeded && Converged (tests/sophus.cpp:42-43)
+    assert np.abs(r["x"] - pstar).max() < 5e-3

@@ -111,3 +111,60 @@ def test_model_shape_errors(ta):
     model.m = 5                                                               # m != n -> invalid argument from the C-ABI
     with pytest.raises(ta.ToaError):
         ta.Optimize(torch.zeros(2, 3, dtype=torch.float64, device="cuda"), model)
+
+
+def _ortho_err(poses):
+    R = poses[:, :9].reshape(-1, 3, 3)
+    return np.abs(np.einsum("pij,pkj->pik", R, R) - np.eye(3)).max()
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_se3_reproj_accumulate_and_fd(ta, oracle, dtype, tdt):
+    """(g, H, cost) vs the oracle, and g = J^T r vs a central finite difference over the RIGHT perturbation
+    (pose * exp(+-eps e_a)), in the spirit of diff/gradient_check.h:96-98."""
+    P, npts = 3, 333
+    data, p0, _ = oracle.synth_se3_reproj(P, npts, dtype, seed=21)
+    model = ta.SE3Reproj(torch.from_numpy(data).cuda(), npts)
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(p0).cuda())
+    g_ref, H_ref, c_ref = oracle.se3_reproj_accumulate(data, p0, npts)
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    scale = np.abs(g_ref).max()
+    assert np.abs(g.cpu().numpy() - g_ref).max() < tol * scale
+    assert np.abs(H.cpu().numpy() - H_ref).max() < tol * np.abs(H_ref).max()
+    assert np.allclose(c.cpu().numpy(), c_ref, rtol=tol)
+    assert (nres.cpu().numpy() == 2 * npts).all()
+    if dtype == np.float64:
+        eps = 1e-6
+        for a in range(6):
+            d = np.zeros((P, 6)); d[:, a] = eps
+            cp = ta.accumulate(model, torch.from_numpy(oracle.se3_plus(p0, d)).cuda(), want_grad=False)[2].cpu().numpy()
+            cm = ta.accumulate(model, torch.from_numpy(oracle.se3_plus(p0, -d)).cuda(), want_grad=False)[2].cpu().numpy()
+            assert np.allclose(0.5 * (cp - cm) / (2 * eps), g.cpu().numpy()[:, a], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,tdt,npts", [(np.float64, torch.float64, 25000), (np.float64, torch.float64, 100),
+                                            (np.float32, torch.float32, 2000)])
+def test_se3_reproj_lm(ta, oracle, dtype, tdt, npts):
+    """BASELINE config 5 (25 000 points = 50 000 residuals, fp64) and smaller: planted pose recovered to the
+    pixel-noise level, same StopReason / iterations as the oracle, poses stay on the manifold."""
+    P = 2
+    data, p0, pstar = oracle.synth_se3_reproj(P, npts, dtype, seed=4)
+    o = ta.Options()
+    ref = oracle.se3_reproj_lm(data, p0, npts, o.to_pod())
+    model = ta.SE3Reproj(torch.from_numpy(data).cuda(), npts)
+    x = torch.from_numpy(p0.copy()).cuda()
+    out = ta.Optimize(x, model, o)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy()
+    stop = out.stop_reason.cpu().numpy()
+    assert (stop >= 1).all() and (stop < 5).all()                      # Succeeded && Converged (tests/sophus.cpp:42-43)
+    assert _ortho_err(xg) < (1e-12 if dtype == np.float64 else 1e-5)
+    noise = 0.5 / 500.0 / np.sqrt(npts) * 50                            # generous: pixel noise / focal / sqrt(N)
+    assert np.abs(xg - pstar).max() < max(noise, 2e-3 if dtype == np.float32 else 1e-4)
+    if dtype == np.float64:
+        assert np.abs(xg - ref["x"]).max() < 1e-9
+        assert np.array_equal(stop, ref["stop"]) and np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+        assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-10)
+        assert np.allclose(out.final_hessian.cpu().numpy(), ref["H"], rtol=1e-9, atol=1e-6 * np.abs(ref["H"]).max())
+    else:
+        assert np.abs(xg - ref["x"]).max() < 5e-4

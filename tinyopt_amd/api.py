@@ -15,7 +15,8 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import F32, F64, MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SQRT2, ToaOptions, ToaResults, check
+from ._capi import (F32, F64, MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ, MODEL_SQRT2, ToaOptions, ToaResults,
+                    check)
 
 
 class StopReason(enum.IntEnum):  # include/tinyopt/stop_reasons.h:14-43
@@ -259,7 +260,25 @@ class Sqrt2:
         return 0
 
 
-_MODELS = (DenseRow, GaussianPrior, Sqrt2)
+class SE3Reproj:
+    """Device residual model: pinhole reprojection of 3-D points under an SE3 pose.
+    x is [P, 12] (rotation matrix row-major + translation); the tangent has n = 6 (upsilon, omega) and the update
+    is the right-multiplicative  pose <- pose * exp(delta)  of include/tinyopt/3rdparty/traits/sophus.h:24-26.
+    data: [P, 8 + 5*npts] = [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point]."""
+    model_id = MODEL_SE3_REPROJ
+    xdim = 12
+
+    def __init__(self, data: torch.Tensor, npts: int):
+        assert data.dim() == 2 and data.shape[1] == 8 + 5 * npts and data.is_cuda
+        self.P, self.n, self.m, self.dtype = data.shape[0], 6, 2 * int(npts), data.dtype
+        self.packed = data.contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return (self.m // 2) * 5 * self.packed.element_size()
+
+
+_MODELS = (DenseRow, GaussianPrior, Sqrt2, SE3Reproj)
 
 
 @dataclass
@@ -299,8 +318,9 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
                         "on the GPU path")
     if not x.is_cuda or not x.is_contiguous():
         raise ValueError("x must be a contiguous GPU tensor")
-    P, n = x.shape
-    if n != cost.n or P != cost.P or x.dtype != cost.dtype:
+    P, xd = x.shape
+    n = cost.n
+    if xd != getattr(cost, "xdim", cost.n) or P != cost.P or x.dtype != cost.dtype:
         raise ValueError("x shape/dtype does not match the model")  # reference: std::invalid_argument
     ctx = ctx or default_context(x.device.index)
     dev = x.device
@@ -344,7 +364,7 @@ def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Cont
     """The Accumulate callback ``acc(x, grad, H) -> Cost`` (docs/API.md:37-57) for a batch.
     Returns (g [P,n], H [P,n,n], cost [P] float64, nres [P]); g/H are None when want_grad is False."""
     ctx = ctx or default_context(x.device.index)
-    P, n = x.shape
+    P, n = x.shape[0], cost.n
     dev = x.device
     g = torch.zeros(P, n, dtype=x.dtype, device=dev) if want_grad else None
     H = torch.zeros(P, n, n, dtype=x.dtype, device=dev) if want_grad else None

@@ -280,6 +280,10 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_SQRT2:
       if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
       return TOA_OK;
+    case TOA_MODEL_SE3_REPROJ:
+      if (n != 6 || m < 2 || (m & 1)) return fail(TOA_E_ARG, "SE3Reproj: n must be 6 and m an even count of residuals");
+      if (!data) return fail(TOA_E_ARG, "SE3Reproj: data pointer ([P][8 + 5*m/2]) is null");
+      return TOA_OK;
     default:
       return fail(TOA_E_UNSUPPORTED, "model not available on this path");
   }

@@ -14,6 +14,7 @@ using InstT = double;
 #ifdef TOA_INST_MISC
 int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, const FusedParams& prm) {
   if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
+  if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
   switch (npad) {
     case 16: return launch_fused<GaussianPriorModel<InstT, 16>>(h, prm);
     case 32: return launch_fused<GaussianPriorModel<InstT, 32>>(h, prm);
@@ -26,6 +27,8 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
                                                        double* cost, int32_t* nres) {
   (void)npad;
   if (model == TOA_MODEL_SQRT2) return launch_accumulate<Sqrt2Model<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_SE3_REPROJ)
+    return launch_accumulate<Se3ReprojModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return launch_accumulate<GaussianPriorModel<InstT, 16>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 #elif defined(TOA_INST_SOLVE)

@@ -28,9 +28,17 @@ namespace toa {
 // Device residual models.  Concept (see lm_device.hpp): Scalar, kNpad, init(n, m, data), bind(p),
 // accumulate / evaluate / write_sym.
 // ------------------------------------------------------------------------------------------------
+// x (+)= sign * d for Euclidean parameter blocks (traits.h:184-190)
+template <typename T>
+__device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign, int lane) {
+  L.xs[lane] += sign * d[lane];
+}
+
 template <typename T, int NBM, int THIN>
 struct DenseRowModel {
   using Scalar = T;
+  static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   static constexpr int kNpad = 16 * (NBM + (THIN > 0 ? 1 : 0));  // n <= kNpad - 1 ... see DenseRowLayout
   DenseRowGram<T, NBM, THIN> gram;
   const T* data;
@@ -66,6 +74,8 @@ struct DenseRowModel {
 template <typename T, int NPAD>
 struct GaussianPriorModel {
   using Scalar = T;
+  static constexpr int kXdim = 0;
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   static constexpr int kNpad = NPAD;
   const T* data;
   const T* y;
@@ -104,6 +114,8 @@ struct GaussianPriorModel {
 template <typename T>
 struct Sqrt2Model {
   using Scalar = T;
+  static constexpr int kXdim = 0;
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   static constexpr int kNpad = 16;
   __device__ __forceinline__ void init(int, int, const void*) {}
   __device__ __forceinline__ void bind(long long) {}
@@ -124,6 +136,141 @@ struct Sqrt2Model {
   template <typename O>
   __device__ __forceinline__ void write_sym(O* M, int, int, int lane) const {
     if (lane == 0) M[0] = O(0);
+  }
+};
+
+// SE3 pinhole reprojection: parameters = a pose stored as R (row-major 9) + t (3) = 12 scalars,
+// tangent n = 6 in Sophus order (upsilon, omega); residual pair per point r = (f X/Z + cx - u, f Y/Z + cy - v),
+// p_c = R p + t; Jacobian w.r.t. the RIGHT perturbation at delta = 0 (what OptimizeWithAutoDiff's user-type
+// branch differentiates, optimize_autodiff.h:48-55,73-77): d p_c/d upsilon = R, d p_c/d omega = -R [p]x; update
+// pose <- pose * exp(delta) (3rdparty/traits/sophus.h:24-26).  Thread-per-residual evaluation: lane l handles
+// points l, l+64, ...; the 7x7 upper Gram of [J | r] (28 values) is accumulated in registers and folded across
+// the wave once per pass.  Data per problem: [f cx cy 0 0 0 0 0 | x y z u v ...] (coalesced 5-scalar records).
+template <typename T>
+struct Se3ReprojModel {
+  using Scalar = T;
+  static constexpr int kNpad = 16;
+  static constexpr int kXdim = 12;
+  const T* data;
+  const T* d;
+  int npts;
+  T G[28];
+  static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
+  __device__ __forceinline__ void init(int, int m, const void* dp) { npts = m / 2; data = static_cast<const T*>(dp); }
+  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (8 + 5 * size_t(npts)); }
+
+  template <bool WANT_H>
+  __device__ __forceinline__ T pass(const WaveLds<T>& L, int lane) {
+    T R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = L.xs[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = L.xs[9 + i];
+    const T f = d[0], cx = d[1], cy = d[2];
+    if (WANT_H) {
+#pragma unroll
+      for (int i = 0; i < 28; ++i) G[i] = T(0);
+    }
+    T csum = 0;
+    const T* pts = d + 8;
+    for (int i = lane; i < npts; i += 64) {
+      const T* q = pts + size_t(i) * 5;
+      const T px = q[0], py = q[1], pz = q[2];
+      const T X = R[0] * px + R[1] * py + R[2] * pz + t[0];
+      const T Y = R[3] * px + R[4] * py + R[5] * pz + t[1];
+      const T Z = R[6] * px + R[7] * py + R[8] * pz + t[2];
+      const T iz = T(1) / Z;
+      T w[2][7];
+      w[0][6] = f * X * iz + cx - q[3];
+      w[1][6] = f * Y * iz + cy - q[4];
+      if (WANT_H) {
+        const T du0 = f * iz, du2 = -f * X * iz * iz;
+        const T dv1 = f * iz, dv2 = -f * Y * iz * iz;
+        T D[3][6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          D[a][0] = R[3 * a]; D[a][1] = R[3 * a + 1]; D[a][2] = R[3 * a + 2];
+          D[a][3] = -(R[3 * a + 1] * pz - R[3 * a + 2] * py);
+          D[a][4] = -(-R[3 * a] * pz + R[3 * a + 2] * px);
+          D[a][5] = -(R[3 * a] * py - R[3 * a + 1] * px);
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          w[0][c] = du0 * D[0][c] + du2 * D[2][c];
+          w[1][c] = dv1 * D[1][c] + dv2 * D[2][c];
+        }
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+          for (int a = 0; a < 7; ++a)
+#pragma unroll
+            for (int b = a; b < 7; ++b) G[tt(a, b)] += w[row][a] * w[row][b];
+      } else {
+        csum += w[0][6] * w[0][6] + w[1][6] * w[1][6];
+      }
+    }
+    if (WANT_H) {
+#pragma unroll
+      for (int i = 0; i < 28; ++i) G[i] = wave_allreduce_sum(G[i]);
+      return G[tt(6, 6)];
+    }
+    return wave_allreduce_sum(csum);
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    cost = pass<true>(L, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { L.g[a] = G[tt(a, 6)]; L.hd[a] = G[tt(a, a)]; }
+    }
+    nres = 2 * npts;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    cost = pass<false>(L, lane);
+    nres = 2 * npts;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int, int lane) const {
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { M[a * LD + b] = O(G[tt(a, b)]); M[b * LD + a] = O(G[tt(a, b)]); }
+    }
+  }
+  // pose <- pose * exp(sign * delta): SO3 Rodrigues with small-angle series, SE3 V matrix (Sophus' formulas)
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const {
+    T dl[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl[i] = sign * dv[i];
+    const T wx = dl[3], wy = dl[4], wz = dl[5];
+    const T t2 = wx * wx + wy * wy + wz * wz;
+    const T th = sqrt(t2);
+    T A, B, Cc;
+    if (t2 < T(1e-10)) { A = T(1) - t2 / T(6); B = T(0.5) - t2 / T(24); Cc = T(1) / T(6) - t2 / T(120); }
+    else { T sn, cs; sincos_t(th, &sn, &cs); A = sn / th; B = (T(1) - cs) / t2; Cc = (th - sn) / (t2 * th); }
+    T Rd[9];
+    Rd[0] = T(1) - B * (wy * wy + wz * wz); Rd[1] = -A * wz + B * wx * wy;          Rd[2] = A * wy + B * wx * wz;
+    Rd[3] = A * wz + B * wx * wy;          Rd[4] = T(1) - B * (wx * wx + wz * wz); Rd[5] = -A * wx + B * wy * wz;
+    Rd[6] = -A * wy + B * wx * wz;         Rd[7] = A * wx + B * wy * wz;          Rd[8] = T(1) - B * (wx * wx + wy * wy);
+    const T c1[3] = {wy * dl[2] - wz * dl[1], wz * dl[0] - wx * dl[2], wx * dl[1] - wy * dl[0]};
+    const T c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
+    T td[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) td[i] = dl[i] + B * c1[i] + Cc * c2[i];
+    T x[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = L.xs[i];
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) L.xs[3 * i + j] = x[3 * i] * Rd[j] + x[3 * i + 1] * Rd[3 + j] + x[3 * i + 2] * Rd[6 + j];
+        L.xs[9 + i] = x[3 * i] * td[0] + x[3 * i + 1] * td[1] + x[3 * i + 2] * td[2] + x[9 + i];
+      }
+    }
+    wave_sync();
   }
 };
 
@@ -171,6 +318,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   Model model;
   model.init(n, prm_g->m, prm_g->data);
   T* X = static_cast<T*>(prm_g->x);
+  const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
   for (;;) {
     int p = 0;
@@ -179,10 +327,10 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     if (p >= P) break;
     model.bind(p);
     wave_sync();
-    L.xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
+    L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
     wave_sync();
     lm_solve_problem<T>(model, L, n, lane, (long long)p);
-    if (lane < n) X[size_t(p) * n + lane] = L.xs[lane];
+    if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
   }
   unsigned long long* counters = prm_g->counters;
   if (counters && lane == 0) {
@@ -205,9 +353,10 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, cons
   const T* X = static_cast<const T*>(x_);
   Model model;
   model.init(n, m, data_);
+  const int xd = Model::kXdim ? Model::kXdim : n;
   for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
     wave_sync();
-    L.xs[lane] = lane < n ? X[size_t(p) * n + lane] : T(0);
+    L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
     wave_sync();
     model.bind(p);
     T c;

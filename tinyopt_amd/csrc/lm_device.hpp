@@ -306,20 +306,18 @@ __device__ __forceinline__ void lm_solve_problem(Model& model, WaveLds<T>& L, co
     const toa_options& opt = *L.opt;
     bool eval_only = false;
     if (status & 1) {                 // :271-279
-      const T d = L.dx[lane];
-      L.xs[lane] += d;                // PlusEq, traits.h:184-190
-      L.ldx[lane] = d;
+      model.plus_eq(L, L.dx, T(1), n, lane);   // ptrait::PlusEq(x, dx): traits.h:184-190 / sophus.h:24-26
+      L.ldx[lane] = L.dx[lane];
       S.has_last_dx = 1;
       S.last_was_success = 1;
       if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
     } else {                          // :281-297
       if (S.has_last_dx) {
-        L.xs[lane] += -L.ldx[lane];
+        model.plus_eq(L, L.ldx, T(-1), n, lane);  // roll back: PlusEq(x, -last_dx)
         S.has_last_dx = 0;
       } else if (status & 2) {
-        const T d = L.dx[lane];
-        L.xs[lane] += d;
-        L.ldx[lane] = d;
+        model.plus_eq(L, L.dx, T(1), n, lane);
+        L.ldx[lane] = L.dx[lane];
         S.has_last_dx = 1;
       }
       eval_only = (S.last_was_success == 0);
