@@ -254,3 +254,61 @@ def test_argument_errors(ta):
     o = ta.Options(); o.hessian.use_ldlt = False
     with pytest.raises(ta.ToaError):
         ta.Optimize(x0, model, o)
+
+
+def test_failure_paths_match_reference_semantics(ta, oracle):
+    """tests/basic.cpp:147-218: NaN / Inf in residuals or Jacobians -> kSystemHasNaNOrInf, at most one iteration,
+    EMPTY history; healthy problems in the same batch are unaffected (per-problem divergence)."""
+    P, n, m = 6, 12, 40
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float64, seed=8)
+    b[1, 3] = np.nan          # NaN residual
+    A[2, 5, 7] = np.inf       # Inf in the Jacobian
+    b[4, 0] = -np.inf         # Inf residual
+    o = ta.Options()
+    ref = oracle.dense_row_lm(A, b, x0, o.to_pod(), history=True)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o, history=True)
+    torch.cuda.synchronize()
+    stop = out.stop_reason.cpu().numpy()
+    iters = out.num_iters.cpu().numpy()
+    assert list(ref["stop"][[1, 2, 4]]) == [-2, -2, -2]
+    assert np.array_equal(stop, ref["stop"]) and np.array_equal(iters, ref["iters"])
+    for p in (1, 2, 4):
+        assert iters[p] <= 1                                           # FailureChecks: num_iters <= max_iters(1)
+        assert not out.errs.cpu().numpy()[p].any()                     # errs / deltas2 / successes empty
+        assert not out.successes.cpu().numpy()[p].any()
+        assert np.array_equal(x.cpu().numpy()[p], x0[p])               # x untouched
+    for p in (0, 3, 5):
+        assert stop[p] >= 1 and np.abs(x.cpu().numpy()[p] - xs[p]).max() < 5e-3
+
+
+def test_tiny_and_empty_batches(ta, oracle):
+    """Ragged edges: fewer rows than one MFMA step (m < 4), m < n (rank-deficient -> LM damping still solves),
+    a single problem, and an empty batch."""
+    for n, m in ((3, 1), (3, 2), (5, 3), (12, 7)):
+        A, b, x0, _ = oracle.synth_dense_row(5, n, m, np.float64, seed=n * 10 + m)
+        o = ta.Options()
+        ref = oracle.dense_row_lm(A, b, x0, o.to_pod())
+        model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, o)
+        torch.cuda.synchronize()
+        stop = out.stop_reason.cpu().numpy()
+        # rank-deficient normal matrices: same verdict class (success / solver failure) as the reference algorithm
+        assert np.array_equal(stop >= 0, ref["stop"] >= 0), (n, m, stop, ref["stop"])
+        good = (stop >= 0) & (stop == ref["stop"])
+        if good.any():
+            assert np.allclose(out.final_cost.cpu().numpy()[good], ref["cost"][good], rtol=1e-6, atol=1e-12)
+    model, x0, _ = ta.DenseRow.synthetic(1, 12, 50, torch.float64)
+    out = ta.Optimize(x0.clone(), model)
+    assert out.stop_reason.shape == (1,) and int(out.stop_reason[0]) >= 1
+    lib = ta.load()
+    ctx = ta.api.default_context()
+    import ctypes as C
+    pod = ta.Options().to_pod()
+    res = ta.ToaResults()
+    dummy = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res.stop_reason = res.num_iters = dummy.data_ptr()
+    res.final_cost = torch.zeros(1, dtype=torch.float64, device="cuda").data_ptr()
+    assert lib.toa_lm_run(ctx.h, 1, 1, 12, 50, 0, model.packed.data_ptr(), x0.data_ptr(), C.byref(pod), C.byref(res), None) == 0
