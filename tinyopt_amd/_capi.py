@@ -74,6 +74,8 @@ PROTOTYPES = {
     "toa_solve_damped": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_double, _P, _P]),
     "toa_lm_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
                              C.POINTER(ToaResults), _P]),
+    "toa_lm_run_split": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
+                                   C.POINTER(ToaResults), _P, C.c_int]),
 }
 
 _lib = None

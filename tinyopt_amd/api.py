@@ -305,7 +305,7 @@ class Output:
 
 
 def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
-             ctx: Optional[Context] = None, out: Optional[Output] = None) -> Output:
+             ctx: Optional[Context] = None, out: Optional[Output] = None, splits: Optional[int] = None) -> Output:
     """``tinyopt::Optimize(x, cost, options)`` (optimize.h:16-77) for a batch of independent problems.
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
@@ -355,8 +355,12 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     res.deltas2 = out.deltas2.data_ptr() if out.deltas2 is not None else None
     res.successes = out.successes.data_ptr() if out.successes is not None else None
     res.hist_stride = out.errs.shape[1] if out.errs is not None else 0
-    check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
-                             x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
+    if splits is None:   # the library decides (row-split for few, huge problems)
+        check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                                 x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
+    else:                # explicit row-split execution with `splits` chunks per problem (0 = automatic count)
+        check(ctx.lib.toa_lm_run_split(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                                       x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr(), int(splits)))
     return out
 
 

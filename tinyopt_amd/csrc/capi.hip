@@ -102,6 +102,17 @@ int toa_inst_misc_fused_1_0(int model, int npad, toa_handle h, const toa::FusedP
 int toa_inst_misc_accumulate_0_0(int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_misc_accumulate_1_0(int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 
+int toa_inst_misc_wide_0_0(int model, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_0_1(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_0_2(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_0_3(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_0_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_misc_wide_1_0(int model, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_1_1(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_1_2(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_1_3(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+
 static thread_local std::string g_err;
 int toa_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -128,6 +139,17 @@ int toa_inst_accumulate(int dtag, int nbm, int thin, toa_handle h, int n, int m,
     case 11: TOA_A(toa_inst_accumulate_1_3); case 12: TOA_A(toa_inst_accumulate_1_4);
   }
 #undef TOA_A
+  return fail(TOA_E_ARG, "bad block count");
+}
+int toa_inst_wide(int dtag, int model, int nbm, int thin, toa_handle h, const FusedParams& prm, int splits) {
+  if (model != TOA_MODEL_DENSE_ROW)
+    return dtag == 0 ? toa_inst_misc_wide_0_0(model, h, prm, splits) : toa_inst_misc_wide_1_0(model, h, prm, splits);
+  switch (dtag * 8 + nbm) {
+    case 1: return toa_inst_wide_0_1(thin, h, prm, splits); case 2: return toa_inst_wide_0_2(thin, h, prm, splits);
+    case 3: return toa_inst_wide_0_3(thin, h, prm, splits); case 4: return toa_inst_wide_0_4(thin, h, prm, splits);
+    case 9: return toa_inst_wide_1_1(thin, h, prm, splits); case 10: return toa_inst_wide_1_2(thin, h, prm, splits);
+    case 11: return toa_inst_wide_1_3(thin, h, prm, splits); case 12: return toa_inst_wide_1_4(thin, h, prm, splits);
+  }
   return fail(TOA_E_ARG, "bad block count");
 }
 int toa_inst_misc_fused(int dtag, int model, int npad, toa_handle h, const FusedParams& prm) {
@@ -216,6 +238,7 @@ int toa_destroy(toa_handle h) {
   (void)hipSetDevice(h->device);
   if (h->queue) (void)hipFree(h->queue);
   if (h->params_dev) (void)hipFree(h->params_dev);
+  if (h->scratch) (void)hipFree(h->scratch);
   delete h;
   return TOA_OK;
 }
@@ -369,8 +392,8 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
   return toa_inst_solve(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, g, scale, dx, ok);
 }
 
-int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
-               const toa_options* options, const toa_results* results, uint64_t* counters) {
+static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+                       const toa_options* options, const toa_results* results, uint64_t* counters, int splits) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (int rc = check_model(model, n, m, data)) return rc;
@@ -396,10 +419,30 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, cons
   prm.opt = *options;
   prm.res = *results;
   prm.counters = reinterpret_cast<unsigned long long*>(counters);
-  if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtype == TOA_F32 ? 0 : 1, model, 16 * ((n + 15) / 16), h, prm);
+  const int dtag = dtype == TOA_F32 ? 0 : 1;
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
-  return toa_inst_fused(dtype == TOA_F32 ? 0 : 1, lay_.nbm, lay_.thin, h, prm);
+  const bool splittable = model == TOA_MODEL_DENSE_ROW || model == TOA_MODEL_SE3_REPROJ;
+  // splits < 0: automatic — row-split when one-wave-per-problem would leave most of the chip idle
+  // (fewer problems than CUs and enough rows to give every chunk >= 256 of them)
+  if (splits < 0) splits = (splittable && P * 4 <= h->num_cus && m >= 1024) ? 0 : -1;
+  if (splits >= 0) {
+    if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
+    return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);
+  }
+  if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtag, model, 16 * ((n + 15) / 16), h, prm);
+  return toa_inst_fused(dtag, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");
+}
+
+int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+               const toa_options* options, const toa_results* results, uint64_t* counters) {
+  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1);
+}
+
+int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+                     const toa_options* options, const toa_results* results, uint64_t* counters, int splits) {
+  if (splits < 0) return fail(TOA_E_ARG, "toa_lm_run_split: splits must be >= 0 (0 = choose automatically)");
+  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, splits);
 }
 
 }  // extern "C"

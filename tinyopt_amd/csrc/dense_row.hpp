@@ -180,36 +180,60 @@ struct RawVec;
 template <>
 struct RawVec<1> {
   unsigned a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a; }
 };
 template <>
 struct RawVec<2> {
   u32x2 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; }
 };
 template <>
 struct RawVec<3> {
   u32x3 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
 };
 template <>
 struct RawVec<4> {
   u32x4 a;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; }
 };
@@ -217,10 +241,17 @@ template <>
 struct RawVec<6> {
   u32x4 a;
   u32x2 b;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
                  : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const {
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1];
@@ -229,10 +260,17 @@ struct RawVec<6> {
 template <>
 struct RawVec<8> {
   u32x4 a, b;
-  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff_in) {
-    const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(soff_in)));  // "s" operand must be provably uniform
-    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+  // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
+  // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
+  template <bool NOP = true>
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
+    if constexpr (NOP) {
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
                  : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    } else {
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    }
   }
   __device__ __forceinline__ void get(unsigned* o) const {
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
@@ -308,11 +346,15 @@ struct DenseRowGram {
   static constexpr int NTM = THIN ? NBM * THIN : 1;             // main x thin products per lane
   using Acc = typename Mfma<T>::Acc;
   Acc acc[NT];
-  T accT[NTM];               // accT[cb*THIN + j] = sum_rows W[row][NBM*c+cb] * thin_j   (this lane's c)
+  T accT[NTM];               // accT[ti(cb, j)] = sum_rows W[row][NBM*c+cb] * thin_j   (this lane's c)
   T accTT[NTT ? NTT : 1];    // thin_j * thin_j' (j <= j'), identical on every lane after the pass
 
   static __device__ __forceinline__ constexpr int tile(int i, int j) { return i * NBM - i * (i - 1) / 2 + (j - i); }
   static __device__ __forceinline__ constexpr int tt(int j, int j2) { return j * THIN - j * (j - 1) / 2 + (j2 - j); }
+  // accT index of (column block cb, thin element j): pairs of blocks adjacent (packed-FMA friendly), odd block last
+  static __device__ __forceinline__ constexpr int ti(int cb, int j) {
+    return cb < 2 * (NBM / 2) ? ((cb / 2) * THIN + j) * 2 + (cb & 1) : 2 * (NBM / 2) * THIN + j;
+  }
 
   __device__ __forceinline__ void clear() {
 #pragma unroll
@@ -358,10 +400,11 @@ struct DenseRowGram {
     constexpr int kDwT = THIN ? THIN * int(sizeof(T)) / 4 : 1;
     RawVec<kDw> nxt[U];
     RawVec<kDwT> nxtT[U];
+    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(step_bytes)));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes);
-      if (THIN) nxtT[u].issue(rsrc, vofft, unsigned(u) * step_bytes);
+      nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes_u);
+      if (THIN) nxtT[u].issue(rsrc, vofft, unsigned(u) * step_bytes_u);
     }
     wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
     if (THIN) wait_batch<kDwT>(nxtT[0], nxtT[1], nxtT[2], nxtT[3]);
@@ -380,11 +423,11 @@ struct DenseRowGram {
         }
       }
       // prefetch the next U steps (past the end: reads 0); pinned here, ahead of this batch's math
-      const unsigned soff0 = unsigned(s0 + U) * step_bytes;
+      const unsigned soff0 = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + U) * step_bytes_u)));
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes);
-        if (THIN) nxtT[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes);
+        nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes_u);
+        if (THIN) nxtT[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -405,16 +448,32 @@ struct DenseRowGram {
 #endif
         const T sc = T(1) + T(0.1) * cs;
         const T rbase = t + T(0.1) * sn;
+        if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
+          using f2 = float __attribute__((ext_vector_type(2)));
+          constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
 #pragma unroll
-        for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
-        if (THIN == 0) {
-          w[NBM - 1] = isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+          for (int cb = 0; cb + 1 < kScaled; cb += 2) {
+            const f2 wp = f2{w[cb], w[cb + 1]} * f2{sc, sc};
+            w[cb] = wp[0];
+            w[cb + 1] = wp[1];
+          }
+          if constexpr (kScaled & 1) w[kScaled - 1] *= sc;
+#pragma unroll
+          for (int j = 0; j + 2 < THIN; j += 2) {
+            const f2 vp = f2{v[j], v[j + 1]} * f2{sc, sc};
+            v[j] = vp[0];
+            v[j + 1] = vp[1];
+          }
+          if constexpr (THIN > 1 && ((THIN - 1) & 1)) v[THIN - 2] *= sc;
         } else {
-          w[NBM - 1] *= sc;
+#pragma unroll
+          for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
+          if (THIN != 0) w[NBM - 1] *= sc;
 #pragma unroll
           for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
-          v[THIN - 1] = rbase - v[THIN - 1];
         }
+        if (THIN == 0) w[NBM - 1] = isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+        else v[THIN - 1] = rbase - v[THIN - 1];
         if (WANT_H) {
 #if defined(TOA_SPLIT_MFMA)
 #pragma unroll
@@ -433,10 +492,31 @@ struct DenseRowGram {
           for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
 #endif
 #ifndef TOA_ABL_NOTHIN
+          if constexpr (sizeof(T) == 4 && THIN > 0) {
+            // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
+            // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
+            using f2 = float __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int cb = 0; cb < NBM; ++cb)
+            for (int pb = 0; pb < NBM / 2; ++pb) {
+              const f2 wp = {w[2 * pb], w[2 * pb + 1]};
 #pragma unroll
-            for (int j = 0; j < THIN; ++j) accT[cb * THIN + j] += w[cb] * v[j];
+              for (int j = 0; j < THIN; ++j) {
+                f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
+                a += wp * f2{v[j], v[j]};
+                accT[ti(2 * pb, j)] = a[0];
+                accT[ti(2 * pb + 1, j)] = a[1];
+              }
+            }
+            if constexpr (NBM & 1) {
+#pragma unroll
+              for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
+            }
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < NBM; ++cb)
+#pragma unroll
+              for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
+          }
 #pragma unroll
           for (int j = 0; j < THIN; ++j)
 #pragma unroll
@@ -501,7 +581,7 @@ struct DenseRowGram {
     if (THIN) {
       if (lane < 16) {
 #pragma unroll
-        for (int cb = 0; cb < NBM; ++cb) g[NBM * cj + cb] = accT[cb * THIN + (THIN - 1)];
+        for (int cb = 0; cb < NBM; ++cb) g[NBM * cj + cb] = accT[ti(cb, THIN - 1)];
       }
       if (lane == 0) {
 #pragma unroll
@@ -547,7 +627,7 @@ struct DenseRowGram {
 #pragma unroll
           for (int j = 0; j + 1 < THIN; ++j) {
             const int q = NBM * cj + cb;
-            const O v = O(accT[cb * THIN + j]);
+            const O v = O(accT[ti(cb, j)]);
             M[q * LD + (nmr + j)] = v;
             M[(nmr + j) * LD + q] = v;
           }

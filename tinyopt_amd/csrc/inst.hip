@@ -22,6 +22,10 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
     default: return launch_fused<GaussianPriorModel<InstT, 64>>(h, prm);
   }
 }
+int TOA_CAT(toa_inst_misc_wide_, TOA_INST_DT, 0)(int model, toa_handle h, const FusedParams& prm, int splits) {
+  if (model == TOA_MODEL_SE3_REPROJ) return launch_wide<Se3ReprojModel<InstT>, 16, Se3Manifold<InstT>>(h, prm, splits);
+  return toa_fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
+}
 int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, int n, int m, int64_t P,
                                                        const void* data, const void* x, int want_grad, void* g, void* H,
                                                        double* cost, int32_t* nres) {
@@ -50,6 +54,19 @@ int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, 
     case 2: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 2>>(h, prm);
     case 3: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 3>>(h, prm);
     case 4: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 4>>(h, prm);
+#endif
+    default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
+  }
+}
+int TOA_CAT(toa_inst_wide_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm, int splits) {
+  constexpr int kNp0 = 16 * TOA_INST_NBM;  // NPAD of the solve: see DenseRowModel::kNpad
+  switch (thin) {
+    case 0: return launch_wide<DenseRowModel<InstT, TOA_INST_NBM, 0>, kNp0, EuclidManifold<InstT>>(h, prm, splits);
+#if TOA_INST_NBM <= 3
+    case 1: return launch_wide<DenseRowModel<InstT, TOA_INST_NBM, 1>, kNp0 + 16, EuclidManifold<InstT>>(h, prm, splits);
+    case 2: return launch_wide<DenseRowModel<InstT, TOA_INST_NBM, 2>, kNp0 + 16, EuclidManifold<InstT>>(h, prm, splits);
+    case 3: return launch_wide<DenseRowModel<InstT, TOA_INST_NBM, 3>, kNp0 + 16, EuclidManifold<InstT>>(h, prm, splits);
+    case 4: return launch_wide<DenseRowModel<InstT, TOA_INST_NBM, 4>, kNp0 + 16, EuclidManifold<InstT>>(h, prm, splits);
 #endif
     default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
   }

@@ -51,6 +51,13 @@ struct DenseRowModel {
     data = static_cast<const T*>(d);
   }
   __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); }
+  // row-split execution: restrict the model to rows [row0, row0 + rows) of problem p (rows % 4 == 0)
+  __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int n) {
+    const DenseRowLayout full = DenseRowLayout::make(n, m);
+    prob = data + size_t(p) * full.elems_per_problem() + size_t(row0) * full.rs;
+    lay = full;
+    lay.m4 = rows;
+  }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     gram.template pass<true>(prob, lay, n, L.xs, lane);
     cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
@@ -139,6 +146,51 @@ struct Sqrt2Model {
   }
 };
 
+// ---- manifold policies: how a step is applied to the stored parameters ---------------------------------
+template <typename T>
+struct EuclidManifold {
+  static constexpr int kXdim = 0;
+  static __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) { euclid_plus_eq(L, d, sign, lane); }
+};
+template <typename T>
+struct Se3Manifold {
+  static constexpr int kXdim = 12;
+  // pose <- pose * exp(sign * delta): SO3 Rodrigues with small-angle series, SE3 V matrix (Sophus' formulas)
+  static __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) {
+    T dl[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl[i] = sign * dv[i];
+    const T wx = dl[3], wy = dl[4], wz = dl[5];
+    const T t2 = wx * wx + wy * wy + wz * wz;
+    const T th = sqrt(t2);
+    T A, B, Cc;
+    if (t2 < T(1e-10)) { A = T(1) - t2 / T(6); B = T(0.5) - t2 / T(24); Cc = T(1) / T(6) - t2 / T(120); }
+    else { T sn, cs; sincos_t(th, &sn, &cs); A = sn / th; B = (T(1) - cs) / t2; Cc = (th - sn) / (t2 * th); }
+    T Rd[9];
+    Rd[0] = T(1) - B * (wy * wy + wz * wz); Rd[1] = -A * wz + B * wx * wy;          Rd[2] = A * wy + B * wx * wz;
+    Rd[3] = A * wz + B * wx * wy;          Rd[4] = T(1) - B * (wx * wx + wz * wz); Rd[5] = -A * wx + B * wy * wz;
+    Rd[6] = -A * wy + B * wx * wz;         Rd[7] = A * wx + B * wy * wz;          Rd[8] = T(1) - B * (wx * wx + wy * wy);
+    const T c1[3] = {wy * dl[2] - wz * dl[1], wz * dl[0] - wx * dl[2], wx * dl[1] - wy * dl[0]};
+    const T c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
+    T td[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) td[i] = dl[i] + B * c1[i] + Cc * c2[i];
+    T x[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = L.xs[i];
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) L.xs[3 * i + j] = x[3 * i] * Rd[j] + x[3 * i + 1] * Rd[3 + j] + x[3 * i + 2] * Rd[6 + j];
+        L.xs[9 + i] = x[3 * i] * td[0] + x[3 * i + 1] * td[1] + x[3 * i + 2] * td[2] + x[9 + i];
+      }
+    }
+    wave_sync();
+  }
+};
+
 // SE3 pinhole reprojection: parameters = a pose stored as R (row-major 9) + t (3) = 12 scalars,
 // tangent n = 6 in Sophus order (upsilon, omega); residual pair per point r = (f X/Z + cx - u, f Y/Z + cy - v),
 // p_c = R p + t; Jacobian w.r.t. the RIGHT perturbation at delta = 0 (what OptimizeWithAutoDiff's user-type
@@ -153,11 +205,16 @@ struct Se3ReprojModel {
   static constexpr int kXdim = 12;
   const T* data;
   const T* d;
-  int npts;
+  int npts, pt0, pt1;
   T G[28];
   static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
   __device__ __forceinline__ void init(int, int m, const void* dp) { npts = m / 2; data = static_cast<const T*>(dp); }
-  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (8 + 5 * size_t(npts)); }
+  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (8 + 5 * size_t(npts)); pt0 = 0; pt1 = npts; }
+  __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int) {
+    d = data + size_t(p) * (8 + 5 * size_t(npts));
+    pt0 = row0 / 2;
+    pt1 = min(npts, (row0 + rows) / 2);
+  }
 
   template <bool WANT_H>
   __device__ __forceinline__ T pass(const WaveLds<T>& L, int lane) {
@@ -173,7 +230,7 @@ struct Se3ReprojModel {
     }
     T csum = 0;
     const T* pts = d + 8;
-    for (int i = lane; i < npts; i += 64) {
+    for (int i = pt0 + lane; i < pt1; i += 64) {
       const T* q = pts + size_t(i) * 5;
       const T px = q[0], py = q[1], pz = q[2];
       const T X = R[0] * px + R[1] * py + R[2] * pz + t[0];
@@ -238,39 +295,8 @@ struct Se3ReprojModel {
         for (int b = a; b < 6; ++b) { M[a * LD + b] = O(G[tt(a, b)]); M[b * LD + a] = O(G[tt(a, b)]); }
     }
   }
-  // pose <- pose * exp(sign * delta): SO3 Rodrigues with small-angle series, SE3 V matrix (Sophus' formulas)
-  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const {
-    T dl[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dl[i] = sign * dv[i];
-    const T wx = dl[3], wy = dl[4], wz = dl[5];
-    const T t2 = wx * wx + wy * wy + wz * wz;
-    const T th = sqrt(t2);
-    T A, B, Cc;
-    if (t2 < T(1e-10)) { A = T(1) - t2 / T(6); B = T(0.5) - t2 / T(24); Cc = T(1) / T(6) - t2 / T(120); }
-    else { T sn, cs; sincos_t(th, &sn, &cs); A = sn / th; B = (T(1) - cs) / t2; Cc = (th - sn) / (t2 * th); }
-    T Rd[9];
-    Rd[0] = T(1) - B * (wy * wy + wz * wz); Rd[1] = -A * wz + B * wx * wy;          Rd[2] = A * wy + B * wx * wz;
-    Rd[3] = A * wz + B * wx * wy;          Rd[4] = T(1) - B * (wx * wx + wz * wz); Rd[5] = -A * wx + B * wy * wz;
-    Rd[6] = -A * wy + B * wx * wz;         Rd[7] = A * wx + B * wy * wz;          Rd[8] = T(1) - B * (wx * wx + wy * wy);
-    const T c1[3] = {wy * dl[2] - wz * dl[1], wz * dl[0] - wx * dl[2], wx * dl[1] - wy * dl[0]};
-    const T c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
-    T td[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) td[i] = dl[i] + B * c1[i] + Cc * c2[i];
-    T x[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = L.xs[i];
-    wave_sync();
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) L.xs[3 * i + j] = x[3 * i] * Rd[j] + x[3 * i + 1] * Rd[3 + j] + x[3 * i + 2] * Rd[6 + j];
-        L.xs[9 + i] = x[3 * i] * td[0] + x[3 * i + 1] * td[1] + x[3 * i + 2] * td[2] + x[9 + i];
-      }
-    }
-    wave_sync();
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
+    Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
   }
 };
 
@@ -416,6 +442,193 @@ __global__ void __launch_bounds__(256) solve_damped_kernel(const void* H_, const
   }
 }
 
+// ================================================================================================
+// Row-split ("wide") execution for few, huge problems (BASELINE configs C2 / C5: P = 1, m = 10^3..5*10^4).
+// One wavefront per problem would leave the chip idle, so the rows of every problem are split over S chunks:
+//   wide_partial_kernel  (P*S waves)  K1/K2 on one chunk each -> partial (H, g, cost) in HBM scratch
+//   wide_step_kernel     (P waves)    sums the S partials in a fixed order (deterministic), then runs ONE
+//                                     iteration of the same state machine (lm_iteration) with the state parked
+//                                     in global memory between launches
+// The host enqueues init + (partial, step) x max_iters on the stream without reading anything back: problems
+// that have stopped make their later launches no-ops.
+// ================================================================================================
+template <typename T>
+struct WideState {
+  LmState<T> st;
+  T xs[64], g[64], hd[64], dx[64], ldx[64];
+};
+
+struct WideParams {
+  const void* data;
+  void* x;
+  long long P;
+  int n, m, splits, chunk_rows;
+  toa_options opt;
+  toa_results res;
+  unsigned long long* counters;
+  void* state;     // WideState<T>[P]
+  void* partials;  // T[P][splits][n*n + n + 1]
+  void* hsum;      // T[P][n*n]
+  int lds_per_wave;
+};
+
+template <typename T>
+__device__ __forceinline__ void wide_copy_pods(WaveLds<T>& L, const WideParams* prm, int lane) {
+  const int* src_o = reinterpret_cast<const int*>(&prm->opt);
+  int* dst_o = reinterpret_cast<int*>(L.opt);
+  for (int i = lane; i < int(sizeof(toa_options) / 4); i += 64) dst_o[i] = src_o[i];
+  const int* src_r = reinterpret_cast<const int*>(&prm->res);
+  int* dst_r = reinterpret_cast<int*>(L.res);
+  for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
+}
+template <typename T>
+__device__ __forceinline__ void wide_load_state(WaveLds<T>& L, const WideState<T>* ws, int lane) {
+  const int* src = reinterpret_cast<const int*>(&ws->st);
+  int* dst = reinterpret_cast<int*>(L.st);
+  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
+  L.xs[lane] = ws->xs[lane]; L.g[lane] = ws->g[lane]; L.hd[lane] = ws->hd[lane];
+  L.dx[lane] = ws->dx[lane]; L.ldx[lane] = ws->ldx[lane];
+  wave_sync();
+}
+template <typename T>
+__device__ __forceinline__ void wide_store_state(const WaveLds<T>& L, WideState<T>* ws, int lane) {
+  wave_sync();
+  const int* src = reinterpret_cast<const int*>(L.st);
+  int* dst = reinterpret_cast<int*>(&ws->st);
+  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
+  ws->xs[lane] = L.xs[lane]; ws->g[lane] = L.g[lane]; ws->hd[lane] = L.hd[lane];
+  ws->dx[lane] = L.dx[lane]; ws->ldx[lane] = L.ldx[lane];
+}
+
+template <typename T, int XD>
+__global__ void __launch_bounds__(256) wide_init_kernel(const WideParams* __restrict__ prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p = (long long)blockIdx.x * 4 + wave;
+  if (p >= prm->P) return;
+  const int n = prm->n;
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm->lds_per_wave, n);
+  wide_copy_pods(L, prm, lane);
+  wave_sync();
+  const int xd = XD ? XD : n;
+  const T* X = static_cast<const T*>(prm->x);
+  L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+  L.g[lane] = T(0);
+  L.hd[lane] = T(0);
+  L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+  lm_init<T>(L, lane);
+  wide_store_state(L, static_cast<WideState<T>*>(prm->state) + p, lane);
+}
+
+template <typename Model>
+__global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __restrict__ prm) {
+  using T = typename Model::Scalar;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = prm->n, S = prm->splits;
+  const long long unit = (long long)blockIdx.x * 4 + wave;
+  if (unit >= prm->P * S) return;
+  const long long p = unit / S;
+  const int sidx = int(unit % S);
+  const WideState<T>* ws = static_cast<const WideState<T>*>(prm->state) + p;
+  if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) return;  // this problem is finished
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm->lds_per_wave, n);
+  L.xs[lane] = ws->xs[lane];
+  wave_sync();
+  const bool do_acc = prm->opt.solver_type != 0 || ws->st.rebuild;
+  const int m4 = (prm->m + 3) & ~3;
+  const int row0 = sidx * prm->chunk_rows;
+  const int rows = min(prm->chunk_rows, m4 - row0);
+  Model model;
+  model.init(n, prm->m, prm->data);
+  model.bind_chunk(p, row0, rows, n);
+  const int stride = n * n + n + 1;
+  T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
+  T c;
+  int nr;
+  if (do_acc) {
+    model.accumulate(L, n, lane, c, nr);
+    model.write_sym(part, n, n, lane);
+    wave_sync();
+    if (lane < n) {
+      part[lane * n + lane] = L.hd[lane];
+      part[n * n + lane] = L.g[lane];
+    }
+  } else {
+    model.evaluate(L, n, lane, c, nr);
+  }
+  if (lane == 0) part[n * n + n] = c;
+}
+
+// Model for the step kernel: "accumulate" = fold the S chunk partials (fixed order => deterministic).
+template <typename T, int NPAD, typename Manifold>
+struct PartialSumModel {
+  using Scalar = T;
+  static constexpr int kNpad = NPAD;
+  static constexpr int kXdim = Manifold::kXdim;
+  const T* part;
+  T* hsum;
+  int S, n_, m;
+  __device__ __forceinline__ T fold(int off) const {
+    T s = 0;
+    const int stride = n_ * n_ + n_ + 1;
+    for (int k = 0; k < S; ++k) s += part[size_t(k) * stride + off];
+    return s;
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    for (int e = lane; e < n * n; e += 64) hsum[e] = fold(e);
+    if (lane < n) { L.g[lane] = fold(n * n + lane); L.hd[lane] = fold(lane * n + lane); }
+    cost = fold(n * n + n);
+    nres = m;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>&, int n, int, T& cost, int& nres) {
+    cost = fold(n * n + n);
+    nres = m;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
+    for (int e = lane; e < n * n; e += 64) M[(e / n) * LD + (e % n)] = O(hsum[e]);
+  }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int n, int lane) const {
+    Manifold::plus_eq(L, d, sign, n, lane);
+  }
+};
+
+template <typename T, int NPAD, typename Manifold>
+__global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __restrict__ prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p = (long long)blockIdx.x * 4 + wave;
+  if (p >= prm->P) return;
+  const int n = prm->n;
+  WideState<T>* ws = static_cast<WideState<T>*>(prm->state) + p;
+  if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) return;
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm->lds_per_wave, n);
+  wide_copy_pods(L, prm, lane);
+  wide_load_state(L, ws, lane);
+  PartialSumModel<T, NPAD, Manifold> model;
+  model.S = prm->splits;
+  model.n_ = n;
+  model.m = prm->m;
+  model.part = static_cast<const T*>(prm->partials) + size_t(p) * prm->splits * (n * n + n + 1);
+  model.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
+  const bool more = lm_iteration<T>(model, L, n, lane, p);
+  if (!more) {
+    lm_finalize<T>(model, L, n, lane, p);  // sets a non-zero StopReason: later launches skip this problem
+    const int xd = Manifold::kXdim ? Manifold::kXdim : n;
+    T* X = static_cast<T*>(prm->x);
+    if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+    if (prm->counters && lane == 0) {
+      atomicAdd(&prm->counters[0], L.st->acc_passes);
+      atomicAdd(&prm->counters[1], L.st->eval_passes);
+      atomicAdd(&prm->counters[2], L.st->solves);
+      atomicAdd(&prm->counters[3], L.st->problems);
+    }
+  }
+  wide_store_state(L, ws, lane);
+}
+
 }  // namespace toa
 
 // ================================================================================================
@@ -430,6 +643,8 @@ struct toa_context {
   char name[128] = {0};
   int* queue = nullptr;  // device work-queue head
   void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
+  void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
+  size_t scratch_bytes = 0;
   // launch-configuration cache: (kernel, dynamic LDS bytes) -> resident workgroups per CU.
   // hipFuncSetAttribute / hipOccupancy* cost milliseconds per call; pay them once per variant.
   struct Cfg { const void* fn; size_t lds; int wg_per_cu; };
@@ -508,6 +723,71 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   return TOA_OK;
 }
 
+// Row-split driver.  Model = the chunk-capable residual model, NPAD / Manifold as for the step kernel.
+template <typename Model, int NPAD, typename Manifold>
+inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
+  using T = typename Model::Scalar;
+  const int n = fp.n, m = fp.m;
+  const long long P = fp.P;
+  const int m4 = (m + 3) & ~3;
+  // chunking: the step kernel folds the S partials serially (cost ~ S * n^2 / 64 per lane) while the partial
+  // kernel's time falls as rows / S, so keep S moderate: >= 256 rows per chunk, <= 64 chunks, and no more waves
+  // than ~8 per CU; chunk rows a multiple of 16.  (C5: 50 000 rows -> 64 chunks: 289 us per solve vs 742 us one-wave.)
+  long long S = splits_req > 0 ? splits_req : m4 / 256;
+  if (splits_req <= 0) {
+    if (S > 64) S = 64;
+    const long long cap = (long long)h->num_cus * 8 / (P > 0 ? P : 1);
+    if (S > cap) S = cap;
+  }
+  if (S > m4 / 16) S = m4 / 16;
+  if (S < 1) S = 1;
+  int chunk = int((m4 + S - 1) / S);
+  chunk = (chunk + 15) & ~15;
+  S = (m4 + chunk - 1) / chunk;
+  size_t pw, pwg;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  const size_t stride = size_t(n) * n + n + 1;
+  const size_t b_state = (size_t(P) * sizeof(WideState<T>) + 255) & ~size_t(255);
+  const size_t b_part = (size_t(P) * S * stride * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_hsum = (size_t(P) * n * n * sizeof(T) + 255) & ~size_t(255);
+  const size_t need = b_state + b_part + b_hsum;
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->scratch, need));
+    h->scratch_bytes = need;
+  }
+  WideParams wp;
+  std::memset(&wp, 0, sizeof(wp));
+  wp.data = fp.data; wp.x = fp.x; wp.P = P; wp.n = n; wp.m = m;
+  wp.splits = int(S); wp.chunk_rows = chunk;
+  wp.opt = fp.opt; wp.res = fp.res; wp.counters = fp.counters;
+  wp.state = h->scratch;
+  wp.partials = static_cast<char*>(h->scratch) + b_state;
+  wp.hsum = static_cast<char*>(h->scratch) + b_state + b_part;
+  wp.lds_per_wave = int(pw);
+  static_assert(sizeof(WideParams) <= 1024, "parameter block too large");
+  HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+  const WideParams* dp = static_cast<const WideParams*>(h->params_dev);
+  auto k_init = wide_init_kernel<T, Manifold::kXdim>;
+  auto k_part = wide_partial_kernel<Model>;
+  auto k_step = wide_step_kernel<T, NPAD, Manifold>;
+  HIP_TRY(hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  const unsigned g_p = unsigned((P + 3) / 4), g_u = unsigned((P * S + 3) / 4);
+  hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  const int iters = fp.opt.max_iters + 1 + (fp.opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(k_part, dim3(g_u), dim3(256), pwg, h->stream, dp);
+    hipLaunchKernelGGL(k_step, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  }
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 template <typename T, int NPAD>
 inline int launch_solve(toa_handle h, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
   long long grid = (P + 3) / 4;
@@ -531,5 +811,6 @@ int toa_inst_accumulate(int dtag, int nbm, int thin, toa_handle h, int n, int m,
 int toa_inst_misc_fused(int dtag, int model, int npad, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data,
                              const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_wide(int dtag, int model, int nbm, int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok);

@@ -274,62 +274,71 @@ __device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const i
   return (is_good_step ? 1 : 0) | 2;
 }
 
-// Runs one problem to its StopReason.  On entry L.xs[] holds x0 (lanes >= n: 0), on exit the result.
-template <typename T, typename Model>
-__device__ __forceinline__ void lm_solve_problem(Model& model, WaveLds<T>& L, const int n, const int lane,
-                                                 const long long p) {
+// ---- the three stages of OptimizeAcc (optimizer.h:242-327), separable so that the same state machine runs either
+//      inside one wave for a whole solve (lm_solve_problem) or one iteration per launch with the state parked in
+//      global memory between launches (the row-split "wide" path for single huge problems, kernels.hpp).
+template <typename T>
+__device__ __forceinline__ void lm_init(WaveLds<T>& L, const int lane) {
   LmState<T>& S = *L.st;
-  const bool in_n = lane < n;
-  {
-    const toa_options& opt = *L.opt;
-    // SolverLM::reset  lm.h:46-52
-    S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;
-    // Output  output.h:104-117
-    S.final_cost = kDblMax; S.final_nres = 0; S.final_rerr = kDblMax;
-    S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
-    S.cost_val = 0; S.cost_nres = 0;
-    // OptimizeAcc locals  optimizer.h:248-263
-    S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
-    S.has_last_dx = 0; S.last_was_success = 1;
-    L.ldx[lane] = T(0);
-    L.dx[lane] = T(0);
-  }
+  const toa_options& opt = *L.opt;
+  // SolverLM::reset  lm.h:46-52
+  S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;
+  // Output  output.h:104-117
+  S.final_cost = kDblMax; S.final_nres = 0; S.final_rerr = kDblMax;
+  S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
+  S.cost_val = 0; S.cost_nres = 0;
+  // OptimizeAcc locals  optimizer.h:248-263
+  S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
+  S.has_last_dx = 0; S.last_was_success = 1;
+  S.iter = 0;
+  L.ldx[lane] = T(0);
+  L.dx[lane] = T(0);
   wave_sync();
-  for (S.iter = 0; S.iter < S.max_iters; S.iter = S.iter + 1) {
-    // ================= Step  optimizer.h:331-539 =================
-    int status = 0;  // bit0 good, bit1 has_dx
-    const int rc = lm_build_and_solve<T>(model, L, n, lane);
-    if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399 (overwrites kMaxConsecNoDecr set just above)
-    if (rc == 0) status = lm_judge_step<T>(L, n, lane, p);
-    wave_sync();
-    // ================= back in OptimizeAcc  optimizer.h:269-309 =================
-    const toa_options& opt = *L.opt;
-    bool eval_only = false;
-    if (status & 1) {                 // :271-279
-      model.plus_eq(L, L.dx, T(1), n, lane);   // ptrait::PlusEq(x, dx): traits.h:184-190 / sophus.h:24-26
+}
+
+// One pass of the loop body at optimizer.h:266-310 (uses and advances S.iter).  Returns false when the loop ends.
+template <typename T, typename Model>
+__device__ __forceinline__ bool lm_iteration(Model& model, WaveLds<T>& L, const int n, const int lane, const long long p) {
+  LmState<T>& S = *L.st;
+  // ================= Step  optimizer.h:331-539 =================
+  int status = 0;  // bit0 good, bit1 has_dx
+  const int rc = lm_build_and_solve<T>(model, L, n, lane);
+  if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399 (overwrites kMaxConsecNoDecr set just above)
+  if (rc == 0) status = lm_judge_step<T>(L, n, lane, p);
+  wave_sync();
+  // ================= back in OptimizeAcc  optimizer.h:269-309 =================
+  const toa_options& opt = *L.opt;
+  bool eval_only = false;
+  if (status & 1) {                 // :271-279
+    model.plus_eq(L, L.dx, T(1), n, lane);   // ptrait::PlusEq(x, dx): traits.h:184-190 / sophus.h:24-26
+    L.ldx[lane] = L.dx[lane];
+    S.has_last_dx = 1;
+    S.last_was_success = 1;
+    if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
+  } else {                          // :281-297
+    if (S.has_last_dx) {
+      model.plus_eq(L, L.ldx, T(-1), n, lane);  // roll back: PlusEq(x, -last_dx)
+      S.has_last_dx = 0;
+    } else if (status & 2) {
+      model.plus_eq(L, L.dx, T(1), n, lane);
       L.ldx[lane] = L.dx[lane];
       S.has_last_dx = 1;
-      S.last_was_success = 1;
-      if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
-    } else {                          // :281-297
-      if (S.has_last_dx) {
-        model.plus_eq(L, L.ldx, T(-1), n, lane);  // roll back: PlusEq(x, -last_dx)
-        S.has_last_dx = 0;
-      } else if (status & 2) {
-        model.plus_eq(L, L.dx, T(1), n, lane);
-        L.ldx[lane] = L.dx[lane];
-        S.has_last_dx = 1;
-      }
-      eval_only = (S.last_was_success == 0);
-      S.last_was_success = 0;
     }
-    if (opt.solver_type == 0) S.rebuild = eval_only ? 0 : 1;  // :299, lm.h:55 (GN: base.h:56 no-op)
-    S.num_iters = S.num_iters + 1;                            // :307
-    wave_sync();
-    if (S.stop != TOA_STOP_NONE) break;                       // :309
+    eval_only = (S.last_was_success == 0);
+    S.last_was_success = 0;
   }
-  if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
+  if (opt.solver_type == 0) S.rebuild = eval_only ? 0 : 1;  // :299, lm.h:55 (GN: base.h:56 no-op)
+  S.num_iters = S.num_iters + 1;                            // :307
+  S.iter = S.iter + 1;
+  wave_sync();
+  return S.stop == TOA_STOP_NONE && S.iter < S.max_iters;   // :309 / loop bound :266
+}
 
+template <typename T, typename Model>
+__device__ __forceinline__ void lm_finalize(Model& model, WaveLds<T>& L, const int n, const int lane, const long long p) {
+  LmState<T>& S = *L.st;
+  const bool in_n = lane < n;
+  if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
   const toa_options& opt = *L.opt;
   const toa_results& res = *L.res;
   // ---- final Hessian, undamped  optimizer.h:313-316, lm.h:157-171
@@ -354,6 +363,15 @@ __device__ __forceinline__ void lm_solve_problem(Model& model, WaveLds<T>& L, co
   }
   S.problems++;
   wave_sync();
+}
+
+// Runs one problem to its StopReason.  On entry L.xs[] holds x0 (lanes >= n: 0), on exit the result.
+template <typename T, typename Model>
+__device__ __forceinline__ void lm_solve_problem(Model& model, WaveLds<T>& L, const int n, const int lane,
+                                                 const long long p) {
+  lm_init<T>(L, lane);
+  while (lm_iteration<T>(model, L, n, lane, p)) {}
+  lm_finalize<T>(model, L, n, lane, p);
 }
 
 }  // namespace toa
