@@ -46,6 +46,10 @@ extern "C" {
 #define TOA_MODEL_GAUSSIAN_PRIOR 2  /* r = (x-y)/sigma, m = n  (benchmarks/dense.cpp:53-66, losses/mahalanobis.h:124-136) */
 #define TOA_MODEL_SQRT2 3           /* r = x*x - 2, n = m = 1   (tests/sqrt2.cpp:30-70) */
 #define TOA_MODEL_SE3_REPROJ 4      /* pinhole reprojection of 3-D points, SE3 right-perturbation */
+/* residual functors differentiated ON THE DEVICE with forward-mode dual numbers (csrc/jet.hpp = ceres::Jet on the GPU;
+ * replaces OptimizeWithAutoDiff, include/tinyopt/diff/optimize_autodiff.h:21-169) */
+#define TOA_MODEL_CIRCLE_FIT 5      /* r_i = ||p_i - c||^2 - radius^2, x = (cx, cy, radius)   (tests/circle.cpp:32-68) */
+#define TOA_MODEL_DENSE_ROW_AD6 6   /* the DenseRow residual, n = 6, written without a hand-derived Jacobian */
 
 /* StopReason — identical values to include/tinyopt/stop_reasons.h:14-43 */
 #define TOA_STOP_OUT_OF_MEMORY (-4)
@@ -158,7 +162,9 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_SE3_REPROJ      n == 6 (tangent, Sophus order upsilon, omega), m = 2 * points; x: [P][12] = rotation matrix
  *                           (row-major) + translation, updated by pose <- pose * exp(delta)
  *                           (include/tinyopt/3rdparty/traits/sophus.h:24-26); data_dev: [P][8 + 5*m/2] =
- *                           [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point]. */
+ *                           [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point].
+ * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
+ * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).

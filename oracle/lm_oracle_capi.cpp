@@ -363,4 +363,51 @@ void oracle_se3_plus(int dtype, int64_t P, void* poses, const void* delta) {
   }
 }
 
+
+// Circle fit (tests/circle.cpp:32-68): x = (cx, cy, radius); r_i = ||p_i - c||^2 - radius^2; the reference
+// differentiates it with Jets — here the analytic Jacobian (identical to rounding) folded as the AD bridge does.
+// obs: [P][npts][2], x: [P][3] in place.
+void oracle_circle_fit_lm(int dtype, int64_t P, int npts, const void* obs, void* x, const toa_options* opts,
+                          int32_t* stop, int32_t* iters, double* cost) {
+  const Options o = from_pod(*opts);
+  for (int64_t p = 0; p < P; ++p) {
+    Output out;
+    if (dtype == TOA_F32) {
+      const float* ob = (const float*)obs + size_t(p) * npts * 2;
+      std::vector<float> xv((float*)x + p * 3, (float*)x + p * 3 + 3);
+      auto acc = [&](const std::vector<float>& v, float* g, float* H) {
+        std::vector<float> r(npts), J(size_t(npts) * 3);
+        for (int i = 0; i < npts; ++i) {
+          const float dx = ob[2 * i] - v[0], dy = ob[2 * i + 1] - v[1];
+          r[i] = dx * dx + dy * dy - v[2] * v[2];
+          J[i * 3] = -2 * dx; J[i * 3 + 1] = -2 * dy; J[i * 3 + 2] = -2 * v[2];
+        }
+        if (g) { std::fill(g, g + 3, 0.f); }
+        return AccumulateFromJ<float>(npts, 3, r.data(), J.data(), g, H);
+      };
+      Optimizer<float> opt(o, 3);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<float>());
+      std::memcpy((float*)x + p * 3, xv.data(), 12);
+    } else {
+      const double* ob = (const double*)obs + size_t(p) * npts * 2;
+      std::vector<double> xv((double*)x + p * 3, (double*)x + p * 3 + 3);
+      auto acc = [&](const std::vector<double>& v, double* g, double* H) {
+        std::vector<double> r(npts), J(size_t(npts) * 3);
+        for (int i = 0; i < npts; ++i) {
+          const double dx = ob[2 * i] - v[0], dy = ob[2 * i + 1] - v[1];
+          r[i] = dx * dx + dy * dy - v[2] * v[2];
+          J[i * 3] = -2 * dx; J[i * 3 + 1] = -2 * dy; J[i * 3 + 2] = -2 * v[2];
+        }
+        return AccumulateFromJ<double>(npts, 3, r.data(), J.data(), g, H);
+      };
+      Optimizer<double> opt(o, 3);
+      out = opt.OptimizeAcc(xv, acc, EuclidPlus<double>());
+      std::memcpy((double*)x + p * 3, xv.data(), 24);
+    }
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (cost) cost[p] = out.final_cost.cost;
+  }
+}
+
 }  // extern "C"

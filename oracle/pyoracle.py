@@ -59,6 +59,7 @@ def load(path: str | None = None):
     lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp]
     lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
     lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
+    lib.oracle_circle_fit_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -214,6 +215,19 @@ def se3_reproj_lm(data, pose0, npts, pod: ToaOptions):
     lib.oracle_se3_reproj_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(data)), _p(x), C.byref(pod), _p(stop), _p(iters),
                              _p(cost), _p(Hf))
     return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf)
+
+
+def circle_fit_lm(obs, x0, pod: ToaOptions):
+    """tests/circle.cpp:32-68 for a batch; obs [P, npts, 2], x0 [P, 3]."""
+    lib = load()
+    P, npts, _ = obs.shape
+    x = np.array(x0, copy=True)
+    stop = np.zeros(P, np.int32)
+    iters = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    lib.oracle_circle_fit_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(obs)), _p(x), C.byref(pod), _p(stop), _p(iters),
+                             _p(cost))
+    return dict(x=x, stop=stop, iters=iters, cost=cost)
 
 
 def run_pin_tests() -> subprocess.CompletedProcess:

@@ -15,8 +15,8 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (F32, F64, MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ, MODEL_SQRT2, ToaOptions, ToaResults,
-                    check)
+from ._capi import (F32, F64, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
+                    MODEL_SQRT2, ToaOptions, ToaResults, check)
 
 
 class StopReason(enum.IntEnum):  # include/tinyopt/stop_reasons.h:14-43
@@ -278,7 +278,37 @@ class SE3Reproj:
         return (self.m // 2) * 5 * self.packed.element_size()
 
 
-_MODELS = (DenseRow, GaussianPrior, Sqrt2, SE3Reproj)
+class CircleFit:
+    """tests/circle.cpp:32-68 on the device, differentiated by forward-mode dual numbers (csrc/jet.hpp):
+    x = (cx, cy, radius), one residual ||p - c||^2 - radius^2 per observed point.  obs: [P, m, 2]."""
+    model_id = MODEL_CIRCLE_FIT
+
+    def __init__(self, obs: torch.Tensor):
+        assert obs.dim() == 3 and obs.shape[2] == 2 and obs.is_cuda
+        self.P, self.m, self.n, self.dtype = obs.shape[0], obs.shape[1], 3, obs.dtype
+        self.packed = obs.contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return self.m * 2 * self.packed.element_size()
+
+
+class DenseRowAD6:
+    """The DenseRow residual for n = 6 written the tinyopt way — residual only, Jacobian by device AD.
+    A: [P, m, 6], b: [P, m] (natural layout)."""
+    model_id = MODEL_DENSE_ROW_AD6
+
+    def __init__(self, A: torch.Tensor, b: torch.Tensor):
+        assert A.dim() == 3 and A.shape[2] == 6 and b.shape == A.shape[:2] and A.is_cuda
+        self.P, self.m, self.n, self.dtype = A.shape[0], A.shape[1], 6, A.dtype
+        self.packed = torch.cat([A, b[..., None]], dim=2).contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return self.m * 7 * self.packed.element_size()
+
+
+_MODELS = (DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
 
 
 @dataclass

@@ -303,6 +303,14 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_SQRT2:
       if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
       return TOA_OK;
+    case TOA_MODEL_CIRCLE_FIT:
+      if (n != 3) return fail(TOA_E_ARG, "CircleFit: n must be 3 (cx, cy, radius)");
+      if (!data) return fail(TOA_E_ARG, "CircleFit: data pointer ([P][m][2] observed points) is null");
+      return TOA_OK;
+    case TOA_MODEL_DENSE_ROW_AD6:
+      if (n != 6) return fail(TOA_E_ARG, "DenseRowAD6: n must be 6");
+      if (!data) return fail(TOA_E_ARG, "DenseRowAD6: data pointer ([P][m][7] = a_i, b_i) is null");
+      return TOA_OK;
     case TOA_MODEL_SE3_REPROJ:
       if (n != 6 || m < 2 || (m & 1)) return fail(TOA_E_ARG, "SE3Reproj: n must be 6 and m an even count of residuals");
       if (!data) return fail(TOA_E_ARG, "SE3Reproj: data pointer ([P][8 + 5*m/2]) is null");

@@ -15,6 +15,8 @@ using InstT = double;
 int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, const FusedParams& prm) {
   if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
   if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
+  if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
+  if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
   switch (npad) {
     case 16: return launch_fused<GaussianPriorModel<InstT, 16>>(h, prm);
     case 32: return launch_fused<GaussianPriorModel<InstT, 32>>(h, prm);
@@ -33,6 +35,10 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
   if (model == TOA_MODEL_SQRT2) return launch_accumulate<Sqrt2Model<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_SE3_REPROJ)
     return launch_accumulate<Se3ReprojModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_CIRCLE_FIT)
+    return launch_accumulate<JetModel<InstT, CircleFitFunctor<InstT>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_DENSE_ROW_AD6)
+    return launch_accumulate<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return launch_accumulate<GaussianPriorModel<InstT, 16>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 #elif defined(TOA_INST_SOLVE)

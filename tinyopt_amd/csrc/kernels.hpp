@@ -17,6 +17,7 @@
 
 #include "../../include/tinyopt_amd.h"
 #include "dense_row.hpp"
+#include "jet.hpp"
 #include "ldlt_lds.hpp"
 #include "ldlt_regs.hpp"
 #include "lm_device.hpp"
@@ -297,6 +298,131 @@ struct Se3ReprojModel {
   }
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
     Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Automatic differentiation on the device: JetModel turns a residual functor written ONCE as a template
+// over its scalar type — the form tinyopt users write (`Optimize(x, [](const auto& x) { return r(x); })`,
+// docs/API.md:21-35) — into the Accumulate contract, exactly as OptimizeWithAutoDiff does on the host
+// (diff/optimize_autodiff.h:91-166): seed x_jet[i].v[i] = 1 (:56-69), evaluate r(x_jet), J.row = r.v, then
+// grad = J^T r, H = J^T J, cost = ||r||^2 (:151-164).  Cost-only calls evaluate the SAME functor on plain T
+// (no wasted dual arithmetic).  Thread-per-item evaluation with the (kN+1)(kN+2)/2 upper Gram of [J | r] in
+// registers, folded across the wave once per pass.
+//
+// Functor concept (all static):  kN parameters (<= 12), kR residuals per item, kD data scalars per item,
+//   kH header scalars per problem;  template <class S> static void eval(const S* x, const T* header,
+//   const T* item, S* r).   Data per problem: [kH | items x kD].
+// A user family = one functor + one line in inst.hip (INTEGRATION.md "bring your own functor").
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename F>
+struct JetModel {
+  using Scalar = T;
+  static constexpr int kNpad = 16;
+  static constexpr int kXdim = 0;
+  static constexpr int kN = F::kN, kW = F::kN + 1, kG = kW * (kW + 1) / 2;
+  static_assert(F::kN >= 1 && F::kN <= 12, "register Gram: kN <= 12");
+  const T* data;
+  const T* d;
+  int items, it0, it1;
+  T G[kG];
+  static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * kW - a * (a - 1) / 2 + (b - a); }
+  __device__ __forceinline__ void init(int, int m, const void* dp) { items = m / F::kR; data = static_cast<const T*>(dp); }
+  __device__ __forceinline__ void bind(long long p) {
+    d = data + size_t(p) * (F::kH + size_t(items) * F::kD);
+    it0 = 0; it1 = items;
+  }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const { euclid_plus_eq(L, dv, sign, lane); }
+
+  template <bool WANT_H>
+  __device__ __forceinline__ T pass(const WaveLds<T>& L, int lane) {
+    T x[kN];
+#pragma unroll
+    for (int i = 0; i < kN; ++i) x[i] = L.xs[i];
+    if (WANT_H) {
+#pragma unroll
+      for (int i = 0; i < kG; ++i) G[i] = T(0);
+    }
+    T csum = 0;
+    const T* itemsp = d + F::kH;
+    for (int i = it0 + lane; i < it1; i += 64) {
+      const T* item = itemsp + size_t(i) * F::kD;
+      if (WANT_H) {
+        Jet<T, kN> xj[kN], r[F::kR];
+#pragma unroll
+        for (int k = 0; k < kN; ++k) xj[k] = Jet<T, kN>(x[k], k);   // optimize_autodiff.h:56-69
+        F::template eval<Jet<T, kN>>(xj, d, item, r);
+#pragma unroll
+        for (int q = 0; q < F::kR; ++q) {
+          T w[kW];
+#pragma unroll
+          for (int a = 0; a < kN; ++a) w[a] = r[q].v[a];             // J.row(i) = res[i].v   (:127-148)
+          w[kN] = r[q].a;
+#pragma unroll
+          for (int a = 0; a < kW; ++a)
+#pragma unroll
+            for (int b = a; b < kW; ++b) G[tt(a, b)] += w[a] * w[b];
+        }
+      } else {
+        T r[F::kR];
+        F::template eval<T>(x, d, item, r);
+#pragma unroll
+        for (int q = 0; q < F::kR; ++q) csum += r[q] * r[q];
+      }
+    }
+    if (WANT_H) {
+#pragma unroll
+      for (int i = 0; i < kG; ++i) G[i] = wave_allreduce_sum(G[i]);
+      return G[tt(kN, kN)];
+    }
+    return wave_allreduce_sum(csum);
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    cost = pass<true>(L, lane);
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < kN; ++a) { L.g[a] = G[tt(a, kN)]; L.hd[a] = G[tt(a, a)]; }
+    }
+    nres = items * F::kR;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    cost = pass<false>(L, lane);
+    nres = items * F::kR;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int, int lane) const {
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < kN; ++a)
+#pragma unroll
+        for (int b = a; b < kN; ++b) { M[a * LD + b] = O(G[tt(a, b)]); M[b * LD + a] = O(G[tt(a, b)]); }
+    }
+  }
+};
+
+// tests/circle.cpp:32-68: x = (cx, cy, radius); one residual per observed point p: ||p - c||^2 - radius^2
+template <typename T>
+struct CircleFitFunctor {
+  static constexpr int kN = 3, kR = 1, kD = 2, kH = 0;
+  template <class S>
+  static __device__ __forceinline__ void eval(const S* x, const T*, const T* p, S* r) {
+    const S dx = p[0] - x[0];
+    const S dy = p[1] - x[1];
+    r[0] = dx * dx + dy * dy - x[2] * x[2];
+  }
+};
+// The DenseRow residual written the tinyopt way (no hand-derived Jacobian): item = [a_0 .. a_{N-1}, b].
+// Exists to cross-check the AD machinery (Jet sin / products) against the analytic MFMA path.
+template <typename T, int NN>
+struct DenseRowAdFunctor {
+  static constexpr int kN = NN, kR = 1, kD = NN + 1, kH = 0;
+  template <class S>
+  static __device__ __forceinline__ void eval(const S* x, const T*, const T* item, S* r) {
+    S t = x[0] * item[0];
+#pragma unroll
+    for (int j = 1; j < NN; ++j) t = t + x[j] * item[j];
+    r[0] = t + T(0.1) * sin(t) - item[NN];
   }
 };
 
