@@ -181,6 +181,11 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);
 
+/* ---- covariance seam (replaces tinyopt::InvCov / DenseInvCov, math.h:41-91, used by Output::Covariance
+ *      output.h:80-94 and SolverLM::Covariance lm.h:174): C = H^-1 by LDL^T against the identity, same acceptance
+ *      rule as SolveLDLT.  H_dev, C_dev: [P][n*n] T; ok_dev: [P] int32 (0 = "not invertible" => std::nullopt). */
+int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, void* C_dev, int32_t* ok_dev);
+
 /* ---- fused batched solve (replaces Optimizer_::OptimizeAcc optimizer.h:242-327 + Step :331-539 +
  *      SolverLM lm.h:46-171 for P independent problems).  x_dev: [P][n] T, updated in place
  *      (reference: `x` by non-const ref).  One launch; no host round trips; each wavefront runs whole

@@ -171,3 +171,31 @@ def test_se3_reproj_lm(ta, oracle, dtype, tdt, npts):
         assert np.allclose(out.final_hessian.cpu().numpy(), ref["H"], rtol=1e-9, atol=1e-6 * np.abs(ref["H"]).max())
     else:
         assert np.abs(xg - ref["x"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_inv_cov_and_output_covariance(ta, oracle, dtype, tdt):
+    """tinyopt::InvCov (math.h:41-57) + Output::Covariance (output.h:80-94), pinned like tests/cov.cpp:20-47:
+    the covariance from the final undamped Hessian recovers the prior standard deviations."""
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 7, 33, 50):
+        J = rng.uniform(-1, 1, (5, 3 * n + 2, n))
+        H = np.einsum("pij,pik->pjk", J, J).astype(dtype)
+        C, ok = ta.inv_cov(torch.from_numpy(H).cuda())
+        assert ok.cpu().numpy().all()
+        I = np.einsum("pij,pjk->pik", H.astype(np.float64), C.cpu().numpy().astype(np.float64))
+        assert np.abs(I - np.eye(n)).max() < (1e-9 if dtype == np.float64 else 5e-3)
+    bad = np.stack([np.diag([1.0, -1.0, 2.0]), np.diag([1.0, 2.0, 3.0])]).astype(dtype)   # indefinite -> nullopt
+    C, ok = ta.inv_cov(torch.from_numpy(bad).cuda())
+    assert list(ok.cpu().numpy()) == [0, 1]
+    # tests/cov.cpp: Gaussian prior, sigma = 4.2 -> sqrt(diag(Cov)) == sigma
+    P, n = 6, 4
+    y = rng.uniform(-10, 10, (P, n)).astype(dtype)
+    sigma = np.full((P, n), 4.2, dtype)
+    model = ta.GaussianPrior(torch.from_numpy(y).cuda(), torch.from_numpy(sigma).cuda())
+    x = torch.zeros(P, n, dtype=tdt, device="cuda")
+    out = ta.Optimize(x, model, ta.Options())
+    assert out.Succeeded().all() and out.Converged().all()
+    Cv, ok = out.Covariance()
+    d = np.sqrt(np.diagonal(Cv.cpu().numpy(), axis1=1, axis2=2))
+    assert ok.cpu().numpy().all() and np.abs(d - 4.2).max() < (1e-7 if dtype == np.float64 else 1e-4)

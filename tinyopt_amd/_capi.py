@@ -72,6 +72,7 @@ PROTOTYPES = {
     "toa_dense_row_synth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int64, _P, _P, _P]),
     "toa_accumulate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),
     "toa_solve_damped": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_double, _P, _P]),
+    "toa_inv_cov": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "toa_lm_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
                              C.POINTER(ToaResults), _P]),
     "toa_lm_run_split": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),

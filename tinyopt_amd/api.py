@@ -327,6 +327,20 @@ class Output:
     successes: Optional[torch.Tensor] = None
     counters: Optional[torch.Tensor] = None  # [acc passes, eval passes, solves, problems]
 
+    def Covariance(self, rescaled: bool = False):
+        """Output::Covariance (output.h:80-94): inverse of the final undamped Hessian per problem; with
+        rescaled=True multiplied by eps^2/(#eps - dims) where #residuals > dims.  Returns (C [P,n,n], ok [P]);
+        ok == 0 where H is not invertible (std::nullopt in the reference)."""
+        if self.final_hessian is None:
+            raise ValueError("final_hessian was not saved (options.hessian.save_last)")
+        C, ok = inv_cov(self.final_hessian)
+        if rescaled:
+            n = self.final_hessian.shape[1]
+            nres = self.final_num_residuals.to(torch.float64)
+            scale = torch.where(nres > n, self.final_cost * self.final_cost / (nres - n).clamp(min=1), torch.ones_like(nres))
+            C = C * scale[:, None, None]
+        return C, ok
+
     def Succeeded(self) -> torch.Tensor:  # output.h:30
         return self.stop_reason >= 0
 
@@ -421,3 +435,15 @@ def solve_damped(H: torch.Tensor, g: torch.Tensor, scale: float = 1.0, ctx: Opti
     check(ctx.lib.toa_solve_damped(ctx.h, _dtype_code(g.dtype), n, P, H.data_ptr(), g.data_ptr(), float(scale),
                                    dx.data_ptr(), ok.data_ptr()))
     return dx, ok
+
+
+def inv_cov(H: torch.Tensor, ctx: Optional[Context] = None):
+    """tinyopt::InvCov (math.h:41-91) for a batch: C = H^-1 via LDL^T with the reference's acceptance rule.
+    Returns (C [P,n,n], ok [P] int32)."""
+    ctx = ctx or default_context(H.device.index)
+    H = H.contiguous()
+    P, n, _ = H.shape
+    Cm = torch.zeros_like(H)
+    ok = torch.zeros(P, dtype=torch.int32, device=H.device)
+    check(ctx.lib.toa_inv_cov(ctx.h, _dtype_code(H.dtype), n, P, H.data_ptr(), Cm.data_ptr(), ok.data_ptr()))
+    return Cm, ok

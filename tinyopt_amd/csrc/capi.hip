@@ -113,6 +113,9 @@ int toa_inst_wide_1_2(int thin, toa_handle h, const toa::FusedParams& prm, int s
 int toa_inst_wide_1_3(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 
+int toa_inst_inv_cov_0_0(int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
+int toa_inst_inv_cov_1_0(int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
+
 static thread_local std::string g_err;
 int toa_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -159,6 +162,9 @@ int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n,
                              const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres) {
   return dtag == 0 ? toa_inst_misc_accumulate_0_0(model, npad, h, n, m, P, data, x, want_grad, g, H, cost, nres)
                    : toa_inst_misc_accumulate_1_0(model, npad, h, n, m, P, data, x, want_grad, g, H, cost, nres);
+}
+int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok) {
+  return dtag == 0 ? toa_inst_inv_cov_0_0(npad, h, n, P, H, C, ok) : toa_inst_inv_cov_1_0(npad, h, n, P, H, C, ok);
 }
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok) {
@@ -398,6 +404,15 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
   if (P == 0) return TOA_OK;
   HIP_TRY(hipSetDevice(h->device));
   return toa_inst_solve(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, g, scale, dx, ok);
+}
+
+int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (int rc = check_shape(dtype, n, 1, P)) return rc;
+  if (!H || !C || !ok) return fail(TOA_E_ARG, "toa_inv_cov: null pointer");
+  if (P == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  return toa_inst_inv_cov(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, C, ok);
 }
 
 static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,

@@ -51,6 +51,14 @@ int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int6
     default: return launch_solve<InstT, 64>(h, n, P, H, g, scale, dx, ok);
   }
 }
+int TOA_CAT(toa_inst_inv_cov_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok) {
+  switch (npad) {
+    case 16: return launch_inv_cov<InstT, 16>(h, n, P, H, C, ok);
+    case 32: return launch_inv_cov<InstT, 32>(h, n, P, H, C, ok);
+    case 48: return launch_inv_cov<InstT, 48>(h, n, P, H, C, ok);
+    default: return launch_inv_cov<InstT, 64>(h, n, P, H, C, ok);
+  }
+}
 #else
 int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm) {
   switch (thin) {

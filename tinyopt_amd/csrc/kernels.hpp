@@ -568,6 +568,50 @@ __global__ void __launch_bounds__(256) solve_damped_kernel(const void* H_, const
   }
 }
 
+// Covariance seam: C = H^-1 by LDL^T against the identity — tinyopt::InvCov / DenseInvCov (include/tinyopt/math.h:41-57:
+// `chol = m.selfadjointView<Upper>().ldlt(); if (Success && isPositive()) return chol.solve(Identity)`; cols()==1:
+// unprotected 1/m), used by Output::Covariance (output.h:80-94) and SolverLM::Covariance (lm.h:174).
+template <typename T, int NPAD>
+__global__ void __launch_bounds__(256) inv_cov_kernel(const void* H_, long long P, int n, void* C_, int* ok_, int lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * lds_per_wave, n);
+  const T* Hg = static_cast<const T*>(H_);
+  T* Cg = static_cast<T*>(C_);
+  for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
+    wave_sync();
+    const T* H = Hg + size_t(p) * n * n;
+    T* C = Cg + size_t(p) * n * n;
+    if (n == 1) {  // math.h:49-50
+      if (lane == 0) { C[0] = T(1) / H[0]; ok_[p] = 1; }
+      continue;
+    }
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e % n;
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      L.M[i * L.LD + j] = H[size_t(b) * n + a];  // upper triangle is authoritative
+    }
+    wave_sync();
+    LdltRegs<T, NPAD> F;
+    F.load(L.M, L.LD, n, lane);
+    bool ok = F.factor(n, lane);
+    if (ok) {
+      for (int j = 0; j < n; ++j) {
+        const T x = F.solve(n, lane, lane == j ? T(1) : T(0));
+        if (lane < n) C[size_t(j) * n + lane] = x;  // column j (symmetric: row j)
+      }
+    } else {
+      ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
+      if (ok)
+        for (int j = 0; j < n; ++j) {
+          const T x = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, lane == j ? T(1) : T(0));
+          if (lane < n) C[size_t(j) * n + lane] = x;
+        }
+    }
+    if (lane == 0) ok_[p] = ok ? 1 : 0;
+  }
+}
+
 // ================================================================================================
 // Row-split ("wide") execution for few, huge problems (BASELINE configs C2 / C5: P = 1, m = 10^3..5*10^4).
 // One wavefront per problem would leave the chip idle, so the rows of every problem are split over S chunks:
@@ -927,6 +971,18 @@ inline int launch_solve(toa_handle h, int n, int64_t P, const void* H, const voi
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
+template <typename T, int NPAD>
+inline int launch_inv_cov(toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok) {
+  long long grid = (P + 3) / 4;
+  const long long cap = (long long)h->num_cus * 8;
+  if (grid > cap) grid = cap;
+  size_t pw, pwg;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  HIP_TRY(hipFuncSetAttribute((const void*)inv_cov_kernel<T, NPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  hipLaunchKernelGGL((inv_cov_kernel<T, NPAD>), dim3((unsigned)grid), dim3(256), pwg, h->stream, H, (long long)P, n, C, ok, (int)pw);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
 }  // namespace toa
 
 // ---- per-(dtype, NBM) entry points defined in inst.hip (dtag: 0 = f32, 1 = f64) ----
@@ -938,5 +994,6 @@ int toa_inst_misc_fused(int dtag, int model, int npad, toa_handle h, const toa::
 int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n, int m, int64_t P, const void* data,
                              const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_wide(int dtag, int model, int nbm, int thin, toa_handle h, const toa::FusedParams& prm, int splits);
+int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok);
