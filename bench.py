@@ -134,7 +134,7 @@ def main():
         _ = int(wacc[0].item())
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
 
     acc = None
@@ -143,7 +143,7 @@ def main():
         acc = step(acc)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     iters_total = int(acc[0].item())

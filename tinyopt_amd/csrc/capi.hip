@@ -245,6 +245,7 @@ int toa_destroy(toa_handle h) {
   if (h->queue) (void)hipFree(h->queue);
   if (h->params_dev) (void)hipFree(h->params_dev);
   if (h->scratch) (void)hipFree(h->scratch);
+  for (int i = 0; i < h->nwgraphs; ++i) (void)hipGraphExecDestroy(h->wgraphs[i].exec);
   delete h;
   return TOA_OK;
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -438,15 +439,6 @@ struct FusedParams {
   int lds_per_wave;
 };
 
-// Minimum resident waves per SIMD the register allocator must honour (2nd __launch_bounds__ argument
-// is waves per SIMD on CDNA).  The fused kernel alternates an MFMA-paced accumulate phase with a
-// latency-bound LDL^T phase, so >= 3 co-resident waves per SIMD are needed to keep the matrix pipe
-// and the HBM queue busy; wide fp64 Gram tiles (NB >= 3: 48-80 accumulator registers) cannot afford it.
-template <typename T, int NB>
-constexpr int fused_min_waves() {
-  return sizeof(T) == 4 ? (NB <= 2 ? 4 : 3) : (NB == 1 ? 4 : (NB == 2 ? 2 : 1));
-}
-
 template <typename Model>
 __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   using T = typename Model::Scalar;
@@ -815,10 +807,14 @@ struct toa_context {
   void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
   void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
   size_t scratch_bytes = 0;
+  // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (TOA_USE_GRAPH=1)
+  struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
+  WideGraph wgraphs[16];
+  int nwgraphs = 0;
   // launch-configuration cache: (kernel, dynamic LDS bytes) -> resident workgroups per CU.
   // hipFuncSetAttribute / hipOccupancy* cost milliseconds per call; pay them once per variant.
   struct Cfg { const void* fn; size_t lds; int wg_per_cu; };
-  Cfg cfg[32];
+  Cfg cfg[256];
   int ncfg = 0;
 };
 
@@ -833,6 +829,15 @@ int toa_fail(int code, const std::string& msg);
   } while (0)
 
 namespace toa {
+// Raise a kernel's dynamic-LDS limit once per (kernel, size): hipFuncSetAttribute costs ~1 ms per call.
+inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
+  for (int i = 0; i < h->ncfg; ++i)
+    if (h->cfg[i].fn == fn && h->cfg[i].lds == bytes) return TOA_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (h->ncfg < 256) h->cfg[h->ncfg++] = {fn, bytes, -1};
+  return TOA_OK;
+}
+
 // waves per workgroup is fixed at 4 (256 threads); LDS per wave decides how many WGs fit per CU.
 template <typename T>
 inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg) {
@@ -854,7 +859,7 @@ inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* 
   if (grid > cap) grid = cap;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
-  HIP_TRY(hipFuncSetAttribute((const void*)accumulate_kernel<Model>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  if (int rc = ensure_lds_attr(h, (const void*)accumulate_kernel<Model>, pwg)) return rc;
   hipLaunchKernelGGL((accumulate_kernel<Model>), dim3((unsigned)grid), dim3(256), pwg, h->stream, data, x, (long long)P, n, m,
                      want_grad, g, H, cost, nres, (int)pw);
   HIP_TRY(hipGetLastError());
@@ -873,12 +878,12 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   auto kern = lm_fused_kernel<Model>;
   int wg_per_cu = 0;
   for (int i = 0; i < h->ncfg; ++i)
-    if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == pwg) wg_per_cu = h->cfg[i].wg_per_cu;
+    if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == pwg && h->cfg[i].wg_per_cu > 0) wg_per_cu = h->cfg[i].wg_per_cu;
   if (wg_per_cu == 0) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, 256, pwg));
     if (wg_per_cu < 1) wg_per_cu = 1;
-    if (h->ncfg < 32) h->cfg[h->ncfg++] = {(const void*)kern, pwg, wg_per_cu};
+    if (h->ncfg < 256) h->cfg[h->ncfg++] = {(const void*)kern, pwg, wg_per_cu};
   }
   long long grid = (long long)h->num_cus * wg_per_cu;
   const long long need = (prm.P + 3) / 4;
@@ -944,16 +949,61 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   auto k_init = wide_init_kernel<T, Manifold::kXdim>;
   auto k_part = wide_partial_kernel<Model>;
   auto k_step = wide_step_kernel<T, NPAD, Manifold>;
-  HIP_TRY(hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  if (int rc = ensure_lds_attr(h, (const void*)k_init, pwg)) return rc;
+  if (int rc = ensure_lds_attr(h, (const void*)k_part, pwg)) return rc;
+  if (int rc = ensure_lds_attr(h, (const void*)k_step, pwg)) return rc;
   const unsigned g_p = unsigned((P + 3) / 4), g_u = unsigned((P * S + 3) / 4);
-  hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
   const int iters = fp.opt.max_iters + 1 + (fp.opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
-  for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(k_part, dim3(g_u), dim3(256), pwg, h->stream, dp);
-    hipLaunchKernelGGL(k_step, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  // Direct launches by default: an A/B on MI355X (tools/latency_probe.py) shows graph replay and eager launches
+  // of this 23..103-kernel sequence within 1 % of each other (C2 71 us, C5 93-99 us device time per solve), as
+  // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  TOA_USE_GRAPH=1 selects the graph path.
+  static const bool use_graph = std::getenv("TOA_USE_GRAPH") != nullptr;
+  if (!use_graph) {
+    hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
+    for (int it = 0; it < iters; ++it) {
+      hipLaunchKernelGGL(k_part, dim3(g_u), dim3(256), pwg, h->stream, dp);
+      hipLaunchKernelGGL(k_step, dim3(g_p), dim3(256), pwg, h->stream, dp);
+    }
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
   }
+  hipGraphExec_t exec = nullptr;
+  for (int i = 0; i < h->nwgraphs; ++i) {
+    const auto& w = h->wgraphs[i];
+    if (w.k_init == (const void*)k_init && w.k_part == (const void*)k_part && w.k_step == (const void*)k_step && w.g_p == g_p &&
+        w.g_u == g_u && w.lds == pwg && w.iters == iters)
+      exec = w.exec;
+  }
+  if (!exec) {
+    hipGraph_t graph;
+    HIP_TRY(hipGraphCreate(&graph, 0));
+    void* args[1] = {(void*)&dp};
+    hipGraphNode_t prev = nullptr;
+    auto add = [&](const void* fn, unsigned grid) -> hipError_t {
+      hipKernelNodeParams kp;
+      std::memset(&kp, 0, sizeof(kp));
+      kp.func = const_cast<void*>(fn);
+      kp.gridDim = dim3(grid);
+      kp.blockDim = dim3(256);
+      kp.sharedMemBytes = (unsigned)pwg;
+      kp.kernelParams = args;
+      hipGraphNode_t node;
+      const hipError_t e = hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+      prev = node;
+      return e;
+    };
+    HIP_TRY(add((const void*)k_init, g_p));
+    for (int it = 0; it < iters; ++it) {
+      HIP_TRY(add((const void*)k_part, g_u));
+      HIP_TRY(add((const void*)k_step, g_p));
+    }
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(graph));
+    if (h->nwgraphs < 16) h->wgraphs[h->nwgraphs++] = {(const void*)k_init, (const void*)k_part, (const void*)k_step, g_p, g_u, pwg, iters, exec};
+  }
+  // the parameter block was uploaded above with hipMemcpyAsync from pageable memory (staged before returning), so
+  // back-to-back calls cannot race on it; the graph itself holds kernels only
+  HIP_TRY(hipGraphLaunch(exec, h->stream));
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
@@ -965,7 +1015,7 @@ inline int launch_solve(toa_handle h, int n, int64_t P, const void* H, const voi
   if (grid > cap) grid = cap;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
-  HIP_TRY(hipFuncSetAttribute((const void*)solve_damped_kernel<T, NPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  if (int rc = ensure_lds_attr(h, (const void*)solve_damped_kernel<T, NPAD>, pwg)) return rc;
   hipLaunchKernelGGL((solve_damped_kernel<T, NPAD>), dim3((unsigned)grid), dim3(256), pwg, h->stream, H, g, (long long)P, n,
                      scale, dx, ok, (int)pw);
   HIP_TRY(hipGetLastError());
@@ -978,7 +1028,7 @@ inline int launch_inv_cov(toa_handle h, int n, int64_t P, const void* H, void* C
   if (grid > cap) grid = cap;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
-  HIP_TRY(hipFuncSetAttribute((const void*)inv_cov_kernel<T, NPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
+  if (int rc = ensure_lds_attr(h, (const void*)inv_cov_kernel<T, NPAD>, pwg)) return rc;
   hipLaunchKernelGGL((inv_cov_kernel<T, NPAD>), dim3((unsigned)grid), dim3(256), pwg, h->stream, H, (long long)P, n, C, ok, (int)pw);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
