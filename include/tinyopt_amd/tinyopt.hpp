@@ -8,7 +8,7 @@
 //   tinyopt::Options options;                               tinyopt_amd::Options options;
 //   auto out = tinyopt::Optimize(x, cost, options);         auto out = tinyopt_amd::Optimize(x, cost, options);
 //     x    : one parameter block, updated in place            x    : P parameter blocks ([P][n] contiguous), in place
-//     cost : any C++ callable (residuals or Accumulate)        cost : a DEVICE model (DenseRow<Scalar>) — host
+//     cost : any C++ callable (residuals or Accumulate)        cost : a DEVICE model (DenseRow, GaussianPrior, Sqrt2, CircleFit, SE3Reproj) — host
 //                                                                       lambdas cannot run on the GPU
 //     out  : tinyopt::Output                                   out  : BatchOutput (one Output row per problem)
 //
@@ -182,6 +182,7 @@ class DenseRow {
   int64_t P() const { return P_; }
   int n() const { return n_; }
   int m() const { return m_; }
+  int xdim() const { return n_; }
   const Scalar* data() const { return packed_.data(); }
   const Context& ctx() const { return *ctx_; }
 
@@ -190,6 +191,55 @@ class DenseRow {
   int64_t P_;
   int n_, m_;
   DeviceBuffer<Scalar> packed_;
+};
+
+// Generic holder for the models whose device data is a plain host array uploaded as is.
+template <typename Scalar, int ModelId>
+class PlainModel {
+ public:
+  PlainModel(const Context& ctx, int64_t P, int n, int m, int xdim, const Scalar* host, size_t count)
+      : ctx_(&ctx), P_(P), n_(n), m_(m), xdim_(xdim), data_(ctx, count ? count : 1) {
+    if (count) data_.upload(host);
+  }
+  static constexpr int model_id = ModelId;
+  int64_t P() const { return P_; }
+  int n() const { return n_; }
+  int m() const { return m_; }
+  int xdim() const { return xdim_; }
+  const Scalar* data() const { return data_.data(); }
+  const Context& ctx() const { return *ctx_; }
+
+ private:
+  const Context* ctx_;
+  int64_t P_;
+  int n_, m_, xdim_;
+  DeviceBuffer<Scalar> data_;
+};
+
+// r = (x - y) / sigma, m = n: the reference's published dense benchmark (benchmarks/dense.cpp:53-66).
+// ys: [P][2][n] = y then sigma per problem.
+template <typename Scalar>
+struct GaussianPrior : PlainModel<Scalar, TOA_MODEL_GAUSSIAN_PRIOR> {
+  GaussianPrior(const Context& ctx, int64_t P, int n, const Scalar* ys)
+      : PlainModel<Scalar, TOA_MODEL_GAUSSIAN_PRIOR>(ctx, P, n, n, n, ys, size_t(P) * 2 * n) {}
+};
+// r = x*x - 2 (tests/sqrt2.cpp:30-70)
+template <typename Scalar>
+struct Sqrt2 : PlainModel<Scalar, TOA_MODEL_SQRT2> {
+  Sqrt2(const Context& ctx, int64_t P) : PlainModel<Scalar, TOA_MODEL_SQRT2>(ctx, P, 1, 1, 1, nullptr, 0) {}
+};
+// tests/circle.cpp:32-68, differentiated on the device by dual numbers.  obs: [P][npts][2]; x = (cx, cy, radius).
+template <typename Scalar>
+struct CircleFit : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT> {
+  CircleFit(const Context& ctx, int64_t P, int npts, const Scalar* obs)
+      : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT>(ctx, P, 3, npts, 3, obs, size_t(P) * npts * 2) {}
+};
+// SE3 pinhole reprojection (3rdparty/traits/sophus.h:13-27 update); x: [P][12] = R (row-major) | t; n = 6.
+// data: [P][8 + 5*npts] = [f cx cy 0 0 0 0 0 | x y z u v ...].
+template <typename Scalar>
+struct SE3Reproj : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ> {
+  SE3Reproj(const Context& ctx, int64_t P, int npts, const Scalar* data)
+      : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ>(ctx, P, 6, 2 * npts, 12, data, size_t(P) * (8 + 5 * size_t(npts))) {}
 };
 
 // include/tinyopt/output.h:26-145, one entry per problem.
@@ -209,7 +259,8 @@ template <typename Scalar, typename Cost>
 BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& options = {}, bool history = false) {
   const int64_t P = cost.P();
   const int n = cost.n();
-  if (int64_t(x.size()) != P * n) throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P*n scalars");
+  if (int64_t(x.size()) != P * cost.xdim())
+    throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P * (parameters per problem) scalars");
   const Context& ctx = cost.ctx();
   DeviceBuffer<Scalar> dx(ctx, x.size());
   dx.upload(x.data());
@@ -263,6 +314,20 @@ void Accumulate(const Cost& cost, const std::vector<Scalar>& x, std::vector<Scal
   cost_out.resize(P);
   dc.download(cost_out.data());
   if (want) { g->resize(size_t(P) * n); dg.download(g->data()); H->resize(size_t(P) * n * n); dH.download(H->data()); }
+}
+
+// tinyopt::InvCov (include/tinyopt/math.h:41-91) for a batch of n x n matrices; ok[p] == 0 <=> std::nullopt.
+template <typename Scalar>
+void InvCov(const Context& ctx, int64_t P, int n, const std::vector<Scalar>& H, std::vector<Scalar>& C, std::vector<int32_t>& ok) {
+  DeviceBuffer<Scalar> dH(ctx, H.size()), dC(ctx, H.size());
+  DeviceBuffer<int32_t> dok(ctx, P);
+  dH.upload(H.data());
+  check(toa_inv_cov(ctx.get(), dtype_of<Scalar>(), n, P, dH.data(), dC.data(), dok.data()));
+  check(toa_synchronize(ctx.get()));
+  C.resize(H.size());
+  dC.download(C.data());
+  ok.resize(P);
+  dok.download(ok.data());
 }
 
 }  // namespace tinyopt_amd

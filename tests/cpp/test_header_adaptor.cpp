@@ -51,7 +51,68 @@ static void run(int P, int n, int m, double tol) {
   REQUIRE(threw);
 }
 
+// tests/sqrt2.cpp:106-112 — x0 in {1, -0.3, 3.2}: Succeeded && Converged && |x| == sqrt(2) +- 1e-5
+template <typename T>
+static void sqrt2() {
+  Context ctx(0);
+  Sqrt2<T> cost(ctx, 3);
+  std::vector<T> x{T(1), T(-0.3), T(3.2)};
+  Options options;
+  options.max_iters = 20;            // tests/sqrt2.cpp:22-28
+  options.max_consec_failures = 0;
+  const auto out = Optimize(x, cost, options);
+  for (int p = 0; p < 3; ++p) {
+    REQUIRE(out.Succeeded(p));
+    REQUIRE(out.Converged(p));
+    REQUIRE(std::abs(std::abs(double(x[p])) - std::sqrt(2.0)) < 1e-5);
+  }
+}
+
+// tests/circle.cpp:32-68 — 10 points on the circle (2, 7, r = 2), x0 = (0, 0, 1), damping_init = 10 -> (2, 7, 2) +- 1e-5
+static void circle() {
+  const int n = 10;
+  std::vector<double> obs(2 * n);
+  double angle = 0;
+  for (int i = 0; i < n; ++i) {
+    obs[2 * i] = 2 + 2 * std::cos(angle);
+    obs[2 * i + 1] = 7 + 2 * std::sin(angle);
+    angle += 2 * 3.14159265358979323846 / (n - 1);
+  }
+  Context ctx(0);
+  CircleFit<double> cost(ctx, 1, n, obs.data());
+  std::vector<double> x{0, 0, 1};
+  Options options;
+  options.lm.damping_init = 1e1;
+  const auto out = Optimize(x, cost, options);
+  REQUIRE(out.Succeeded(0));
+  REQUIRE(std::abs(x[0] - 2) < 1e-5);
+  REQUIRE(std::abs(x[1] - 7) < 1e-5);
+  REQUIRE(std::abs(std::abs(x[2]) - 2) < 1e-5);
+}
+
+// tests/cov.cpp:20-47 — Gaussian prior with sigma = 4.2: covariance from the final Hessian recovers sigma
+static void prior_cov() {
+  Context ctx(0);
+  const int n = 2;
+  std::vector<double> ys{3.0, -8.0, 4.2, 4.2};  // y, sigma
+  GaussianPrior<double> cost(ctx, 1, n, ys.data());
+  std::vector<double> x{0, 0};
+  const auto out = Optimize(x, cost, Options());
+  REQUIRE(out.Succeeded(0));
+  REQUIRE(out.Converged(0));
+  REQUIRE(std::abs(x[0] - 3.0) < 1e-6 && std::abs(x[1] + 8.0) < 1e-6);
+  std::vector<double> C;
+  std::vector<int32_t> ok;
+  InvCov(ctx, 1, n, out.final_hessian, C, ok);
+  REQUIRE(ok[0] == 1);
+  REQUIRE(std::abs(std::sqrt(C[0]) - 4.2) < 1e-7 && std::abs(std::sqrt(C[3]) - 4.2) < 1e-7);
+}
+
 int main() {
+  sqrt2<double>();
+  sqrt2<float>();
+  circle();
+  prior_cov();
   run<double>(5, 12, 200, 1e-7);
   run<float>(3, 50, 600, 2e-3);
   std::printf("test_header_adaptor: %s\n", fails ? "FAILED" : "ok");
