@@ -187,6 +187,12 @@ def main():
     kern_avg_s = float(np.mean(kern_ms)) * 1e-3
     passes_per_launch = passes_total / args.steps
     achieved = bytes_per_pass * passes_per_launch / kern_avg_s / 1e9
+    # measured STREAM-like read ceiling over the same packed buffer, next to the nominal peak
+    try:
+        stream_read = ctx.hbm_read_GBps(model.packed, reps=5)
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] hbm read probe failed: {e}")
+        stream_read = None
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_file):
@@ -212,6 +218,8 @@ def main():
                    "device": info["name"], "num_cus": info["num_cus"]},
         "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_read_ceiling_GBps": stream_read,
+                     "frac_of_measured_ceiling": (achieved / stream_read) if stream_read else None,
                      "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_per_launch,
                      "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_all": kern_ms},
     }

@@ -51,6 +51,16 @@ extern "C" {
 #define TOA_MODEL_CIRCLE_FIT 5      /* r_i = ||p_i - c||^2 - radius^2, x = (cx, cy, radius)   (tests/circle.cpp:32-68) */
 #define TOA_MODEL_DENSE_ROW_AD6 6   /* the DenseRow residual, n = 6, written without a hand-derived Jacobian */
 
+/* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
+#define TOA_LOSS_L2 0
+#define TOA_LOSS_TRUNCATED 1
+#define TOA_LOSS_HUBER 2
+#define TOA_LOSS_TUKEY 3
+#define TOA_LOSS_ARCTAN 4
+#define TOA_LOSS_CAUCHY 5
+#define TOA_LOSS_GEMAN_MCCLURE 6
+#define TOA_LOSS_BLAKE_ZISSERMAN 7
+
 /* StopReason — identical values to include/tinyopt/stop_reasons.h:14-43 */
 #define TOA_STOP_OUT_OF_MEMORY (-4)
 #define TOA_STOP_SOLVER_FAILED (-3)
@@ -118,6 +128,7 @@ typedef struct toa_results {
   uint8_t* successes;          /* [P][hist_stride] Output::successes           output.h:142 */
   int32_t hist_stride;         /* >= max_iters+2 when history pointers are given */
   int32_t _pad;
+  float* final_inlier_ratio;   /* [P]  Output::final_cost.inlier_ratio (cost.h:84-95); 1 for models without a robust loss; NULL: skipped */
 } toa_results;
 
 typedef struct toa_context* toa_handle;
@@ -128,6 +139,10 @@ int toa_destroy(toa_handle h);
 const char* toa_last_error(void);
 /* Device properties the measurement needs (CU count, clock, name). */
 int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size_t name_len);
+
+/* Measured read ceiling of this GPU's HBM (SURVEY §8d asks for a STREAM-like figure next to the nominal 8 TB/s):
+ * streams `bytes` from src_dev `reps` times with 16-byte loads and reports GB/s between two HIP events. */
+int toa_hbm_read_probe(toa_handle h, const void* src_dev, size_t bytes, int reps, double* gb_per_s);
 
 /* ---- device memory conveniences for non-torch callers (the C++ header adaptor) ---- */
 int toa_malloc(toa_handle h, void** dev_ptr, size_t bytes);
@@ -162,7 +177,10 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_SE3_REPROJ      n == 6 (tangent, Sophus order upsilon, omega), m = 2 * points; x: [P][12] = rotation matrix
  *                           (row-major) + translation, updated by pose <- pose * exp(delta)
  *                           (include/tinyopt/3rdparty/traits/sophus.h:24-26); data_dev: [P][8 + 5*m/2] =
- *                           [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point].
+ *                           [f, cx, cy, loss, th2, 0,0,0 | x, y, z, u, v per point].  loss = TOA_LOSS_* (0 = plain
+ *                           squared L2), th2 = squared threshold in px^2: each point's ||r||^2 goes through the
+ *                           M-estimator (cost += l, the point's J^T J and J^T r are scaled by s; robust_norms.h:20-26);
+ *                           a point is an inlier when ||r||^2 <= th2 (results: final_inlier_ratio).
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6]. */
 
@@ -180,6 +198,11 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
  *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure). */
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);
+
+/* ---- robust norms alone (replaces `losses::Huber(n2, th2, true)` & co., robust_norms.h:32-316, docs/API.md:396-406):
+ *      loss_dev[i], scale_dev[i] = rho(n2_dev[i], th2) for `count` squared norms of type `dtype`; kind = TOA_LOSS_*. */
+int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void* n2_dev, double th2,
+                    void* loss_dev, void* scale_dev);
 
 /* ---- covariance seam (replaces tinyopt::InvCov / DenseInvCov, math.h:41-91, used by Output::Covariance
  *      output.h:80-94 and SolverLM::Covariance lm.h:174): C = H^-1 by LDL^T against the identity, same acceptance

@@ -236,6 +236,8 @@ struct CircleFit : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT> {
 };
 // SE3 pinhole reprojection (3rdparty/traits/sophus.h:13-27 update); x: [P][12] = R (row-major) | t; n = 6.
 // data: [P][8 + 5*npts] = [f cx cy 0 0 0 0 0 | x y z u v ...].
+// Optional M-estimator on each point's squared reprojection error: data[3] = TOA_LOSS_*, data[4] = th^2
+// (losses/robust_norms.h:32-316); set them in the host array before constructing the model.
 template <typename Scalar>
 struct SE3Reproj : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ> {
   SE3Reproj(const Context& ctx, int64_t P, int npts, const Scalar* data)
@@ -246,6 +248,7 @@ struct SE3Reproj : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ> {
 struct BatchOutput {
   std::vector<int32_t> stop_reason, num_iters, num_failures, num_consec_failures, final_num_residuals;
   std::vector<double> final_cost, final_rerr_dec;
+  std::vector<float> final_inlier_ratio;      // Output::final_cost.inlier_ratio (cost.h:84-95); 1 without a robust loss
   std::vector<double> final_hessian;          // [P][n*n], undamped; empty unless options.hessian.save_last
   std::vector<double> errs, deltas2;          // [P][hist_stride] (only with history = true)
   std::vector<uint8_t> successes;
@@ -266,12 +269,14 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   dx.upload(x.data());
   DeviceBuffer<int32_t> stop(ctx, P), iters(ctx, P), fails(ctx, P), cfails(ctx, P), nres(ctx, P);
   DeviceBuffer<double> fc(ctx, P), fr(ctx, P);
+  DeviceBuffer<float> inl(ctx, P);
   DeviceBuffer<double> fH, errs, d2;
   DeviceBuffer<uint8_t> succ;
   toa_results r{};
   r.stop_reason = stop.data(); r.num_iters = iters.data(); r.num_failures = fails.data();
   r.num_consec_failures = cfails.data(); r.final_cost = fc.data(); r.final_num_residuals = nres.data();
   r.final_rerr_dec = fr.data();
+  r.final_inlier_ratio = inl.data();
   BatchOutput out;
   if (options.hessian.save_last) { fH = DeviceBuffer<double>(ctx, size_t(P) * n * n); fH.zero(); r.final_hessian = fH.data(); }
   if (history) {
@@ -288,7 +293,7 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   auto get = [&](auto& vec, const auto& buf) { vec.resize(buf.size()); buf.download(vec.data()); };
   get(out.stop_reason, stop); get(out.num_iters, iters); get(out.num_failures, fails);
   get(out.num_consec_failures, cfails); get(out.final_num_residuals, nres); get(out.final_cost, fc);
-  get(out.final_rerr_dec, fr);
+  get(out.final_rerr_dec, fr); get(out.final_inlier_ratio, inl);
   if (options.hessian.save_last) get(out.final_hessian, fH);
   if (history) { get(out.errs, errs); get(out.deltas2, d2); get(out.successes, succ); }
   return out;
@@ -314,6 +319,20 @@ void Accumulate(const Cost& cost, const std::vector<Scalar>& x, std::vector<Scal
   cost_out.resize(P);
   dc.download(cost_out.data());
   if (want) { g->resize(size_t(P) * n); dg.download(g->data()); H->resize(size_t(P) * n * n); dH.download(H->data()); }
+}
+
+// losses::Huber(n2, th2, true) & co. (losses/robust_norms.h:32-316) for an array of squared norms: kind = TOA_LOSS_*.
+template <typename Scalar>
+void RobustNorm(const Context& ctx, int kind, const std::vector<Scalar>& n2, Scalar th2, std::vector<Scalar>& loss,
+                std::vector<Scalar>& scale) {
+  DeviceBuffer<Scalar> dn(ctx, n2.size()), dl(ctx, n2.size()), ds(ctx, n2.size());
+  dn.upload(n2.data());
+  check(toa_robust_norm(ctx.get(), kind, dtype_of<Scalar>(), int64_t(n2.size()), dn.data(), double(th2), dl.data(), ds.data()));
+  check(toa_synchronize(ctx.get()));
+  loss.resize(n2.size());
+  scale.resize(n2.size());
+  dl.download(loss.data());
+  ds.download(scale.data());
 }
 
 // tinyopt::InvCov (include/tinyopt/math.h:41-91) for a batch of n x n matrices; ok[p] == 0 <=> std::nullopt.

@@ -138,7 +138,7 @@ static void run_batch_dense_row(int64_t P, int n, int m, const T* A, const T* b,
 
 template <typename T>
 static void se3_lm_t(int64_t P, int npts, const T* data, T* poses, const Options& o, int32_t* stop, int32_t* iters,
-                     double* cost, double* finalH) {
+                     double* cost, double* finalH, float* inlier_ratio) {
   for (int64_t p = 0; p < P; ++p) {
     const T* d = data + size_t(p) * (8 + 5 * size_t(npts));
     se3::ReprojAcc<T> acc{npts, d, d + 8};
@@ -150,6 +150,7 @@ static void se3_lm_t(int64_t P, int npts, const T* data, T* poses, const Options
     if (stop) stop[p] = out.stop_reason;
     if (iters) iters[p] = out.num_iters;
     if (cost) cost[p] = out.final_cost.cost;
+    if (inlier_ratio) inlier_ratio[p] = out.final_cost.inlier_ratio;
     if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * 36, out.final_hessian.data(), sizeof(double) * 36);
   }
 }
@@ -318,10 +319,10 @@ void oracle_sqrt2_lm(int dtype, int64_t P, void* x, const toa_options* opts, int
 // ---- SE3 reprojection.  poses: [P][12] (R row-major, t), data: [P][8 + 5*npts]
 //      ([f cx cy 0 0 0 0 0 | x y z u v ...]), updated in place.
 void oracle_se3_reproj_lm(int dtype, int64_t P, int npts, const void* data, void* poses, const toa_options* opts,
-                          int32_t* stop, int32_t* iters, double* cost, double* finalH) {
+                          int32_t* stop, int32_t* iters, double* cost, double* finalH, float* inlier_ratio) {
   const Options o = from_pod(*opts);
-  if (dtype == TOA_F32) se3_lm_t<float>(P, npts, (const float*)data, (float*)poses, o, stop, iters, cost, finalH);
-  else se3_lm_t<double>(P, npts, (const double*)data, (double*)poses, o, stop, iters, cost, finalH);
+  if (dtype == TOA_F32) se3_lm_t<float>(P, npts, (const float*)data, (float*)poses, o, stop, iters, cost, finalH, inlier_ratio);
+  else se3_lm_t<double>(P, npts, (const double*)data, (double*)poses, o, stop, iters, cost, finalH, inlier_ratio);
 }
 // one Accumulate call: g [P][6], H [P][36], cost [P]
 void oracle_se3_reproj_accumulate(int dtype, int64_t P, int npts, const void* data, const void* poses, void* g, void* H,
@@ -343,6 +344,18 @@ void oracle_se3_reproj_accumulate(int dtype, int64_t P, int npts, const void* da
       double* gp = (double*)g + p * 6; double* Hp = (double*)H + p * 36;
       std::fill(gp, gp + 6, 0.0); std::fill(Hp, Hp + 36, 0.0);
       cost[p] = acc(x, gp, Hp).cost;
+    }
+  }
+}
+// the M-estimators alone (oracle/robust.hpp): loss[i], scale[i] = rho(n2[i], th2)
+void oracle_robust_norm(int kind, int dtype, int64_t count, const void* n2, double th2, void* loss, void* scale) {
+  for (int64_t i = 0; i < count; ++i) {
+    if (dtype == TOA_F32) {
+      const auto ls = robust::Apply<float>(kind, ((const float*)n2)[i], float(th2));
+      ((float*)loss)[i] = ls.l; ((float*)scale)[i] = ls.s;
+    } else {
+      const auto ls = robust::Apply<double>(kind, ((const double*)n2)[i], th2);
+      ((double*)loss)[i] = ls.l; ((double*)scale)[i] = ls.s;
     }
   }
 }

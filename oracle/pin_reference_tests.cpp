@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "lm_oracle.hpp"
+#include "robust.hpp"
 
 using namespace oracle;
 
@@ -513,6 +514,55 @@ static void ldlt_policy() {
   }
 }
 
+// tests/robust_norms.cpp:53-115 — closed forms (LOSS_WRAPPER expected_code) and the derivative check the
+// reference does with CalculateJac (here: central differences of the loss), margin 1e-5, th = 1.3;
+// scalar n2 = 0.5, inlier 0.3, outlier 2.3^2; vector x = (.1,-.2,-.3,.4) with th = 1.3 (inlier) and 0.03 (outlier).
+static double robust_expected(int kind, double n2, double th2) {
+  const double th = std::sqrt(th2), n = std::sqrt(n2);
+  switch (kind) {
+    case oracle::robust::kTruncated: return n > th ? th2 : n2;
+    case oracle::robust::kHuber: return n > th ? (2.0 * th * n - th2) : n2;
+    case oracle::robust::kTukey: return n > th ? th2 : (th2 * (1.0 - std::pow(1.0 - n2 / th2, 3.0)));
+    case oracle::robust::kArctan: return th * std::atan2(n2, th);
+    case oracle::robust::kCauchy: return th2 * std::log(1.0 + n2 / th2);
+    case oracle::robust::kGemanMcClure: return n2 / (n2 + th2);
+    default: return -std::log(std::exp(-n2) + std::exp(-th2));
+  }
+}
+static void robust_norms() {
+  using namespace oracle::robust;
+  for (int kind = kTruncated; kind <= kBlakeZisserman; ++kind) {
+    const double th = 1.3, th2 = th * th;
+    CHECK_NEAR(Apply(kind, 0.5, th2).l, robust_expected(kind, 0.5, th2), 1e-5);  // "Scalar"
+    for (double n2 : {0.3, 2.3 * 2.3}) {                                          // "Scalar Inlier" / "Scalar Outlier"
+      const auto ls = Apply(kind, n2, th2);
+      CHECK_NEAR(ls.l, robust_expected(kind, n2, th2), 1e-5);
+      const double h = 1e-6;
+      const double fd = (Apply(kind, n2 + h, th2).l - Apply(kind, n2 - h, th2).l) / (2 * h);
+      CHECK_NEAR(ls.s, fd, 1e-5);
+    }
+    const double x[4] = {.1, -0.2, -0.3, 0.4};
+    for (double thv : {1.3, 0.03}) {  // "Vec Inlier" / "Vec Outlier": J = s * d(||x||^2)/dx = s * 2x
+      const double t2 = thv * thv;
+      double n2 = 0;
+      for (double v : x) n2 += v * v;
+      const auto ls = Apply(kind, n2, t2);
+      CHECK_NEAR(ls.l, robust_expected(kind, n2, t2), 1e-5);
+      for (int i = 0; i < 4; ++i) {
+        const double h = 1e-6;
+        double xp[4] = {x[0], x[1], x[2], x[3]}, xm[4] = {x[0], x[1], x[2], x[3]};
+        xp[i] += h; xm[i] -= h;
+        double np = 0, nm = 0;
+        for (int k = 0; k < 4; ++k) { np += xp[k] * xp[k]; nm += xm[k] * xm[k]; }
+        const double fd = (Apply(kind, np, t2).l - Apply(kind, nm, t2).l) / (2 * h);
+        CHECK_NEAR(ls.s * 2 * x[i], fd, 1e-5);
+      }
+    }
+  }
+  // docs/API.md:399 — `Huber(y.squaredNorm(), 0.8)`: inlier below the squared threshold returns n2 itself
+  CHECK(Huber(0.5, 0.8).l == 0.5 && Huber(0.5, 0.8).s == 1.0);
+}
+
 int main() {
   for (float x0 : {1.0f, -0.3f, 3.2f}) {  // tests/sqrt2.cpp:106-112
     sqrt2_manual(x0);
@@ -532,6 +582,7 @@ int main() {
   circle();
   cov_prior();
   ldlt_policy();
+  robust_norms();
   std::printf("pin_reference_tests: %d passed, %d failed\n", g_pass, g_fail);
   return g_fail ? 1 : 0;
 }

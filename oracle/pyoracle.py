@@ -56,7 +56,8 @@ def load(path: str | None = None):
     lib.oracle_gaussian_prior_lm.restype = C.c_double
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
-    lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp]
+    lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_robust_norm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.c_double, vp, vp]
     lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
     lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
     lib.oracle_circle_fit_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
@@ -212,9 +213,46 @@ def se3_reproj_lm(data, pose0, npts, pod: ToaOptions):
     iters = np.zeros(P, np.int32)
     cost = np.zeros(P, np.float64)
     Hf = np.zeros((P, 6, 6), np.float64) if pod.save_last else None
+    inl = np.zeros(P, np.float32)
     lib.oracle_se3_reproj_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(data)), _p(x), C.byref(pod), _p(stop), _p(iters),
-                             _p(cost), _p(Hf))
-    return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf)
+                             _p(cost), _p(Hf), _p(inl))
+    return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf, inlier_ratio=inl)
+
+
+LOSS_KINDS = {"l2": 0, "truncated": 1, "huber": 2, "tukey": 3, "arctan": 4, "cauchy": 5, "geman_mcclure": 6,
+              "blake_zisserman": 7}
+
+
+def robust_norm(kind, n2, th2):
+    """(loss, scale) of the reference's M-estimators (losses/robust_norms.h) for an array of squared norms."""
+    lib = load()
+    n2 = np.ascontiguousarray(n2)
+    loss = np.empty_like(n2)
+    scale = np.empty_like(n2)
+    k = LOSS_KINDS[kind] if isinstance(kind, str) else int(kind)
+    lib.oracle_robust_norm(k, _code(n2.dtype), n2.size, _p(n2), float(th2), _p(loss), _p(scale))
+    return loss, scale
+
+
+def se3_set_loss(data, kind, th2):
+    """Write the robust-loss header slots of SE3Reproj data ([3] = kind, [4] = th2); returns a copy."""
+    out = np.array(data, copy=True)
+    out[:, 3] = LOSS_KINDS[kind] if isinstance(kind, str) else int(kind)
+    out[:, 4] = th2
+    return out
+
+
+def se3_add_outliers(data, npts, frac, seed=7, amplitude=80.0):
+    """Replace a fraction of the observed pixels by gross outliers (uniform +-amplitude px); returns (copy, mask)."""
+    rng = np.random.default_rng(seed)
+    out = np.array(data, copy=True)
+    P = out.shape[0]
+    pts = out[:, 8:].reshape(P, npts, 5)
+    mask = rng.uniform(size=(P, npts)) < frac
+    noise = rng.uniform(-amplitude, amplitude, (P, npts, 2)).astype(out.dtype)
+    pts[..., 3:5] += noise * mask[..., None]
+    out[:, 8:] = pts.reshape(P, -1)
+    return out, mask
 
 
 def circle_fit_lm(obs, x0, pod: ToaOptions):

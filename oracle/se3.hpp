@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "lm_oracle.hpp"
+#include "robust.hpp"
 
 namespace oracle {
 namespace se3 {
@@ -75,6 +76,10 @@ struct Plus {
 // Reprojection residuals of npts points: r = (f X/Z + cx - u, f Y/Z + cy - v), p_c = R p + t;
 // Jacobian w.r.t. the right perturbation at delta = 0: d p_c/d upsilon = R, d p_c/d omega = -R [p]x.
 // data per point: [x y z u v]; folded as the AD bridge folds a residual vector (optimize_autodiff.h:123-164).
+// Robust variant: header slots intr[3] = loss kind (robust::Kind), intr[4] = th2.  Per point the
+// squared norm n2 = ||r||^2 goes through the M-estimator: cost += l, and the scale s multiplies the point's
+// contribution to the normal equations "JtJ * dx = Jt*res*s" (robust_norms.h:20-26); a point is an inlier when
+// n2 <= th2 (the inlier branch of Truncated/Huber/Tukey), reported through Cost::inlier_ratio (cost.h:84-95).
 template <typename T>
 struct ReprojAcc {
   int npts;
@@ -108,21 +113,28 @@ struct ReprojAcc {
   }
   Cost operator()(const Pose<T>& x, T* g, T* H) const {
     T c = 0;
+    const int kind = int(intr[3]);
+    const T th2 = intr[4];
+    int inliers = 0;
     for (int i = 0; i < npts; ++i) {
       T r[2], J[12];
       row_pair(x, i, r, g ? J : nullptr);
-      c += r[0] * r[0] + r[1] * r[1];
+      const T n2 = r[0] * r[0] + r[1] * r[1];
+      const auto ls = robust::Apply(kind, n2, th2);  // kind 0: {n2, 1}
+      c += ls.l;
+      inliers += (kind == 0 || n2 <= th2) ? 2 : 0;
       if (g) {
         for (int row = 0; row < 2; ++row) {
           const T* Jr = J + 6 * row;
           for (int a = 0; a < 6; ++a) {
-            g[a] += Jr[a] * r[row];
-            if (H) for (int b = 0; b < 6; ++b) H[size_t(b) * 6 + a] += Jr[a] * Jr[b];
+            const T sJ = ls.s * Jr[a];
+            g[a] += sJ * r[row];
+            if (H) for (int b = 0; b < 6; ++b) H[size_t(b) * 6 + a] += sJ * Jr[b];
           }
         }
       }
     }
-    return Cost(double(c), 2 * npts);
+    return Cost(double(c), 2 * npts, npts ? float(inliers) / float(2 * npts) : 1.0f);
   }
 };
 

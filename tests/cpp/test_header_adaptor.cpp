@@ -108,7 +108,19 @@ static void prior_cov() {
   REQUIRE(std::abs(std::sqrt(C[0]) - 4.2) < 1e-7 && std::abs(std::sqrt(C[3]) - 4.2) < 1e-7);
 }
 
+// docs/API.md:402-406 — `const auto &[robust_norm2, J] = Huber(y.squaredNorm(), 0.8, true);`
+static void huber() {
+  Context ctx(0);
+  std::vector<double> n2{0.5, 0.8, 4.0}, l, s;
+  RobustNorm(ctx, TOA_LOSS_HUBER, n2, 0.8, l, s);
+  REQUIRE(l[0] == 0.5 && s[0] == 1.0);                                     // inlier: untouched
+  REQUIRE(l[1] == 0.8 && s[1] == 1.0);
+  REQUIRE(std::abs(l[2] - (2 * std::sqrt(0.8) * 2.0 - 0.8)) < 1e-14);      // tests/robust_norms.cpp:54
+  REQUIRE(std::abs(s[2] - std::sqrt(0.8) / 2.0) < 1e-14);                  // th / n
+}
+
 int main() {
+  huber();
   sqrt2<double>();
   sqrt2<float>();
   circle();

@@ -63,8 +63,31 @@ def ldlt_cases():
                           for H, g, n in zip(Hs, gs, (1, 2, 3, 6, 12))]))
 
 
+def robust_cases():
+    """(loss, scale) of every M-estimator (losses/robust_norms.h) on a fixed grid of squared norms, th = 1.3 as in
+    tests/robust_norms.cpp:66, plus a robust SE3 solve with planted outliers (Huber, 3 px)."""
+    n2 = np.concatenate([np.array([0.0, 0.3, 0.5, 1.69, 2.3 * 2.3]), 10.0 ** np.linspace(-5, 1.5, 60)])
+    th2 = 1.3 * 1.3
+    out = {"n2": n2, "th2": np.float64(th2)}
+    for kind in ("truncated", "huber", "tukey", "arctan", "cauchy", "geman_mcclure", "blake_zisserman"):
+        loss, scale = pyoracle.robust_norm(kind, n2, th2)
+        out[f"{kind}_loss"], out[f"{kind}_scale"] = loss, scale
+    P, npts = 2, 200
+    data, p0, pstar = pyoracle.synth_se3_reproj(P, npts, np.float64, seed=11)
+    data, mask = pyoracle.se3_add_outliers(data, npts, 0.10, seed=5)
+    data = pyoracle.se3_set_loss(data, "huber", 9.0)
+    r = pyoracle.se3_reproj_lm(data, p0, npts, Options().to_pod())
+    out.update(se3_data=data, se3_p0=p0, se3_pstar=pstar, se3_x=r["x"], se3_stop=r["stop"], se3_iters=r["iters"],
+               se3_cost=r["cost"], se3_inlier_ratio=r["inlier_ratio"])
+    np.savez_compressed(os.path.join(OUT, "robust_f64.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-robust" in sys.argv:
+        robust_cases()
+        sys.exit(0)
     sqrt2_traces()
     dense_row_cases()
     ldlt_cases()
+    robust_cases()
     print("golden fixtures written to", OUT)

@@ -114,3 +114,22 @@ def test_se3_manifold_and_reprojection_pins(oracle):
     r = oracle.se3_reproj_lm(data, p0, 150, Options().to_pod())
     assert ((r["stop"] >= 1) & (r["stop"] < 5)).all()                 # Succeeded && Converged (tests/sophus.cpp:42-43)
     assert np.abs(r["x"] - pstar).max() < 5e-3
+
+
+def test_robust_golden(oracle):
+    """The oracle's M-estimators (oracle/robust.hpp, pinned to tests/robust_norms.cpp by pin_reference_tests) and the
+    robust SE3 solve reproduce the committed fixture."""
+    g = np.load(os.path.join(GOLD, "robust_f64.npz"))
+    for kind in ("truncated", "huber", "tukey", "arctan", "cauchy", "geman_mcclure", "blake_zisserman"):
+        loss, scale = oracle.robust_norm(kind, g["n2"], float(g["th2"]))
+        assert np.allclose(loss, g[f"{kind}_loss"], rtol=1e-14, atol=1e-16)
+        assert np.allclose(scale, g[f"{kind}_scale"], rtol=1e-14, atol=1e-16)
+    # Huber closed form (tests/robust_norms.cpp:54) on the fixture itself
+    n2, th2 = g["n2"], float(g["th2"])
+    assert np.allclose(g["huber_loss"], np.where(n2 > th2, 2 * np.sqrt(th2 * n2) - th2, n2), rtol=1e-13)
+    import tinyopt_amd as ta_host  # Options only (no GPU use)
+    r = oracle.se3_reproj_lm(g["se3_data"], g["se3_p0"], 200, ta_host.Options().to_pod())
+    assert np.array_equal(r["stop"], g["se3_stop"]) and np.array_equal(r["iters"], g["se3_iters"])
+    assert np.allclose(r["x"], g["se3_x"], atol=1e-10) and np.allclose(r["cost"], g["se3_cost"], rtol=1e-10)
+    assert np.allclose(r["inlier_ratio"], g["se3_inlier_ratio"])
+    assert np.abs(r["x"] - g["se3_pstar"]).max() < 1e-2     # 200 points, 0.5 px noise: outliers do not drag the pose away

@@ -48,6 +48,7 @@ class ToaResults(C.Structure):
         ("final_num_residuals", C.c_void_p), ("final_rerr_dec", C.c_void_p),
         ("final_hessian", C.c_void_p), ("errs", C.c_void_p), ("deltas2", C.c_void_p),
         ("successes", C.c_void_p), ("hist_stride", C.c_int32), ("_pad", C.c_int32),
+        ("final_inlier_ratio", C.c_void_p),
     ]
 
 
@@ -60,6 +61,8 @@ PROTOTYPES = {
     "toa_destroy": (C.c_int, [_P]),
     "toa_last_error": (C.c_char_p, []),
     "toa_device_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "toa_robust_norm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_double, _P, _P]),
+    "toa_hbm_read_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "toa_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "toa_free": (C.c_int, [_P, _P]),
     "toa_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -146,6 +146,13 @@ class Context:
         check(self.lib.toa_device_info(self.h, C.byref(cus), C.byref(khz), name, 128))
         return {"num_cus": cus.value, "clock_khz": khz.value, "name": name.value.decode()}
 
+    def hbm_read_GBps(self, tensor, reps: int = 5) -> float:
+        """Measured streaming-read rate over `tensor`'s bytes (the STREAM-like ceiling of SURVEY §8d)."""
+        out = C.c_double()
+        check(self.lib.toa_hbm_read_probe(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(),
+                                          int(reps), C.byref(out)))
+        return out.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.toa_destroy(self.h)
@@ -264,14 +271,23 @@ class SE3Reproj:
     """Device residual model: pinhole reprojection of 3-D points under an SE3 pose.
     x is [P, 12] (rotation matrix row-major + translation); the tangent has n = 6 (upsilon, omega) and the update
     is the right-multiplicative  pose <- pose * exp(delta)  of include/tinyopt/3rdparty/traits/sophus.h:24-26.
-    data: [P, 8 + 5*npts] = [f, cx, cy, 0,0,0,0,0 | x, y, z, u, v per point]."""
+    data: [P, 8 + 5*npts] = [f, cx, cy, loss, th2, 0,0,0 | x, y, z, u, v per point].
+
+    loss / th: optional M-estimator on each point's squared reprojection error (the reference's
+    losses/robust_norms.h:32-316): ``loss`` in LOSS_KINDS ("huber", "cauchy", ...), ``th`` the threshold in pixels
+    (th2 = th*th is what the reference's functions take).  The inlier ratio lands in Output.final_inlier_ratio."""
     model_id = MODEL_SE3_REPROJ
     xdim = 12
 
-    def __init__(self, data: torch.Tensor, npts: int):
+    def __init__(self, data: torch.Tensor, npts: int, loss: Optional[str] = None, th: float = 0.0):
         assert data.dim() == 2 and data.shape[1] == 8 + 5 * npts and data.is_cuda
         self.P, self.n, self.m, self.dtype = data.shape[0], 6, 2 * int(npts), data.dtype
         self.packed = data.contiguous()
+        if loss is not None:
+            if self.packed.data_ptr() == data.data_ptr():
+                self.packed = self.packed.clone()
+            self.packed[:, 3] = float(LOSS_KINDS[loss])
+            self.packed[:, 4] = float(th) * float(th)
 
     @property
     def algorithmic_bytes_per_pass(self) -> int:
@@ -313,7 +329,8 @@ _MODELS = (DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
 
 @dataclass
 class Output:
-    """tinyopt::Output (output.h:26-145), one row per problem; tensors live on the GPU."""
+    """tinyopt::Output (output.h:26-145), one row per problem; tensors live on the GPU.
+    final_inlier_ratio = Output::final_cost.inlier_ratio (cost.h:84-95)."""
     stop_reason: torch.Tensor
     num_iters: torch.Tensor
     num_failures: torch.Tensor
@@ -326,6 +343,7 @@ class Output:
     deltas2: Optional[torch.Tensor] = None
     successes: Optional[torch.Tensor] = None
     counters: Optional[torch.Tensor] = None  # [acc passes, eval passes, solves, problems]
+    final_inlier_ratio: Optional[torch.Tensor] = None
 
     def Covariance(self, rescaled: bool = False):
         """Output::Covariance (output.h:80-94): inverse of the final undamped Hessian per problem; with
@@ -376,7 +394,8 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
             stop_reason=torch.zeros(P, **i32), num_iters=torch.zeros(P, **i32), num_failures=torch.zeros(P, **i32),
             num_consec_failures=torch.zeros(P, **i32), final_cost=torch.zeros(P, **f64),
             final_num_residuals=torch.zeros(P, **i32), final_rerr_dec=torch.zeros(P, **f64),
-            counters=torch.zeros(4, dtype=torch.int64, device=dev))
+            counters=torch.zeros(4, dtype=torch.int64, device=dev),
+            final_inlier_ratio=torch.ones(P, dtype=torch.float32, device=dev))
         if options.hessian.save_last:
             out.final_hessian = torch.zeros(P, n, n, **f64)
         if history:
@@ -399,6 +418,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     res.deltas2 = out.deltas2.data_ptr() if out.deltas2 is not None else None
     res.successes = out.successes.data_ptr() if out.successes is not None else None
     res.hist_stride = out.errs.shape[1] if out.errs is not None else 0
+    res.final_inlier_ratio = out.final_inlier_ratio.data_ptr() if out.final_inlier_ratio is not None else None
     if splits is None:   # the library decides (row-split for few, huge problems)
         check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                  x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
@@ -435,6 +455,22 @@ def solve_damped(H: torch.Tensor, g: torch.Tensor, scale: float = 1.0, ctx: Opti
     check(ctx.lib.toa_solve_damped(ctx.h, _dtype_code(g.dtype), n, P, H.data_ptr(), g.data_ptr(), float(scale),
                                    dx.data_ptr(), ok.data_ptr()))
     return dx, ok
+
+
+LOSS_KINDS = {"l2": 0, "truncated": 1, "huber": 2, "tukey": 3, "arctan": 4, "cauchy": 5, "geman_mcclure": 6,
+              "blake_zisserman": 7}
+
+
+def robust_norm(kind: str, n2: torch.Tensor, th2: float, ctx: Optional[Context] = None):
+    """The reference's M-estimators in their ``Name(n2, th2, true)`` form (losses/robust_norms.h:32-316,
+    docs/API.md:402-406): returns (loss, scale) tensors shaped like ``n2`` (squared norms, GPU, float32/64)."""
+    ctx = ctx or default_context(n2.device.index)
+    n2 = n2.contiguous()
+    loss = torch.empty_like(n2)
+    scale = torch.empty_like(n2)
+    check(ctx.lib.toa_robust_norm(ctx.h, LOSS_KINDS[kind], _dtype_code(n2.dtype), n2.numel(), n2.data_ptr(), float(th2),
+                                  loss.data_ptr(), scale.data_ptr()))
+    return loss, scale
 
 
 def inv_cov(H: torch.Tensor, ctx: Optional[Context] = None):

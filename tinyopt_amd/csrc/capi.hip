@@ -5,6 +5,33 @@
 
 namespace toa {
 
+// STREAM-like read ceiling ("a measured copy ceiling reported next to the nominal one"): every lane
+// streams 16-byte loads, 4 in flight, and folds them into one word that is (practically never) written.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) hbm_read_probe_kernel(const u32x4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+  const size_t stride = size_t(gridDim.x) * 256;
+  size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) { const u32x4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+  if (acc == 0x9E3779B9u) *sink = acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) robust_norm_kernel(int kind, long long count, const T* __restrict__ n2, T th2,
+                                                          T* __restrict__ loss, T* __restrict__ scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  T l, s;
+  robust_norm(kind, n2[i], th2, l, s);
+  loss[i] = l;
+  scale[i] = s;
+}
+
 // Natural (A [P][m][n], b [P][m]) -> packed [P][m4][RS] (layout: DenseRowLayout).
 template <typename T>
 __global__ void dense_row_pack_kernel(const T* __restrict__ A, const T* __restrict__ b, T* __restrict__ out,
@@ -290,6 +317,47 @@ int toa_memset(toa_handle h, void* dst, int value, size_t bytes) {
   HIP_TRY(hipMemsetAsync(dst, value, bytes, h->stream));
   return TOA_OK;
 }
+int toa_hbm_read_probe(toa_handle h, const void* src_dev, size_t bytes, int reps, double* gb_per_s) {
+  if (!h || !src_dev || !gb_per_s || reps < 1 || bytes < 16) return fail(TOA_E_ARG, "toa_hbm_read_probe: bad argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n16 = bytes / 16;
+  const int grid = h->num_cus * 16;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  uint32_t* sink = reinterpret_cast<uint32_t*>(h->queue) + 32;  // unused tail of the 256-byte queue block
+  hipLaunchKernelGGL(toa::hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const toa::u32x4*)src_dev, n16, sink);  // warm
+  HIP_TRY(hipEventRecord(e0, h->stream));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(toa::hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const toa::u32x4*)src_dev, n16, sink);
+  HIP_TRY(hipEventRecord(e1, h->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(hipGetLastError());
+  *gb_per_s = double(n16) * 16.0 * reps / (double(ms) * 1e-3) * 1e-9;
+  return TOA_OK;
+}
+
+int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void* n2, double th2, void* loss, void* scale) {
+  if (!h || !n2 || !loss || !scale || count < 0) return fail(TOA_E_ARG, "toa_robust_norm: null argument");
+  if (kind < TOA_LOSS_L2 || kind > TOA_LOSS_BLAKE_ZISSERMAN) return fail(TOA_E_ARG, "toa_robust_norm: unknown loss kind");
+  if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "toa_robust_norm: dtype must be TOA_F32 or TOA_F64");
+  if (count == 0) return TOA_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const unsigned grid = unsigned((count + 255) / 256);
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::robust_norm_kernel<float>, dim3(grid), dim3(256), 0, h->stream, kind, (long long)count,
+                       (const float*)n2, float(th2), (float*)loss, (float*)scale);
+  else
+    hipLaunchKernelGGL(toa::robust_norm_kernel<double>, dim3(grid), dim3(256), 0, h->stream, kind, (long long)count,
+                       (const double*)n2, th2, (double*)loss, (double*)scale);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 int toa_synchronize(toa_handle h) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   HIP_TRY(hipSetDevice(h->device));

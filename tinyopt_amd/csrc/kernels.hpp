@@ -22,6 +22,7 @@
 #include "ldlt_lds.hpp"
 #include "ldlt_regs.hpp"
 #include "lm_device.hpp"
+#include "robust.hpp"
 #include "wave_utils.hpp"
 
 namespace toa {
@@ -208,6 +209,7 @@ struct Se3ReprojModel {
   const T* data;
   const T* d;
   int npts, pt0, pt1;
+  int ninl;  // inlier residuals of the last pass (cost.h:84 NumInliers)
   T G[28];
   static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
   __device__ __forceinline__ void init(int, int m, const void* dp) { npts = m / 2; data = static_cast<const T*>(dp); }
@@ -226,11 +228,14 @@ struct Se3ReprojModel {
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = L.xs[9 + i];
     const T f = d[0], cx = d[1], cy = d[2];
+    const int loss = int(d[3]);  // TOA_LOSS_*; 0 = plain squared L2 (wave-uniform)
+    const T th2 = d[4];
     if (WANT_H) {
 #pragma unroll
       for (int i = 0; i < 28; ++i) G[i] = T(0);
     }
     T csum = 0;
+    T inl = 0;  // exact in T: <= 2 * points per lane
     const T* pts = d + 8;
     for (int i = pt0 + lane; i < pt1; i += 64) {
       const T* q = pts + size_t(i) * 5;
@@ -258,20 +263,45 @@ struct Se3ReprojModel {
           w[0][c] = du0 * D[0][c] + du2 * D[2][c];
           w[1][c] = dv1 * D[1][c] + dv2 * D[2][c];
         }
+        if (loss == TOA_LOSS_L2) {
 #pragma unroll
-        for (int row = 0; row < 2; ++row)
+          for (int row = 0; row < 2; ++row)
 #pragma unroll
-          for (int a = 0; a < 7; ++a)
+            for (int a = 0; a < 7; ++a)
 #pragma unroll
-            for (int b = a; b < 7; ++b) G[tt(a, b)] += w[row][a] * w[row][b];
+              for (int b = a; b < 7; ++b) G[tt(a, b)] += w[row][a] * w[row][b];
+        } else {  // M-estimator: cost += l, the point's J^T J and J^T r are scaled by s (robust_norms.h:20-26)
+          const T n2 = w[0][6] * w[0][6] + w[1][6] * w[1][6];
+          T l, s;
+          robust_norm(loss, n2, th2, l, s);
+          csum += l;
+          inl += n2 <= th2 ? T(2) : T(0);
+#pragma unroll
+          for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              const T sw = s * w[row][a];
+#pragma unroll
+              for (int b = a; b < 7; ++b) G[tt(a, b)] += sw * w[row][b];
+            }
+        }
       } else {
-        csum += w[0][6] * w[0][6] + w[1][6] * w[1][6];
+        const T n2 = w[0][6] * w[0][6] + w[1][6] * w[1][6];
+        if (loss == TOA_LOSS_L2) csum += n2;
+        else {
+          T l, s;
+          robust_norm(loss, n2, th2, l, s);
+          csum += l;
+          inl += n2 <= th2 ? T(2) : T(0);
+        }
       }
     }
+    if (loss == TOA_LOSS_L2) ninl = 2 * (pt1 - pt0);
+    else ninl = int(wave_allreduce_sum(inl));
     if (WANT_H) {
 #pragma unroll
       for (int i = 0; i < 28; ++i) G[i] = wave_allreduce_sum(G[i]);
-      return G[tt(6, 6)];
+      if (loss == TOA_LOSS_L2) return G[tt(6, 6)];
     }
     return wave_allreduce_sum(csum);
   }
@@ -629,7 +659,7 @@ struct WideParams {
   toa_results res;
   unsigned long long* counters;
   void* state;     // WideState<T>[P]
-  void* partials;  // T[P][splits][n*n + n + 1]
+  void* partials;  // T[P][splits][n*n + n + 2]  (H, g, cost, inlier residuals)
   void* hsum;      // T[P][n*n]
   int lds_per_wave;
 };
@@ -704,7 +734,7 @@ __global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __r
   Model model;
   model.init(n, prm->m, prm->data);
   model.bind_chunk(p, row0, rows, n);
-  const int stride = n * n + n + 1;
+  const int stride = n * n + n + 2;
   T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
   T c;
   int nr;
@@ -719,7 +749,7 @@ __global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __r
   } else {
     model.evaluate(L, n, lane, c, nr);
   }
-  if (lane == 0) part[n * n + n] = c;
+  if (lane == 0) { part[n * n + n] = c; part[n * n + n + 1] = T(model_inliers(model, -1, 0)); }  // -1: model has no robust loss
 }
 
 // Model for the step kernel: "accumulate" = fold the S chunk partials (fixed order => deterministic).
@@ -731,9 +761,10 @@ struct PartialSumModel {
   const T* part;
   T* hsum;
   int S, n_, m;
+  int ninl;
   __device__ __forceinline__ T fold(int off) const {
     T s = 0;
-    const int stride = n_ * n_ + n_ + 1;
+    const int stride = n_ * n_ + n_ + 2;
     for (int k = 0; k < S; ++k) s += part[size_t(k) * stride + off];
     return s;
   }
@@ -741,11 +772,15 @@ struct PartialSumModel {
     for (int e = lane; e < n * n; e += 64) hsum[e] = fold(e);
     if (lane < n) { L.g[lane] = fold(n * n + lane); L.hd[lane] = fold(lane * n + lane); }
     cost = fold(n * n + n);
+    ninl = int(fold(n * n + n + 1));
+    if (ninl < 0) ninl = m;
     nres = m;
     wave_sync();
   }
   __device__ __forceinline__ void evaluate(WaveLds<T>&, int n, int, T& cost, int& nres) {
     cost = fold(n * n + n);
+    ninl = int(fold(n * n + n + 1));
+    if (ninl < 0) ninl = m;
     nres = m;
   }
   template <typename O>
@@ -773,7 +808,7 @@ __global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __rest
   model.S = prm->splits;
   model.n_ = n;
   model.m = prm->m;
-  model.part = static_cast<const T*>(prm->partials) + size_t(p) * prm->splits * (n * n + n + 1);
+  model.part = static_cast<const T*>(prm->partials) + size_t(p) * prm->splits * (n * n + n + 2);
   model.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
   const bool more = lm_iteration<T>(model, L, n, lane, p);
   if (!more) {
@@ -921,7 +956,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   S = (m4 + chunk - 1) / chunk;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
-  const size_t stride = size_t(n) * n + n + 1;
+  const size_t stride = size_t(n) * n + n + 2;
   const size_t b_state = (size_t(P) * sizeof(WideState<T>) + 255) & ~size_t(255);
   const size_t b_part = (size_t(P) * S * stride * sizeof(T) + 255) & ~size_t(255);
   const size_t b_hsum = (size_t(P) * n * n * sizeof(T) + 255) & ~size_t(255);

@@ -33,6 +33,13 @@ __device__ __forceinline__ double float_epsilon<double>() { return double(1e-7f)
 
 constexpr double kDblMax = 1.7976931348623157e+308;
 
+// Inlier residuals of the model's last pass: models with a robust loss expose `ninl`, the others count every
+// residual as an inlier (Cost's default inlier_ratio = 1, cost.h:23,95).
+template <typename M>
+__device__ __forceinline__ auto model_inliers(const M& m, int, int) -> decltype(m.ninl) { return m.ninl; }
+template <typename M>
+__device__ __forceinline__ int model_inliers(const M&, int nres, long) { return nres; }
+
 // Compiler-only barrier: nothing held in registers may be assumed equal to memory across it.
 __device__ __forceinline__ void reg_fence() { asm volatile("" ::: "memory"); }
 
@@ -47,6 +54,7 @@ struct LmState {
   int cost_nres;
   // Output  output.h:104-117
   int final_nres;
+  int cost_ninl, final_ninl;  // inlier residuals (Cost::NumInliers, cost.h:84); == nres for models without a robust loss
   double final_cost, final_rerr;
   int stop, num_iters;
   unsigned num_failures, num_consec;  // uint8_t in the reference: wrapped explicitly
@@ -158,6 +166,7 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
     if (do_acc) S.acc_passes++; else S.eval_passes++;
     S.cost_val = normalize_cost(double(c), nres, opt);
     S.cost_nres = nres;
+    S.cost_ninl = model_inliers(model, nres, 0);
     built = nres > 0 && S.cost_val != kDblMax;  // cost.h:83 isValid
     if (built && do_acc) {
       if (opt.grad_clipping != 0) {  // base.h:29-38
@@ -252,6 +261,7 @@ __device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const i
     S.num_consec = 0;
     S.final_cost = err;
     S.final_nres = S.cost_nres;
+    S.final_ninl = S.cost_ninl;
     S.final_rerr = rel_derr;
   } else {  // :447-460
     lm_bad_step(S, opt);
@@ -284,7 +294,7 @@ __device__ __forceinline__ void lm_init(WaveLds<T>& L, const int lane) {
   // SolverLM::reset  lm.h:46-52
   S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;
   // Output  output.h:104-117
-  S.final_cost = kDblMax; S.final_nres = 0; S.final_rerr = kDblMax;
+  S.final_cost = kDblMax; S.final_nres = 0; S.final_ninl = 0; S.cost_ninl = 0; S.final_rerr = kDblMax;
   S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
   S.cost_val = 0; S.cost_nres = 0;
   // OptimizeAcc locals  optimizer.h:248-263
@@ -360,6 +370,7 @@ __device__ __forceinline__ void lm_finalize(Model& model, WaveLds<T>& L, const i
     if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
     if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
     if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
   }
   S.problems++;
   wave_sync();
