@@ -63,6 +63,14 @@ struct GramStep;
     static __device__ __forceinline__ void run(Acc* acc, const T* w) {                                  \
       asm volatile("s_nop 1\n\t" BODY : ACCS : WS);                                                    \
     }                                                                                                   \
+    /* Same, and when `last` != 0 (wave-uniform SGPR) wait out the MFMA pipeline INSIDE the statement:  \
+       hipcc cannot see the XDL-write -> accvgpr-read hazard of an asm MFMA, and any accumulator copy   \
+       it places after the loop's final step must not overtake the matrix core. */                      \
+    static __device__ __forceinline__ void run_tail(Acc* acc, const T* w, int last) {                   \
+      asm volatile("s_nop 1\n\t" BODY                                                                  \
+                   "s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 2\n\ts_nop 15\n\ts_nop 15\n\t"            \
+                   : ACCS : WS TOA_C [last] "s"(last) : "scc");                                         \
+    }                                                                                                   \
   };
 // tile order matches DenseRowGram::tile(i, j): (0,0),(0,1)..(0,NB-1),(1,1)...
 TOA_GRAM_STEP(float, F32, 1, TOA_MF32(0, 1, 1), "+a"(acc[0]), "v"(w[0]))
@@ -350,7 +358,8 @@ struct DenseRowGram {
   T accTT[NTT ? NTT : 1];    // thin_j * thin_j' (j <= j'), identical on every lane after the pass
 
   static __device__ __forceinline__ constexpr int tile(int i, int j) { return i * NBM - i * (i - 1) / 2 + (j - i); }
-  static __device__ __forceinline__ constexpr int tt(int j, int j2) { return j * THIN - j * (j - 1) / 2 + (j2 - j); }
+  // thin x thin product (j <= j2): stored column by column so that (j, j2), (j+1, j2) are adjacent (packed FMA)
+  static __device__ __forceinline__ constexpr int tt(int j, int j2) { return j2 * (j2 + 1) / 2 + j; }
   // accT index of (column block cb, thin element j): pairs of blocks adjacent (packed-FMA friendly), odd block last
   static __device__ __forceinline__ constexpr int ti(int cb, int j) {
     return cb < 2 * (NBM / 2) ? ((cb / 2) * THIN + j) * 2 + (cb & 1) : 2 * (NBM / 2) * THIN + j;
@@ -365,24 +374,196 @@ struct DenseRowGram {
     for (int t = 0; t < (NTT ? NTT : 1); ++t) accTT[t] = T(0);
   }
 
+#ifndef TOA_U
+#define TOA_U 4
+#endif
+  static constexpr int U = TOA_U;  // steps (of 4 rows) per batch; one batch is in flight while the other computes
+  static_assert(U == 4, "wait_batch ties exactly four slots");
+  static constexpr int kDw = NBM * int(sizeof(T)) / 4;
+  static constexpr int kDwT = THIN ? THIN * int(sizeof(T)) / 4 : 1;
+  using Slots = RawVec<kDw>[U];
+  using SlotsT = RawVec<kDwT>[U];
+
+  // Loop-invariant per-lane operands of a pass.
+  struct PassCtx {
+    T xr[NBM];
+    T xt[THIN > 1 ? THIN - 1 : 1];
+    bool isB_lane;
+    int c;
+  };
+
+  static __device__ __forceinline__ void issue_batch(Slots& m, SlotsT& t, const i32x4 rsrc, const unsigned voff,
+                                                     const unsigned vofft, const unsigned soff0, const unsigned step_bytes_u) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes_u);
+      if (THIN) t[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
+    }
+  }
+  static __device__ __forceinline__ void wait_slots(Slots& m, SlotsT& t) {
+    wait_batch<kDw>(m[0], m[1], m[2], m[3]);
+    if (THIN) wait_batch<kDwT>(t[0], t[1], t[2], t[3]);
+  }
+
+  // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
+  // of `m` / `tv` (no staging copies: the other slot set is the one being refilled meanwhile).
+  template <bool WANT_H, bool TAIL = false>
+  __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, const PassCtx& pc, T& csum,
+                                                const int last = 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      T w[NBM];
+      T v[THIN ? THIN : 1];
+      {
+        unsigned raw[kDw];
+        m[u].get(raw);
+        __builtin_memcpy(&w[0], &raw[0], sizeof(raw));
+        if (THIN) {
+          unsigned rawT[kDwT];
+          tv[u].get(rawT);
+          __builtin_memcpy(&v[0], &rawT[0], sizeof(T) * THIN);
+        }
+      }
+      T part = 0;
+#pragma unroll
+      for (int cb = 0; cb < NBM; ++cb) part += w[cb] * pc.xr[cb];
+      T t = row16_allreduce_sum(part);
+#pragma unroll
+      for (int j = 0; j + 1 < THIN; ++j) t += v[j] * pc.xt[j];
+      T sn, cs;
+#ifndef TOA_ABL_NOSINCOS
+      sincos_t(t, &sn, &cs);
+#else
+      sn = t; cs = t;
+#endif
+      const T sc = T(1) + T(0.1) * cs;
+      const T rbase = t + T(0.1) * sn;
+      if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
+        using f2 = float __attribute__((ext_vector_type(2)));
+        constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
+#pragma unroll
+        for (int cb = 0; cb + 1 < kScaled; cb += 2) {
+          const f2 wp = f2{w[cb], w[cb + 1]} * f2{sc, sc};
+          w[cb] = wp[0];
+          w[cb + 1] = wp[1];
+        }
+        if constexpr (kScaled & 1) w[kScaled - 1] *= sc;
+#pragma unroll
+        for (int j = 0; j + 2 < THIN; j += 2) {
+          const f2 vp = f2{v[j], v[j + 1]} * f2{sc, sc};
+          v[j] = vp[0];
+          v[j + 1] = vp[1];
+        }
+        if constexpr (THIN > 1 && ((THIN - 1) & 1)) v[THIN - 2] *= sc;
+      } else {
+#pragma unroll
+        for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
+        if (THIN != 0) w[NBM - 1] *= sc;
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
+      }
+      if (THIN == 0) w[NBM - 1] = pc.isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+      else v[THIN - 1] = rbase - v[THIN - 1];
+      if (WANT_H) {
+#if defined(TOA_SPLIT_MFMA)
+#pragma unroll
+        for (int i = 0; i < NBM; ++i)
+#pragma unroll
+          for (int j = i; j < NBM; ++j) {
+            if constexpr (sizeof(T) == 4)
+              asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+            else
+              asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+          }
+#elif !defined(TOA_ABL_NOMFMA)
+        if (TAIL && u == U - 1) GramStep<T, NBM>::run_tail(acc, w, last);
+        else GramStep<T, NBM>::run(acc, w);
+#else
+#pragma unroll
+        for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
+#endif
+#ifndef TOA_ABL_NOTHIN
+        if constexpr (sizeof(T) == 4 && THIN > 0) {
+          // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
+          // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
+          using f2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int pb = 0; pb < NBM / 2; ++pb) {
+            const f2 wp = {w[2 * pb], w[2 * pb + 1]};
+#pragma unroll
+            for (int j = 0; j < THIN; ++j) {
+              f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
+              a += wp * f2{v[j], v[j]};
+              accT[ti(2 * pb, j)] = a[0];
+              accT[ti(2 * pb + 1, j)] = a[1];
+            }
+          }
+          if constexpr (NBM & 1) {
+#pragma unroll
+            for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
+          }
+          // thin x thin corner, column j2 at a time: (j, j+1) pairs against a splat of v[j2] in one packed FMA
+#pragma unroll
+          for (int j2 = 0; j2 < THIN; ++j2) {
+#pragma unroll
+            for (int j = 0; j + 1 <= j2; j += 2) {
+              f2 a = {accTT[tt(j, j2)], accTT[tt(j + 1, j2)]};
+              a += f2{v[j], v[j + 1]} * f2{v[j2], v[j2]};
+              accTT[tt(j, j2)] = a[0];
+              accTT[tt(j + 1, j2)] = a[1];
+            }
+            if ((j2 & 1) == 0) accTT[tt(j2, j2)] += v[j2] * v[j2];
+          }
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < NBM; ++cb)
+#pragma unroll
+            for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
+#pragma unroll
+          for (int j = 0; j < THIN; ++j)
+#pragma unroll
+            for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
+        }
+#else
+#pragma unroll
+        for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
+#endif
+      } else {
+        if (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
+        else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
+      }
+    }
+  }
+
+  // Belt and braces after the loop (the final step already waited inside its own asm statement, see
+  // GramStep::run_tail); tools/isa_lint.py checks the built objects for accumulator reads that could overtake an MFMA.
+  __device__ __forceinline__ void mfma_retire() {
+    asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+  }
+
   // One pass over the problem's rows.  WANT_H: full Gram (K1).  !WANT_H: cost only (K2) — returns
   // the wave-reduced sum of squares.  xs: x in LDS.  prob: packed [m4][RS].
+  // Software pipeline: two sets of load registers (A, B) alternate between "being refilled by buffer loads" and
+  // "being consumed by the arithmetic", so no register-to-register staging copies are needed (24 v_mov per batch
+  // in the single-set version = 13 % of the VALU issue slots of this issue-bound loop).
   template <bool WANT_H>
   __device__ __forceinline__ T pass(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
                                     const T* __restrict__ xs, const int lane) {
     const int k = lane >> 4, c = lane & 15;
     const int RS = lay.rs, rsm = lay.rsm;
     const bool active = c * NBM < rsm;
-    T xr[NBM];
+    PassCtx pc;
+    pc.c = c;
 #pragma unroll
     for (int cb = 0; cb < NBM; ++cb) {
       const int q = NBM * c + cb;
-      xr[cb] = (q < lay.nmr) ? xs[q] : T(0);  // b slot and padding contribute nothing to a_i.x
+      pc.xr[cb] = (q < lay.nmr) ? xs[q] : T(0);  // b slot and padding contribute nothing to a_i.x
     }
-    T xt[THIN > 1 ? THIN - 1 : 1];
 #pragma unroll
-    for (int j = 0; j + 1 < THIN; ++j) xt[j] = xs[lay.nmr + j];
-    const bool isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
+    for (int j = 0; j + 1 < THIN; ++j) pc.xt[j] = xs[lay.nmr + j];
+    pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
     if (WANT_H) clear();
     T csum = 0;
     const int steps = lay.m4 >> 2;
@@ -392,154 +573,30 @@ struct DenseRowGram {
     const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
     const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));  // same address for the 16 lanes of a row group
     const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
-#ifndef TOA_U
-#define TOA_U 4
-#endif
-    constexpr int U = TOA_U;  // steps per batch; the next batch's loads are in flight while this one computes
-    constexpr int kDw = NBM * int(sizeof(T)) / 4;
-    constexpr int kDwT = THIN ? THIN * int(sizeof(T)) / 4 : 1;
-    RawVec<kDw> nxt[U];
-    RawVec<kDwT> nxtT[U];
     const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(step_bytes)));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      nxt[u].issue(rsrc, voff, unsigned(u) * step_bytes_u);
-      if (THIN) nxtT[u].issue(rsrc, vofft, unsigned(u) * step_bytes_u);
-    }
-    wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
-    if (THIN) wait_batch<kDwT>(nxtT[0], nxtT[1], nxtT[2], nxtT[3]);
-    for (int s0 = 0; s0 < steps; s0 += U) {
-      T cur[U][NBM];
-      T curT[U][THIN ? THIN : 1];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        unsigned raw[kDw];
-        nxt[u].get(raw);
-        __builtin_memcpy(&cur[u][0], &raw[0], sizeof(raw));
-        if (THIN) {
-          unsigned rawT[kDwT];
-          nxtT[u].get(rawT);
-          __builtin_memcpy(&curT[u][0], &rawT[0], sizeof(T) * THIN);
-        }
-      }
-      // prefetch the next U steps (past the end: reads 0); pinned here, ahead of this batch's math
-      const unsigned soff0 = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + U) * step_bytes_u)));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        nxt[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes_u);
-        if (THIN) nxtT[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
-      }
+    Slots A, B;
+    SlotsT At, Bt;
+    issue_batch(A, At, rsrc, voff, vofft, 0u, step_bytes_u);
+    wait_slots(A, At);
+    // Two batches per iteration, one exit at the bottom: a single loop-carried copy of the accumulators (a mid-loop
+    // exit makes hipcc keep one AGPR set per half and shuffle 24 registers between them).  An odd batch count
+    // runs one batch of zero rows (loads past the end return 0, and an all-zero row adds nothing).
+    for (int s0 = 0; s0 < steps; s0 += 2 * U) {
+      const unsigned soffB = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + U) * step_bytes_u)));
+      issue_batch(B, Bt, rsrc, voff, vofft, soffB, step_bytes_u);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        T(&w)[NBM] = cur[u];
-        T(&v)[THIN ? THIN : 1] = curT[u];
-        T part = 0;
-#pragma unroll
-        for (int cb = 0; cb < NBM; ++cb) part += w[cb] * xr[cb];
-        T t = row16_allreduce_sum(part);
-#pragma unroll
-        for (int j = 0; j + 1 < THIN; ++j) t += v[j] * xt[j];
-        T sn, cs;
-#ifndef TOA_ABL_NOSINCOS
-        sincos_t(t, &sn, &cs);
-#else
-        sn = t; cs = t;
-#endif
-        const T sc = T(1) + T(0.1) * cs;
-        const T rbase = t + T(0.1) * sn;
-        if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
-          using f2 = float __attribute__((ext_vector_type(2)));
-          constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
-#pragma unroll
-          for (int cb = 0; cb + 1 < kScaled; cb += 2) {
-            const f2 wp = f2{w[cb], w[cb + 1]} * f2{sc, sc};
-            w[cb] = wp[0];
-            w[cb + 1] = wp[1];
-          }
-          if constexpr (kScaled & 1) w[kScaled - 1] *= sc;
-#pragma unroll
-          for (int j = 0; j + 2 < THIN; j += 2) {
-            const f2 vp = f2{v[j], v[j + 1]} * f2{sc, sc};
-            v[j] = vp[0];
-            v[j + 1] = vp[1];
-          }
-          if constexpr (THIN > 1 && ((THIN - 1) & 1)) v[THIN - 2] *= sc;
-        } else {
-#pragma unroll
-          for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
-          if (THIN != 0) w[NBM - 1] *= sc;
-#pragma unroll
-          for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
-        }
-        if (THIN == 0) w[NBM - 1] = isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
-        else v[THIN - 1] = rbase - v[THIN - 1];
-        if (WANT_H) {
-#if defined(TOA_SPLIT_MFMA)
-#pragma unroll
-          for (int i = 0; i < NBM; ++i)
-#pragma unroll
-            for (int j = i; j < NBM; ++j) {
-              if constexpr (sizeof(T) == 4)
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
-              else
-                asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
-            }
-#elif !defined(TOA_ABL_NOMFMA)
-          GramStep<T, NBM>::run(acc, w);
-#else
-#pragma unroll
-          for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
-#endif
-#ifndef TOA_ABL_NOTHIN
-          if constexpr (sizeof(T) == 4 && THIN > 0) {
-            // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
-            // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
-            using f2 = float __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int pb = 0; pb < NBM / 2; ++pb) {
-              const f2 wp = {w[2 * pb], w[2 * pb + 1]};
-#pragma unroll
-              for (int j = 0; j < THIN; ++j) {
-                f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
-                a += wp * f2{v[j], v[j]};
-                accT[ti(2 * pb, j)] = a[0];
-                accT[ti(2 * pb + 1, j)] = a[1];
-              }
-            }
-            if constexpr (NBM & 1) {
-#pragma unroll
-              for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
-            }
-          } else {
-#pragma unroll
-            for (int cb = 0; cb < NBM; ++cb)
-#pragma unroll
-              for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
-          }
-#pragma unroll
-          for (int j = 0; j < THIN; ++j)
-#pragma unroll
-            for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
-#else
-#pragma unroll
-          for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
-#endif
-        } else {
-          if (THIN == 0) csum += isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
-          else csum += (c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
-        }
-      }
+      compute_batch<WANT_H>(A, At, pc, csum);
       __builtin_amdgcn_sched_barrier(0);
-      wait_batch<kDw>(nxt[0], nxt[1], nxt[2], nxt[3]);
-      if (THIN) wait_batch<kDwT>(nxtT[0], nxtT[1], nxtT[2], nxtT[3]);
+      wait_slots(B, Bt);
+      const unsigned soffA = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 2 * U) * step_bytes_u)));
+      issue_batch(A, At, rsrc, voff, vofft, soffA, step_bytes_u);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_batch<WANT_H, true>(B, Bt, pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + 2 * U >= steps)));
+      __builtin_amdgcn_sched_barrier(0);
+      wait_slots(A, At);
     }
+    if (WANT_H) mfma_retire();
     if (WANT_H) {
-      // the last MFMAs must retire before compiler-generated code reads the accumulators
-      // (XDL write -> VALU/accvgpr read needs up to 18 wait states that hipcc cannot see)
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
       if (THIN) {  // fold the 4 row groups: every lane ends with the totals for its column set
 #pragma unroll
         for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
