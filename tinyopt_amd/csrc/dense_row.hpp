@@ -66,7 +66,8 @@ struct GramStep;
     /* Same, and when `last` != 0 (wave-uniform SGPR) wait out the MFMA pipeline INSIDE the statement:  \
        hipcc cannot see the XDL-write -> accvgpr-read hazard of an asm MFMA, and any accumulator copy   \
        it places after the loop's final step must not overtake the matrix core. */                      \
-    static __device__ __forceinline__ void run_tail(Acc* acc, const T* w, int last) {                   \
+    static __device__ __forceinline__ void run_tail(Acc* acc, const T* w, int last_in) {                \
+      const int last = __builtin_amdgcn_readfirstlane(last_in); /* "s" needs a provably uniform value */ \
       asm volatile("s_nop 1\n\t" BODY                                                                  \
                    "s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 2\n\ts_nop 15\n\ts_nop 15\n\t"            \
                    : ACCS : WS TOA_C [last] "s"(last) : "scc");                                         \
@@ -387,8 +388,9 @@ struct DenseRowGram {
   // Loop-invariant per-lane operands of a pass.
   struct PassCtx {
     T xr[NBM];
-    T xt[THIN > 1 ? THIN - 1 : 1];
+    T xt[THIN > 1 ? THIN - 1 : 1];  // x of the thin columns on lane c == 0, zero elsewhere (they join the row reduction once)
     bool isB_lane;
+    bool q0, q1;                     // bits of the lane's quad position: the batch step whose a_i.x this lane finishes
     int c;
   };
 
@@ -410,34 +412,42 @@ struct DenseRowGram {
   template <bool WANT_H, bool TAIL = false>
   __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, const PassCtx& pc, T& csum,
                                                 const int last = 0) {
+    T wa[U][NBM];
+    T va[U][THIN ? THIN : 1];
+    T part[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      T w[NBM];
-      T v[THIN ? THIN : 1];
-      {
-        unsigned raw[kDw];
-        m[u].get(raw);
-        __builtin_memcpy(&w[0], &raw[0], sizeof(raw));
-        if (THIN) {
-          unsigned rawT[kDwT];
-          tv[u].get(rawT);
-          __builtin_memcpy(&v[0], &rawT[0], sizeof(T) * THIN);
-        }
+      unsigned raw[kDw];
+      m[u].get(raw);
+      __builtin_memcpy(&wa[u][0], &raw[0], sizeof(raw));
+      if (THIN) {
+        unsigned rawT[kDwT];
+        tv[u].get(rawT);
+        __builtin_memcpy(&va[u][0], &rawT[0], sizeof(T) * THIN);
       }
-      T part = 0;
+      T pu = 0;
 #pragma unroll
-      for (int cb = 0; cb < NBM; ++cb) part += w[cb] * pc.xr[cb];
-      T t = row16_allreduce_sum(part);
+      for (int cb = 0; cb < NBM; ++cb) pu += wa[u][cb] * pc.xr[cb];
 #pragma unroll
-      for (int j = 0; j + 1 < THIN; ++j) t += v[j] * pc.xt[j];
-      T sn, cs;
+      for (int j = 0; j + 1 < THIN; ++j) pu += va[u][j] * pc.xt[j];
+      part[u] = pu;
+    }
+    // a_i.x of the four steps in one transposed reduction; quad lane q then owns step q: ONE sin/cos per batch
+    const T tsel = quad_transpose_reduce(part, pc.q0, pc.q1);
+    T sn, cs;
 #ifndef TOA_ABL_NOSINCOS
-      sincos_t(t, &sn, &cs);
+    sincos_t(tsel, &sn, &cs);
 #else
-      sn = t; cs = t;
+    sn = tsel; cs = tsel;
 #endif
-      const T sc = T(1) + T(0.1) * cs;
-      const T rbase = t + T(0.1) * sn;
+    const T sc_sel = T(1) + T(0.1) * cs;
+    const T rb_sel = tsel + T(0.1) * sn;
+    static_for<U>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      T(&w)[NBM] = wa[u];
+      T(&v)[THIN ? THIN : 1] = va[u];
+      const T sc = quad_bcast<u>(sc_sel);
+      const T rbase = quad_bcast<u>(rb_sel);
       if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
         using f2 = float __attribute__((ext_vector_type(2)));
         constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
@@ -532,7 +542,7 @@ struct DenseRowGram {
         if (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
         else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
       }
-    }
+    });
   }
 
   // Belt and braces after the loop (the final step already waited inside its own asm statement, see
@@ -562,7 +572,9 @@ struct DenseRowGram {
       pc.xr[cb] = (q < lay.nmr) ? xs[q] : T(0);  // b slot and padding contribute nothing to a_i.x
     }
 #pragma unroll
-    for (int j = 0; j + 1 < THIN; ++j) pc.xt[j] = xs[lay.nmr + j];
+    for (int j = 0; j + 1 < THIN; ++j) pc.xt[j] = (c == 0) ? xs[lay.nmr + j] : T(0);
+    pc.q0 = (lane & 1) != 0;
+    pc.q1 = (lane & 2) != 0;
     pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
     if (WANT_H) clear();
     T csum = 0;

@@ -53,7 +53,11 @@ struct DenseRowModel {
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
   }
+#ifdef TOA_ABL_REUSE  // ablation: every wave streams one of 64 problems (cache-resident data, same instruction stream)
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); }
+#else
   __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); }
+#endif
   // row-split execution: restrict the model to rows [row0, row0 + rows) of problem p (rows % 4 == 0)
   __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int n) {
     const DenseRowLayout full = DenseRowLayout::make(n, m);

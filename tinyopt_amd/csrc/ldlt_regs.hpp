@@ -28,15 +28,16 @@
 
 namespace toa {
 
-// Compile-time loop: every index below must be a constant for row[] to stay in registers (a
-// `#pragma unroll` that hipcc declines — it does at NPAD = 64 — turns row[] into scratch memory).
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+// static_for (wave_utils.hpp): every index below must be a compile-time constant for row[] to stay in registers
+// (a `#pragma unroll` that hipcc declines — it does at NPAD = 64 — turns row[] into scratch memory).
+
+// Opaque copy of a wave-uniform value.  n is constant for a whole launch, so every `j < n` / `k < n` gate of the
+// unrolled code below is loop-invariant with respect to the problem / iteration loops of the fused kernel; LICM
+// hoists all ~200 of them and parks their SGPR masks in VGPR lanes for the entire kernel (883 SGPR spills = 14
+// VGPRs at n = 50).  Recomputing a scalar compare per call is free next to that.
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
 }
 
 template <typename T, int NPAD>
@@ -45,7 +46,8 @@ struct LdltRegs {
   T dvec;
 
   // Lane i loads row i of the symmetric n×n LDS image (LD-strided); everything beyond n is zero.
-  __device__ __forceinline__ void load(const T* __restrict__ M, const int LD, const int n, const int lane) {
+  __device__ __forceinline__ void load(const T* __restrict__ M, const int LD, const int n_in, const int lane) {
+    const int n = opaque_uniform(n_in);
     const bool in_n = lane < n;
     const T* r = M + (in_n ? lane : 0) * LD;
     static_for<NPAD / 8>([&](auto jbc) __attribute__((always_inline)) {
@@ -63,7 +65,8 @@ struct LdltRegs {
   }
 
   // Returns true iff every pivot was finite and > min_normal (then the factorisation is complete).
-  __device__ __forceinline__ bool factor(const int n, const int lane) {
+  __device__ __forceinline__ bool factor(const int n_in, const int lane) {
+    const int n = opaque_uniform(n_in);
     bool ok = true;
     static_for<NPAD>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
@@ -98,7 +101,8 @@ struct LdltRegs {
   }
 
   // x = A^-1 b using the factors above.  b_lane / return: element `lane` (lanes >= n: 0).
-  __device__ __forceinline__ T solve(const int n, const int lane, const T b_lane) const {
+  __device__ __forceinline__ T solve(const int n_in, const int lane, const T b_lane) const {
+    const int n = opaque_uniform(n_in);
     T y = lane < n ? b_lane : T(0);
     static_for<NPAD - 1>([&](auto kc) __attribute__((always_inline)) {  // L y' = b   (unit lower, column sweep)
       constexpr int k = decltype(kc)::value;

@@ -6,9 +6,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace toa {
 
 constexpr int kWave = 64;
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -24,8 +36,9 @@ __device__ __forceinline__ void wave_sync() {
 // ---- DPP row rotate (within each 16-lane row): returns src from lane ((l + N) mod 16) of the row.
 template <int N>
 __device__ __forceinline__ int dpp_row_ror_i32(int v) {
-  // dpp_ctrl 0x120 + N = row_ror:N ; row_mask = bank_mask = 0xf ; bound_ctrl = false
-  return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false);
+  // dpp_ctrl 0x120 + N = row_ror:N ; row_mask = bank_mask = 0xf ; every lane has a source, so `old` is never
+  // used: old = 0 + bound_ctrl avoids the register copy that seeding `old` with v costs
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, true);
 }
 template <int N>
 __device__ __forceinline__ float dpp_row_ror(float v) {
@@ -39,6 +52,42 @@ __device__ __forceinline__ double dpp_row_ror(double v) {
   const int lo = dpp_row_ror_i32<N>(int(b & 0xffffffffll));
   const int hi = dpp_row_ror_i32<N>(int(b >> 32));
   return __longlong_as_double((long long)(unsigned)lo | ((long long)hi << 32));
+}
+
+// ---- DPP quad permute (within each group of 4 adjacent lanes): lane i of the quad reads lane SEL_i.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, int(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, int(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(unsigned)lo | ((long long)hi << 32));
+}
+constexpr int kQuadSwap1 = 0xB1;  // quad_perm:[1,0,3,2]  (partner = lane ^ 1)
+constexpr int kQuadSwap2 = 0x4E;  // quad_perm:[2,3,0,1]  (partner = lane ^ 2)
+// Broadcast quad lane U to the whole quad.
+template <int U, typename T>
+__device__ __forceinline__ T quad_bcast(T v) { return dpp_quad<U * 0x55>(v); }
+
+// Transposed row reduction of FOUR values at once: p[0..3] are per-lane partial sums of four independent
+// 16-lane row reductions; on return the lane at quad position q = lane & 3 holds the complete row total of p[q]
+// (all 16 lanes of a row that share q hold the same number).  11 DPP-adds / selects for f32 instead of the 16 that
+// four separate all-reduces cost, and the result arrives already distributed "one value per quad lane", which is
+// what lets the caller run the expensive per-row function (sin/cos) once per batch instead of four times.
+template <typename T>
+__device__ __forceinline__ T quad_transpose_reduce(const T (&p)[4], const bool bit0, const bool bit1) {
+  const T keep01 = bit0 ? p[1] : p[0], send01 = bit0 ? p[0] : p[1];
+  const T keep23 = bit0 ? p[3] : p[2], send23 = bit0 ? p[2] : p[3];
+  const T r01 = keep01 + dpp_quad<kQuadSwap1>(send01);
+  const T r23 = keep23 + dpp_quad<kQuadSwap1>(send23);
+  const T keep = bit1 ? r23 : r01, send = bit1 ? r01 : r23;
+  T s = keep + dpp_quad<kQuadSwap2>(send);
+  s += dpp_row_ror<4>(s);
+  s += dpp_row_ror<8>(s);
+  return s;
 }
 
 // All-reduce (sum) across each 16-lane DPP row; every lane of the row gets the row total.

@@ -3,7 +3,7 @@
 accumulator copy it inserts (v_accvgpr_read / v_accvgpr_mov / any non-MFMA reader of an AGPR) could overtake
 the matrix core.  This scans the gfx950 code objects of the built translation units and fails if such a
 reader follows an MFMA that wrote the same AGPR with fewer than MIN_WAIT wait states in between
-(every instruction = 1, `s_nop N` = N + 1; straight-line approximation, conservative).
+(every instruction = 1, `s_nop N` = N + 1, a later MFMA = its passes - 1; straight-line approximation, conservative).
 
 usage: python tools/isa_lint.py [objects...]    (default: tinyopt_amd/csrc/_obj/*.o)
 """
@@ -57,6 +57,9 @@ def lint_object(obj):
                     step = int(rest.strip()) + 1
                 if op.startswith("v_mfma"):
                     dst = rest.split(",")[0]
+                    # the matrix core runs one MFMA at a time: this one could only issue once the previous one was
+                    # (passes - 1) issue slots into its execution (8-pass f32 16x16x4, 16-pass f64 16x16x4)
+                    step = 15 if "f64" in op else 7
                     for r in last_write:
                         last_write[r] += step
                     for r in aregs(dst):
