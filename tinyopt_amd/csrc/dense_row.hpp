@@ -287,16 +287,20 @@ struct RawVec<8> {
 };
 // Wait for every outstanding VMEM load of this wave; the operands make the four batch slots
 // data-dependent on the wait so that no consumer is hoisted above it.
-template <int kDwords>
+// kLeave: how many YOUNGER vector-memory accesses may stay outstanding (loads retire in issue order).
+template <int kLeave, int kDwords>
 __device__ __forceinline__ void wait_batch(RawVec<kDwords>& v0, RawVec<kDwords>& v1, RawVec<kDwords>& v2, RawVec<kDwords>& v3) {
+  static_assert(kLeave >= 0 && kLeave < 64, "vmcnt is a 6-bit counter");
   if constexpr (kDwords <= 4) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a) : : "memory");
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a) : [n] "n"(kLeave) : "memory");
   } else {
-    asm volatile("s_waitcnt vmcnt(0)"
+    asm volatile("s_waitcnt vmcnt(%[n])"
                  : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a), "+v"(v0.b), "+v"(v1.b), "+v"(v2.b), "+v"(v3.b)
-                 : : "memory");
+                 : [n] "n"(kLeave) : "memory");
   }
 }
+template <int kDwords>
+constexpr int rawvec_loads() { return kDwords <= 4 ? 1 : 2; }
 
 // Host+device layout helper.
 //
@@ -402,9 +406,16 @@ struct DenseRowGram {
       if (THIN) t[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
     }
   }
+#ifndef TOA_DEPTH
+#define TOA_DEPTH 2
+#endif
+  static constexpr int kDepth = TOA_DEPTH;  // slot sets in the ring: kDepth - 1 batches are in flight while one computes
+  static_assert(kDepth >= 2 && kDepth <= 4, "ring depth");
+  static constexpr int kLoadsPerBatch = U * (rawvec_loads<kDw>() + (THIN ? rawvec_loads<kDwT>() : 0));
+  static constexpr int kLeave = (kDepth - 2) * kLoadsPerBatch;  // younger batches that may stay outstanding at a wait
   static __device__ __forceinline__ void wait_slots(Slots& m, SlotsT& t) {
-    wait_batch<kDw>(m[0], m[1], m[2], m[3]);
-    if (THIN) wait_batch<kDwT>(t[0], t[1], t[2], t[3]);
+    wait_batch<kLeave, kDw>(m[0], m[1], m[2], m[3]);
+    if (THIN) wait_batch<kLeave, kDwT>(t[0], t[1], t[2], t[3]);
   }
 
   // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
@@ -472,7 +483,7 @@ struct DenseRowGram {
 #pragma unroll
         for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
       }
-      if (THIN == 0) w[NBM - 1] = pc.isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+      if constexpr (THIN == 0) w[NBM - 1] = pc.isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
       else v[THIN - 1] = rbase - v[THIN - 1];
       if (WANT_H) {
 #if defined(TOA_SPLIT_MFMA)
@@ -539,7 +550,7 @@ struct DenseRowGram {
         for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
 #endif
       } else {
-        if (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
+        if constexpr (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
         else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
       }
     });
@@ -586,26 +597,40 @@ struct DenseRowGram {
     const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));  // same address for the 16 lanes of a row group
     const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
     const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(step_bytes)));
-    Slots A, B;
-    SlotsT At, Bt;
-    issue_batch(A, At, rsrc, voff, vofft, 0u, step_bytes_u);
-    wait_slots(A, At);
-    // Two batches per iteration, one exit at the bottom: a single loop-carried copy of the accumulators (a mid-loop
-    // exit makes hipcc keep one AGPR set per half and shuffle 24 registers between them).  An odd batch count
-    // runs one batch of zero rows (loads past the end return 0, and an all-zero row adds nothing).
-    for (int s0 = 0; s0 < steps; s0 += 2 * U) {
-      const unsigned soffB = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + U) * step_bytes_u)));
-      issue_batch(B, Bt, rsrc, voff, vofft, soffB, step_bytes_u);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_batch<WANT_H>(A, At, pc, csum);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_slots(B, Bt);
-      const unsigned soffA = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 2 * U) * step_bytes_u)));
-      issue_batch(A, At, rsrc, voff, vofft, soffA, step_bytes_u);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_batch<WANT_H, true>(B, Bt, pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + 2 * U >= steps)));
-      __builtin_amdgcn_sched_barrier(0);
-      wait_slots(A, At);
+    // Ring of kDepth slot sets: while set i is consumed, the kDepth - 1 younger batches are in flight.  One exit at the
+    // bottom keeps a single loop-carried copy of the accumulators (a mid-loop exit makes hipcc keep one AGPR set per
+    // segment and shuffle 24 registers between them); a batch count that is not a multiple of kDepth runs up to
+    // kDepth - 1 batches of zero rows (loads past the end return 0, and an all-zero row adds nothing).
+    // With kDepth > 2 one set is in flight across the back-edge: tools/isa_lint.py proves no instruction touches a
+    // register whose load is still outstanding (a compiler-inserted copy there would read stale data).
+    Slots S[kDepth];
+    SlotsT St[kDepth];
+    static_for<kDepth - 1>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      issue_batch(S[i], St[i], rsrc, voff, vofft, unsigned(i * U) * step_bytes_u, step_bytes_u);
+    });
+    wait_slots(S[0], St[0]);
+    for (int s0 = 0; s0 < steps; s0 += kDepth * U) {
+      static_for<kDepth>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int refill = (i + kDepth - 1) % kDepth;  // consumed in the previous segment
+        const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + (i + kDepth - 1) * U) * step_bytes_u)));
+        issue_batch(S[refill], St[refill], rsrc, voff, vofft, soff, step_bytes_u);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i == kDepth - 1)
+          compute_batch<WANT_H, true>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + kDepth * U >= steps)));
+        else
+          compute_batch<WANT_H>(S[i], St[i], pc, csum);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_slots(S[(i + 1) % kDepth], St[(i + 1) % kDepth]);
+      });
+    }
+    if constexpr (kDepth > 2) {  // drain the prefetches past the end before their registers are reused
+      static_for<kDepth>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        wait_batch<0, kDw>(S[i][0], S[i][1], S[i][2], S[i][3]);
+        if (THIN) wait_batch<0, kDwT>(St[i][0], St[i][1], St[i][2], St[i][3]);
+      });
     }
     if (WANT_H) mfma_retire();
     if (WANT_H) {

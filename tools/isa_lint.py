@@ -19,6 +19,109 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 MIN_WAIT = 19  # XDL write VGPR -> VALU read, 16-pass op (CDNA3/4 ISA guide, software wait states)
 
 AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+VMEM = re.compile(r"^(buffer|global|flat|scratch)_(load|store|atomic)")
+
+
+def vregs(text):
+    out = set()
+    for m in VREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def touched_vregs(op, text):
+    """VGPRs an instruction reads or writes.  Packed-f32 ops name 64-bit pairs but a source whose op_sel and
+    op_sel_hi pick the same half reads only that one register (the other may legally belong to a pending load)."""
+    if not op.startswith("v_pk_") or "f32" not in op:
+        return vregs(text)
+    ops_txt = re.split(r"\s+op_sel", text)[0]
+    fields = [f.strip() for f in ops_txt.split(",")]
+    nsrc = len(fields) - 1
+    sel = [0] * nsrc
+    sel_hi = [1] * nsrc
+    m = re.search(r"op_sel:\[([\d,]+)\]", text)
+    if m:
+        sel = [int(x) for x in m.group(1).split(",")][:nsrc] + [0] * max(0, nsrc - len(m.group(1).split(",")))
+    m = re.search(r"op_sel_hi:\[([\d,]+)\]", text)
+    if m:
+        sel_hi = [int(x) for x in m.group(1).split(",")][:nsrc] + [1] * max(0, nsrc - len(m.group(1).split(",")))
+    out = set(vregs(fields[0]))
+    for k, f in enumerate(fields[1:]):
+        regs = sorted(vregs(f))
+        if len(regs) == 2:
+            out.add(regs[sel[k]])
+            out.add(regs[sel_hi[k]])
+        else:
+            out.update(regs)
+    return out
+
+
+def lint_inflight(func, insts):
+    """Second rule: the load pipeline keeps buffer loads in flight across arithmetic (asm statements whose outputs
+    are only valid after a later `s_waitcnt vmcnt`).  No instruction may touch the destination VGPRs of a load
+    that is still outstanding - e.g. a register copy the compiler inserts at a loop back-edge would read stale
+    data.  insts: [(offset, op, rest)].  Dataflow over the control-flow graph: the state is the in-order list of
+    outstanding vector-memory accesses; `s_waitcnt vmcnt(n)` leaves the youngest n."""
+    problems = set()
+    index_of = {off: i for i, (off, _, _) in enumerate(insts)}
+    n_inst = len(insts)
+
+    def target(rest):
+        m = re.search(r"\+0x([0-9a-f]+)>", rest)
+        return index_of.get(int(m.group(1), 16)) if m else None
+
+    seen = set()
+    work = [(0, ())]
+    while work:
+        i, state = work.pop()
+        while True:
+            if i >= n_inst or (i, state) in seen:
+                break
+            seen.add((i, state))
+            off, op, rest = insts[i]
+            if op == "s_endpgm":
+                break
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", rest)
+                if m:
+                    n = int(m.group(1))
+                    state = state[len(state) - n:] if n < len(state) else state
+                    if n == 0:
+                        state = ()
+                    while state and not state[0][0]:
+                        state = state[1:]
+            else:
+                touched = touched_vregs(op, rest.split("<")[0])
+                for dst, loff in state:
+                    hit = touched & set(dst)
+                    if hit:
+                        problems.add(f"{func[:90]}: `{op} {rest.split('<')[0].strip()}` (+{off:#x}) touches v{min(hit)} while the load issued at +{loff:#x} is in flight")
+                if VMEM.match(op):
+                    # only the hand-written pipeline's loads (`buffer_load ... offen` from the asm statements) are
+                    # protected; every other vector-memory access just occupies a vmcnt slot behind them
+                    prot = op.startswith("buffer_load") and "offen" in rest
+                    dst = tuple(sorted(vregs(rest.split(",")[0]))) if prot else ()
+                    state = state + ((dst, off if prot else 0),)
+                    while state and not state[0][0]:   # unprotected accesses older than every protected one retire first
+                        state = state[1:]
+                    if len(state) > 63:
+                        state = state[-63:]
+            if op == "s_branch":
+                t = target(rest)
+                if t is None:
+                    break
+                i = t
+                continue
+            if op.startswith("s_cbranch"):
+                t = target(rest)
+                if t is not None:
+                    work.append((t, state))
+            i += 1
+    return sorted(problems)
 
 
 def aregs(text):
@@ -42,16 +145,25 @@ def lint_object(obj):
         for co in cos:
             dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
             func = "?"
+            func_addr = 0
+            insts = []
             last_write = {}   # agpr -> wait states since the MFMA that wrote it
-            for line in dis.splitlines():
-                m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            for line in dis.splitlines() + ["0 <end>:"]:
+                m = re.match(r"^([0-9a-f]+) <(.+)>:", line)
                 if m:
-                    func, last_write = m.group(1), {}
+                    if insts:
+                        problems += [f"{os.path.basename(obj)}: {q}" for q in lint_inflight(func, insts)]
+                    func, last_write, insts = m.group(2), {}, []
+                    func_addr = int(m.group(1), 16)
                     continue
                 ins = line.split("//")[0].strip()
                 if not ins or ins.startswith("."):
                     continue
                 op, _, rest = ins.partition(" ")
+                am = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+                tm = re.search(r"<[^>]*\+0x[0-9a-f]+>", line)
+                if am:
+                    insts.append((int(am.group(1), 16) - func_addr, op, rest + (" " + tm.group(0) if tm else "")))
                 step = 1
                 if op == "s_nop":
                     step = int(rest.strip()) + 1
