@@ -42,7 +42,9 @@ struct DenseRowModel {
   using Scalar = T;
   static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
-  static constexpr int kNpad = 16 * (NBM + (THIN > 0 ? 1 : 0));  // n <= kNpad - 1 ... see DenseRowLayout
+  // register-LDL^T width: the largest n this (NBM, THIN) layout serves, rounded to the 8-column chunk (n = 50: 56, not 64)
+  static constexpr int kNmax = THIN > 0 ? 16 * NBM + THIN - 1 : 16 * NBM - 1;
+  static constexpr int kNpad = (kNmax + 7) & ~7;
   DenseRowGram<T, NBM, THIN> gram;
   const T* data;
   const T* prob;

@@ -12,8 +12,16 @@
 // chain per pivot: ~80k SIMD cycles at n = 50, a quarter of the fused kernel).  Here lane i holds row
 // i of the matrix in NPAD registers, every index is a compile-time constant (the k and j loops are
 // fully unrolled; `n` only gates uniform branches), the pivot column is broadcast with v_readlane and
-// the right-looking update is one v_fmac per element: ~2 instructions per updated column, no LDS
-// traffic, no synchronisation (~4 µs at n = 50).
+// the right-looking update is one FMA per element, no LDS traffic, no synchronisation.
+//
+// Issue-slot economy of the update (tools/ubench/issue_probe.hip, ns per wave-instruction per SIMD):
+// v_readlane 1.84, v_fmac 1.97 (SGPR operand), v_pk_fma_f32 with an SGPR-PAIR operand 2.22.  fp32 therefore
+// keeps the row as aligned register pairs and updates two columns with one v_pk_fma_f32 whose multiplier is
+// the SGPR pair written by two v_readlanes: 3 instructions per 2 columns instead of 4.  All broadcasts of a
+// chunk are issued before its FMAs: a v_readlane feeding the very next VALU instruction costs an s_nop.
+// (Broadcasting the pivot column through LDS instead — ds_read_b128, same address on all lanes — was measured:
+// fewer VALU slots but either +56 live registers when hipcc hoists the reads, or an exposed LDS latency per
+// chunk when they are pinned; slower than this version in the fused kernel both ways.)
 //
 // Layout in registers after factor():  row[j], j < lane : L[lane][j]
 //                                       row[lane]        : d_lane (also kept in `dvec`)
@@ -28,9 +36,6 @@
 
 namespace toa {
 
-// static_for (wave_utils.hpp): every index below must be a compile-time constant for row[] to stay in registers
-// (a `#pragma unroll` that hipcc declines — it does at NPAD = 64 — turns row[] into scratch memory).
-
 // Opaque copy of a wave-uniform value.  n is constant for a whole launch, so every `j < n` / `k < n` gate of the
 // unrolled code below is loop-invariant with respect to the problem / iteration loops of the fused kernel; LICM
 // hoists all ~200 of them and parks their SGPR masks in VGPR lanes for the entire kernel (883 SGPR spills = 14
@@ -40,9 +45,25 @@ __device__ __forceinline__ int opaque_uniform(int v) {
   return v;
 }
 
+// Row storage: element J through get<J>() / set<J>().  fp32 rows are (2p, 2p+1) register pairs.
+template <typename T, int NPAD>
+struct RowRegs {
+  T r[NPAD];
+  template <int J> __device__ __forceinline__ T get() const { return r[J]; }
+  template <int J> __device__ __forceinline__ void set(T v) { r[J] = v; }
+};
+template <int NPAD>
+struct RowRegs<float, NPAD> {
+  using P = float __attribute__((ext_vector_type(2)));
+  P r[NPAD / 2];
+  template <int J> __device__ __forceinline__ float get() const { return r[J / 2][J & 1]; }
+  template <int J> __device__ __forceinline__ void set(float v) { r[J / 2][J & 1] = v; }
+};
+
 template <typename T, int NPAD>
 struct LdltRegs {
-  T row[NPAD];
+  static_assert(NPAD % 8 == 0, "columns are processed in chunks of 8");
+  RowRegs<T, NPAD> row;
   T dvec;
 
   // Lane i loads row i of the symmetric n×n LDS image (LD-strided); everything beyond n is zero.
@@ -55,13 +76,53 @@ struct LdltRegs {
       if (jb < n) {
         static_for<8>([&](auto jjc) __attribute__((always_inline)) {
           constexpr int j = jb + decltype(jjc)::value;
-          row[j] = (in_n && j < n) ? r[j] : T(0);
+          row.template set<j>((in_n && j < n) ? r[j] : T(0));
         });
       } else {
-        static_for<8>([&](auto jjc) __attribute__((always_inline)) { row[jb + decltype(jjc)::value] = T(0); });
+        static_for<8>([&](auto jjc) __attribute__((always_inline)) { row.template set<jb + decltype(jjc)::value>(T(0)); });
       }
     });
     dvec = T(1);
+  }
+
+  // One 8-column chunk of the right-looking update  S[i][j] -= l_i * S[j][k],  j in [JB, JB + 8), j > K.
+  template <int K, int JB>
+  __device__ __forceinline__ void update_chunk(const T c, const T l) {
+    if constexpr (sizeof(T) == 4) {
+      using P = float __attribute__((ext_vector_type(2)));
+      // pairs (2p, 2p+1) entirely right of the pivot: two broadcasts -> one SGPR pair -> one packed FMA
+      P cp[4];
+      float cs = 0;  // a leading odd column (j = K + 1 odd) is updated on its own
+      static_for<4>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int j = JB + 2 * decltype(pc)::value;
+        if constexpr (j > K) cp[decltype(pc)::value] = P{wave_bcast(c, j), wave_bcast(c, j + 1)};
+        else if constexpr (j + 1 > K) cs = wave_bcast(c, j + 1);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      const P nl2 = {-l, -l};
+      static_for<4>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int j = JB + 2 * p;
+        if constexpr (j > K) {
+          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(row.r[j / 2]) : "v"(nl2), "s"(cp[p]));
+        } else if constexpr (j + 1 > K) {
+          row.template set<j + 1>(fma(-l, cs, row.template get<j + 1>()));
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      T cj[8];
+      static_for<8>([&](auto jjc) __attribute__((always_inline)) {
+        constexpr int j = JB + decltype(jjc)::value;
+        if constexpr (j > K) cj[decltype(jjc)::value] = wave_bcast(c, j);  // S[j][k] = S[k][j]
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<8>([&](auto jjc) __attribute__((always_inline)) {
+        constexpr int j = JB + decltype(jjc)::value;
+        if constexpr (j > K) row.template set<j>(fma(-l, cj[decltype(jjc)::value], row.template get<j>()));
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // Returns true iff every pivot was finite and > min_normal (then the factorisation is complete).
@@ -71,28 +132,20 @@ struct LdltRegs {
     static_for<NPAD>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       if (k < n && ok) {  // wave-uniform
-        const T d = wave_bcast(row[k], k);
+        const T c = row.template get<k>();  // lane i > k: S[i][k]
+        const T d = wave_bcast(c, k);
         if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
           ok = false;
         } else {
-          const T c = row[k];              // lane i > k: S[i][k]
           const T inv = T(1) / d;
           const bool below = lane > k;
           const T l = below ? c * inv : T(0);
-          row[k] = below ? l : row[k];     // lane k keeps d_k, lanes < k keep their Schur row entry
+          row.template set<k>(below ? l : c);  // lane k keeps d_k, lanes < k keep their Schur row entry
           dvec = (lane == k) ? d : dvec;
           constexpr int jb0 = ((k + 1) / 8);
           static_for<NPAD / 8 - jb0>([&](auto jbc) __attribute__((always_inline)) {
             constexpr int jb = (jb0 + decltype(jbc)::value) * 8;
-            if (jb < n) {  // wave-uniform: skip column chunks that are entirely padding
-              static_for<8>([&](auto jjc) __attribute__((always_inline)) {
-                constexpr int j = jb + decltype(jjc)::value;
-                if constexpr (j > k) {
-                  const T cj = wave_bcast(c, j);  // S[j][k] = S[k][j]
-                  row[j] = fma(-l, cj, row[j]);
-                }
-              });
-            }
+            if (jb < n) update_chunk<k, jb>(c, l);  // wave-uniform: skip column chunks that are entirely padding
           });
         }
       }
@@ -108,7 +161,7 @@ struct LdltRegs {
       constexpr int k = decltype(kc)::value;
       if (k + 1 < n) {
         const T s = wave_bcast(y, k);
-        y = (lane > k) ? fma(-row[k], s, y) : y;
+        y = (lane > k) ? fma(-row.template get<k>(), s, y) : y;
       }
     });
     const T invd = T(1) / dvec;
@@ -117,7 +170,7 @@ struct LdltRegs {
       constexpr int j = NPAD - 1 - decltype(jc)::value;
       if (j < n) {
         const T xj = wave_bcast(y * invd, j);
-        y = (lane < j) ? fma(-row[j], xj, y) : y;
+        y = (lane < j) ? fma(-row.template get<j>(), xj, y) : y;
       }
     });
     return lane < n ? y * invd : T(0);

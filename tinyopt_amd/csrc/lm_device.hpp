@@ -82,8 +82,10 @@ struct WaveLds {
   toa_results* res;
   int LD;
   static __host__ __device__ int ld_for(int n) { return n | 1; }
+  // workspace elements, rounded so that the 64-element vectors behind it stay 16-byte aligned (ds_read_b128)
+  static __host__ __device__ size_t m_elems(int n) { return (size_t(n) * ld_for(n) + 3) & ~size_t(3); }
   static __host__ __device__ size_t bytes(int n) {
-    size_t b = (size_t(n) * ld_for(n) + 7 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t b = (m_elems(n) + 7 * 64) * sizeof(T) + 64 * sizeof(int);
     b = (b + 15) & ~size_t(15);
     b += (sizeof(LmState<T>) + 15) & ~size_t(15);
     b += (sizeof(toa_options) + 15) & ~size_t(15);
@@ -94,7 +96,7 @@ struct WaveLds {
     WaveLds w;
     w.LD = ld_for(n);
     T* p = reinterpret_cast<T*>(base);
-    w.M = p; p += size_t(n) * w.LD;
+    w.M = p; p += m_elems(n);
     w.xs = p; p += 64;
     w.g = p; p += 64;
     w.hd = p; p += 64;
@@ -103,7 +105,7 @@ struct WaveLds {
     w.dx = p; p += 64;
     w.ldx = p; p += 64;
     w.perm = reinterpret_cast<int*>(p);
-    size_t off = (size_t(n) * w.LD + 7 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t off = (m_elems(n) + 7 * 64) * sizeof(T) + 64 * sizeof(int);
     off = (off + 15) & ~size_t(15);
     w.st = reinterpret_cast<LmState<T>*>(base + off);
     off += (sizeof(LmState<T>) + 15) & ~size_t(15);
