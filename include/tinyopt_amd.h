@@ -50,6 +50,11 @@ extern "C" {
  * replaces OptimizeWithAutoDiff, include/tinyopt/diff/optimize_autodiff.h:21-169) */
 #define TOA_MODEL_CIRCLE_FIT 5      /* r_i = ||p_i - c||^2 - radius^2, x = (cx, cy, radius)   (tests/circle.cpp:32-68) */
 #define TOA_MODEL_DENSE_ROW_AD6 6   /* the DenseRow residual, n = 6, written without a hand-derived Jacobian */
+/* the analytic functions of the reference's optimizer tests as manual Accumulate callbacks with exact Hessians
+ * (tests/optimize_easy.cpp:35-221, tests/optimize_hard.cpp:34-102): data_dev = [1] function id
+ * (0 Rosenbrock, 1 plateau, 2 Powell [n = 4], 3 Beale, 4 Himmelblau); n = 2 or 4; m = residual count reported
+ * in Cost (1, 1, 1, 3, 2); x: [P][n] = a batch of starting points */
+#define TOA_MODEL_TESTFN 7
 
 /* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
 #define TOA_LOSS_L2 0
@@ -181,6 +186,7 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  *                           squared L2), th2 = squared threshold in px^2: each point's ||r||^2 goes through the
  *                           M-estimator (cost += l, the point's J^T J and J^T r are scaled by s; robust_norms.h:20-26);
  *                           a point is an inlier when ||r||^2 <= th2 (results: final_inlier_ratio).
+ * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6]. */
 

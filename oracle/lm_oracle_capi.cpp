@@ -8,6 +8,7 @@
 #include "../include/tinyopt_amd.h"
 #include "lm_oracle.hpp"
 #include "se3.hpp"
+#include "testfns.hpp"
 #include "synth.hpp"
 
 #ifdef _OPENMP
@@ -347,6 +348,50 @@ void oracle_se3_reproj_accumulate(int dtype, int64_t P, int npts, const void* da
     }
   }
 }
+// The reference's analytic optimizer test functions (oracle/testfns.hpp) for a batch of starts.  x: [P][n] in place.
+void oracle_testfn_lm(int fn, int dtype, int64_t P, void* x, const toa_options* opts, int32_t* stop, int32_t* iters,
+                      int32_t* fails, double* cost, double* errs, double* deltas2, uint8_t* succ, int hist_stride) {
+  const Options o = from_pod(*opts);
+  const int n = testfn::dims(fn);
+  for (int64_t p = 0; p < P; ++p) {
+    Output out;
+    if (dtype == TOA_F32) {
+      std::vector<float> xv((float*)x + p * n, (float*)x + p * n + n);
+      Optimizer<float> opt(o, n);
+      out = opt.OptimizeAcc(xv, testfn::Acc<float>{fn}, EuclidPlus<float>());
+      std::memcpy((float*)x + p * n, xv.data(), sizeof(float) * n);
+    } else {
+      std::vector<double> xv((double*)x + p * n, (double*)x + p * n + n);
+      Optimizer<double> opt(o, n);
+      out = opt.OptimizeAcc(xv, testfn::Acc<double>{fn}, EuclidPlus<double>());
+      std::memcpy((double*)x + p * n, xv.data(), sizeof(double) * n);
+    }
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (fails) fails[p] = out.num_failures;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (errs)
+      for (size_t k = 0; k < out.errs.size() && int(k) < hist_stride; ++k) {
+        errs[size_t(p) * hist_stride + k] = out.errs[k];
+        if (deltas2) deltas2[size_t(p) * hist_stride + k] = out.deltas2[k];
+        if (succ) succ[size_t(p) * hist_stride + k] = out.successes[k];
+      }
+  }
+}
+// one Accumulate call of a test function: g [P][n], H [P][n*n] (col-major), cost [P]
+void oracle_testfn_accumulate(int fn, int dtype, int64_t P, const void* x, void* g, void* H, double* cost) {
+  const int n = testfn::dims(fn);
+  for (int64_t p = 0; p < P; ++p) {
+    if (dtype == TOA_F32) {
+      std::vector<float> xv((const float*)x + p * n, (const float*)x + p * n + n);
+      cost[p] = testfn::accumulate<float>(fn, xv, (float*)g + p * n, (float*)H + p * n * n).cost;
+    } else {
+      std::vector<double> xv((const double*)x + p * n, (const double*)x + p * n + n);
+      cost[p] = testfn::accumulate<double>(fn, xv, (double*)g + p * n, (double*)H + p * n * n).cost;
+    }
+  }
+}
+
 // the M-estimators alone (oracle/robust.hpp): loss[i], scale[i] = rho(n2[i], th2)
 void oracle_robust_norm(int kind, int dtype, int64_t count, const void* n2, double th2, void* loss, void* scale) {
   for (int64_t i = 0; i < count; ++i) {

@@ -15,6 +15,7 @@
 
 #include "lm_oracle.hpp"
 #include "robust.hpp"
+#include "testfns.hpp"
 
 using namespace oracle;
 
@@ -283,27 +284,10 @@ static void solvers() {
 }
 
 // ---- tests/optimize_easy.cpp:35-79 Rosenbrock with user Hessian (bad-step branches) ----
-static void rosenbrock() {
+static void rosenbrock() {  // tests/optimize_easy.cpp:35-79
   Vec<double> x{-1.2, 1.0};
-  auto acc = [](const Vec<double>& v, double* g, double* H) {
-    double xv = v[0], yv = v[1];
-    double t1 = 1.0 - xv, t2 = yv - xv * xv;
-    if (g) {
-      g[0] = -2.0 * t1 - 400.0 * xv * t2;
-      g[1] = 200.0 * t2;
-      H[0] = 2.0 - 400.0 * yv + 1200.0 * xv * xv;  // (0,0)
-      H[2] = -400.0 * xv;                           // (0,1) col-major
-      H[1] = -400.0 * xv;                           // (1,0)
-      H[3] = 200.0;
-    }
-    return Cost(t1 * t1 + 100.0 * t2 * t2);
-  };
-  Options o;
-  o.max_iters = 200;
-  o.min_rerr_dec = 0;
-  o.max_consec_failures = 20;
-  Optimizer<double> opt(o, 2);
-  Output out = opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  Optimizer<double> opt(testfn::reference_options(testfn::kRosenbrock), 2);
+  Output out = opt.OptimizeAcc(x, testfn::Acc<double>{testfn::kRosenbrock}, EuclidPlus<double>());
   CHECK(out.Succeeded());
   CHECK(out.Converged());
   CHECK_NEAR(x[0], 1.0, 1e-5);
@@ -318,25 +302,8 @@ static void rosenbrock() {
 static void plateau() {
   const double PI = std::acos(-1.0);
   Vec<double> x{3.0, 3.0};
-  auto acc = [&](const Vec<double>& v, double* g, double* H) {
-    double dx = v[0] - PI, dy = v[1] - PI;
-    double ex = std::exp(-(dx * dx + dy * dy));
-    double cx = std::cos(v[0]), cy = std::cos(v[1]), sx = std::sin(v[0]), sy = std::sin(v[1]);
-    double cost = 1.0 - (cx * cy * ex);
-    if (g) {
-      g[0] = cy * ex * (sx + 2.0 * dx * cx);
-      g[1] = cx * ex * (sy + 2.0 * dy * cy);
-      H[0] = cy * ex * (cx - 4.0 * dx * sx + (2.0 - 4.0 * dx * dx) * cx);
-      H[3] = cx * ex * (cy - 4.0 * dy * sy + (2.0 - 4.0 * dy * dy) * cy);
-      H[2] = ex * (sx + 2.0 * dx * cx) * (sy + 2.0 * dy * cy);
-      H[1] = H[2];
-    }
-    return Cost(cost);
-  };
-  Options o;
-  o.damping_init = 1e-6;
-  Optimizer<double> opt(o, 2);
-  Output out = opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  Optimizer<double> opt(testfn::reference_options(testfn::kPlateau), 2);
+  Output out = opt.OptimizeAcc(x, testfn::Acc<double>{testfn::kPlateau}, EuclidPlus<double>());
   CHECK(out.Succeeded());
   CHECK_NEAR(x[0], PI, 1e-4);
   CHECK_NEAR(x[1], PI, 1e-4);
@@ -345,33 +312,8 @@ static void plateau() {
 // ---- tests/optimize_easy.cpp:153-221 Powell singular ----
 static void powell() {
   Vec<double> x{3.0, -1.0, 0.0, 1.0};
-  auto acc = [](const Vec<double>& v, double* g, double* Hc) {
-    double x1 = v[0], x2 = v[1], x3 = v[2], x4 = v[3];
-    double t1 = x1 + 10.0 * x2, t2 = x3 - x4, t3 = x2 - 2.0 * x3, t4 = x1 - x4;
-    if (g) {
-      auto H = [&](int r, int c) -> double& { return Hc[c * 4 + r]; };
-      g[0] = 2.0 * t1 + 40.0 * std::pow(t4, 3);
-      g[1] = 20.0 * t1 + 4.0 * std::pow(t3, 3);
-      g[2] = 10.0 * t2 - 8.0 * std::pow(t3, 3);
-      g[3] = -10.0 * t2 - 40.0 * std::pow(t4, 3);
-      for (int i = 0; i < 16; ++i) Hc[i] = 0;
-      H(0, 0) = 2.0; H(0, 1) = 20.0; H(1, 0) = 20.0; H(1, 1) = 200.0;
-      H(2, 2) += 10.0; H(2, 3) += -10.0; H(3, 2) += -10.0; H(3, 3) += 10.0;
-      double d3 = 12.0 * t3 * t3;
-      H(1, 1) += d3; H(1, 2) += -2.0 * d3; H(2, 1) += -2.0 * d3; H(2, 2) += 4.0 * d3;
-      double d4 = 120.0 * t4 * t4;
-      H(0, 0) += d4; H(0, 3) += -d4; H(3, 0) += -d4; H(3, 3) += d4;
-    }
-    return Cost(t1 * t1 + 5.0 * t2 * t2 + std::pow(t3, 4) + std::pow(t4, 4) * 10.0);
-  };
-  Options o;
-  o.max_iters = 200;
-  o.max_consec_failures = 0;
-  o.min_error = 1e-30;
-  o.min_rerr_dec = 1e-30;
-  o.damping_init = 1e-1;
-  Optimizer<double> opt(o, 4);
-  Output out = opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  Optimizer<double> opt(testfn::reference_options(testfn::kPowell), 4);
+  Output out = opt.OptimizeAcc(x, testfn::Acc<double>{testfn::kPowell}, EuclidPlus<double>());
   CHECK(out.Succeeded());
   for (int i = 0; i < 4; ++i) CHECK(std::abs(x[i]) < 1e-3);
 }
@@ -379,19 +321,8 @@ static void powell() {
 // ---- tests/optimize_hard.cpp:34-63 Beale (AD residual vector) ----
 static void beale() {
   Vec<double> x{1.0, 1.0};
-  auto acc = [](const Vec<double>& v, double* g, double* H) {
-    double xv = v[0], yv = v[1];
-    double r[3] = {1.5 - xv + xv * yv, 2.25 - xv + xv * yv * yv, 2.625 - xv + xv * yv * yv * yv};
-    double J[6] = {-1 + yv, xv, -1 + yv * yv, 2 * xv * yv, -1 + yv * yv * yv, 3 * xv * yv * yv};
-    return AccumulateFromJ<double>(3, 2, r, J, g, H);
-  };
-  Options o;
-  o.max_iters = 200;
-  o.max_consec_failures = 0;
-  o.min_error = 1e-30;
-  o.damping_init = 1e-3;
-  Optimizer<double> opt(o, 2);
-  Output out = opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  Optimizer<double> opt(testfn::reference_options(testfn::kBeale), 2);
+  Output out = opt.OptimizeAcc(x, testfn::Acc<double>{testfn::kBeale}, EuclidPlus<double>());
   CHECK(out.Succeeded());
   CHECK_NEAR(x[0], 3.0, 1e-4);
   CHECK_NEAR(x[1], 0.5, 1e-4);
@@ -400,18 +331,8 @@ static void beale() {
 // ---- tests/optimize_hard.cpp:72-102 Himmelblau ----
 static void himmelblau() {
   Vec<double> x{3.5, 2.5};
-  auto acc = [](const Vec<double>& v, double* g, double* H) {
-    double r[2] = {v[0] * v[0] + v[1] - 11.0, v[0] + v[1] * v[1] - 7.0};
-    double J[4] = {2 * v[0], 1, 1, 2 * v[1]};
-    return AccumulateFromJ<double>(2, 2, r, J, g, H);
-  };
-  Options o;
-  o.max_iters = 200;
-  o.max_consec_failures = 0;
-  o.min_error = 1e-30;
-  o.damping_init = 1e-4;
-  Optimizer<double> opt(o, 2);
-  (void)opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  Optimizer<double> opt(testfn::reference_options(testfn::kHimmelblau), 2);
+  (void)opt.OptimizeAcc(x, testfn::Acc<double>{testfn::kHimmelblau}, EuclidPlus<double>());
   CHECK_NEAR(x[0], 3.0, 1e-4);
   CHECK_NEAR(x[1], 2.0, 1e-4);
 }

@@ -57,6 +57,8 @@ def load(path: str | None = None):
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_testfn_lm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.oracle_testfn_accumulate.argtypes = [C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp]
     lib.oracle_robust_norm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.c_double, vp, vp]
     lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
     lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
@@ -266,6 +268,45 @@ def circle_fit_lm(obs, x0, pod: ToaOptions):
     lib.oracle_circle_fit_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(obs)), _p(x), C.byref(pod), _p(stop), _p(iters),
                              _p(cost))
     return dict(x=x, stop=stop, iters=iters, cost=cost)
+
+
+TESTFNS = {"rosenbrock": 0, "plateau": 1, "powell": 2, "beale": 3, "himmelblau": 4}
+
+
+def testfn_options(name):
+    """The reference test's own options for each function (tests/optimize_easy.cpp, optimize_hard.cpp) as a
+    dict of (attribute path, value) for tinyopt_amd.Options."""
+    return {
+        "rosenbrock": {"max_iters": 200, "min_rerr_dec": 0.0, "max_consec_failures": 20},
+        "plateau": {"lm.damping_init": 1e-6},
+        "powell": {"max_iters": 200, "max_consec_failures": 0, "min_error": 1e-30, "min_rerr_dec": 1e-30, "lm.damping_init": 1e-1},
+        "beale": {"max_iters": 200, "max_consec_failures": 0, "min_error": 1e-30, "lm.damping_init": 1e-3},
+        "himmelblau": {"max_iters": 200, "max_consec_failures": 0, "min_error": 1e-30, "lm.damping_init": 1e-4},
+    }[name]
+
+
+def testfn_lm(name, x0, pod: ToaOptions, hist_stride=0):
+    """LM on one of the reference's analytic test functions for a batch of starts x0 [P, n]."""
+    lib = load()
+    x = np.array(x0, copy=True)
+    P = x.shape[0]
+    stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); fails = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64)
+    errs = np.zeros((P, hist_stride)) if hist_stride else None
+    d2 = np.zeros((P, hist_stride)) if hist_stride else None
+    succ = np.zeros((P, hist_stride), np.uint8) if hist_stride else None
+    lib.oracle_testfn_lm(TESTFNS[name], _code(x.dtype), P, _p(x), C.byref(pod), _p(stop), _p(iters), _p(fails), _p(cost),
+                         _p(errs), _p(d2), _p(succ), int(hist_stride))
+    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, errs=errs, deltas2=d2, succ=succ)
+
+
+def testfn_accumulate(name, x):
+    lib = load()
+    x = np.ascontiguousarray(x)
+    P, n = x.shape
+    g = np.zeros((P, n), x.dtype); H = np.zeros((P, n, n), x.dtype); cost = np.zeros(P, np.float64)
+    lib.oracle_testfn_accumulate(TESTFNS[name], _code(x.dtype), P, _p(x), _p(g), _p(H), _p(cost))
+    return g, H, cost
 
 
 def run_pin_tests() -> subprocess.CompletedProcess:

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (F32, F64, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
+from ._capi import (F32, F64, MODEL_TESTFN, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
                     MODEL_SQRT2, ToaOptions, ToaResults, check)
 
 
@@ -309,6 +309,25 @@ class CircleFit:
         return self.m * 2 * self.packed.element_size()
 
 
+class TestFn:
+    """The analytic functions of the reference's optimizer tests (tests/optimize_easy.cpp, tests/optimize_hard.cpp) as
+    manual Accumulate callbacks with their exact Hessians: "rosenbrock", "plateau", "powell" (n = 4), "beale",
+    "himmelblau".  x: [P, n] is a batch of starting points.  Exercises the bad-step / failed-solve / rollback
+    branches of the LM loop on the device."""
+    model_id = MODEL_TESTFN
+    __test__ = False  # not a pytest class
+    FUNCTIONS = {"rosenbrock": (0, 2, 1), "plateau": (1, 2, 1), "powell": (2, 4, 1), "beale": (3, 2, 3), "himmelblau": (4, 2, 2)}
+
+    def __init__(self, name: str, P: int, dtype=torch.float64, device="cuda"):
+        fid, n, m = self.FUNCTIONS[name]
+        self.name, self.P, self.n, self.m, self.dtype = name, int(P), n, m, dtype
+        self.packed = torch.full((1,), float(fid), dtype=dtype, device=device)
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return 0
+
+
 class DenseRowAD6:
     """The DenseRow residual for n = 6 written the tinyopt way — residual only, Jacobian by device AD.
     A: [P, m, 6], b: [P, m] (natural layout)."""
@@ -324,7 +343,7 @@ class DenseRowAD6:
         return self.m * 7 * self.packed.element_size()
 
 
-_MODELS = (DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
+_MODELS = (TestFn, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
 
 
 @dataclass

@@ -378,6 +378,10 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_SQRT2:
       if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
       return TOA_OK;
+    case TOA_MODEL_TESTFN:
+      if (n != 2 && n != 4) return fail(TOA_E_ARG, "TestFn: n must be 2 (Rosenbrock, plateau, Beale, Himmelblau) or 4 (Powell)");
+      if (!data) return fail(TOA_E_ARG, "TestFn: data pointer ([1] = function id) is null");
+      return TOA_OK;
     case TOA_MODEL_CIRCLE_FIT:
       if (n != 3) return fail(TOA_E_ARG, "CircleFit: n must be 3 (cx, cy, radius)");
       if (!data) return fail(TOA_E_ARG, "CircleFit: data pointer ([P][m][2] observed points) is null");

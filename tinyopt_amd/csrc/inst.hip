@@ -14,6 +14,7 @@ using InstT = double;
 #ifdef TOA_INST_MISC
 int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, const FusedParams& prm) {
   if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
+  if (model == TOA_MODEL_TESTFN) return launch_fused<TestFnModel<InstT>>(h, prm);
   if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
   if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
   if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
@@ -33,6 +34,7 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
                                                        double* cost, int32_t* nres) {
   (void)npad;
   if (model == TOA_MODEL_SQRT2) return launch_accumulate<Sqrt2Model<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_TESTFN) return launch_accumulate<TestFnModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_SE3_REPROJ)
     return launch_accumulate<Se3ReprojModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_CIRCLE_FIT)

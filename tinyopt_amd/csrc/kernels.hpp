@@ -126,6 +126,130 @@ struct GaussianPriorModel {
   }
 };
 
+// The analytic test functions of the reference's optimizer tests as MANUAL Accumulate callbacks
+// (`auto loss = [&](const auto& v, auto& grad, auto& H)`), exact Hessians included — they drive the LM state
+// machine through its bad-step, failed-solve (indefinite H) and rollback branches:
+//   0 Rosenbrock  tests/optimize_easy.cpp:35-79     1 plateau (Easom-like)  :88-144     2 Powell singular  :153-221
+//   3 Beale       tests/optimize_hard.cpp:34-63     4 Himmelblau            :72-102   (residual vectors, J^T J / J^T r)
+// data: [1] = function id (as T).  Every lane evaluates the same scalars (n <= 4): no divergence, no reductions.
+template <typename T>
+struct TestFnModel {
+  using Scalar = T;
+  static constexpr int kXdim = 0;
+  static constexpr int kNpad = 16;
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
+  int fn;
+  T H[16];
+  __device__ __forceinline__ void init(int, int, const void* d) { fn = int(static_cast<const T*>(d)[0]); }
+  __device__ __forceinline__ void bind(long long) {}
+  static __device__ __forceinline__ T pw(T t, int e) { return T(::pow(double(t), double(e))); }  // std::pow(t, 3): double
+  template <bool WANT>
+  __device__ __forceinline__ T eval(const WaveLds<T>& L, T* g, int& nres) {
+    const T v0 = L.xs[0], v1 = L.xs[1], v2 = L.xs[2], v3 = L.xs[3];
+    nres = 1;
+    if (fn == 0) {
+      const T t1 = T(1.0) - v0, t2 = v1 - v0 * v0;
+      if (WANT) {
+        g[0] = T(-2.0) * t1 - T(400.0) * v0 * t2;
+        g[1] = T(200.0) * t2;
+        H[0] = T(2.0) - T(400.0) * v1 + T(1200.0) * v0 * v0;
+        H[1] = H[4] = T(-400.0) * v0;
+        H[5] = T(200.0);
+      }
+      return t1 * t1 + T(100.0) * t2 * t2;
+    }
+    if (fn == 1) {
+      const T PI = T(3.14159265358979323846);
+      const T dx = v0 - PI, dy = v1 - PI;
+      const T ex = T(::exp(-(dx * dx + dy * dy)));
+      const T cx = T(::cos(v0)), cy = T(::cos(v1)), sx = T(::sin(v0)), sy = T(::sin(v1));
+      if (WANT) {
+        g[0] = cy * ex * (sx + T(2.0) * dx * cx);
+        g[1] = cx * ex * (sy + T(2.0) * dy * cy);
+        H[0] = cy * ex * (cx - T(4.0) * dx * sx + (T(2.0) - T(4.0) * dx * dx) * cx);
+        H[5] = cx * ex * (cy - T(4.0) * dy * sy + (T(2.0) - T(4.0) * dy * dy) * cy);
+        H[1] = H[4] = ex * (sx + T(2.0) * dx * cx) * (sy + T(2.0) * dy * cy);
+      }
+      return T(1.0) - (cx * cy * ex);
+    }
+    if (fn == 2) {
+      const T t1 = v0 + T(10.0) * v1, t2 = v2 - v3, t3 = v1 - T(2.0) * v2, t4 = v0 - v3;
+      if (WANT) {
+        g[0] = T(2.0) * t1 + T(40.0) * pw(t4, 3);
+        g[1] = T(20.0) * t1 + T(4.0) * pw(t3, 3);
+        g[2] = T(10.0) * t2 - T(8.0) * pw(t3, 3);
+        g[3] = T(-10.0) * t2 - T(40.0) * pw(t4, 3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) H[i] = T(0);
+        const T d3 = T(12.0) * t3 * t3, d4 = T(120.0) * t4 * t4;
+        H[0 * 4 + 0] = T(2.0) + d4;  H[0 * 4 + 1] = T(20.0);           H[0 * 4 + 3] = -d4;
+        H[1 * 4 + 0] = T(20.0);      H[1 * 4 + 1] = T(200.0) + d3;     H[1 * 4 + 2] = T(-2.0) * d3;
+        H[2 * 4 + 1] = T(-2.0) * d3; H[2 * 4 + 2] = T(10.0) + T(4.0) * d3; H[2 * 4 + 3] = T(-10.0);
+        H[3 * 4 + 0] = -d4;          H[3 * 4 + 2] = T(-10.0);          H[3 * 4 + 3] = T(10.0) + d4;
+      }
+      return t1 * t1 + T(5.0) * t2 * t2 + pw(t3, 4) + pw(t4, 4) * T(10.0);
+    }
+    // residual-vector functions: grad = J^T r, H = J^T J, cost = ||r||^2 (optimize_autodiff.h:151-164)
+    T r[3], J[3][2];
+    int mr;
+    if (fn == 3) {
+      mr = 3;
+      r[0] = T(1.5) - v0 + v0 * v1; r[1] = T(2.25) - v0 + v0 * v1 * v1; r[2] = T(2.625) - v0 + v0 * v1 * v1 * v1;
+      J[0][0] = T(-1) + v1;           J[0][1] = v0;
+      J[1][0] = T(-1) + v1 * v1;      J[1][1] = T(2) * v0 * v1;
+      J[2][0] = T(-1) + v1 * v1 * v1; J[2][1] = T(3) * v0 * v1 * v1;
+    } else {
+      mr = 2;
+      r[0] = v0 * v0 + v1 - T(11.0); r[1] = v0 + v1 * v1 - T(7.0); r[2] = T(0);
+      J[0][0] = T(2) * v0; J[0][1] = T(1);
+      J[1][0] = T(1);      J[1][1] = T(2) * v1;
+      J[2][0] = J[2][1] = T(0);
+    }
+    nres = mr;
+    if (WANT) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        T s = 0;
+        for (int i = 0; i < mr; ++i) s += J[i][a] * r[i];
+        g[a] = s;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          T q = 0;
+          for (int i = 0; i < mr; ++i) q += J[i][a] * J[i][b];
+          H[a * 4 + b] = q;
+        }
+      }
+    }
+    T c = 0;
+    for (int i = 0; i < mr; ++i) c += r[i] * r[i];
+    return c;
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    T g[4] = {0, 0, 0, 0};
+    cost = eval<true>(L, g, nres);
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (a < n) { L.g[a] = g[a]; L.hd[a] = H[a * 4 + a]; }
+    }
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int, T& cost, int& nres) {
+    T g[4];
+    cost = eval<false>(L, g, nres);
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (a < n && b < n) M[a * LD + b] = O(H[a * 4 + b]);
+    }
+  }
+};
+
 // sqrt(2):  r = x*x - 2, n = m = 1 (tests/sqrt2.cpp:30-70): grad = J r, H = J^2, cost = r^2 (1 residual).
 template <typename T>
 struct Sqrt2Model {
