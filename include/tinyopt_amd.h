@@ -228,8 +228,9 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
 /* ---- row-split execution of the same solve, for FEW, HUGE problems (BASELINE configs C2 / C5: P = 1,
  *      m = 10^3 .. 5*10^4).  Same contract and results as toa_lm_run; the rows of each problem are split into
  *      `splits` chunks (0 = choose automatically) whose partial (H, g, cost) are folded in a fixed order before
- *      each LM iteration, one (partial, step) kernel pair per iteration, nothing read back by the host.
- *      toa_lm_run selects this path by itself when P*4 <= #CUs and m >= 1024.  DenseRow and SE3Reproj only. */
+ *      each LM iteration, nothing read back by the host: ONE persistent launch when P * chunks <= #CUs (the chunk waves
+ *      hand over through generation counters in HBM), else one (partial, step) kernel pair per iteration.
+ *      toa_lm_run selects this path by itself when P*4 <= #CUs and m >= 512.  DenseRow and SE3Reproj only. */
 int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                      const void* data_dev, void* x_dev, const toa_options* options,
                      const toa_results* results, uint64_t* counters_dev, int splits);

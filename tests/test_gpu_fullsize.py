@@ -57,7 +57,7 @@ def test_full_size_properties(ta, oracle, tag, P, n, m, dtype, tdt, tol_star, to
 
     # batch independence + sampled oracle parity
     for first in (0, P // 2 + 37, P - 72):
-        S = 72   # > #CUs / 4 problems: stays on the fused path (a smaller batch of m >= 1024 problems is row-split,
+        S = 72   # > #CUs / 4 problems: stays on the fused path (a smaller batch of m >= 512 problems is row-split,
                  # which folds the rows in a different order and is compared with a tolerance in test_gpu_split.py)
         sub_model, sub_x0, _ = ta.DenseRow.synthetic(S, n, m, tdt, problem0=first)
         assert torch.equal(sub_x0, x0[first:first + S])

@@ -520,7 +520,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   const bool splittable = model == TOA_MODEL_DENSE_ROW || model == TOA_MODEL_SE3_REPROJ;
   // splits < 0: automatic — row-split when one-wave-per-problem would leave most of the chip idle
   // (fewer problems than CUs and enough rows to give every chunk >= 256 of them)
-  if (splits < 0) splits = (splittable && P * 4 <= h->num_cus && m >= 1024) ? 0 : -1;
+  if (splits < 0) splits = (splittable && P * 4 <= h->num_cus && m >= 512) ? 0 : -1;
   if (splits >= 0) {
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);

@@ -791,6 +791,7 @@ struct WideParams {
   void* state;     // WideState<T>[P]
   void* partials;  // T[P][splits][n*n + n + 2]  (H, g, cost, inlier residuals)
   void* hsum;      // T[P][n*n]
+  unsigned* sync;  // persistent form: [P][2] = (arrive, go) generation counters, then [1] abort flag; zeroed per launch
   int lds_per_wave;
 };
 
@@ -895,21 +896,72 @@ struct PartialSumModel {
   __device__ __forceinline__ T fold(int off) const {
     T s = 0;
     const int stride = n_ * n_ + n_ + 2;
-    for (int k = 0; k < S; ++k) s += part[size_t(k) * stride + off];
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {  // four loads in flight, added in index order (fixed association => deterministic)
+      const T a0 = part[size_t(k) * stride + off], a1 = part[size_t(k + 1) * stride + off];
+      const T a2 = part[size_t(k + 2) * stride + off], a3 = part[size_t(k + 3) * stride + off];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < S; ++k) s += part[size_t(k) * stride + off];
     return s;
   }
+  // Small systems (n*n + n + 2 <= 64, i.e. n <= 6: BASELINE configs C2 / C5): lane j fetches the WHOLE partial of
+  // chunk j with all its loads in flight at once, then each element is summed across the lanes by a fixed reduction
+  // tree — ~3 us for 64 chunks, where a per-element serial walk over the chunks is 64 dependent HBM round trips.
+  // Returns this lane's element total (lane e <-> element e of [H | g | cost | inliers]).
+  __device__ __forceinline__ T fold_small(int lane, bool full) const {
+    const int stride = n_ * n_ + n_ + 2;
+    const int e0 = full ? 0 : n_ * n_ + n_;  // cost-only: just the last two elements
+    T tot = 0;
+    for (int base = 0; base < S; base += 64) {
+      const int k = base + lane;
+      const bool valid = k < S;
+      const T* src = part + size_t(valid ? k : 0) * stride;
+      T v[64];
+#pragma unroll
+      for (int e = 0; e < 64; ++e) v[e] = (valid && e >= e0 && e < stride) ? src[e] : T(0);
+#pragma unroll
+      for (int e = 0; e < 64; ++e) {
+        if (e >= e0 && e < stride) {  // wave-uniform
+          const T t = wave_allreduce_sum(v[e]);
+          tot += (lane == e) ? t : T(0);
+        }
+      }
+    }
+    return tot;
+  }
+  __device__ __forceinline__ bool small() const { return n_ * n_ + n_ + 2 <= 64; }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    for (int e = lane; e < n * n; e += 64) hsum[e] = fold(e);
-    if (lane < n) { L.g[lane] = fold(n * n + lane); L.hd[lane] = fold(lane * n + lane); }
-    cost = fold(n * n + n);
-    ninl = int(fold(n * n + n + 1));
+    if (small()) {
+      const T tot = fold_small(lane, true);
+      const int nn = n * n;
+      if (lane < nn) {
+        hsum[lane] = tot;
+        if (lane / n == lane % n) L.hd[lane / n] = tot;
+      } else if (lane < nn + n) {
+        L.g[lane - nn] = tot;
+      }
+      cost = wave_bcast(tot, nn + n);
+      ninl = int(wave_bcast(tot, nn + n + 1));
+    } else {
+      for (int e = lane; e < n * n; e += 64) hsum[e] = fold(e);
+      if (lane < n) { L.g[lane] = fold(n * n + lane); L.hd[lane] = fold(lane * n + lane); }
+      cost = fold(n * n + n);
+      ninl = int(fold(n * n + n + 1));
+    }
     if (ninl < 0) ninl = m;
     nres = m;
     wave_sync();
   }
-  __device__ __forceinline__ void evaluate(WaveLds<T>&, int n, int, T& cost, int& nres) {
-    cost = fold(n * n + n);
-    ninl = int(fold(n * n + n + 1));
+  __device__ __forceinline__ void evaluate(WaveLds<T>&, int n, int lane, T& cost, int& nres) {
+    if (small()) {
+      const T tot = fold_small(lane, false);
+      cost = wave_bcast(tot, n * n + n);
+      ninl = int(wave_bcast(tot, n * n + n + 1));
+    } else {
+      cost = fold(n * n + n);
+      ninl = int(fold(n * n + n + 1));
+    }
     if (ninl < 0) ninl = m;
     nres = m;
   }
@@ -954,6 +1006,148 @@ __global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __rest
     }
   }
   wide_store_state(L, ws, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the row-split solve: ONE launch for the whole solve instead of 1 + 2 x (max_iters + 1).
+// The multi-launch form is bound by the GPU's kernel-to-kernel dependency latency (~10 us per launch, the same
+// eager or replayed from a hipGraph); here the S chunk-waves of a problem stay resident and hand over through two
+// generation counters in HBM:
+//     every chunk wave: partial (H, g, cost) of its rows -> HBM, release, arrive += 1
+//     leader (chunk 0): waits arrive == S * gen, acquire, folds the partials in fixed order, runs ONE lm_iteration
+//                       (state in its LDS for the whole solve), publishes x + flags, release, go = gen + 1
+//     the others      : wait go > gen, acquire, pick up x (or leave when the problem has stopped)
+// Agent-scope release/acquire fences order the HBM hand-over across XCDs (separate L2s).  The launcher uses this
+// form only when every workgroup is certainly co-resident (P * S <= #CUs, one 64-thread workgroup each); the waits
+// poll with s_sleep and give up after ~2 s (abort flag -> StopReason kTimedOut) instead of hanging the device.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool persistent_wait(unsigned* addr, const unsigned target, unsigned* abort_flag) {
+  const unsigned long long t0 = wall_clock64();  // constant 100 MHz
+  for (;;) {
+    if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    if (wall_clock64() - t0 > 200000000ull) {
+      __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+template <typename Model, int NPAD, typename Manifold>
+__global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* __restrict__ prm) {
+  using T = typename Model::Scalar;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int n = prm->n, S = prm->splits;
+  const long long p = (long long)blockIdx.x / S;
+  const int sidx = int((long long)blockIdx.x % S);
+  const bool leader = sidx == 0;
+  WaveLds<T> L = WaveLds<T>::carve(smem, n);
+  WideState<T>* ws = static_cast<WideState<T>*>(prm->state) + p;  // mailbox: x + flags published by the leader
+  unsigned* arrive = prm->sync + 2 * p;
+  unsigned* go = arrive + 1;
+  unsigned* abort_flag = prm->sync + 2 * prm->P;
+  const int xd = Manifold::kXdim ? Manifold::kXdim : n;
+
+  const int m4 = (prm->m + 3) & ~3;
+  const int row0 = sidx * prm->chunk_rows;
+  const int rows = min(prm->chunk_rows, m4 - row0);
+  Model model;
+  model.init(n, prm->m, prm->data);
+  model.bind_chunk(p, row0, rows, n);
+  const int stride = n * n + n + 2;
+  T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
+
+  PartialSumModel<T, NPAD, Manifold> fold;
+  fold.S = S; fold.n_ = n; fold.m = prm->m;
+  fold.part = static_cast<const T*>(prm->partials) + size_t(p) * S * stride;
+  fold.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
+
+  auto publish = [&](int stop) __attribute__((always_inline)) {
+    ws->xs[lane] = L.xs[lane];
+    if (lane == 0) { ws->st.rebuild = L.st->rebuild; ws->st.stop = stop; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  };
+
+  if (leader) {
+    wide_copy_pods(L, prm, lane);
+    wave_sync();
+    const T* X = static_cast<const T*>(prm->x);
+    L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+    L.g[lane] = T(0);
+    L.hd[lane] = T(0);
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    lm_init<T>(L, lane);
+    publish(TOA_STOP_NONE);
+    if (lane == 0) __hip_atomic_store(go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+#ifdef TOA_PERSIST_TIMING
+  unsigned long long tk[4] = {0, 0, 0, 0}, tprev = wall_clock64();
+#define TOA_TICK(i) { const unsigned long long tn = wall_clock64(); tk[i] += tn - tprev; tprev = tn; }
+#else
+#define TOA_TICK(i)
+#endif
+  for (unsigned gen = 1;; ++gen) {
+    bool do_acc;
+    if (leader) {
+      do_acc = prm->opt.solver_type != 0 || L.st->rebuild;
+    } else {
+      if (!persistent_wait(go, gen, abort_flag)) return;
+      if (ws->st.stop != TOA_STOP_NONE) return;  // the problem has finished
+      L.xs[lane] = ws->xs[lane];
+      wave_sync();
+      do_acc = prm->opt.solver_type != 0 || ws->st.rebuild;
+    }
+    T c;
+    int nr;
+    if (do_acc) {
+      model.accumulate(L, n, lane, c, nr);
+      model.write_sym(part, n, n, lane);
+      wave_sync();
+      if (lane < n) {
+        part[lane * n + lane] = L.hd[lane];
+        part[n * n + lane] = L.g[lane];
+      }
+    } else {
+      model.evaluate(L, n, lane, c, nr);
+    }
+    if (lane == 0) { part[n * n + n] = c; part[n * n + n + 1] = T(model_inliers(model, -1, 0)); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!leader) continue;
+    TOA_TICK(0)
+    if (!persistent_wait(arrive, unsigned(S) * gen, abort_flag)) {
+      if (lane == 0) prm->res.stop_reason[p] = TOA_STOP_TIMED_OUT;
+      return;
+    }
+    TOA_TICK(1)
+    const bool more = lm_iteration<T>(fold, L, n, lane, p);
+    TOA_TICK(2)
+    if (!more) {
+      lm_finalize<T>(fold, L, n, lane, p);
+      T* X = static_cast<T*>(prm->x);
+      if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+      if (prm->counters && lane == 0) {
+        atomicAdd(&prm->counters[0], L.st->acc_passes);
+        atomicAdd(&prm->counters[1], L.st->eval_passes);
+        atomicAdd(&prm->counters[2], L.st->solves);
+        atomicAdd(&prm->counters[3], L.st->problems);
+      }
+    }
+    publish(more ? TOA_STOP_NONE : (L.st->stop != TOA_STOP_NONE ? L.st->stop : TOA_STOP_MAX_ITERS));
+    if (lane == 0) __hip_atomic_store(go, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TOA_TICK(3)
+#ifdef TOA_PERSIST_TIMING
+    if (!more && lane == 0)
+      printf("persistent p=%lld S=%d gens=%u  partial %.1f us  wait %.1f us  iteration %.1f us  publish+finalize %.1f us\n", p, S, gen,
+             tk[0] * 0.01, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01);
+#endif
+    if (!more) return;
+  }
 }
 
 }  // namespace toa
@@ -1070,14 +1264,14 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   const int n = fp.n, m = fp.m;
   const long long P = fp.P;
   const int m4 = (m + 3) & ~3;
-  // chunking: the step kernel folds the S partials serially (cost ~ S * n^2 / 64 per lane) while the partial
-  // kernel's time falls as rows / S, so keep S moderate: >= 256 rows per chunk, <= 64 chunks, and no more waves
-  // than ~8 per CU; chunk rows a multiple of 16.  (C5: 50 000 rows -> 64 chunks: 289 us per solve vs 742 us one-wave.)
-  long long S = splits_req > 0 ? splits_req : m4 / 256;
+  // chunking (automatic): short chunks keep the per-iteration latency down — one wave streams its chunk at HBM
+  // round-trip pace (~2 us per 16-row batch) — while the fold of the S partials costs ~3 us per 64 chunks for n <= 6
+  // and S * n^2 / 64 serial loads per lane beyond; and P * S <= #CUs keeps the one-launch persistent form available.
+  long long S = splits_req > 0 ? splits_req : m4 / (n <= 6 ? 64 : 256);
   if (splits_req <= 0) {
     if (S > 64) S = 64;
-    const long long cap = (long long)h->num_cus * 8 / (P > 0 ? P : 1);
-    if (S > cap) S = cap;
+    const long long cap = (long long)h->num_cus / (P > 0 ? P : 1);
+    if (cap >= 1 && S > cap) S = cap;
   }
   if (S > m4 / 16) S = m4 / 16;
   if (S < 1) S = 1;
@@ -1090,7 +1284,8 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   const size_t b_state = (size_t(P) * sizeof(WideState<T>) + 255) & ~size_t(255);
   const size_t b_part = (size_t(P) * S * stride * sizeof(T) + 255) & ~size_t(255);
   const size_t b_hsum = (size_t(P) * n * n * sizeof(T) + 255) & ~size_t(255);
-  const size_t need = b_state + b_part + b_hsum;
+  const size_t b_sync = (size_t(2 * P + 1) * sizeof(unsigned) + 255) & ~size_t(255);
+  const size_t need = b_state + b_part + b_hsum + b_sync;
   if (need > h->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->scratch) (void)hipFree(h->scratch);
@@ -1107,6 +1302,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   wp.state = h->scratch;
   wp.partials = static_cast<char*>(h->scratch) + b_state;
   wp.hsum = static_cast<char*>(h->scratch) + b_state + b_part;
+  wp.sync = reinterpret_cast<unsigned*>(static_cast<char*>(h->scratch) + b_state + b_part + b_hsum);
   wp.lds_per_wave = int(pw);
   static_assert(sizeof(WideParams) <= 1024, "parameter block too large");
   HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
@@ -1122,6 +1318,17 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   // Direct launches by default: an A/B on MI355X (tools/latency_probe.py) shows graph replay and eager launches
   // of this 23..103-kernel sequence within 1 % of each other (C2 71 us, C5 93-99 us device time per solve), as
   // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  TOA_USE_GRAPH=1 selects the graph path.
+  // Persistent form (one launch for the whole solve) whenever every workgroup is certainly co-resident: one
+  // 64-thread workgroup per chunk, at most one per CU.  TOA_WIDE_MULTILAUNCH=1 forces the launch-per-iteration form.
+  static const bool multilaunch = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
+  if (!multilaunch && P * S <= (long long)h->num_cus && pw <= 64 * 1024) {
+    auto k_pers = wide_persistent_kernel<Model, NPAD, Manifold>;
+    if (int rc = ensure_lds_attr(h, (const void*)k_pers, pw)) return rc;
+    HIP_TRY(hipMemsetAsync(wp.sync, 0, size_t(2 * P + 1) * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(k_pers, dim3(unsigned(P * S)), dim3(64), pw, h->stream, dp);
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  }
   static const bool use_graph = std::getenv("TOA_USE_GRAPH") != nullptr;
   if (!use_graph) {
     hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
