@@ -55,6 +55,9 @@ extern "C" {
  * (0 Rosenbrock, 1 plateau, 2 Powell [n = 4], 3 Beale, 4 Himmelblau); n = 2 or 4; m = residual count reported
  * in Cost (1, 1, 1, 3, 2); x: [P][n] = a batch of starting points */
 #define TOA_MODEL_TESTFN 7
+/* Gaussian prior with a general covariance: res = U (x - y), U = upper Cholesky factor of the information matrix
+ * (losses/mahalanobis.h:160-171 MahaWhitenedInfoU, tests/cov.cpp:91-146); m == n; data_dev: [P][n + n*n] = y, U row-major */
+#define TOA_MODEL_MAHA_PRIOR 8
 
 /* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
 #define TOA_LOSS_L2 0

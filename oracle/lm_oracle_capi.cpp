@@ -155,6 +155,41 @@ static void se3_lm_t(int64_t P, int npts, const T* data, T* poses, const Options
     if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * 36, out.final_hessian.data(), sizeof(double) * 36);
   }
 }
+// Gaussian prior with a GENERAL covariance, whitened by the upper Cholesky factor U of the information matrix:
+// res = U (x - y), J = U  (losses/mahalanobis.h:160-171 MahaWhitenedInfoU; the AD form of tests/cov.cpp:127-146
+// `res = Lt * (x - y)`), folded as the AD bridge folds a residual vector: grad = J^T res, H = J^T J, cost = ||res||^2
+// over n residuals.  data: [P][n + n*n] = y, then U row-major (strictly upper triangular + diagonal).
+template <typename T>
+struct MahaPriorAcc {
+  int n;
+  const T* y;
+  const T* U;
+  Cost operator()(const std::vector<T>& x, T* g, T* H) const {
+    std::vector<T> r(n), J(size_t(n) * n);
+    for (int i = 0; i < n; ++i) {
+      T s = 0;
+      for (int j = i; j < n; ++j) s += U[size_t(i) * n + j] * (x[j] - y[j]);  // triangularView<Upper>
+      r[i] = s;
+      for (int j = 0; j < n; ++j) J[size_t(i) * n + j] = U[size_t(i) * n + j];
+    }
+    return AccumulateFromJ<T>(n, n, r.data(), J.data(), g, H);
+  }
+};
+template <typename T>
+static void maha_prior_lm_t(int64_t P, int n, const T* data, T* x, const Options& o, int32_t* stop, int32_t* iters,
+                            double* cost, double* finalH) {
+  for (int64_t p = 0; p < P; ++p) {
+    const T* d = data + size_t(p) * (n + size_t(n) * n);
+    std::vector<T> xv(x + p * n, x + p * n + n);
+    Optimizer<T> opt(o, n);
+    Output out = opt.OptimizeAcc(xv, MahaPriorAcc<T>{n, d, d + n}, EuclidPlus<T>());
+    std::memcpy(x + p * n, xv.data(), sizeof(T) * n);
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
+  }
+}
 extern "C" {
 
 int oracle_num_threads_max() {
@@ -348,6 +383,13 @@ void oracle_se3_reproj_accumulate(int dtype, int64_t P, int npts, const void* da
     }
   }
 }
+void oracle_maha_prior_lm(int dtype, int64_t P, int n, const void* data, void* x, const toa_options* opts, int32_t* stop,
+                          int32_t* iters, double* cost, double* finalH) {
+  const Options o = from_pod(*opts);
+  if (dtype == TOA_F32) maha_prior_lm_t<float>(P, n, (const float*)data, (float*)x, o, stop, iters, cost, finalH);
+  else maha_prior_lm_t<double>(P, n, (const double*)data, (double*)x, o, stop, iters, cost, finalH);
+}
+
 // The reference's analytic optimizer test functions (oracle/testfns.hpp) for a batch of starts.  x: [P][n] in place.
 void oracle_testfn_lm(int fn, int dtype, int64_t P, void* x, const toa_options* opts, int32_t* stop, int32_t* iters,
                       int32_t* fails, double* cost, double* errs, double* deltas2, uint8_t* succ, int hist_stride) {

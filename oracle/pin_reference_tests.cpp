@@ -399,6 +399,36 @@ static void cov_prior() {
   }
 }
 
+// ---- tests/cov.cpp:91-146: prior with the general covariance Cy = [[10,2],[2,4]], whitened by Lt = chol(Cy^-1).U;
+//      the covariance from the final Hessian equals Cy +-1e-5 ----
+static void cov_prior_general() {
+  const double Cy[4] = {10, 2, 2, 4};
+  const double det = Cy[0] * Cy[3] - Cy[1] * Cy[2];
+  const double I[4] = {Cy[3] / det, -Cy[1] / det, -Cy[2] / det, Cy[0] / det};   // information matrix
+  // upper Cholesky factor U of I (I = U^T U)
+  const double u00 = std::sqrt(I[0]), u01 = I[1] / u00, u11 = std::sqrt(I[3] - u01 * u01);
+  const double y[2] = {1.3, -0.7}, U[4] = {u00, u01, 0, u11};
+  auto acc = [&](const Vec<double>& x, double* g, double* H) {
+    const double d0 = x[0] - y[0], d1 = x[1] - y[1];
+    const double r[2] = {U[0] * d0 + U[1] * d1, U[3] * d1};     // mahalanobis.h:160-171 (UU * res)
+    return AccumulateFromJ<double>(2, 2, r, U, g, H);
+  };
+  Vec<double> x{0, 0};
+  Optimizer<double> opt(Options(), 2);
+  Output out = opt.OptimizeAcc(x, acc, EuclidPlus<double>());
+  CHECK(out.Succeeded());
+  CHECK(out.Converged());
+  CHECK_NEAR(x[0], y[0], 1e-8);
+  CHECK_NEAR(x[1], y[1], 1e-8);
+  CHECK(out.final_hessian.size() == 4);
+  if (out.final_hessian.size() == 4) {
+    const double* H = out.final_hessian.data();
+    const double dh = H[0] * H[3] - H[1] * H[2];
+    const double Cv[4] = {H[3] / dh, -H[1] / dh, -H[2] / dh, H[0] / dh};
+    for (int i = 0; i < 4; ++i) CHECK_NEAR(Cv[i], Cy[i], 1e-5);
+  }
+}
+
 // ---- LDLT restatement: SPD solve accuracy, pivoting, and the reference's failure policy
 //      (math.h:236: fail iff info()!=Success || !isPositive()) ----
 static void ldlt_policy() {
@@ -502,6 +532,7 @@ int main() {
   himmelblau();
   circle();
   cov_prior();
+  cov_prior_general();
   ldlt_policy();
   robust_norms();
   std::printf("pin_reference_tests: %d passed, %d failed\n", g_pass, g_fail);

@@ -57,6 +57,7 @@ def load(path: str | None = None):
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_maha_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp]
     lib.oracle_testfn_lm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_testfn_accumulate.argtypes = [C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp]
     lib.oracle_robust_norm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.c_double, vp, vp]
@@ -268,6 +269,25 @@ def circle_fit_lm(obs, x0, pod: ToaOptions):
     lib.oracle_circle_fit_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(obs)), _p(x), C.byref(pod), _p(stop), _p(iters),
                              _p(cost))
     return dict(x=x, stop=stop, iters=iters, cost=cost)
+
+
+def maha_prior_data(y, cov):
+    """[P, n + n*n] = y then U (row-major), U = upper Cholesky factor of cov^-1 (tests/cov.cpp:96: `Cy.inverse().llt().matrixU()`)."""
+    y = np.asarray(y)
+    P, n = y.shape
+    U = np.stack([np.linalg.cholesky(np.linalg.inv(np.asarray(c, np.float64))).T for c in cov])
+    return np.concatenate([y, U.reshape(P, n * n)], axis=1).astype(y.dtype)
+
+
+def maha_prior_lm(data, x0, pod: ToaOptions):
+    lib = load()
+    x = np.array(x0, copy=True)
+    P, n = x.shape
+    stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); cost = np.zeros(P, np.float64)
+    Hf = np.zeros((P, n, n), np.float64) if pod.save_last else None
+    lib.oracle_maha_prior_lm(_code(x.dtype), P, n, _p(np.ascontiguousarray(data)), _p(x), C.byref(pod), _p(stop), _p(iters),
+                             _p(cost), _p(Hf))
+    return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf)
 
 
 TESTFNS = {"rosenbrock": 0, "plateau": 1, "powell": 2, "beale": 3, "himmelblau": 4}

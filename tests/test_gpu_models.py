@@ -199,3 +199,48 @@ def test_inv_cov_and_output_covariance(ta, oracle, dtype, tdt):
     Cv, ok = out.Covariance()
     d = np.sqrt(np.diagonal(Cv.cpu().numpy(), axis1=1, axis2=2))
     assert ok.cpu().numpy().all() and np.abs(d - 4.2).max() < (1e-7 if dtype == np.float64 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_maha_prior_general_covariance(ta, oracle, dtype, tdt):
+    """tests/cov.cpp:91-146: a prior with the general covariance Cy = [[10,2],[2,4]] whitened by Lt = chol(Cy^-1).U;
+    the solve lands on y and the covariance from the final Hessian equals Cy +-1e-5.  Plus random SPD covariances
+    up to n = 50 against the oracle (MahaWhitenedInfoU, losses/mahalanobis.h:160-171)."""
+    Cy = np.array([[[10.0, 2.0], [2.0, 4.0]]])
+    y = np.array([[1.3, -0.7]], dtype)
+    model = ta.MahaPrior.from_covariance(torch.from_numpy(y).cuda(), torch.from_numpy(Cy).cuda())
+    x = torch.zeros(1, 2, dtype=tdt, device="cuda")
+    out = ta.Optimize(x, model, ta.Options())
+    torch.cuda.synchronize()
+    assert bool(out.Succeeded().all()) and bool(out.Converged().all())            # REQUIRE(out.Succeeded/Converged)
+    assert np.abs(x.cpu().numpy() - y).max() < (1e-8 if dtype == np.float64 else 1e-5)
+    C, ok = out.Covariance()
+    assert ok.cpu().numpy().all()
+    assert np.abs(C.cpu().numpy() - Cy).max() < (1e-5 if dtype == np.float64 else 2e-3)   # REQUIRE((C - Cy) ~ 0, 1e-5)
+
+    rng = np.random.default_rng(8)
+    for n in (2, 6, 12, 33, 50):
+        P = 6
+        A = rng.uniform(-1, 1, (P, n + 3, n))
+        cov = np.einsum("pij,pik->pjk", A, A) + 0.5 * np.eye(n)
+        yy = rng.uniform(-2, 2, (P, n)).astype(dtype)
+        data = oracle.maha_prior_data(yy, cov)
+        x0 = np.zeros((P, n), dtype)
+        o = ta.Options()
+        ref = oracle.maha_prior_lm(data, x0, o.to_pod())
+        m2 = ta.MahaPrior.from_covariance(torch.from_numpy(yy).cuda(), torch.from_numpy(cov).cuda())
+        assert np.allclose(m2.packed.cpu().numpy(), data, rtol=1e-9 if dtype == np.float64 else 1e-5, atol=1e-12 if dtype == np.float64 else 1e-6)
+        xg = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(xg, m2, o)
+        torch.cuda.synchronize()
+        assert (out.stop_reason.cpu().numpy() >= 0).all() and (ref["stop"] >= 0).all()
+        tol = 1e-8 if dtype == np.float64 else 2e-3
+        assert np.abs(xg.cpu().numpy() - ref["x"]).max() < tol
+        assert np.abs(xg.cpu().numpy() - yy).max() < tol
+        if dtype == np.float64:
+            assert np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"])
+            assert np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+            assert np.allclose(out.final_hessian.cpu().numpy(), ref["H"], rtol=1e-9, atol=1e-12 * np.abs(ref["H"]).max())
+            C, ok = out.Covariance()
+            assert ok.cpu().numpy().all()
+            assert np.allclose(C.cpu().numpy(), cov, rtol=1e-7, atol=1e-9 * np.abs(cov).max())

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (F32, F64, MODEL_TESTFN, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
+from ._capi import (F32, F64, MODEL_TESTFN, MODEL_MAHA_PRIOR, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
                     MODEL_SQRT2, ToaOptions, ToaResults, check)
 
 
@@ -309,6 +309,30 @@ class CircleFit:
         return self.m * 2 * self.packed.element_size()
 
 
+class MahaPrior:
+    """Gaussian prior with a GENERAL covariance per problem: res = U (x - y) with U the upper Cholesky factor of the
+    information matrix (the reference's MahaWhitenedInfoU, losses/mahalanobis.h:160-171; tests/cov.cpp:91-146).
+    y: [P, n]; U: [P, n, n] upper triangular.  H = U^T U = cov^-1, so Output.Covariance() returns the prior covariance."""
+    model_id = MODEL_MAHA_PRIOR
+
+    def __init__(self, y: torch.Tensor, U: torch.Tensor):
+        assert y.dim() == 2 and U.shape == (y.shape[0], y.shape[1], y.shape[1]) and y.is_cuda and U.dtype == y.dtype
+        self.P, self.n = y.shape
+        self.m, self.dtype = self.n, y.dtype
+        self.packed = torch.cat([y, torch.triu(U).reshape(self.P, -1)], dim=1).contiguous()
+
+    @staticmethod
+    def from_covariance(y: torch.Tensor, cov: torch.Tensor):
+        """`Lt = Cy.inverse().llt().matrixU()` (tests/cov.cpp:96) for a batch; model set-up, not the hot path."""
+        info = torch.linalg.inv(cov.to(torch.float64))
+        U = torch.linalg.cholesky(info).transpose(-1, -2).to(y.dtype)
+        return MahaPrior(y, U.contiguous())
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return (self.n + self.n * self.n) * self.packed.element_size()
+
+
 class TestFn:
     """The analytic functions of the reference's optimizer tests (tests/optimize_easy.cpp, tests/optimize_hard.cpp) as
     manual Accumulate callbacks with their exact Hessians: "rosenbrock", "plateau", "powell" (n = 4), "beale",
@@ -343,7 +367,7 @@ class DenseRowAD6:
         return self.m * 7 * self.packed.element_size()
 
 
-_MODELS = (TestFn, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
+_MODELS = (TestFn, MahaPrior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
 
 
 @dataclass

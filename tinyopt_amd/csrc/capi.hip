@@ -378,6 +378,10 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_SQRT2:
       if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
       return TOA_OK;
+    case TOA_MODEL_MAHA_PRIOR:
+      if (m != n) return fail(TOA_E_ARG, "MahaPrior: m must equal n (one whitened residual per parameter)");
+      if (!data) return fail(TOA_E_ARG, "MahaPrior: data pointer ([P][n + n*n]: y, U) is null");
+      return TOA_OK;
     case TOA_MODEL_TESTFN:
       if (n != 2 && n != 4) return fail(TOA_E_ARG, "TestFn: n must be 2 (Rosenbrock, plateau, Beale, Himmelblau) or 4 (Powell)");
       if (!data) return fail(TOA_E_ARG, "TestFn: data pointer ([1] = function id) is null");

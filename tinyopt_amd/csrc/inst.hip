@@ -18,6 +18,14 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
   if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
   if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
   if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
+  if (model == TOA_MODEL_MAHA_PRIOR) {
+    switch (npad) {
+      case 16: return launch_fused<MahaPriorModel<InstT, 16>>(h, prm);
+      case 32: return launch_fused<MahaPriorModel<InstT, 32>>(h, prm);
+      case 48: return launch_fused<MahaPriorModel<InstT, 48>>(h, prm);
+      default: return launch_fused<MahaPriorModel<InstT, 64>>(h, prm);
+    }
+  }
   switch (npad) {
     case 16: return launch_fused<GaussianPriorModel<InstT, 16>>(h, prm);
     case 32: return launch_fused<GaussianPriorModel<InstT, 32>>(h, prm);
@@ -41,6 +49,7 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
     return launch_accumulate<JetModel<InstT, CircleFitFunctor<InstT>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_DENSE_ROW_AD6)
     return launch_accumulate<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_MAHA_PRIOR) return launch_accumulate<MahaPriorModel<InstT, 16>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return launch_accumulate<GaussianPriorModel<InstT, 16>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 #elif defined(TOA_INST_SOLVE)

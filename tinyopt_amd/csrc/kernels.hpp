@@ -126,6 +126,68 @@ struct GaussianPriorModel {
   }
 };
 
+// Gaussian prior with a GENERAL covariance, whitened by the upper Cholesky factor U of the information matrix:
+// res = U (x - y), J = U  (losses/mahalanobis.h:160-171 MahaWhitenedInfoU; tests/cov.cpp:91-146), folded as the AD
+// bridge folds a residual vector: grad = J^T res, H = J^T J (= cov^-1), cost = ||res||^2 over n residuals.
+// data: [P][n + n*n] = y, then U row-major (upper triangular).  Lane a owns residual a / gradient entry a / row a of H.
+// A parity model (tests/cov.cpp: the covariance of the solve must equal the prior's), not a throughput model: H is
+// recomputed from U at every build.
+template <typename T, int NPAD>
+struct MahaPriorModel {
+  using Scalar = T;
+  static constexpr int kXdim = 0;
+  static constexpr int kNpad = NPAD;
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
+  const T* data;
+  const T* y;
+  const T* U;
+  int n_;
+  __device__ __forceinline__ void init(int n, int, const void* d) { n_ = n; data = static_cast<const T*>(d); }
+  __device__ __forceinline__ void bind(long long p) { y = data + size_t(p) * (n_ + size_t(n_) * n_); U = y + n_; }
+  __device__ __forceinline__ T residual(WaveLds<T>& L, int n, int lane) const {
+    L.tmp[lane] = lane < n ? L.xs[lane] - y[lane] : T(0);
+    wave_sync();
+    T r = 0;
+    if (lane < n)
+      for (int j = lane; j < n; ++j) r += U[size_t(lane) * n + j] * L.tmp[j];  // triangularView<Upper>
+    return r;
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    const T r = residual(L, n, lane);
+    L.vec[lane] = r;
+    wave_sync();
+    if (lane < n) {
+      T g = 0, hd = 0;
+      for (int i = 0; i <= lane; ++i) {  // column `lane` of U has its non-zeros in rows 0..lane
+        const T u = U[size_t(i) * n + lane];
+        g += u * L.vec[i];
+        hd += u * u;
+      }
+      L.g[lane] = g;
+      L.hd[lane] = hd;
+    }
+    cost = wave_allreduce_sum(r * r);
+    nres = n;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    const T r = residual(L, n, lane);
+    cost = wave_allreduce_sum(r * r);
+    nres = n;
+    wave_sync();
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
+    if (lane < n)
+      for (int b = 0; b < n; ++b) {  // H[a][b] = sum_i U[i][a] U[i][b], i <= min(a, b)
+        const int top = lane < b ? lane : b;
+        T h = 0;
+        for (int i = 0; i <= top; ++i) h += U[size_t(i) * n + lane] * U[size_t(i) * n + b];
+        M[lane * LD + b] = O(h);
+      }
+  }
+};
+
 // The analytic test functions of the reference's optimizer tests as MANUAL Accumulate callbacks
 // (`auto loss = [&](const auto& v, auto& grad, auto& H)`), exact Hessians included — they drive the LM state
 // machine through its bad-step, failed-solve (indefinite H) and rollback branches:
