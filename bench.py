@@ -158,8 +158,15 @@ def main():
         s = torch.tensor([iters_total, passes_total], dtype=torch.int64, device="cuda")
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         iters_all, passes_all = int(s[0].item()), int(s[1].item())
+        # per-GPU imbalance of the data-dependent work (no inter-GPU rebalancing, report the spread)
+        lo = torch.tensor([iters_total], dtype=torch.int64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rank_iters = [int(lo.item()) / args.steps, int(hi.item()) / args.steps]
     else:
         iters_all, passes_all = iters_total, passes_total
+        rank_iters = [iters_total / args.steps, iters_total / args.steps]
 
     # ---- the single end-of-job collective: gather results to rank 0 (timed separately)
     tg = time.perf_counter()
@@ -215,6 +222,7 @@ def main():
                    "options": "benchmarks/options.h (max_iters 10, min_error 0, min_rerr_dec 1e-12, min_step_norm2 1e-16, max_consec_failures 3)",
                    "parallelism": f"problem-sharded x{world}, no data-path collective, one result gather",
                    "gather_ms": gather_ms, "lm_iterations_per_step_all_gpus": iters_all / args.steps,
+                   "lm_iterations_per_step_per_gpu_min_max": rank_iters,
                    "device": info["name"], "num_cus": info["num_cus"]},
         "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
