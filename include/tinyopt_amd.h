@@ -58,6 +58,10 @@ extern "C" {
 /* Gaussian prior with a general covariance: res = U (x - y), U = upper Cholesky factor of the information matrix
  * (losses/mahalanobis.h:160-171 MahaWhitenedInfoU, tests/cov.cpp:91-146); m == n; data_dev: [P][n + n*n] = y, U row-major */
 #define TOA_MODEL_MAHA_PRIOR 8
+/* SE3 pose prior, the reference's manifold test (tests/sophus.cpp:26-44): residual = log(prior_inv * x) in R^6,
+ * differentiated on the device by dual numbers over the right perturbation; n == m == 6; x: [P][12] poses;
+ * data_dev: [P][12] = prior_inv (rotation matrix row-major, translation) */
+#define TOA_MODEL_SE3_PRIOR 9
 
 /* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
 #define TOA_LOSS_L2 0

@@ -446,6 +446,44 @@ void oracle_robust_norm(int kind, int dtype, int64_t count, const void* n2, doub
     }
   }
 }
+// SE3 pose prior (tests/sophus.cpp:26-44): residual log(prior_inv * x).  prior_inv, poses: [P][12] (R row-major, t).
+void oracle_se3_prior_lm(int dtype, int64_t P, const void* prior_inv, void* poses, const toa_options* opts, int32_t* stop,
+                         int32_t* iters, double* cost) {
+  const Options o = from_pod(*opts);
+  for (int64_t p = 0; p < P; ++p) {
+    Output out;
+    if (dtype == TOA_F32) {
+      se3::Pose<float> x;
+      for (int i = 0; i < 12; ++i) x[i] = ((float*)poses)[p * 12 + i];
+      Optimizer<float> opt(o, 6);
+      out = opt.OptimizeAcc(x, se3::PosePriorAcc<float>{(const float*)prior_inv + p * 12}, se3::Plus<float>());
+      for (int i = 0; i < 12; ++i) ((float*)poses)[p * 12 + i] = x[i];
+    } else {
+      se3::Pose<double> x;
+      for (int i = 0; i < 12; ++i) x[i] = ((double*)poses)[p * 12 + i];
+      Optimizer<double> opt(o, 6);
+      out = opt.OptimizeAcc(x, se3::PosePriorAcc<double>{(const double*)prior_inv + p * 12}, se3::Plus<double>());
+      for (int i = 0; i < 12; ++i) ((double*)poses)[p * 12 + i] = x[i];
+    }
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (cost) cost[p] = out.final_cost.cost;
+  }
+}
+// one Accumulate call of the pose prior: g [P][6], H [P][36] col-major, cost [P]
+void oracle_se3_prior_accumulate(int64_t P, const double* prior_inv, const double* poses, double* g, double* H, double* cost) {
+  for (int64_t p = 0; p < P; ++p) {
+    se3::Pose<double> x;
+    for (int i = 0; i < 12; ++i) x[i] = poses[p * 12 + i];
+    std::fill(g + p * 6, g + p * 6 + 6, 0.0);
+    std::fill(H + p * 36, H + p * 36 + 36, 0.0);
+    cost[p] = se3::PosePriorAcc<double>{prior_inv + p * 12}(x, g + p * 6, H + p * 36).cost;
+  }
+}
+// xi = log(pose) for a batch: [P][6] (upsilon, omega)
+void oracle_se3_log(int64_t P, const double* poses, double* xi) {
+  for (int64_t p = 0; p < P; ++p) se3::se3_log<double, double>(poses + p * 12, poses + p * 12 + 9, xi + p * 6);
+}
 // pose <- pose * exp(delta) for a batch (tests of the manifold update)
 void oracle_se3_plus(int dtype, int64_t P, void* poses, const void* delta) {
   for (int64_t p = 0; p < P; ++p) {

@@ -15,6 +15,7 @@
 
 #include "lm_oracle.hpp"
 #include "robust.hpp"
+#include "se3.hpp"
 #include "testfns.hpp"
 
 using namespace oracle;
@@ -429,6 +430,64 @@ static void cov_prior_general() {
   }
 }
 
+// ---- tests/sophus.cpp:26-44: SE3 pose prior, residual log(prior_inv * x) differentiated by Jets over the right
+//      perturbation; Succeeded && Converged && ||log(pose * prior_inv)|| < 1e-5.  Plus the pieces it stands on:
+//      log(exp(xi)) == xi, and the Jet Jacobian against central differences of the right perturbation. ----
+static void se3_pose_prior() {
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  for (int trial = 0; trial < 8; ++trial) {
+    se3::Pose<double> ident{};
+    ident[0] = ident[4] = ident[8] = 1;
+    // exp / log round trip (also through the small-angle branch)
+    const double scale = trial == 0 ? 1e-3 : (trial == 1 ? 0.03 : 0.9);
+    std::vector<double> xi(6);
+    for (auto& v : xi) v = scale * U(rng);
+    se3::Pose<double> T = ident;
+    se3::plus_eq(T, xi, 1.0);
+    double back[6];
+    se3::se3_log<double, double>(T.data(), T.data() + 9, back);
+    for (int i = 0; i < 6; ++i) CHECK_NEAR(back[i], xi[i], 1e-11);
+    // the reference test
+    std::vector<double> a(6), b(6);
+    for (auto& v : a) v = 0.8 * U(rng);
+    for (auto& v : b) v = 0.8 * U(rng);
+    se3::Pose<double> prior_inv = ident, pose = ident;
+    se3::plus_eq(prior_inv, a, 1.0);
+    se3::plus_eq(pose, b, 1.0);
+    se3::PosePriorAcc<double> acc{prior_inv.data()};
+    {  // Jacobian check at the start pose
+      double g[6], H[36];
+      (void)acc(pose, g, H);
+      const double eps = 1e-6;
+      for (int k = 0; k < 6; ++k) {
+        std::vector<double> d(6, 0.0);
+        d[k] = eps;
+        se3::Pose<double> pp = pose, pm = pose;
+        se3::plus_eq(pp, d, 1.0);
+        se3::plus_eq(pm, d, -1.0);
+        const double cp = acc(pp, nullptr, nullptr).cost, cm = acc(pm, nullptr, nullptr).cost;
+        CHECK_NEAR(0.5 * (cp - cm) / (2 * eps), g[k], 1e-6 * (1 + std::abs(g[k])));   // grad of 1/2 ||r||^2 = J^T r
+      }
+    }
+    Optimizer<double> opt(Options(), 6);
+    Output out = opt.OptimizeAcc(pose, acc, se3::Plus<double>());
+    CHECK(out.Succeeded());
+    CHECK(out.Converged());
+    // (pose * prior_inv).log().norm() < 1e-5
+    se3::Pose<double> prod;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j)
+        prod[3 * i + j] = pose[3 * i] * prior_inv[j] + pose[3 * i + 1] * prior_inv[3 + j] + pose[3 * i + 2] * prior_inv[6 + j];
+      prod[9 + i] = pose[3 * i] * prior_inv[9] + pose[3 * i + 1] * prior_inv[10] + pose[3 * i + 2] * prior_inv[11] + pose[9 + i];
+    }
+    double lg[6], nrm = 0;
+    se3::se3_log<double, double>(prod.data(), prod.data() + 9, lg);
+    for (double v : lg) nrm += v * v;
+    CHECK(std::sqrt(nrm) < 1e-5);
+  }
+}
+
 // ---- LDLT restatement: SPD solve accuracy, pivoting, and the reference's failure policy
 //      (math.h:236: fail iff info()!=Success || !isPositive()) ----
 static void ldlt_policy() {
@@ -533,6 +592,7 @@ int main() {
   circle();
   cov_prior();
   cov_prior_general();
+  se3_pose_prior();
   ldlt_policy();
   robust_norms();
   std::printf("pin_reference_tests: %d passed, %d failed\n", g_pass, g_fail);

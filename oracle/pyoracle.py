@@ -57,6 +57,9 @@ def load(path: str | None = None):
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_se3_prior_lm.argtypes = [C.c_int, C.c_int64, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
+    lib.oracle_se3_prior_accumulate.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
+    lib.oracle_se3_log.argtypes = [C.c_int64, vp, vp]
     lib.oracle_maha_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp]
     lib.oracle_testfn_lm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_testfn_accumulate.argtypes = [C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp]
@@ -268,6 +271,44 @@ def circle_fit_lm(obs, x0, pod: ToaOptions):
     cost = np.zeros(P, np.float64)
     lib.oracle_circle_fit_lm(_code(x.dtype), P, npts, _p(np.ascontiguousarray(obs)), _p(x), C.byref(pod), _p(stop), _p(iters),
                              _p(cost))
+    return dict(x=x, stop=stop, iters=iters, cost=cost)
+
+
+def se3_log(poses):
+    """xi = (upsilon, omega) = log(pose) for [P, 12] poses (fp64)."""
+    lib = load()
+    poses = np.ascontiguousarray(poses, np.float64)
+    xi = np.zeros((poses.shape[0], 6))
+    lib.oracle_se3_log(poses.shape[0], _p(poses), _p(xi))
+    return xi
+
+
+def se3_compose(a, b):
+    """a * b for [P, 12] poses."""
+    Ra, ta = a[:, :9].reshape(-1, 3, 3), a[:, 9:]
+    Rb, tb = b[:, :9].reshape(-1, 3, 3), b[:, 9:]
+    R = np.einsum("pij,pjk->pik", Ra, Rb)
+    t = np.einsum("pij,pj->pi", Ra, tb) + ta
+    return np.concatenate([R.reshape(-1, 9), t], axis=1)
+
+
+def se3_prior_accumulate(prior_inv, poses):
+    lib = load()
+    P = poses.shape[0]
+    g = np.zeros((P, 6)); H = np.zeros((P, 6, 6)); cost = np.zeros(P)
+    lib.oracle_se3_prior_accumulate(P, _p(np.ascontiguousarray(prior_inv, np.float64)), _p(np.ascontiguousarray(poses, np.float64)),
+                                    _p(g), _p(H), _p(cost))
+    return g, H, cost
+
+
+def se3_prior_lm(prior_inv, pose0, pod: ToaOptions):
+    """tests/sophus.cpp:26-44 for a batch: residual log(prior_inv * x)."""
+    lib = load()
+    x = np.array(pose0, copy=True)
+    P = x.shape[0]
+    stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); cost = np.zeros(P, np.float64)
+    lib.oracle_se3_prior_lm(_code(x.dtype), P, _p(np.ascontiguousarray(prior_inv.astype(x.dtype))), _p(x), C.byref(pod), _p(stop),
+                            _p(iters), _p(cost))
     return dict(x=x, stop=stop, iters=iters, cost=cost)
 
 

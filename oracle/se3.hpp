@@ -14,6 +14,7 @@
 #include <cmath>
 #include <vector>
 
+#include "jet.hpp"
 #include "lm_oracle.hpp"
 #include "robust.hpp"
 
@@ -71,6 +72,99 @@ inline void plus_eq(Pose<T>& x, const std::vector<T>& delta, T sign) {
 template <typename T>
 struct Plus {
   void operator()(Pose<T>& x, const std::vector<T>& dx, T sign) const { plus_eq(x, dx, sign); }
+};
+
+// ---- log maps, written once over the scalar type S (plain T for the cost-only callback, Jet<T, 6> for the
+//      differentiated one), from a rotation MATRIX.  Sophus (un-vendored, unpinned: cmake/ThirdParties.cmake:74-77)
+//      computes the same maps through a unit quaternion; the published formulas are restated:
+//        SO3:  omega = (theta / sin theta) * vee(R - R^T)/2,   cos theta = (tr R - 1)/2
+//        SE3:  upsilon = V^-1 t,  V^-1 = I - 1/2 [w]x + (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2 [w]x^2
+//      Near the identity (cos theta > 0.999) both coefficients are evaluated by their power series in sin^2 theta /
+//      theta^2, which are smooth there — a square root of a vanishing quantity would make every Jet derivative
+//      infinite exactly at the solution of a pose prior.  Domain: theta < ~3 rad (the branch at pi is not needed).
+using std::sqrt; using std::sin; using std::cos; using std::atan2;
+
+template <typename S, typename T>
+inline void so3_log(const S* R, S* w, S& theta2, bool& small) {
+  const S c = (R[0] + R[4] + R[8] - T(1.0)) * T(0.5);
+  const S v[3] = {(R[7] - R[5]) * T(0.5), (R[2] - R[6]) * T(0.5), (R[3] - R[1]) * T(0.5)};  // sin(theta) * axis
+  const S s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  small = scalar_part(c) > T(0.999);
+  S k;  // theta / sin(theta)
+  if (small) {  // asin(x)/x = 1 + x^2/6 + 3x^4/40 + 5x^6/112 + 35x^8/1152, x = sin(theta)
+    k = T(1.0) + s2 * (T(1.0 / 6.0) + s2 * (T(3.0 / 40.0) + s2 * (T(5.0 / 112.0) + s2 * T(35.0 / 1152.0))));
+  } else {
+    const S sn = sqrt(s2);
+    k = atan2(sn, c) / sn;
+  }
+  for (int i = 0; i < 3; ++i) w[i] = v[i] * k;
+  theta2 = s2 * k * k;
+}
+
+// xi = (upsilon, omega) = log of the pose (R, t)
+template <typename S, typename T>
+inline void se3_log(const S* R, const S* t, S* xi) {
+  S w[3], th2;
+  bool small;
+  so3_log<S, T>(R, w, th2, small);
+  S coef;
+  if (small) {  // (1 - (theta/2) cot(theta/2)) / theta^2 = 1/12 + theta^2/720 + theta^4/30240 + theta^6/1209600
+    coef = T(1.0 / 12.0) + th2 * (T(1.0 / 720.0) + th2 * (T(1.0 / 30240.0) + th2 * T(1.0 / 1209600.0)));
+  } else {
+    const S th = sqrt(th2), h = th * T(0.5);
+    coef = (T(1.0) - th * cos(h) / (T(2.0) * sin(h))) / th2;
+  }
+  const S c1[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};        // w x t
+  const S c2[3] = {w[1] * c1[2] - w[2] * c1[1], w[2] * c1[0] - w[0] * c1[2], w[0] * c1[1] - w[1] * c1[0]};  // w x (w x t)
+  for (int i = 0; i < 3; ++i) {
+    xi[i] = t[i] - c1[i] * T(0.5) + coef * c2[i];
+    xi[3 + i] = w[i];
+  }
+}
+
+// Pose prior (tests/sophus.cpp:26-44): residual(x) = log(prior_inv * x) in R^6, differentiated by Jets over the
+// right perturbation x * exp(delta) at delta = 0 (optimize_autodiff.h:48-77; sophus.h:24-26).  exp(delta) enters the
+// Jets through its first-order part I + [omega]x, upsilon — exact for first derivatives at 0.
+template <typename T>
+struct PosePriorAcc {
+  const T* Pinv;  // R (row-major 9), t (3)
+  template <typename S>
+  void residual(const S* Rx, const S* tx, S* xi) const {
+    S RA[9], tA[3];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) RA[3 * i + j] = Rx[j] * Pinv[3 * i] + Rx[3 + j] * Pinv[3 * i + 1] + Rx[6 + j] * Pinv[3 * i + 2];
+      tA[i] = tx[0] * Pinv[3 * i] + tx[1] * Pinv[3 * i + 1] + tx[2] * Pinv[3 * i + 2] + Pinv[9 + i];
+    }
+    se3_log<S, T>(RA, tA, xi);
+  }
+  Cost operator()(const Pose<T>& x, T* g, T* H) const {
+    if (!g) {
+      T xi[6];
+      residual<T>(x.data(), x.data() + 9, xi);
+      T c = 0;
+      for (int i = 0; i < 6; ++i) c += xi[i] * xi[i];
+      return Cost(double(c), 6);
+    }
+    using J6 = Jet<T, 6>;
+    J6 d[6];
+    for (int k = 0; k < 6; ++k) d[k] = J6(T(0), k);  // delta = (upsilon, omega) seeded at 0
+    const T* R = x.data();
+    J6 Rj[9], tj[3];
+    for (int i = 0; i < 3; ++i) {  // R (I + [omega]x): column j of [omega]x is omega x e_j
+      Rj[3 * i + 0] = R[3 * i + 0] + (d[5] * R[3 * i + 1] - d[4] * R[3 * i + 2]);
+      Rj[3 * i + 1] = R[3 * i + 1] + (d[3] * R[3 * i + 2] - d[5] * R[3 * i + 0]);
+      Rj[3 * i + 2] = R[3 * i + 2] + (d[4] * R[3 * i + 0] - d[3] * R[3 * i + 1]);
+      tj[i] = x[9 + i] + (d[0] * R[3 * i] + d[1] * R[3 * i + 1] + d[2] * R[3 * i + 2]);
+    }
+    J6 xi[6];
+    residual<J6>(Rj, tj, xi);
+    T r[6], J[36];
+    for (int i = 0; i < 6; ++i) {
+      r[i] = xi[i].a;
+      for (int k = 0; k < 6; ++k) J[6 * i + k] = xi[i].v[k];
+    }
+    return AccumulateFromJ<T>(6, 6, r, J, g, H);
+  }
 };
 
 // Reprojection residuals of npts points: r = (f X/Z + cx - u, f Y/Z + cy - v), p_c = R p + t;

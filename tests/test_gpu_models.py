@@ -244,3 +244,44 @@ def test_maha_prior_general_covariance(ta, oracle, dtype, tdt):
             C, ok = out.Covariance()
             assert ok.cpu().numpy().all()
             assert np.allclose(C.cpu().numpy(), cov, rtol=1e-7, atol=1e-9 * np.abs(cov).max())
+
+
+def test_se3_pose_prior_reference_test(ta, oracle):
+    """tests/sophus.cpp:26-44: prior_inv = exp(random), pose = exp(random), residual log(prior_inv * x) differentiated by
+    Jets over the right perturbation -> Succeeded && Converged && ||log(pose * prior_inv)|| < 1e-5.  The device
+    Accumulate (Jet<T,6> through SE3 log) against the oracle's, then the whole solve against the oracle's trajectory."""
+    rng = np.random.default_rng(44)
+    P = 64
+    ident = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (P, 1))
+    prior_inv = oracle.se3_plus(ident, 0.8 * rng.uniform(-1, 1, (P, 6)))
+    pose0 = oracle.se3_plus(ident, 0.8 * rng.uniform(-1, 1, (P, 6)))
+    pose0[0] = oracle.se3_plus(_inverse_pose(prior_inv[:1]), 1e-3 * rng.uniform(-1, 1, (1, 6)))[0]   # inside the small-angle branch
+    model = ta.SE3Prior(torch.from_numpy(prior_inv).cuda())
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(pose0).cuda())
+    g_ref, H_ref, c_ref = oracle.se3_prior_accumulate(prior_inv, pose0)
+    assert np.allclose(g.cpu().numpy(), g_ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(H.cpu().numpy(), H_ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(c.cpu().numpy(), c_ref, rtol=1e-12, atol=1e-300) and (nres.cpu().numpy() == 6).all()
+    c0 = ta.accumulate(model, torch.from_numpy(pose0).cuda(), want_grad=False)[2]
+    assert np.allclose(c0.cpu().numpy(), c_ref, rtol=1e-12, atol=1e-300)
+
+    o = ta.Options()
+    ref = oracle.se3_prior_lm(prior_inv, pose0, o.to_pod())
+    x = torch.from_numpy(pose0.copy()).cuda()
+    out = ta.Optimize(x, model, o)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy()
+    assert bool(out.Succeeded().all()) and bool(out.Converged().all())          # REQUIRE(out.Succeeded / Converged)
+    resid = np.linalg.norm(oracle.se3_log(oracle.se3_compose(xg, prior_inv)), axis=1)
+    assert resid.max() < 1e-5                                                   # REQUIRE((pose * prior_inv).log().norm() ~ 0)
+    assert _ortho_err(xg) < 1e-12
+    assert np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"])
+    assert np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+    assert np.abs(xg - ref["x"]).max() < 1e-9
+
+
+def _inverse_pose(p):
+    R = p[:, :9].reshape(-1, 3, 3)
+    Rt = np.transpose(R, (0, 2, 1))
+    t = -np.einsum("pij,pj->pi", Rt, p[:, 9:])
+    return np.concatenate([Rt.reshape(-1, 9), t], axis=1)

@@ -17,6 +17,7 @@ F32, F64 = 0, 1
 MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SQRT2, MODEL_SE3_REPROJ, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW_AD6 = 1, 2, 3, 4, 5, 6
 MODEL_TESTFN = 7
 MODEL_MAHA_PRIOR = 8
+MODEL_SE3_PRIOR = 9
 
 # StopReason, same integers as include/tinyopt/stop_reasons.h:14-43
 STOP_NAMES = {

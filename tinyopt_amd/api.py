@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (F32, F64, MODEL_TESTFN, MODEL_MAHA_PRIOR, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
+from ._capi import (F32, F64, MODEL_TESTFN, MODEL_MAHA_PRIOR, MODEL_SE3_PRIOR, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
                     MODEL_SQRT2, ToaOptions, ToaResults, check)
 
 
@@ -309,6 +309,23 @@ class CircleFit:
         return self.m * 2 * self.packed.element_size()
 
 
+class SE3Prior:
+    """SE3 pose prior — the reference's own manifold test (tests/sophus.cpp:26-44): residual(x) = log(prior_inv * x),
+    differentiated on the device by dual numbers over the right perturbation (optimize_autodiff.h:48-77, sophus.h:24-26).
+    prior_inv: [P, 12] (rotation matrix row-major + translation); x: [P, 12], updated by pose <- pose * exp(delta)."""
+    model_id = MODEL_SE3_PRIOR
+    xdim = 12
+
+    def __init__(self, prior_inv: torch.Tensor):
+        assert prior_inv.dim() == 2 and prior_inv.shape[1] == 12 and prior_inv.is_cuda
+        self.P, self.n, self.m, self.dtype = prior_inv.shape[0], 6, 6, prior_inv.dtype
+        self.packed = prior_inv.contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return 12 * self.packed.element_size()
+
+
 class MahaPrior:
     """Gaussian prior with a GENERAL covariance per problem: res = U (x - y) with U the upper Cholesky factor of the
     information matrix (the reference's MahaWhitenedInfoU, losses/mahalanobis.h:160-171; tests/cov.cpp:91-146).
@@ -367,7 +384,7 @@ class DenseRowAD6:
         return self.m * 7 * self.packed.element_size()
 
 
-_MODELS = (TestFn, MahaPrior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
+_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6)
 
 
 @dataclass

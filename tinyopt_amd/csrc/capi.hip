@@ -378,6 +378,10 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_SQRT2:
       if (n != 1 || m != 1) return fail(TOA_E_ARG, "Sqrt2: n and m must be 1");
       return TOA_OK;
+    case TOA_MODEL_SE3_PRIOR:
+      if (n != 6 || m != 6) return fail(TOA_E_ARG, "SE3Prior: n and m must be 6");
+      if (!data) return fail(TOA_E_ARG, "SE3Prior: data pointer ([P][12] = prior_inv) is null");
+      return TOA_OK;
     case TOA_MODEL_MAHA_PRIOR:
       if (m != n) return fail(TOA_E_ARG, "MahaPrior: m must equal n (one whitened residual per parameter)");
       if (!data) return fail(TOA_E_ARG, "MahaPrior: data pointer ([P][n + n*n]: y, U) is null");

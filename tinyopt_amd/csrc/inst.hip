@@ -16,6 +16,7 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
   if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
   if (model == TOA_MODEL_TESTFN) return launch_fused<TestFnModel<InstT>>(h, prm);
   if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
+  if (model == TOA_MODEL_SE3_PRIOR) return launch_fused<Se3PriorModel<InstT>>(h, prm);
   if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
   if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
   if (model == TOA_MODEL_MAHA_PRIOR) {
@@ -45,6 +46,8 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
   if (model == TOA_MODEL_TESTFN) return launch_accumulate<TestFnModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_SE3_REPROJ)
     return launch_accumulate<Se3ReprojModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (model == TOA_MODEL_SE3_PRIOR)
+    return launch_accumulate<Se3PriorModel<InstT>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_CIRCLE_FIT)
     return launch_accumulate<JetModel<InstT, CircleFitFunctor<InstT>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model == TOA_MODEL_DENSE_ROW_AD6)

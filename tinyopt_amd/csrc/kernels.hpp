@@ -386,6 +386,140 @@ struct Se3Manifold {
   }
 };
 
+// ---- SE3 / SO3 log maps over the scalar type S (plain T for cost-only passes, Jet<T, 6> for differentiated ones), from a
+//      rotation MATRIX (the published Sophus formulas; Sophus itself is an un-vendored dependency of the reference):
+//        SO3: omega = (theta / sin theta) vee(R - R^T)/2, cos theta = (tr R - 1)/2
+//        SE3: upsilon = V^-1 t, V^-1 = I - 1/2 [w]x + (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2 [w]x^2
+//      Near the identity (cos theta > 0.999) the coefficients come from their power series, smooth there: a square root
+//      of a vanishing quantity would make every Jet derivative infinite exactly at the solution of a pose prior.
+template <typename T> __device__ __forceinline__ T jet_scalar(const T& x) { return x; }
+template <typename T, int N> __device__ __forceinline__ T jet_scalar(const Jet<T, N>& x) { return x.a; }
+
+template <typename S, typename T>
+__device__ __forceinline__ void se3_log(const S* R, const S* t, S* xi) {
+  const S c = (R[0] + R[4] + R[8] - T(1.0)) * T(0.5);
+  const S v[3] = {(R[7] - R[5]) * T(0.5), (R[2] - R[6]) * T(0.5), (R[3] - R[1]) * T(0.5)};  // sin(theta) * axis
+  const S s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  const bool small = jet_scalar(c) > T(0.999);
+  S k, coef;
+  if (small) {  // asin(x)/x, x = sin(theta)
+    k = T(1.0) + s2 * (T(1.0 / 6.0) + s2 * (T(3.0 / 40.0) + s2 * (T(5.0 / 112.0) + s2 * T(35.0 / 1152.0))));
+  } else {
+    const S sn = sqrt(s2);
+    k = atan2(sn, c) / sn;
+  }
+  const S th2 = s2 * k * k;
+  if (small) {  // (1 - (theta/2) cot(theta/2)) / theta^2
+    coef = T(1.0 / 12.0) + th2 * (T(1.0 / 720.0) + th2 * (T(1.0 / 30240.0) + th2 * T(1.0 / 1209600.0)));
+  } else {
+    const S th = sqrt(th2), h = th * T(0.5);
+    coef = (T(1.0) - th * cos(h) / (T(2.0) * sin(h))) / th2;
+  }
+  const S w[3] = {v[0] * k, v[1] * k, v[2] * k};
+  const S c1[3] = {w[1] * t[2] - w[2] * t[1], w[2] * t[0] - w[0] * t[2], w[0] * t[1] - w[1] * t[0]};
+  const S c2[3] = {w[1] * c1[2] - w[2] * c1[1], w[2] * c1[0] - w[0] * c1[2], w[0] * c1[1] - w[1] * c1[0]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xi[i] = t[i] - c1[i] * T(0.5) + coef * c2[i];
+    xi[3 + i] = w[i];
+  }
+}
+
+// SE3 pose prior — the reference's own manifold test (tests/sophus.cpp:26-44): residual(x) = log(prior_inv * x) in R^6,
+// differentiated on the device by Jet<T, 6> over the RIGHT perturbation x * exp(delta) at delta = 0, exactly what
+// OptimizeWithAutoDiff does for a user type (optimize_autodiff.h:48-77 with sophus.h:24-26): exp(delta) enters the Jets
+// through its first-order part I + [omega]x, upsilon (exact for first derivatives at 0).  data: [P][12] = prior_inv
+// (R row-major, t); x: [P][12].  One wave per problem; the 6 x 6 system is evaluated redundantly by every lane.
+template <typename T>
+struct Se3PriorModel {
+  using Scalar = T;
+  static constexpr int kNpad = 16;
+  static constexpr int kXdim = 12;
+  const T* data;
+  const T* P;
+  T G[28];  // upper Gram of [J | r] (7 x 7)
+  static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
+  __device__ __forceinline__ void init(int, int, const void* dp) { data = static_cast<const T*>(dp); }
+  __device__ __forceinline__ void bind(long long p) { P = data + size_t(p) * 12; }
+  template <typename S>
+  __device__ __forceinline__ void residual(const S* Rx, const S* tx, S* xi) const {
+    S RA[9], tA[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) RA[3 * i + j] = Rx[j] * P[3 * i] + Rx[3 + j] * P[3 * i + 1] + Rx[6 + j] * P[3 * i + 2];
+      tA[i] = tx[0] * P[3 * i] + tx[1] * P[3 * i + 1] + tx[2] * P[3 * i + 2] + P[9 + i];
+    }
+    se3_log<S, T>(RA, tA, xi);
+  }
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    using J6 = Jet<T, 6>;
+    T R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = L.xs[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = L.xs[9 + i];
+    J6 d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = J6(T(0), k);  // delta = (upsilon, omega) seeded at 0
+    J6 Rj[9], tj[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // R (I + [omega]x)
+      Rj[3 * i + 0] = R[3 * i + 0] + (d[5] * R[3 * i + 1] - d[4] * R[3 * i + 2]);
+      Rj[3 * i + 1] = R[3 * i + 1] + (d[3] * R[3 * i + 2] - d[5] * R[3 * i + 0]);
+      Rj[3 * i + 2] = R[3 * i + 2] + (d[4] * R[3 * i + 0] - d[3] * R[3 * i + 1]);
+      tj[i] = t[i] + (d[0] * R[3 * i] + d[1] * R[3 * i + 1] + d[2] * R[3 * i + 2]);
+    }
+    J6 xi[6];
+    residual<J6>(Rj, tj, xi);
+#pragma unroll
+    for (int i = 0; i < 28; ++i) G[i] = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {  // fold residual i: w = [J_i | r_i]
+      T w[7];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = xi[i].v[k];
+      w[6] = xi[i].a;
+#pragma unroll
+      for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = a; b < 7; ++b) G[tt(a, b)] += w[a] * w[b];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { L.g[a] = G[tt(a, 6)]; L.hd[a] = G[tt(a, a)]; }
+    }
+    cost = G[tt(6, 6)];
+    nres = 6;
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int, T& cost, int& nres) {
+    T R[9], t[3], xi[6];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = L.xs[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = L.xs[9 + i];
+    residual<T>(R, t, xi);
+    T c = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c += xi[i] * xi[i];
+    cost = c;
+    nres = 6;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int, int lane) const {
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { M[a * LD + b] = O(G[tt(a, b)]); M[b * LD + a] = O(G[tt(a, b)]); }
+    }
+  }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
+    Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
+  }
+};
+
 // SE3 pinhole reprojection: parameters = a pose stored as R (row-major 9) + t (3) = 12 scalars,
 // tangent n = 6 in Sophus order (upsilon, omega); residual pair per point r = (f X/Z + cx - u, f Y/Z + cy - v),
 // p_c = R p + t; Jacobian w.r.t. the RIGHT perturbation at delta = 0 (what OptimizeWithAutoDiff's user-type
