@@ -52,8 +52,8 @@ extern "C" {
 #define TOA_MODEL_DENSE_ROW_AD6 6   /* the DenseRow residual, n = 6, written without a hand-derived Jacobian */
 /* the analytic functions of the reference's optimizer tests as manual Accumulate callbacks with exact Hessians
  * (tests/optimize_easy.cpp:35-221, tests/optimize_hard.cpp:34-102): data_dev = [1] function id
- * (0 Rosenbrock, 1 plateau, 2 Powell [n = 4], 3 Beale, 4 Himmelblau); n = 2 or 4; m = residual count reported
- * in Cost (1, 1, 1, 3, 2); x: [P][n] = a batch of starting points */
+ * (0 Rosenbrock, 1 plateau, 2 Powell [n = 4], 3 Beale, 4 Himmelblau, 5 `x - 2` [n = 1, tests/basic.cpp:41-87]);
+ * m = residual count reported in Cost (1, 1, 1, 3, 2, 1); x: [P][n] = a batch of starting points */
 #define TOA_MODEL_TESTFN 7
 /* Gaussian prior with a general covariance: res = U (x - y), U = upper Cholesky factor of the information matrix
  * (losses/mahalanobis.h:160-171 MahaWhitenedInfoU, tests/cov.cpp:91-146); m == n; data_dev: [P][n + n*n] = y, U row-major */

@@ -331,7 +331,7 @@ def maha_prior_lm(data, x0, pod: ToaOptions):
     return dict(x=x, stop=stop, iters=iters, cost=cost, H=Hf)
 
 
-TESTFNS = {"rosenbrock": 0, "plateau": 1, "powell": 2, "beale": 3, "himmelblau": 4}
+TESTFNS = {"rosenbrock": 0, "plateau": 1, "powell": 2, "beale": 3, "himmelblau": 4, "x_minus_2": 5}
 
 
 def testfn_options(name):

@@ -5,6 +5,7 @@
 //   kPowell      tests/optimize_easy.cpp:153-221  Powell singular, exact Hessian (singular at the solution)
 //   kBeale       tests/optimize_hard.cpp:34-63    residual vector (3), J^T J / J^T r as the AD bridge folds it
 //   kHimmelblau  tests/optimize_hard.cpp:72-102   residual vector (2)
+//   kXMinus2     tests/basic.cpp:41-54,72-87      scalar x - 2: grad = res, H = 1, cost = |res| (LM -> kMinDeltaNorm, GN -> kMinError)
 // One definition shared by oracle/pin_reference_tests.cpp (the reference's own starts, options and known answers)
 // and oracle_testfn_lm (batches of starts, for the GPU parity tests of the LM state machine's bad-step,
 // failed-solve and rollback branches).
@@ -17,8 +18,8 @@
 namespace oracle {
 namespace testfn {
 
-enum Id { kRosenbrock = 0, kPlateau = 1, kPowell = 2, kBeale = 3, kHimmelblau = 4 };
-inline int dims(int fn) { return fn == kPowell ? 4 : 2; }
+enum Id { kRosenbrock = 0, kPlateau = 1, kPowell = 2, kBeale = 3, kHimmelblau = 4, kXMinus2 = 5 };
+inline int dims(int fn) { return fn == kPowell ? 4 : (fn == kXMinus2 ? 1 : 2); }
 
 template <typename T>
 inline Cost accumulate(int fn, const std::vector<T>& v, T* g, T* Hc) {
@@ -70,6 +71,11 @@ inline Cost accumulate(int fn, const std::vector<T>& v, T* g, T* Hc) {
         H(0, 0) += d4; H(0, 3) += -d4; H(3, 0) += -d4; H(3, 3) += d4;
       }
       return Cost(double(t1 * t1 + T(5.0) * t2 * t2 + T(std::pow(t3, 4)) + T(std::pow(t4, 4)) * T(10.0)));
+    }
+    case kXMinus2: {
+      const T res = v[0] - T(2);
+      if (g) { Hc[0] = T(1); g[0] = res; }
+      return Cost(double(std::abs(res)));
     }
     case kBeale: {
       const T xv = v[0], yv = v[1];

@@ -312,3 +312,15 @@ def test_tiny_and_empty_batches(ta, oracle):
     res.stop_reason = res.num_iters = dummy.data_ptr()
     res.final_cost = torch.zeros(1, dtype=torch.float64, device="cuda").data_ptr()
     assert lib.toa_lm_run(ctx.h, 1, 1, 12, 50, 0, model.packed.data_ptr(), x0.data_ptr(), C.byref(pod), C.byref(res), None) == 0
+
+
+def test_solver_one_shot_reference(ta):
+    """tests/solvers.cpp:74-110 (`SolverLM<Mat2>`: grad = x - y with y = (4, 5), H = I, x = 0): Build's Marquardt damping
+    H_ii *= (1 + lambda_0) followed by Solve gives dx == y to 1e-2."""
+    H = torch.eye(2, dtype=torch.float64, device="cuda")[None]
+    g = torch.tensor([[-4.0, -5.0]], dtype=torch.float64, device="cuda")
+    dx, ok = ta.solve_damped(H, g, 1.0 + 1e-4)      # options.h:133 damping_init = 1e-4
+    torch.cuda.synchronize()
+    assert int(ok[0]) == 1
+    assert abs(float(dx[0, 0]) - 4.0) < 1e-2 and abs(float(dx[0, 1]) - 5.0) < 1e-2
+    assert abs(float(dx[0, 0]) - 4.0 / 1.0001) < 1e-12

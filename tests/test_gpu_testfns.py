@@ -119,3 +119,34 @@ def test_batch_of_starts_matches_oracle(ta, oracle, name):
     assert k0 is None                         # the reference's own start runs identically to the end
     if name in ("rosenbrock", "plateau", "beale"):
         assert ref["fails"].sum() > 0 and fails.sum() > 0     # rejected steps did occur on both sides
+
+
+def _success_checks(out, expected_stop, min_iters=2, max_iters=5):
+    """SuccessChecks of tests/basic.cpp:22-37."""
+    assert int(out.stop_reason[0]) >= 0                                  # Succeeded()
+    k = int(out.num_iters[0])
+    assert min_iters <= k <= max_iters
+    assert float(out.final_cost[0]) < 1e-5
+    assert 1 <= int(out.stop_reason[0]) < 5                              # Converged()
+    assert out.final_hessian is not None and float(out.final_hessian[0, 0, 0]) > 0
+    assert int(out.stop_reason[0]) == expected_stop
+
+
+def test_basic_x_minus_2(ta, oracle):
+    """tests/basic.cpp:41-54 (LM -> kMinDeltaNorm), :72-87 (GaussNewton -> kMinError), :107-124 (min_error = 1e-2 with
+    GaussNewton -> kMinError): the scalar callback grad = res, H = 1, cost = |res|, x0 = 1."""
+    for solver, min_error, expected in ((0, None, ta.StopReason.kMinDeltaNorm),      # 0 = LevenbergMarquardt, 1 = GaussNewton
+                                        (1, None, ta.StopReason.kMinError), (1, 1e-2, ta.StopReason.kMinError)):
+        o = ta.Options()
+        o.solver_type = solver
+        if min_error is not None:
+            o.min_error = min_error
+        x = torch.ones(1, 1, dtype=torch.float64, device="cuda")
+        out = ta.Optimize(x, ta.TestFn("x_minus_2", 1), o, history=True)
+        torch.cuda.synchronize()
+        _success_checks(out, int(expected))
+        ref = oracle.testfn_lm("x_minus_2", np.ones((1, 1)), o.to_pod(), hist_stride=o.max_iters + 2)
+        assert int(out.stop_reason[0]) == ref["stop"][0] and int(out.num_iters[0]) == ref["iters"][0]
+        k = int(out.num_iters[0])
+        assert np.allclose(out.errs.cpu().numpy()[0, :k], ref["errs"][0, :k], rtol=1e-12, atol=1e-300)
+        assert abs(float(x[0, 0]) - ref["x"][0, 0]) < 1e-12

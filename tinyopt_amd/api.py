@@ -357,7 +357,7 @@ class TestFn:
     branches of the LM loop on the device."""
     model_id = MODEL_TESTFN
     __test__ = False  # not a pytest class
-    FUNCTIONS = {"rosenbrock": (0, 2, 1), "plateau": (1, 2, 1), "powell": (2, 4, 1), "beale": (3, 2, 3), "himmelblau": (4, 2, 2)}
+    FUNCTIONS = {"rosenbrock": (0, 2, 1), "plateau": (1, 2, 1), "powell": (2, 4, 1), "beale": (3, 2, 3), "himmelblau": (4, 2, 2), "x_minus_2": (5, 1, 1)}
 
     def __init__(self, name: str, P: int, dtype=torch.float64, device="cuda"):
         fid, n, m = self.FUNCTIONS[name]

@@ -387,7 +387,7 @@ static int check_model(int model, int n, int m, const void* data) {
       if (!data) return fail(TOA_E_ARG, "MahaPrior: data pointer ([P][n + n*n]: y, U) is null");
       return TOA_OK;
     case TOA_MODEL_TESTFN:
-      if (n != 2 && n != 4) return fail(TOA_E_ARG, "TestFn: n must be 2 (Rosenbrock, plateau, Beale, Himmelblau) or 4 (Powell)");
+      if (n != 1 && n != 2 && n != 4) return fail(TOA_E_ARG, "TestFn: n must be 1 (x - 2), 2 (Rosenbrock, plateau, Beale, Himmelblau) or 4 (Powell)");
       if (!data) return fail(TOA_E_ARG, "TestFn: data pointer ([1] = function id) is null");
       return TOA_OK;
     case TOA_MODEL_CIRCLE_FIT:

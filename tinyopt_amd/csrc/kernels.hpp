@@ -193,6 +193,7 @@ struct MahaPriorModel {
 // machine through its bad-step, failed-solve (indefinite H) and rollback branches:
 //   0 Rosenbrock  tests/optimize_easy.cpp:35-79     1 plateau (Easom-like)  :88-144     2 Powell singular  :153-221
 //   3 Beale       tests/optimize_hard.cpp:34-63     4 Himmelblau            :72-102   (residual vectors, J^T J / J^T r)
+//   5 x - 2       tests/basic.cpp:41-54,72-87 (n = 1): grad = res, H = 1, cost = |res|
 // data: [1] = function id (as T).  Every lane evaluates the same scalars (n <= 4): no divergence, no reductions.
 template <typename T>
 struct TestFnModel {
@@ -209,6 +210,11 @@ struct TestFnModel {
   __device__ __forceinline__ T eval(const WaveLds<T>& L, T* g, int& nres) {
     const T v0 = L.xs[0], v1 = L.xs[1], v2 = L.xs[2], v3 = L.xs[3];
     nres = 1;
+    if (fn == 5) {
+      const T res = v0 - T(2);
+      if (WANT) { g[0] = res; H[0] = T(1); }
+      return res < T(0) ? -res : res;
+    }
     if (fn == 0) {
       const T t1 = T(1.0) - v0, t2 = v1 - v0 * v0;
       if (WANT) {
