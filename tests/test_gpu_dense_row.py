@@ -324,3 +324,32 @@ def test_solver_one_shot_reference(ta):
     assert int(ok[0]) == 1
     assert abs(float(dx[0, 0]) - 4.0) < 1e-2 and abs(float(dx[0, 1]) - 5.0) < 1e-2
     assert abs(float(dx[0, 0]) - 4.0 / 1.0001) < 1e-12
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_every_n_layout_accumulate_and_solve(ta, oracle, dtype, tdt):
+    """Every supported n (1..63: all MFMA block counts, every thin-tail width, b in the main block or in the tail) at
+    ragged row counts: the Accumulate seam and a short LM solve against the oracle."""
+    tol = 1e-10 if dtype == np.float64 else 3e-5
+    opts = ta.Options.benchmark()
+    for n in range(1, 64):
+        for m in (n + 3, 4 * n + 37 if n % 7 == 0 else 2 * n + 5):
+            P = 3
+            A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=1000 + n)
+            g_ref, H_ref, c_ref, _ = oracle.dense_row_accumulate(A, b, x0)
+            model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+            g, H, c, nres = ta.accumulate(model, torch.from_numpy(x0).cuda())
+            assert np.abs(g.cpu().numpy() - g_ref).max() <= tol * np.abs(g_ref).max(), (n, m)
+            assert np.abs(H.cpu().numpy() - H_ref).max() <= tol * np.abs(H_ref).max(), (n, m)
+            assert np.allclose(c.cpu().numpy(), c_ref, rtol=tol), (n, m)
+            assert (nres.cpu().numpy() == m).all()
+        if n % 3 == 0 or n in (1, 2, 16, 17, 31, 32, 47, 48, 49, 50, 63):
+            m = 6 * n + 11
+            A, b, x0, xs = oracle.synth_dense_row(4, n, m, dtype, seed=7 * n)
+            ref = oracle.dense_row_lm(A, b, x0, opts.to_pod())
+            model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+            x = torch.from_numpy(x0.copy()).cuda()
+            out = ta.Optimize(x, model, opts)
+            torch.cuda.synchronize()
+            assert (out.stop_reason.cpu().numpy() >= 0).all() and (ref["stop"] >= 0).all(), n
+            assert np.abs(x.cpu().numpy() - ref["x"]).max() < (1e-8 if dtype == np.float64 else 3e-3), n
