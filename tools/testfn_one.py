@@ -1,3 +1,4 @@
+"""Debug helper (GPU): one test-function problem, device history vs the oracle's.  usage: testfn_one.py <name> <start-index>"""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
