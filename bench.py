@@ -76,8 +76,8 @@ def cpu_baseline(n, m, np_dtype, pod, budget_problems):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--problems", type=int, default=0, help="override problems per GPU (debug; invalidates the metric)")
     ap.add_argument("--cpu-problems", type=int, default=0, help="CPU baseline sample size (0 = auto)")
