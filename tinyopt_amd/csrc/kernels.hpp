@@ -569,8 +569,22 @@ struct Se3ReprojModel {
     T csum = 0;
     T inl = 0;  // exact in T: <= 2 * points per lane
     const T* pts = d + 8;
-    for (int i = pt0 + lane; i < pt1; i += 64) {
-      const T* q = pts + size_t(i) * 5;
+    // one point ahead: the next point's five scalars are in flight while this one is folded (a single resident wave
+    // per chunk on the row-split path would otherwise pay one HBM round trip per point)
+    T nq[5];
+    int i = pt0 + lane;
+    if (i < pt1) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) nq[k] = pts[size_t(i) * 5 + k];
+    }
+    for (; i < pt1; i += 64) {
+      T q[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) q[k] = nq[k];
+      if (i + 64 < pt1) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) nq[k] = pts[size_t(i + 64) * 5 + k];
+      }
       const T px = q[0], py = q[1], pz = q[2];
       const T X = R[0] * px + R[1] * py + R[2] * pz + t[0];
       const T Y = R[3] * px + R[4] * py + R[5] * pz + t[1];
@@ -1232,7 +1246,7 @@ __device__ __forceinline__ bool persistent_wait(unsigned* addr, const unsigned t
       __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(2);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return true;
@@ -1266,7 +1280,8 @@ __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* _
   PartialSumModel<T, NPAD, Manifold> fold;
   fold.S = S; fold.n_ = n; fold.m = prm->m;
   fold.part = static_cast<const T*>(prm->partials) + size_t(p) * S * stride;
-  fold.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
+  // n <= 8: the folded H stays in LDS (L.aux) instead of making an HBM round trip between fold and factorisation
+  fold.hsum = (n * n <= 64) ? L.aux : static_cast<T*>(prm->hsum) + size_t(p) * n * n;
 
   auto publish = [&](int stop) __attribute__((always_inline)) {
     ws->xs[lane] = L.xs[lane];
@@ -1469,7 +1484,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   // chunking (automatic): short chunks keep the per-iteration latency down — one wave streams its chunk at HBM
   // round-trip pace (~2 us per 16-row batch) — while the fold of the S partials costs ~3 us per 64 chunks for n <= 6
   // and S * n^2 / 64 serial loads per lane beyond; and P * S <= #CUs keeps the one-launch persistent form available.
-  long long S = splits_req > 0 ? splits_req : m4 / (n <= 6 ? 64 : 256);
+  long long S = splits_req > 0 ? splits_req : m4 / (n <= 6 ? 32 : 256);
   if (splits_req <= 0) {
     if (S > 64) S = 64;
     const long long cap = (long long)h->num_cus / (P > 0 ? P : 1);

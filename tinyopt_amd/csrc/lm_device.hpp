@@ -76,6 +76,7 @@ struct WaveLds {
   T* vec;     // scratch
   T* dx;      // step of the current iteration
   T* ldx;     // last accepted / tried step (optimizer.h:262 last_dx)
+  T* aux;     // model scratch that survives the factorisation (row-split path: folded H for n <= 8)
   int* perm;  // pivot permutation
   LmState<T>* st;
   toa_options* opt;
@@ -85,7 +86,7 @@ struct WaveLds {
   // workspace elements, rounded so that the 64-element vectors behind it stay 16-byte aligned (ds_read_b128)
   static __host__ __device__ size_t m_elems(int n) { return (size_t(n) * ld_for(n) + 3) & ~size_t(3); }
   static __host__ __device__ size_t bytes(int n) {
-    size_t b = (m_elems(n) + 7 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t b = (m_elems(n) + 8 * 64) * sizeof(T) + 64 * sizeof(int);
     b = (b + 15) & ~size_t(15);
     b += (sizeof(LmState<T>) + 15) & ~size_t(15);
     b += (sizeof(toa_options) + 15) & ~size_t(15);
@@ -104,8 +105,9 @@ struct WaveLds {
     w.vec = p; p += 64;
     w.dx = p; p += 64;
     w.ldx = p; p += 64;
+    w.aux = p; p += 64;
     w.perm = reinterpret_cast<int*>(p);
-    size_t off = (m_elems(n) + 7 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t off = (m_elems(n) + 8 * 64) * sizeof(T) + 64 * sizeof(int);
     off = (off + 15) & ~size_t(15);
     w.st = reinterpret_cast<LmState<T>*>(base + off);
     off += (sizeof(LmState<T>) + 15) & ~size_t(15);
