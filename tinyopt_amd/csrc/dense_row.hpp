@@ -133,24 +133,31 @@ __device__ __forceinline__ void sincos_t(float t, float* s, float* c) {
   *c = ((q + 1) & 2) ? -cv : cv;
 }
 #endif
+// Horner step acc * z + c as a three-address v_fma_f64: hipcc otherwise emits v_fmac_f64 into a COPY of the
+// coefficient (one v_mov_b64 per step: the coefficients are loop-invariant registers it must not clobber).
+__device__ __forceinline__ double horner_f64(double acc, double z, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(acc), "v"(z), "v"(c));
+  return d;
+}
 __device__ __forceinline__ void sincos_t(double t, double* s, double* c) {
   const double j = rint(t * 0.63661977236758134308);
   double y = fma(-j, 1.5707963267948966, t);
   y = fma(-j, 6.123233995736766e-17, y);
   const double z = y * y;
   double ps = 1.58962301576546568060e-10;
-  ps = fma(ps, z, -2.50507477628578072866e-8);
-  ps = fma(ps, z, 2.75573136213857245213e-6);
-  ps = fma(ps, z, -1.98412698295895385996e-4);
-  ps = fma(ps, z, 8.33333333332211858878e-3);
-  ps = fma(ps, z, -1.66666666666666307295e-1);
+  ps = horner_f64(ps, z, -2.50507477628578072866e-8);
+  ps = horner_f64(ps, z, 2.75573136213857245213e-6);
+  ps = horner_f64(ps, z, -1.98412698295895385996e-4);
+  ps = horner_f64(ps, z, 8.33333333332211858878e-3);
+  ps = horner_f64(ps, z, -1.66666666666666307295e-1);
   ps = fma(ps, z * y, y);
   double pc = -1.13585365213876817300e-11;
-  pc = fma(pc, z, 2.08757008419747316778e-9);
-  pc = fma(pc, z, -2.75573141792967388112e-7);
-  pc = fma(pc, z, 2.48015872888517045348e-5);
-  pc = fma(pc, z, -1.38888888888730564116e-3);
-  pc = fma(pc, z, 4.16666666666665929218e-2);
+  pc = horner_f64(pc, z, 2.08757008419747316778e-9);
+  pc = horner_f64(pc, z, -2.75573141792967388112e-7);
+  pc = horner_f64(pc, z, 2.48015872888517045348e-5);
+  pc = horner_f64(pc, z, -1.38888888888730564116e-3);
+  pc = horner_f64(pc, z, 4.16666666666665929218e-2);
   pc = fma(pc, z * z, fma(-0.5, z, 1.0));
   const int q = int(j) & 3;
   const double sv = (q & 1) ? pc : ps;
@@ -394,6 +401,7 @@ struct DenseRowGram {
     T xr[NBM];
     T xt[THIN > 1 ? THIN - 1 : 1];  // x of the thin columns on lane c == 0, zero elsewhere (they join the row reduction once)
     bool isB_lane;
+    T mA, mB;                        // (1, 0) on ordinary lanes, (0, 1) on the lane whose last main element is b
     bool q0, q1;                     // bits of the lane's quad position: the batch step whose a_i.x this lane finishes
     int c;
   };
@@ -483,7 +491,9 @@ struct DenseRowGram {
 #pragma unroll
         for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
       }
-      if constexpr (THIN == 0) w[NBM - 1] = pc.isB_lane ? (rbase - w[NBM - 1]) : w[NBM - 1] * sc;
+      // THIN == 0: the lane holding b turns it into r = rbase - b, every other lane scales its column by sc; written as
+      // one FMA with per-lane constants (mA, mB) = (1, 0) / (0, 1) instead of a select (fp64: no exec-mask branch)
+      if constexpr (THIN == 0) w[NBM - 1] = fma(w[NBM - 1], fma(sc, pc.mA, -pc.mB), rbase * pc.mB);
       else v[THIN - 1] = rbase - v[THIN - 1];
       if (WANT_H) {
 #if defined(TOA_SPLIT_MFMA)
@@ -587,6 +597,8 @@ struct DenseRowGram {
     pc.q0 = (lane & 1) != 0;
     pc.q1 = (lane & 2) != 0;
     pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
+    pc.mA = pc.isB_lane ? T(0) : T(1);
+    pc.mB = pc.isB_lane ? T(1) : T(0);
     if (WANT_H) clear();
     T csum = 0;
     const int steps = lay.m4 >> 2;
