@@ -1235,14 +1235,14 @@ __global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __rest
 //     the others      : wait go > gen, acquire, pick up x (or leave when the problem has stopped)
 // Agent-scope release/acquire fences order the HBM hand-over across XCDs (separate L2s).  The launcher uses this
 // form only when every workgroup is certainly co-resident (P * S <= #CUs, one 64-thread workgroup each); the waits
-// poll with s_sleep and give up after ~2 s (abort flag -> StopReason kTimedOut) instead of hanging the device.
+// poll with s_sleep and give up after ~5 s (abort flag -> StopReason kTimedOut) instead of hanging the device.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool persistent_wait(unsigned* addr, const unsigned target, unsigned* abort_flag) {
   const unsigned long long t0 = wall_clock64();  // constant 100 MHz
   for (;;) {
     if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    if (wall_clock64() - t0 > 200000000ull) {
+    if (wall_clock64() - t0 > 500000000ull) {  // 5 s at the constant 100 MHz
       __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
