@@ -232,6 +232,25 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                const void* data_dev, void* x_dev, const toa_options* options,
                const toa_results* results, uint64_t* counters_dev);
 
+/* ---- stepping form (replaces `lm::Optimizer<H_t> optimizer(options)` + `optimizer.Step(x, acc, out)`,
+ *      include/tinyopt/optimizers/optimizer.h:199,331-539; the class form `optimizer(x, f, max_iters)` is a loop of
+ *      steps): the same state machine as toa_lm_run, ONE pass of the loop body (optimizer.h:266-310) per call for every
+ *      problem that is still running, with the per-problem state (damping, counters, last step, ...) parked in
+ *      state_dev (toa_lm_state_bytes(dtype, n, P) bytes of device memory, opaque: the scalar state plus the H of each
+ *      problem's last build, which eval-only iterations keep solving with — lm.h:96-117) between calls.
+ *        toa_lm_begin  constructs the state from x and the options (no data pass);
+ *        toa_lm_step   runs one iteration: x_dev is updated in place (as the reference does at every Step), finished
+ *                      problems get their full results exactly as in toa_lm_run and are skipped by later calls,
+ *                      running ones report num_iters / final_cost so far with stop_reason == kNone;
+ *                      active_dev (optional, int32, zeroed by the caller) += 1 per problem still running.
+ */
+size_t toa_lm_state_bytes(int dtype, int n, int64_t P);
+int toa_lm_begin(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,
+                 const toa_options* options, const toa_results* results, void* state_dev);
+int toa_lm_step(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,
+                const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
+                int32_t* active_dev);
+
 /* ---- row-split execution of the same solve, for FEW, HUGE problems (BASELINE configs C2 / C5: P = 1,
  *      m = 10^3 .. 5*10^4).  Same contract and results as toa_lm_run; the rows of each problem are split into
  *      `splits` chunks (0 = choose automatically) whose partial (H, g, cost) are folded in a fixed order before

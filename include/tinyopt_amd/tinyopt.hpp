@@ -299,6 +299,75 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   return out;
 }
 
+// The reference's class / stepping form (`lm::Optimizer<H_t> optimizer(options)`; `optimizer.Step(x, acc, out)` one loop
+// pass at a time; `optimizer(x, f, max_iters)` — include/tinyopt/optimizers/optimizer.h:199,331-539) for a batch.
+// x stays on the device between steps; `x()` downloads the current iterate, `output()` the results so far.
+template <typename Scalar, typename Cost>
+class Optimizer {
+ public:
+  Optimizer(std::vector<Scalar>& x, const Cost& cost, const Options& options = {})
+      : x_(&x), cost_(&cost), options_(options), pod_(options.to_pod()), P_(cost.P()), n_(cost.n()),
+        dx_(cost.ctx(), x.size()), stop_(cost.ctx(), P_), iters_(cost.ctx(), P_), fails_(cost.ctx(), P_), cfails_(cost.ctx(), P_),
+        nres_(cost.ctx(), P_), fc_(cost.ctx(), P_), fr_(cost.ctx(), P_), inl_(cost.ctx(), P_), active_(cost.ctx(), 1),
+        state_(cost.ctx(), toa_lm_state_bytes(dtype_of<Scalar>(), n_, P_)) {
+    if (int64_t(x.size()) != P_ * cost.xdim())
+      throw std::invalid_argument("tinyopt_amd::Optimizer: x must hold P * (parameters per problem) scalars");
+    dx_.upload(x.data());
+    stop_.zero(); iters_.zero(); fc_.zero();
+    r_ = toa_results{};
+    r_.stop_reason = stop_.data(); r_.num_iters = iters_.data(); r_.num_failures = fails_.data();
+    r_.num_consec_failures = cfails_.data(); r_.final_cost = fc_.data(); r_.final_num_residuals = nres_.data();
+    r_.final_rerr_dec = fr_.data(); r_.final_inlier_ratio = inl_.data();
+    if (options.hessian.save_last) { fH_ = DeviceBuffer<double>(cost.ctx(), size_t(P_) * n_ * n_); fH_.zero(); r_.final_hessian = fH_.data(); }
+    check(toa_lm_begin(cost.ctx().get(), Cost::model_id, dtype_of<Scalar>(), n_, cost.m(), P_, cost.data(), dx_.data(), &pod_, &r_,
+                       state_.data()));
+  }
+  // One pass of the loop body for every running problem; returns how many are still running.
+  int64_t Step() {
+    const Context& ctx = cost_->ctx();
+    active_.zero();
+    check(toa_lm_step(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
+                      nullptr, state_.data(), active_.data()));
+    check(toa_synchronize(ctx.get()));
+    int32_t a = 0;
+    active_.download(&a);
+    dx_.download(x_->data());  // x by reference, updated in place at every Step (optimizer.h:271-279)
+    return a;
+  }
+  // `optimizer(x, f, max_iters)`
+  BatchOutput operator()(int max_iters = -1) {
+    const int limit = max_iters < 0 ? int(options_.max_iters) + 2 : max_iters;
+    for (int i = 0; i < limit; ++i)
+      if (Step() == 0) break;
+    return output();
+  }
+  BatchOutput output() const {
+    BatchOutput out;
+    auto get = [&](auto& vec, const auto& buf) { vec.resize(buf.size()); buf.download(vec.data()); };
+    get(out.stop_reason, stop_); get(out.num_iters, iters_); get(out.num_failures, fails_);
+    get(out.num_consec_failures, cfails_); get(out.final_num_residuals, nres_); get(out.final_cost, fc_);
+    get(out.final_rerr_dec, fr_); get(out.final_inlier_ratio, inl_);
+    if (options_.hessian.save_last) get(out.final_hessian, fH_);
+    return out;
+  }
+
+ private:
+  std::vector<Scalar>* x_;
+  const Cost* cost_;
+  Options options_;
+  toa_options pod_;
+  int64_t P_;
+  int n_;
+  DeviceBuffer<Scalar> dx_;
+  DeviceBuffer<int32_t> stop_, iters_, fails_, cfails_, nres_;
+  DeviceBuffer<double> fc_, fr_;
+  DeviceBuffer<float> inl_;
+  DeviceBuffer<int32_t> active_;
+  DeviceBuffer<unsigned char> state_;
+  DeviceBuffer<double> fH_;
+  toa_results r_;
+};
+
 // The Accumulate-callback seam `acc(x, grad, H) -> Cost` (docs/API.md:37-57) for a batch; grad == nullptr
 // (cost only) when g / H are null.  g: [P][n], H: [P][n*n], cost: [P] (= ||r||^2), all host.
 template <typename Scalar, typename Cost>

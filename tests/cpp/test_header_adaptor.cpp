@@ -119,7 +119,30 @@ static void huber() {
   REQUIRE(std::abs(s[2] - std::sqrt(0.8) / 2.0) < 1e-14);                  // th / n
 }
 
+// lm::Optimizer + Step (optimizer.h:199,331-539): stepping to the end == Optimize; x is updated at every step
+static void stepping() {
+  Context ctx(0);
+  Sqrt2<double> cost(ctx, 3);
+  Options options;
+  options.max_iters = 20;
+  options.max_consec_failures = 0;
+  std::vector<double> xa{1.0, -0.3, 3.2}, xb = xa;
+  const auto ref = Optimize(xa, cost, options);
+  Optimizer<double, Sqrt2<double>> optimizer(xb, cost, options);
+  REQUIRE(xb[0] == 1.0);
+  REQUIRE(optimizer.Step() == 3);                    // every problem still running after the first pass
+  REQUIRE(xb[0] != 1.0);                             // ... and x already moved (README trace: 1 -> 1.49995)
+  REQUIRE(std::abs(xb[0] - 1.49995) < 1e-4);
+  const auto out = optimizer();
+  for (int p = 0; p < 3; ++p) {
+    REQUIRE(out.stop_reason[p] == ref.stop_reason[p]);
+    REQUIRE(out.num_iters[p] == ref.num_iters[p]);
+    REQUIRE(std::abs(xb[p] - xa[p]) < 1e-14);
+  }
+}
+
 int main() {
+  stepping();
   huber();
   sqrt2<double>();
   sqrt2<float>();

@@ -426,45 +426,37 @@ class Output:
         return (self.stop_reason >= 1) & (self.stop_reason < 5)
 
 
-def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
-             ctx: Optional[Context] = None, out: Optional[Output] = None, splits: Optional[int] = None) -> Output:
-    """``tinyopt::Optimize(x, cost, options)`` (optimize.h:16-77) for a batch of independent problems.
-
-    x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
-    cost: a device model (``DenseRow``).  Returns the per-problem Output.  One kernel launch,
-    asynchronous on torch's current stream.
-    """
-    options = options or Options()
+def _check_call(x: torch.Tensor, cost):
     if not isinstance(cost, _MODELS):
-        raise TypeError("cost must be a device model (DenseRow, GaussianPrior, Sqrt2); host callables cannot run "
+        raise TypeError("cost must be a device model (DenseRow, GaussianPrior, Sqrt2, ...); host callables cannot run "
                         "on the GPU path")
     if not x.is_cuda or not x.is_contiguous():
         raise ValueError("x must be a contiguous GPU tensor")
     P, xd = x.shape
-    n = cost.n
     if xd != getattr(cost, "xdim", cost.n) or P != cost.P or x.dtype != cost.dtype:
         raise ValueError("x shape/dtype does not match the model")  # reference: std::invalid_argument
-    ctx = ctx or default_context(x.device.index)
-    dev = x.device
-    pod = options.to_pod()
-    if out is None:
-        i32 = dict(dtype=torch.int32, device=dev)
-        f64 = dict(dtype=torch.float64, device=dev)
-        out = Output(
-            stop_reason=torch.zeros(P, **i32), num_iters=torch.zeros(P, **i32), num_failures=torch.zeros(P, **i32),
-            num_consec_failures=torch.zeros(P, **i32), final_cost=torch.zeros(P, **f64),
-            final_num_residuals=torch.zeros(P, **i32), final_rerr_dec=torch.zeros(P, **f64),
-            counters=torch.zeros(4, dtype=torch.int64, device=dev),
-            final_inlier_ratio=torch.ones(P, dtype=torch.float32, device=dev))
-        if options.hessian.save_last:
-            out.final_hessian = torch.zeros(P, n, n, **f64)
-        if history:
-            hs = options.max_iters + 2
-            out.errs = torch.zeros(P, hs, **f64)
-            out.deltas2 = torch.zeros(P, hs, **f64)
-            out.successes = torch.zeros(P, hs, dtype=torch.uint8, device=dev)
-    else:
-        out.counters.zero_()
+
+
+def _alloc_output(P: int, n: int, options: Options, history: bool, dev) -> Output:
+    i32 = dict(dtype=torch.int32, device=dev)
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = Output(
+        stop_reason=torch.zeros(P, **i32), num_iters=torch.zeros(P, **i32), num_failures=torch.zeros(P, **i32),
+        num_consec_failures=torch.zeros(P, **i32), final_cost=torch.zeros(P, **f64),
+        final_num_residuals=torch.zeros(P, **i32), final_rerr_dec=torch.zeros(P, **f64),
+        counters=torch.zeros(4, dtype=torch.int64, device=dev),
+        final_inlier_ratio=torch.ones(P, dtype=torch.float32, device=dev))
+    if options.hessian.save_last:
+        out.final_hessian = torch.zeros(P, n, n, **f64)
+    if history:
+        hs = options.max_iters + 2
+        out.errs = torch.zeros(P, hs, **f64)
+        out.deltas2 = torch.zeros(P, hs, **f64)
+        out.successes = torch.zeros(P, hs, dtype=torch.uint8, device=dev)
+    return out
+
+
+def _results_pod(out: Output) -> ToaResults:
     res = ToaResults()
     res.stop_reason = out.stop_reason.data_ptr()
     res.num_iters = out.num_iters.data_ptr()
@@ -479,6 +471,27 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     res.successes = out.successes.data_ptr() if out.successes is not None else None
     res.hist_stride = out.errs.shape[1] if out.errs is not None else 0
     res.final_inlier_ratio = out.final_inlier_ratio.data_ptr() if out.final_inlier_ratio is not None else None
+    return res
+
+
+def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
+             ctx: Optional[Context] = None, out: Optional[Output] = None, splits: Optional[int] = None) -> Output:
+    """``tinyopt::Optimize(x, cost, options)`` (optimize.h:16-77) for a batch of independent problems.
+
+    x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
+    cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
+    asynchronous on torch's current stream.
+    """
+    options = options or Options()
+    _check_call(x, cost)
+    P, n = x.shape[0], cost.n
+    ctx = ctx or default_context(x.device.index)
+    pod = options.to_pod()
+    if out is None:
+        out = _alloc_output(P, n, options, history, x.device)
+    else:
+        out.counters.zero_()
+    res = _results_pod(out)
     if splits is None:   # the library decides (row-split for few, huge problems)
         check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                  x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
@@ -486,6 +499,47 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
         check(ctx.lib.toa_lm_run_split(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                        x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr(), int(splits)))
     return out
+
+
+class Optimizer:
+    """The reference's class / stepping form: ``lm::Optimizer<H_t> optimizer(options)`` then ``optimizer.Step(x, acc, out)``
+    one loop pass at a time (optimizer.h:199,331-539), or ``optimizer(x, cost, max_iters)`` for a bounded run — for a
+    batch of independent problems.  The per-problem LM state (damping, counters, last step, ...) lives on the device
+    between steps; x is updated in place at every step; ``out`` fills in as problems finish."""
+
+    def __init__(self, x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
+                 ctx: Optional[Context] = None):
+        self.options = options or Options()
+        _check_call(x, cost)
+        self.x, self.cost = x, cost
+        self.ctx = ctx or default_context(x.device.index)
+        self.pod = self.options.to_pod()
+        P, n = x.shape[0], cost.n
+        self.out = _alloc_output(P, n, self.options, history, x.device)
+        self._res = _results_pod(self.out)
+        nbytes = self.ctx.lib.toa_lm_state_bytes(_dtype_code(x.dtype), n, P)
+        self._state = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=x.device)
+        self._active = torch.zeros(1, dtype=torch.int32, device=x.device)
+        check(self.ctx.lib.toa_lm_begin(self.ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                                        x.data_ptr(), C.byref(self.pod), C.byref(self._res), self._state.data_ptr()))
+
+    def Step(self, sync: bool = True) -> Optional[int]:
+        """One pass of the loop body for every running problem.  Returns how many are still running (host sync), or
+        None with sync=False (stream-ordered, nothing read back)."""
+        x, cost = self.x, self.cost
+        self._active.zero_()
+        check(self.ctx.lib.toa_lm_step(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
+                                       cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
+                                       self.out.counters.data_ptr(), self._state.data_ptr(), self._active.data_ptr()))
+        return int(self._active.item()) if sync else None
+
+    def __call__(self, max_iters: Optional[int] = None) -> Output:
+        """``optimizer(x, cost, max_iters)``: step until every problem has stopped (or max_iters passes were made)."""
+        limit = self.options.max_iters + 2 if max_iters is None else int(max_iters)
+        for _ in range(limit):
+            if self.Step() == 0:
+                break
+        return self.out
 
 
 def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Context] = None):

@@ -496,8 +496,15 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* 
   return toa_inst_inv_cov(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, C, ok);
 }
 
+// stepping-form state: [ WideState[P] (256-byte aligned) | H[P][n*n] ]
+static size_t lm_state_head_bytes(int dtype, int64_t P) {
+  const size_t b = size_t(P) * (dtype == TOA_F32 ? sizeof(toa::WideState<float>) : sizeof(toa::WideState<double>));
+  return (b + 255) & ~size_t(255);
+}
+
 static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
-                       const toa_options* options, const toa_results* results, uint64_t* counters, int splits) {
+                       const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
+                       int mode = 0, void* state = nullptr, int32_t* active = nullptr) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (int rc = check_model(model, n, m, data)) return rc;
@@ -523,12 +530,20 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   prm.opt = *options;
   prm.res = *results;
   prm.counters = reinterpret_cast<unsigned long long*>(counters);
+  prm.mode = mode;
+  prm.state = state;
+  prm.hstore = state ? static_cast<char*>(state) + lm_state_head_bytes(dtype, P) : nullptr;
+  prm.active = active;
+  if (mode != 0) {
+    if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
+    splits = -2;  // the stepping form always runs one wavefront per problem
+  }
   const int dtag = dtype == TOA_F32 ? 0 : 1;
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
   const bool splittable = model == TOA_MODEL_DENSE_ROW || model == TOA_MODEL_SE3_REPROJ;
   // splits < 0: automatic — row-split when one-wave-per-problem would leave most of the chip idle
   // (fewer problems than CUs and enough rows to give every chunk >= 256 of them)
-  if (splits < 0) splits = (splittable && P * 4 <= h->num_cus && m >= 512) ? 0 : -1;
+  if (splits == -1) splits = (splittable && P * 4 <= h->num_cus && m >= 512) ? 0 : -1;
   if (splits >= 0) {
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);
@@ -541,6 +556,22 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                const toa_options* options, const toa_results* results, uint64_t* counters) {
   return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1);
+}
+
+size_t toa_lm_state_bytes(int dtype, int n, int64_t P) {
+  if (P < 0 || n < 1) return 0;
+  return lm_state_head_bytes(dtype, P) + size_t(P) * n * n * (dtype == TOA_F32 ? 4 : 8);
+}
+
+int toa_lm_begin(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+                 const toa_options* options, const toa_results* results, void* state_dev) {
+  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, nullptr, -1, 1, state_dev, nullptr);
+}
+
+int toa_lm_step(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+                const toa_options* options, const toa_results* results, uint64_t* counters, void* state_dev,
+                int32_t* active_dev) {
+  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1, 2, state_dev, active_dev);
 }
 
 int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,

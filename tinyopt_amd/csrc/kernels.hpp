@@ -803,6 +803,33 @@ struct DenseRowAdFunctor {
   }
 };
 
+// Per-problem LM state parked in HBM between launches: the stepping form (`Optimizer_::Step`, optimizer.h:331-539, one
+// loop pass per call) and the launch-per-iteration row-split path both resume the same state machine from it.
+template <typename T>
+struct WideState {
+  LmState<T> st;
+  T xs[64], g[64], hd[64], dx[64], ldx[64];
+};
+
+template <typename T>
+__device__ __forceinline__ void wide_load_state(WaveLds<T>& L, const WideState<T>* ws, int lane) {
+  const int* src = reinterpret_cast<const int*>(&ws->st);
+  int* dst = reinterpret_cast<int*>(L.st);
+  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
+  L.xs[lane] = ws->xs[lane]; L.g[lane] = ws->g[lane]; L.hd[lane] = ws->hd[lane];
+  L.dx[lane] = ws->dx[lane]; L.ldx[lane] = ws->ldx[lane];
+  wave_sync();
+}
+template <typename T>
+__device__ __forceinline__ void wide_store_state(const WaveLds<T>& L, WideState<T>* ws, int lane) {
+  wave_sync();
+  const int* src = reinterpret_cast<const int*>(L.st);
+  int* dst = reinterpret_cast<int*>(&ws->st);
+  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
+  ws->xs[lane] = L.xs[lane]; ws->g[lane] = L.g[lane]; ws->hd[lane] = L.hd[lane];
+  ws->dx[lane] = L.dx[lane]; ws->ldx[lane] = L.ldx[lane];
+}
+
 struct FusedParams {
   const void* data;
   void* x;
@@ -813,6 +840,10 @@ struct FusedParams {
   unsigned long long* counters;  // [4] or null
   int* queue;                    // work-queue head
   int lds_per_wave;
+  int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem
+  void* state;                   // modes 1, 2: WideState<T>[P]
+  void* hstore;                  // modes 1, 2: T[P][n*n], the undamped H of each problem's last build
+  int* active;                   // mode 2 (optional): += 1 per problem that is still running after this pass
 };
 
 template <typename Model>
@@ -851,6 +882,111 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     wave_sync();
     lm_solve_problem<T>(model, L, n, lane, (long long)p);
     if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+  }
+  unsigned long long* counters = prm_g->counters;
+  if (counters && lane == 0) {
+    atomicAdd(&counters[0], L.st->acc_passes);
+    atomicAdd(&counters[1], L.st->eval_passes);
+    atomicAdd(&counters[2], L.st->solves);
+    atomicAdd(&counters[3], L.st->problems);
+  }
+}
+
+// Model wrapper for the stepping form: H of the last build must survive between launches (on eval-only iterations the
+// reference keeps solving with the H and g built at the last accepted point while x sits at a trial point,
+// optimizer.h:281-299 + lm.h:96-117), but a model keeps it in registers.  Every build is mirrored to HBM and the
+// factorisation workspace is filled from there.
+template <typename Model>
+struct StepModel {
+  using Scalar = typename Model::Scalar;
+  using T = Scalar;
+  static constexpr int kNpad = Model::kNpad;
+  static constexpr int kXdim = Model::kXdim;
+  Model& inner;
+  T* hst;
+  int ninl;
+  __device__ __forceinline__ StepModel(Model& m, T* h) : inner(m), hst(h), ninl(0) {}
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    inner.accumulate(L, n, lane, cost, nres);
+    ninl = model_inliers(inner, nres, 0);
+    inner.write_sym(hst, n, n, lane);
+    wave_sync();
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    inner.evaluate(L, n, lane, cost, nres);
+    ninl = model_inliers(inner, nres, 0);
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
+    for (int e = lane; e < n * n; e += 64) M[(e / n) * LD + (e % n)] = O(hst[e]);
+  }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int n, int lane) const { inner.plus_eq(L, d, sign, n, lane); }
+};
+
+// The stepping form (`lm::Optimizer<H_t> optimizer(options)` + `optimizer.Step(x, acc, out)`, optimizer.h:199,331-539):
+// the state machine of lm_solve_problem, one piece per launch, with the per-problem state parked in HBM.  A separate
+// kernel on purpose: inlining a second copy of lm_iteration into lm_fused_kernel cost it 48 registers (3 -> 2 waves/SIMD).
+template <typename Model>
+__global__ void __launch_bounds__(256) lm_step_kernel(const FusedParams* __restrict__ prm_g) {
+  using T = typename Model::Scalar;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = prm_g->n;
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave, n);
+  {
+    const int* src_o = reinterpret_cast<const int*>(&prm_g->opt);
+    int* dst_o = reinterpret_cast<int*>(L.opt);
+    for (int i = lane; i < int(sizeof(toa_options) / 4); i += 64) dst_o[i] = src_o[i];
+    const int* src_r = reinterpret_cast<const int*>(&prm_g->res);
+    int* dst_r = reinterpret_cast<int*>(L.res);
+    for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+  }
+  wave_sync();
+  const long long P = prm_g->P;
+  Model model;
+  model.init(n, prm_g->m, prm_g->data);
+  T* X = static_cast<T*>(prm_g->x);
+  const int xd = Model::kXdim ? Model::kXdim : n;
+  for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
+    model.bind(p);
+    wave_sync();
+    // ---- stepping form: the state machine of lm_solve_problem, one piece per launch ----
+    WideState<T>* ws = static_cast<WideState<T>*>(prm_g->state) + p;
+    if (prm_g->mode == 1) {  // Optimizer construction + loop prologue (optimizer.h:248-263)
+      L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+      L.g[lane] = T(0);
+      L.hd[lane] = T(0);
+      wave_sync();
+      const unsigned long long keep[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
+      lm_init<T>(L, lane);
+      L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+      wide_store_state(L, ws, lane);
+      wave_sync();
+      L.st->acc_passes = keep[0]; L.st->eval_passes = keep[1]; L.st->solves = keep[2]; L.st->problems = keep[3];
+      continue;
+    }
+    if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) continue;  // this problem has finished
+    const unsigned long long keep[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
+    wide_load_state(L, ws, lane);
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    StepModel<Model> sm(model, static_cast<T*>(prm_g->hstore) + size_t(p) * n * n);
+    const bool more = lm_iteration<T>(sm, L, n, lane, (long long)p);
+    if (!more) lm_finalize<T>(sm, L, n, lane, (long long)p);
+    if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];  // the reference updates x in place at every Step
+    if (more && lane == 0) {
+      prm_g->res.num_iters[p] = L.st->num_iters;
+      prm_g->res.final_cost[p] = L.st->final_cost;
+      prm_g->res.stop_reason[p] = TOA_STOP_NONE;
+      if (prm_g->active) atomicAdd(prm_g->active, 1);
+    }
+    const unsigned long long done[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    wide_store_state(L, ws, lane);
+    wave_sync();
+    L.st->acc_passes = keep[0] + done[0]; L.st->eval_passes = keep[1] + done[1];
+    L.st->solves = keep[2] + done[2]; L.st->problems = keep[3] + done[3];
   }
   unsigned long long* counters = prm_g->counters;
   if (counters && lane == 0) {
@@ -990,12 +1126,6 @@ __global__ void __launch_bounds__(256) inv_cov_kernel(const void* H_, long long 
 // The host enqueues init + (partial, step) x max_iters on the stream without reading anything back: problems
 // that have stopped make their later launches no-ops.
 // ================================================================================================
-template <typename T>
-struct WideState {
-  LmState<T> st;
-  T xs[64], g[64], hd[64], dx[64], ldx[64];
-};
-
 struct WideParams {
   const void* data;
   void* x;
@@ -1020,25 +1150,6 @@ __device__ __forceinline__ void wide_copy_pods(WaveLds<T>& L, const WideParams* 
   int* dst_r = reinterpret_cast<int*>(L.res);
   for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
 }
-template <typename T>
-__device__ __forceinline__ void wide_load_state(WaveLds<T>& L, const WideState<T>* ws, int lane) {
-  const int* src = reinterpret_cast<const int*>(&ws->st);
-  int* dst = reinterpret_cast<int*>(L.st);
-  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
-  L.xs[lane] = ws->xs[lane]; L.g[lane] = ws->g[lane]; L.hd[lane] = ws->hd[lane];
-  L.dx[lane] = ws->dx[lane]; L.ldx[lane] = ws->ldx[lane];
-  wave_sync();
-}
-template <typename T>
-__device__ __forceinline__ void wide_store_state(const WaveLds<T>& L, WideState<T>* ws, int lane) {
-  wave_sync();
-  const int* src = reinterpret_cast<const int*>(L.st);
-  int* dst = reinterpret_cast<int*>(&ws->st);
-  for (int i = lane; i < int(sizeof(LmState<T>) / 4); i += 64) dst[i] = src[i];
-  ws->xs[lane] = L.xs[lane]; ws->g[lane] = L.g[lane]; ws->hd[lane] = L.hd[lane];
-  ws->dx[lane] = L.dx[lane]; ws->ldx[lane] = L.ldx[lane];
-}
-
 template <typename T, int XD>
 __global__ void __launch_bounds__(256) wide_init_kernel(const WideParams* __restrict__ prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1449,6 +1560,18 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
+  if (prm.mode != 0) {  // stepping form: begin / one pass per problem
+    auto ks = lm_step_kernel<Model>;
+    if (int rc = ensure_lds_attr(h, (const void*)ks, pwg)) return rc;
+    long long g = (prm.P + 3) / 4;
+    const long long cap = (long long)h->num_cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(ks, dim3((unsigned)g), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  }
   prm.queue = h->queue;
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
   auto kern = lm_fused_kernel<Model>;
