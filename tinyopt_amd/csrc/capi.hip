@@ -496,12 +496,6 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* 
   return toa_inst_inv_cov(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, C, ok);
 }
 
-// stepping-form state: [ WideState[P] (256-byte aligned) | H[P][n*n] ]
-static size_t lm_state_head_bytes(int dtype, int64_t P) {
-  const size_t b = size_t(P) * (dtype == TOA_F32 ? sizeof(toa::WideState<float>) : sizeof(toa::WideState<double>));
-  return (b + 255) & ~size_t(255);
-}
-
 static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                        const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
                        int mode = 0, void* state = nullptr, int32_t* active = nullptr) {
@@ -532,11 +526,12 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   prm.counters = reinterpret_cast<unsigned long long*>(counters);
   prm.mode = mode;
   prm.state = state;
-  prm.hstore = state ? static_cast<char*>(state) + lm_state_head_bytes(dtype, P) : nullptr;
   prm.active = active;
   if (mode != 0) {
     if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
-    splits = -2;  // the stepping form always runs one wavefront per problem
+    // the stepping form runs on the launch-per-iteration kernels with one chunk per problem (launch_stepping)
+    const DenseRowLayout lay_s = DenseRowLayout::make(n, m);
+    return toa_inst_wide(dtype == TOA_F32 ? 0 : 1, model, lay_s.nbm, lay_s.thin, h, prm, 1);
   }
   const int dtag = dtype == TOA_F32 ? 0 : 1;
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
@@ -560,7 +555,7 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, cons
 
 size_t toa_lm_state_bytes(int dtype, int n, int64_t P) {
   if (P < 0 || n < 1) return 0;
-  return lm_state_head_bytes(dtype, P) + size_t(P) * n * n * (dtype == TOA_F32 ? 4 : 8);
+  return dtype == TOA_F32 ? toa::stepping_state_bytes<float>(n, P) : toa::stepping_state_bytes<double>(n, P);
 }
 
 int toa_lm_begin(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,

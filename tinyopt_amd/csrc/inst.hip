@@ -36,7 +36,32 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
 }
 int TOA_CAT(toa_inst_misc_wide_, TOA_INST_DT, 0)(int model, toa_handle h, const FusedParams& prm, int splits) {
   if (model == TOA_MODEL_SE3_REPROJ) return launch_wide<Se3ReprojModel<InstT>, 16, Se3Manifold<InstT>>(h, prm, splits);
-  return toa_fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
+  if (prm.mode == 0) return toa_fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
+  // stepping form: every model, one chunk per problem
+  using E = EuclidManifold<InstT>;
+  switch (model) {
+    case TOA_MODEL_SQRT2: return launch_stepping<Sqrt2Model<InstT>, 16, E>(h, prm);
+    case TOA_MODEL_TESTFN: return launch_stepping<TestFnModel<InstT>, 16, E>(h, prm);
+    case TOA_MODEL_SE3_PRIOR: return launch_stepping<Se3PriorModel<InstT>, 16, Se3Manifold<InstT>>(h, prm);
+    case TOA_MODEL_CIRCLE_FIT: return launch_stepping<JetModel<InstT, CircleFitFunctor<InstT>>, 16, E>(h, prm);
+    case TOA_MODEL_DENSE_ROW_AD6: return launch_stepping<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>, 16, E>(h, prm);
+    default: break;
+  }
+  const int npad = 16 * ((prm.n + 15) / 16);
+  if (model == TOA_MODEL_MAHA_PRIOR) {
+    switch (npad) {
+      case 16: return launch_stepping<MahaPriorModel<InstT, 16>, 16, E>(h, prm);
+      case 32: return launch_stepping<MahaPriorModel<InstT, 32>, 32, E>(h, prm);
+      case 48: return launch_stepping<MahaPriorModel<InstT, 48>, 48, E>(h, prm);
+      default: return launch_stepping<MahaPriorModel<InstT, 64>, 64, E>(h, prm);
+    }
+  }
+  switch (npad) {  // TOA_MODEL_GAUSSIAN_PRIOR
+    case 16: return launch_stepping<GaussianPriorModel<InstT, 16>, 16, E>(h, prm);
+    case 32: return launch_stepping<GaussianPriorModel<InstT, 32>, 32, E>(h, prm);
+    case 48: return launch_stepping<GaussianPriorModel<InstT, 48>, 48, E>(h, prm);
+    default: return launch_stepping<GaussianPriorModel<InstT, 64>, 64, E>(h, prm);
+  }
 }
 int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, int n, int m, int64_t P,
                                                        const void* data, const void* x, int want_grad, void* g, void* H,

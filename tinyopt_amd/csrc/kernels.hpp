@@ -99,6 +99,7 @@ struct GaussianPriorModel {
   int n_;
   __device__ __forceinline__ void init(int n, int, const void* d) { n_ = n; data = static_cast<const T*>(d); }
   __device__ __forceinline__ void bind(long long p) { y = data + size_t(p) * 2 * n_; sigma = y + n_; }
+  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }  // not row-splittable: one chunk
   __device__ __forceinline__ T residual(const WaveLds<T>& L, int n, int lane, T& inv_sigma) const {
     if (lane >= n) { inv_sigma = T(0); return T(0); }
     const T s = sigma[lane];
@@ -144,6 +145,7 @@ struct MahaPriorModel {
   int n_;
   __device__ __forceinline__ void init(int n, int, const void* d) { n_ = n; data = static_cast<const T*>(d); }
   __device__ __forceinline__ void bind(long long p) { y = data + size_t(p) * (n_ + size_t(n_) * n_); U = y + n_; }
+  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }
   __device__ __forceinline__ T residual(WaveLds<T>& L, int n, int lane) const {
     L.tmp[lane] = lane < n ? L.xs[lane] - y[lane] : T(0);
     wave_sync();
@@ -205,6 +207,7 @@ struct TestFnModel {
   T H[16];
   __device__ __forceinline__ void init(int, int, const void* d) { fn = int(static_cast<const T*>(d)[0]); }
   __device__ __forceinline__ void bind(long long) {}
+  __device__ __forceinline__ void bind_chunk(long long, int, int, int) {}
   static __device__ __forceinline__ T pw(T t, int e) { return T(::pow(double(t), double(e))); }  // std::pow(t, 3): double
   template <bool WANT>
   __device__ __forceinline__ T eval(const WaveLds<T>& L, T* g, int& nres) {
@@ -327,6 +330,7 @@ struct Sqrt2Model {
   static constexpr int kNpad = 16;
   __device__ __forceinline__ void init(int, int, const void*) {}
   __device__ __forceinline__ void bind(long long) {}
+  __device__ __forceinline__ void bind_chunk(long long, int, int, int) {}
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
     const T x = L.xs[0];
     const T r = x * x - T(2), J = T(2) * x;
@@ -447,6 +451,7 @@ struct Se3PriorModel {
   static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
   __device__ __forceinline__ void init(int, int, const void* dp) { data = static_cast<const T*>(dp); }
   __device__ __forceinline__ void bind(long long p) { P = data + size_t(p) * 12; }
+  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }
   template <typename S>
   __device__ __forceinline__ void residual(const S* Rx, const S* tx, S* xi) const {
     S RA[9], tA[3];
@@ -709,6 +714,7 @@ struct JetModel {
     d = data + size_t(p) * (F::kH + size_t(items) * F::kD);
     it0 = 0; it1 = items;
   }
+  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }  // one chunk (stepping form)
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const { euclid_plus_eq(L, dv, sign, lane); }
 
   template <bool WANT_H>
@@ -840,9 +846,8 @@ struct FusedParams {
   unsigned long long* counters;  // [4] or null
   int* queue;                    // work-queue head
   int lds_per_wave;
-  int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem
-  void* state;                   // modes 1, 2: WideState<T>[P]
-  void* hstore;                  // modes 1, 2: T[P][n*n], the undamped H of each problem's last build
+  int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form)
+  void* state;                   // modes 1, 2: caller's state block (see launch_wide)
   int* active;                   // mode 2 (optional): += 1 per problem that is still running after this pass
 };
 
@@ -882,111 +887,6 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     wave_sync();
     lm_solve_problem<T>(model, L, n, lane, (long long)p);
     if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
-  }
-  unsigned long long* counters = prm_g->counters;
-  if (counters && lane == 0) {
-    atomicAdd(&counters[0], L.st->acc_passes);
-    atomicAdd(&counters[1], L.st->eval_passes);
-    atomicAdd(&counters[2], L.st->solves);
-    atomicAdd(&counters[3], L.st->problems);
-  }
-}
-
-// Model wrapper for the stepping form: H of the last build must survive between launches (on eval-only iterations the
-// reference keeps solving with the H and g built at the last accepted point while x sits at a trial point,
-// optimizer.h:281-299 + lm.h:96-117), but a model keeps it in registers.  Every build is mirrored to HBM and the
-// factorisation workspace is filled from there.
-template <typename Model>
-struct StepModel {
-  using Scalar = typename Model::Scalar;
-  using T = Scalar;
-  static constexpr int kNpad = Model::kNpad;
-  static constexpr int kXdim = Model::kXdim;
-  Model& inner;
-  T* hst;
-  int ninl;
-  __device__ __forceinline__ StepModel(Model& m, T* h) : inner(m), hst(h), ninl(0) {}
-  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    inner.accumulate(L, n, lane, cost, nres);
-    ninl = model_inliers(inner, nres, 0);
-    inner.write_sym(hst, n, n, lane);
-    wave_sync();
-  }
-  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    inner.evaluate(L, n, lane, cost, nres);
-    ninl = model_inliers(inner, nres, 0);
-  }
-  template <typename O>
-  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
-    for (int e = lane; e < n * n; e += 64) M[(e / n) * LD + (e % n)] = O(hst[e]);
-  }
-  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int n, int lane) const { inner.plus_eq(L, d, sign, n, lane); }
-};
-
-// The stepping form (`lm::Optimizer<H_t> optimizer(options)` + `optimizer.Step(x, acc, out)`, optimizer.h:199,331-539):
-// the state machine of lm_solve_problem, one piece per launch, with the per-problem state parked in HBM.  A separate
-// kernel on purpose: inlining a second copy of lm_iteration into lm_fused_kernel cost it 48 registers (3 -> 2 waves/SIMD).
-template <typename Model>
-__global__ void __launch_bounds__(256) lm_step_kernel(const FusedParams* __restrict__ prm_g) {
-  using T = typename Model::Scalar;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int n = prm_g->n;
-  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave, n);
-  {
-    const int* src_o = reinterpret_cast<const int*>(&prm_g->opt);
-    int* dst_o = reinterpret_cast<int*>(L.opt);
-    for (int i = lane; i < int(sizeof(toa_options) / 4); i += 64) dst_o[i] = src_o[i];
-    const int* src_r = reinterpret_cast<const int*>(&prm_g->res);
-    int* dst_r = reinterpret_cast<int*>(L.res);
-    for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
-    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
-  }
-  wave_sync();
-  const long long P = prm_g->P;
-  Model model;
-  model.init(n, prm_g->m, prm_g->data);
-  T* X = static_cast<T*>(prm_g->x);
-  const int xd = Model::kXdim ? Model::kXdim : n;
-  for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
-    model.bind(p);
-    wave_sync();
-    // ---- stepping form: the state machine of lm_solve_problem, one piece per launch ----
-    WideState<T>* ws = static_cast<WideState<T>*>(prm_g->state) + p;
-    if (prm_g->mode == 1) {  // Optimizer construction + loop prologue (optimizer.h:248-263)
-      L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
-      L.g[lane] = T(0);
-      L.hd[lane] = T(0);
-      wave_sync();
-      const unsigned long long keep[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
-      lm_init<T>(L, lane);
-      L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
-      wide_store_state(L, ws, lane);
-      wave_sync();
-      L.st->acc_passes = keep[0]; L.st->eval_passes = keep[1]; L.st->solves = keep[2]; L.st->problems = keep[3];
-      continue;
-    }
-    if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) continue;  // this problem has finished
-    const unsigned long long keep[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
-    wide_load_state(L, ws, lane);
-    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
-    StepModel<Model> sm(model, static_cast<T*>(prm_g->hstore) + size_t(p) * n * n);
-    const bool more = lm_iteration<T>(sm, L, n, lane, (long long)p);
-    if (!more) lm_finalize<T>(sm, L, n, lane, (long long)p);
-    if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];  // the reference updates x in place at every Step
-    if (more && lane == 0) {
-      prm_g->res.num_iters[p] = L.st->num_iters;
-      prm_g->res.final_cost[p] = L.st->final_cost;
-      prm_g->res.stop_reason[p] = TOA_STOP_NONE;
-      if (prm_g->active) atomicAdd(prm_g->active, 1);
-    }
-    const unsigned long long done[4] = {L.st->acc_passes, L.st->eval_passes, L.st->solves, L.st->problems};
-    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
-    wide_store_state(L, ws, lane);
-    wave_sync();
-    L.st->acc_passes = keep[0] + done[0]; L.st->eval_passes = keep[1] + done[1];
-    L.st->solves = keep[2] + done[2]; L.st->problems = keep[3] + done[3];
   }
   unsigned long long* counters = prm_g->counters;
   if (counters && lane == 0) {
@@ -1137,6 +1037,8 @@ struct WideParams {
   void* state;     // WideState<T>[P]
   void* partials;  // T[P][splits][n*n + n + 2]  (H, g, cost, inlier residuals)
   void* hsum;      // T[P][n*n]
+  int step_mode;   // stepping form: publish x and the running results at every pass
+  int* active;     // stepping form (optional): += 1 per problem still running after the pass
   unsigned* sync;  // persistent form: [P][2] = (arrive, go) generation counters, then [1] abort flag; zeroed per launch
   int lds_per_wave;
 };
@@ -1320,6 +1222,17 @@ __global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __rest
   model.part = static_cast<const T*>(prm->partials) + size_t(p) * prm->splits * (n * n + n + 2);
   model.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
   const bool more = lm_iteration<T>(model, L, n, lane, p);
+  if (more && prm->step_mode) {  // the reference's Step updates x in place every time (optimizer.h:271-279)
+    const int xd = Manifold::kXdim ? Manifold::kXdim : n;
+    T* X = static_cast<T*>(prm->x);
+    if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+    if (lane == 0) {
+      prm->res.num_iters[p] = L.st->num_iters;
+      prm->res.final_cost[p] = L.st->final_cost;
+      prm->res.stop_reason[p] = TOA_STOP_NONE;
+      if (prm->active) atomicAdd(prm->active, 1);
+    }
+  }
   if (!more) {
     lm_finalize<T>(model, L, n, lane, p);  // sets a non-zero StopReason: later launches skip this problem
     const int xd = Manifold::kXdim ? Manifold::kXdim : n;
@@ -1560,18 +1473,6 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
-  if (prm.mode != 0) {  // stepping form: begin / one pass per problem
-    auto ks = lm_step_kernel<Model>;
-    if (int rc = ensure_lds_attr(h, (const void*)ks, pwg)) return rc;
-    long long g = (prm.P + 3) / 4;
-    const long long cap = (long long)h->num_cus * 8;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(ks, dim3((unsigned)g), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
-    HIP_TRY(hipGetLastError());
-    return TOA_OK;
-  }
   prm.queue = h->queue;
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
   auto kern = lm_fused_kernel<Model>;
@@ -1597,10 +1498,67 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   return TOA_OK;
 }
 
+// Stepping form (`lm::Optimizer<H_t> optimizer(options)`; `optimizer.Step(x, acc, out)`, optimizer.h:199,331-539) on the
+// launch-per-iteration kernels above with ONE chunk per problem: begin = wide_init_kernel, a step = the data pass
+// (wide_partial_kernel<Model>: H, g, cost of the current x into the caller's state block) + wide_step_kernel (one
+// lm_iteration).  The H of the last build stays in the state block, which is what eval-only iterations keep solving
+// with while x sits at a trial point (optimizer.h:281-299, lm.h:96-117).
+// State block layout: [ WideState<T>[P] | partial (H, g, cost, inliers)[P] | folded H [P][n*n] ], each 256-byte aligned.
+template <typename T>
+inline size_t stepping_state_bytes(int n, long long P, size_t* o_part = nullptr, size_t* o_hsum = nullptr) {
+  const size_t stride = size_t(n) * n + n + 2;
+  const size_t b_state = (size_t(P) * sizeof(WideState<T>) + 255) & ~size_t(255);
+  const size_t b_part = (size_t(P) * stride * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_hsum = (size_t(P) * n * n * sizeof(T) + 255) & ~size_t(255);
+  if (o_part) *o_part = b_state;
+  if (o_hsum) *o_hsum = b_state + b_part;
+  return b_state + b_part + b_hsum;
+}
+
+template <typename Model, int NPAD, typename Manifold>
+inline int launch_stepping(toa_handle h, const FusedParams& fp) {
+  using T = typename Model::Scalar;
+  const int n = fp.n, m = fp.m;
+  const long long P = fp.P;
+  size_t pw, pwg, o_part, o_hsum;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  (void)stepping_state_bytes<T>(n, P, &o_part, &o_hsum);
+  WideParams wp;
+  std::memset(&wp, 0, sizeof(wp));
+  wp.data = fp.data; wp.x = fp.x; wp.P = P; wp.n = n; wp.m = m;
+  wp.splits = 1;
+  wp.chunk_rows = (((m + 3) & ~3) + 15) & ~15;
+  wp.opt = fp.opt; wp.res = fp.res; wp.counters = fp.counters;
+  wp.state = fp.state;
+  wp.partials = static_cast<char*>(fp.state) + o_part;
+  wp.hsum = static_cast<char*>(fp.state) + o_hsum;
+  wp.step_mode = 1;
+  wp.active = fp.active;
+  wp.lds_per_wave = int(pw);
+  HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+  const WideParams* dp = static_cast<const WideParams*>(h->params_dev);
+  const unsigned g_p = unsigned((P + 3) / 4);
+  if (fp.mode == 1) {
+    auto k_init = wide_init_kernel<T, Manifold::kXdim>;
+    if (int rc = ensure_lds_attr(h, (const void*)k_init, pwg)) return rc;
+    hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  } else {
+    auto k_part = wide_partial_kernel<Model>;
+    auto k_step = wide_step_kernel<T, NPAD, Manifold>;
+    if (int rc = ensure_lds_attr(h, (const void*)k_part, pwg)) return rc;
+    if (int rc = ensure_lds_attr(h, (const void*)k_step, pwg)) return rc;
+    hipLaunchKernelGGL(k_part, dim3(g_p), dim3(256), pwg, h->stream, dp);
+    hipLaunchKernelGGL(k_step, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  }
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 // Row-split driver.  Model = the chunk-capable residual model, NPAD / Manifold as for the step kernel.
 template <typename Model, int NPAD, typename Manifold>
 inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   using T = typename Model::Scalar;
+  if (fp.mode != 0) return launch_stepping<Model, NPAD, Manifold>(h, fp);
   const int n = fp.n, m = fp.m;
   const long long P = fp.P;
   const int m4 = (m + 3) & ~3;
@@ -1660,14 +1618,18 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  TOA_USE_GRAPH=1 selects the graph path.
   // Persistent form (one launch for the whole solve) whenever every workgroup is certainly co-resident: one
   // 64-thread workgroup per chunk, at most one per CU.  TOA_WIDE_MULTILAUNCH=1 forces the launch-per-iteration form.
+  // Instantiated for the small systems only (n <= 15: BASELINE configs C2 / C5 are n = 6): the kernel carries a whole
+  // lm_iteration with the NPAD-unrolled register LDL^T per residual-model layout, and 40 copies of it tripled the build.
   static const bool multilaunch = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
-  if (!multilaunch && P * S <= (long long)h->num_cus && pw <= 64 * 1024) {
-    auto k_pers = wide_persistent_kernel<Model, NPAD, Manifold>;
-    if (int rc = ensure_lds_attr(h, (const void*)k_pers, pw)) return rc;
-    HIP_TRY(hipMemsetAsync(wp.sync, 0, size_t(2 * P + 1) * sizeof(unsigned), h->stream));
-    hipLaunchKernelGGL(k_pers, dim3(unsigned(P * S)), dim3(64), pw, h->stream, dp);
-    HIP_TRY(hipGetLastError());
-    return TOA_OK;
+  if constexpr (NPAD <= 16) {
+    if (!multilaunch && P * S <= (long long)h->num_cus && pw <= 64 * 1024) {
+      auto k_pers = wide_persistent_kernel<Model, NPAD, Manifold>;
+      if (int rc = ensure_lds_attr(h, (const void*)k_pers, pw)) return rc;
+      HIP_TRY(hipMemsetAsync(wp.sync, 0, size_t(2 * P + 1) * sizeof(unsigned), h->stream));
+      hipLaunchKernelGGL(k_pers, dim3(unsigned(P * S)), dim3(64), pw, h->stream, dp);
+      HIP_TRY(hipGetLastError());
+      return TOA_OK;
+    }
   }
   static const bool use_graph = std::getenv("TOA_USE_GRAPH") != nullptr;
   if (!use_graph) {
