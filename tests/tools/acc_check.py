@@ -1,7 +1,7 @@
 """Debug helper: accumulate seam vs the oracle over a grid of shapes (prints max relative errors)."""
 import sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tinyopt_amd as ta
 from oracle import pyoracle
 

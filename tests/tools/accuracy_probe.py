@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy of the device Accumulate (g, H, cost) against an fp64 numpy reference, at x0 and near x*."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import tinyopt_amd as ta
 from oracle import pyoracle

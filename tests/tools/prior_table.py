@@ -4,7 +4,7 @@ mean wall time of one whole Optimize() call on the Gaussian-prior problem r = (x
 manual-Jacobian callback, benchmarks/options.h options.  Prints, per n: published tinyopt us (unknown x86 CPU),
 the CPU oracle us on this host (1 thread), and the batched GPU time per solve (1 MI355X, P problems in flight)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import tinyopt_amd as ta
 from oracle import pyoracle

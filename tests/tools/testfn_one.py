@@ -1,10 +1,10 @@
 """Debug helper (GPU): one test-function problem, device history vs the oracle's.  usage: testfn_one.py <name> <start-index>"""
 import sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tinyopt_amd as ta
 from oracle import pyoracle
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from test_gpu_testfns import CASES, _options
 name, p = sys.argv[1], int(sys.argv[2])
 x0 = CASES[name][0]

@@ -108,7 +108,7 @@ TOA_GRAM_STEP(double, F64, 4,
 // footprint would halve the occupancy of the whole fused kernel for arguments that never occur.
 #if !defined(TOA_POLY_SINCOS)
 // fp32: v_sin_f32 / v_cos_f32 (inputs in revolutions) — 3 VALU instructions instead of ~28.  Measured on
-// MI355X against an fp64 reference (tools/accuracy_probe.py, n=50, m=2000): g / H / cost errors are
+// MI355X against an fp64 reference (tests/tools/accuracy_probe.py, n=50, m=2000): g / H / cost errors are
 // indistinguishable from the polynomial version and smaller than the fp32 CPU oracle's own error.
 // The accumulate pass is VALU-issue-bound (f32 MFMA shares the VALU's issue slots), so this is
 // worth ~15 % of the pass.  -DTOA_POLY_SINCOS selects the ~1.5 ulp polynomial instead.

@@ -1613,7 +1613,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   if (int rc = ensure_lds_attr(h, (const void*)k_step, pwg)) return rc;
   const unsigned g_p = unsigned((P + 3) / 4), g_u = unsigned((P * S + 3) / 4);
   const int iters = fp.opt.max_iters + 1 + (fp.opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
-  // Direct launches by default: an A/B on MI355X (tools/latency_probe.py) shows graph replay and eager launches
+  // Direct launches by default: an A/B on MI355X (tests/tools/latency_probe.py) shows graph replay and eager launches
   // of this 23..103-kernel sequence within 1 % of each other (C2 71 us, C5 93-99 us device time per solve), as
   // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  TOA_USE_GRAPH=1 selects the graph path.
   // Persistent form (one launch for the whole solve) whenever every workgroup is certainly co-resident: one
