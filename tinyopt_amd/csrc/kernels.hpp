@@ -851,6 +851,9 @@ struct FusedParams {
   int* active;                   // mode 2 (optional): += 1 per problem that is still running after this pass
 };
 
+// (An occupancy request via __launch_bounds__'s second argument is NOT usable here: under the tighter register budget
+// hipcc parks the destination registers of the in-flight asm loads in AGPRs right after issuing them — tools/isa_lint.py
+// caught exactly that when 5 waves/SIMD were requested for the fp64 n <= 15 kernel.)
 template <typename Model>
 __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   using T = typename Model::Scalar;
