@@ -325,7 +325,7 @@ int toa_hbm_read_probe(toa_handle h, const void* src_dev, size_t bytes, int reps
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  uint32_t* sink = reinterpret_cast<uint32_t*>(h->queue) + 32;  // unused tail of the 256-byte queue block
+  uint32_t* sink = reinterpret_cast<uint32_t*>(h->queue) + 60;  // unused tail of the 256-byte queue block
   hipLaunchKernelGGL(toa::hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const toa::u32x4*)src_dev, n16, sink);  // warm
   HIP_TRY(hipEventRecord(e0, h->stream));
   for (int r = 0; r < reps; ++r)

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/tinyopt_amd.h"
 #include "dense_row.hpp"
@@ -836,6 +837,46 @@ __device__ __forceinline__ void wide_store_state(const WaveLds<T>& L, WideState<
   ws->dx[lane] = L.dx[lane]; ws->ldx[lane] = L.ldx[lane];
 }
 
+// Work-item hand-over inside the fused kernel: everything of the per-problem state except the per-WAVE work counters
+// that happen to live in the same LDS record.  Every word goes through an agent-scope RELAXED atomic (sc1: written
+// through to / fetched from memory), so the hand-over is coherent across XCDs without agent-scope fences — a
+// release/acquire pair per work item writes back and invalidates a whole L2 and made the launch slower, not faster.
+template <typename W>
+__device__ __forceinline__ void coh_store(W* dst, W v) {
+  if constexpr (sizeof(W) == 4) {
+    __hip_atomic_store(reinterpret_cast<int*>(dst), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(reinterpret_cast<long long*>(dst), __builtin_bit_cast(long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <typename W>
+__device__ __forceinline__ W coh_load(const W* src) {
+  if constexpr (sizeof(W) == 4) {
+    return __builtin_bit_cast(W, __hip_atomic_load(reinterpret_cast<const int*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    return __builtin_bit_cast(W, __hip_atomic_load(reinterpret_cast<const long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void park_store(const WaveLds<T>& L, WideState<T>* ws, int lane) {
+  wave_sync();
+  const int* src = reinterpret_cast<const int*>(L.st);
+  int* dst = reinterpret_cast<int*>(&ws->st);
+  for (int i = lane; i < int(offsetof(LmState<T>, acc_passes) / 4); i += 64) coh_store(dst + i, src[i]);
+  coh_store(&ws->xs[lane], L.xs[lane]); coh_store(&ws->g[lane], L.g[lane]); coh_store(&ws->hd[lane], L.hd[lane]);
+  coh_store(&ws->dx[lane], L.dx[lane]); coh_store(&ws->ldx[lane], L.ldx[lane]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the state has left this CU before the problem is re-queued
+}
+template <typename T>
+__device__ __forceinline__ void park_load(WaveLds<T>& L, const WideState<T>* ws, int lane) {
+  const int* src = reinterpret_cast<const int*>(&ws->st);
+  int* dst = reinterpret_cast<int*>(L.st);
+  for (int i = lane; i < int(offsetof(LmState<T>, acc_passes) / 4); i += 64) dst[i] = coh_load(src + i);
+  L.xs[lane] = coh_load(&ws->xs[lane]); L.g[lane] = coh_load(&ws->g[lane]); L.hd[lane] = coh_load(&ws->hd[lane]);
+  L.dx[lane] = coh_load(&ws->dx[lane]); L.ldx[lane] = coh_load(&ws->ldx[lane]);
+  wave_sync();
+}
+
 struct FusedParams {
   const void* data;
   void* x;
@@ -844,7 +885,11 @@ struct FusedParams {
   toa_options opt;
   toa_results res;
   unsigned long long* counters;  // [4] or null
-  int* queue;                    // work-queue head
+  int* queue;                    // [0] pop counter, [16] push counter, [32] problems finished (separate cache lines)
+  int* ring;                     // re-queued problems, in push order; -1 = not yet published
+  int ring_cap;
+  void* park;                    // WideState<T>[P]: the state of a problem between two of its work items
+  unsigned long long* timeline;  // debug (TOA_TIMELINE=file): [P][2] start / end of every problem in 100 MHz ticks
   int lds_per_wave;
   int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form)
   void* state;                   // modes 1, 2: caller's state block (see launch_wide)
@@ -879,7 +924,8 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   T* X = static_cast<T*>(prm_g->x);
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
-  for (;;) {
+#ifndef TOA_QUEUE_DRAIN
+  for (;;) {  // one work item = one whole problem
     int p = 0;
     if (lane == 0) p = atomicAdd(queue, 1);
     p = __builtin_amdgcn_readfirstlane(p);
@@ -888,9 +934,77 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     wave_sync();
     L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
     wave_sync();
+    const unsigned long long tl0 = prm_g->timeline ? wall_clock64() : 0ull;
     lm_solve_problem<T>(model, L, n, lane, (long long)p);
     if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+    if (prm_g->timeline && lane == 0) { prm_g->timeline[2 * size_t(p)] = tl0; prm_g->timeline[2 * size_t(p) + 1] = wall_clock64(); }
   }
+#else
+  // EXPERIMENT (-DTOA_QUEUE_DRAIN), off by default.  The timeline of a launch (TOA_TIMELINE=file, tools/timeline.py)
+  // shows ~2 500 problems in flight until the queue runs dry at 80 % of the launch and then a 1.9 ms drain during which
+  // SIMDs go idle one after the other (~10 % of a C4 launch, 30 % of a C3 launch).  This variant lets idle waves take
+  // over unfinished problems: a problem that is not finished parks its state in HBM (1.3 KB against the 408 KB its next
+  // data pass streams) and is re-queued — after every iteration once the queue is dry (whole problems before that).
+  // Results stay bit-identical.  Measured: C4 shard 9.07 -> 8.94 ms (8.82 when every iteration is an item from the
+  // start), but C3 0.73 -> 1.13 ms (1.50): for 50 us items the hand-over (same-address queue atomics, sc1 round trips)
+  // costs more than the drain it removes.  With agent-scope release/acquire fences per item instead of the sc1 accesses
+  // every hand-over wrote back / invalidated a whole L2: C4 10.5 ms.  A problem is only parked when its next iteration
+  // rebuilds H (rebuild == 1): on eval-only iterations H lives in this wave's registers (lm.h:96-117).
+  //   queue[0] pop counter: items 0..P-1 are the problems themselves (first iteration), item P + s is ring[s]
+  //   queue[1] push counter, queue[2] problems finished (exit condition for waves waiting on an empty queue)
+  int* ring = prm_g->ring;
+  WideState<T>* park = static_cast<WideState<T>*>(prm_g->park);
+  for (;;) {
+    int idx = 0;
+    if (lane == 0) idx = atomicAdd(&queue[0], 1);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    int p;
+    const bool fresh = idx < P;
+    if (fresh) {
+      p = idx;
+    } else {
+      const int slot = idx - int(P);
+      if (slot >= prm_g->ring_cap) break;
+      int v;
+      for (;;) {
+        v = __hip_atomic_load(&ring[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= 0) break;
+        if (__hip_atomic_load(&queue[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= int(P)) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (v < 0) break;  // every problem has finished
+      p = __builtin_amdgcn_readfirstlane(v);
+    }
+    model.bind(p);
+    wave_sync();
+    if (fresh) {
+      L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+      wave_sync();
+      lm_init<T>(L, lane);
+    } else {
+      park_load(L, park + p, lane);
+    }
+    // Whole problems while the queue still has fresh ones (no hand-over cost in steady state); once it has run dry —
+    // the drain, when SIMDs go idle one after the other — a problem that is not finished is parked after each iteration
+    // so that the idle waves waiting on the ring can take it over.
+    bool more;
+    do {
+      more = lm_iteration<T>(model, L, n, lane, (long long)p);
+    } while (more && !(L.st->rebuild == 1 &&
+                       __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= int(P)));
+    if (more) {
+      park_store(L, park + p, lane);
+      if (lane == 0) {
+        const int s = atomicAdd(&queue[16], 1);
+        __hip_atomic_store(&ring[s], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      lm_finalize<T>(model, L, n, lane, (long long)p);
+      if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+      if (lane == 0) atomicAdd(&queue[32], 1);
+    }
+  }
+#endif
   unsigned long long* counters = prm_g->counters;
   if (counters && lane == 0) {
     atomicAdd(&counters[0], L.st->acc_passes);
@@ -1477,7 +1591,29 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
-  HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));  // [0] pops, [16] pushes, [32] finished: one cache line each
+#ifdef TOA_QUEUE_DRAIN
+  {  // iteration-granular work queue: park states + ring of re-queued problems in the context's scratch block
+    const long long iters_max = (long long)prm.opt.max_iters + 3;
+    const size_t b_park = (size_t(prm.P) * sizeof(WideState<T>) + 255) & ~size_t(255);
+    const size_t ring_cap = size_t(prm.P) * size_t(iters_max);
+    const size_t b_ring = (ring_cap * sizeof(int) + 255) & ~size_t(255);
+    if (ring_cap > 0x7fffffffull) return toa_fail(TOA_E_UNSUPPORTED, "P * (max_iters + 3) exceeds the work-queue index range");
+    const size_t need = b_park + b_ring;
+    if (need > h->scratch_bytes) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->scratch) (void)hipFree(h->scratch);
+      h->scratch = nullptr;
+      h->scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&h->scratch, need));
+      h->scratch_bytes = need;
+    }
+    prm.park = h->scratch;
+    prm.ring = reinterpret_cast<int*>(static_cast<char*>(h->scratch) + b_park);
+    prm.ring_cap = int(ring_cap);
+    HIP_TRY(hipMemsetAsync(prm.ring, 0xFF, ring_cap * sizeof(int), h->stream));
+  }
+#endif
   auto kern = lm_fused_kernel<Model>;
   int wg_per_cu = 0;
   for (int i = 0; i < h->ncfg; ++i)
@@ -1492,12 +1628,46 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   const long long need = (prm.P + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
+  // Balanced rounds: a launch is quantised in whole problem times (one wavefront per problem), so when the batch is only
+  // a few rounds deep run P / rounds waves instead of every slot the chip has — 10 000 equal problems over 4 096
+  // slots take 3 rounds with the last one 44 % full, over 2 500 slots 4 full rounds of proportionally shorter problems
+  // (the pass is issue-bound: fewer waves per SIMD run faster each).  Not below ~2 waves per SIMD.
+  {
+    const long long slots = grid * 4;
+    const long long rounds = (prm.P + slots - 1) / slots;
+    if (rounds >= 2 && rounds <= 16) {
+      long long g2 = ((prm.P + rounds - 1) / rounds + 3) / 4;
+      const long long floor_wgs = (long long)h->num_cus * 2;
+      if (g2 < floor_wgs) g2 = floor_wgs;
+      if (g2 < grid) grid = g2;
+    }
+    static const char* cap_env = std::getenv("TOA_MAX_WGS");
+    if (cap_env && std::atoll(cap_env) > 0 && grid > std::atoll(cap_env)) grid = std::atoll(cap_env);
+  }
   static_assert(sizeof(FusedParams) <= 1024, "parameter block too large");
   // stream-ordered upload of the parameter block (kept out of the kernarg segment so that its ~60
   // scalars are loaded on demand instead of being pinned in SGPRs across the hot loop)
   HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+  static const char* tl_path = std::getenv("TOA_TIMELINE");
+  unsigned long long* tl_dev = nullptr;
+  if (tl_path) {  // debug: per-problem start / end stamps of this launch, appended to the file as text
+    HIP_TRY(hipMalloc(&tl_dev, size_t(prm.P) * 16));
+    HIP_TRY(hipMemsetAsync(tl_dev, 0, size_t(prm.P) * 16, h->stream));
+    prm.timeline = tl_dev;
+    HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
   HIP_TRY(hipGetLastError());
+  if (tl_path) {
+    std::vector<unsigned long long> tl(size_t(prm.P) * 2);
+    HIP_TRY(hipMemcpy(tl.data(), tl_dev, tl.size() * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(tl_dev);
+    if (FILE* f = std::fopen(tl_path, "a")) {
+      std::fprintf(f, "# launch P=%lld grid=%lld\n", prm.P, grid);
+      for (long long q = 0; q < prm.P; ++q) std::fprintf(f, "%llu %llu\n", tl[2 * q], tl[2 * q + 1]);
+      std::fclose(f);
+    }
+  }
   return TOA_OK;
 }
 
