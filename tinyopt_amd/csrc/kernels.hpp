@@ -1628,20 +1628,10 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   const long long need = (prm.P + 3) / 4;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
-  // Balanced rounds: a launch is quantised in whole problem times (one wavefront per problem), so when the batch is only
-  // a few rounds deep run P / rounds waves instead of every slot the chip has — 10 000 equal problems over 4 096
-  // slots take 3 rounds with the last one 44 % full, over 2 500 slots 4 full rounds of proportionally shorter problems
-  // (the pass is issue-bound: fewer waves per SIMD run faster each).  Not below ~2 waves per SIMD.
+  // (Sizing the grid to P / rounds waves so that every round is full was tried: at the BASELINE shard size 625 workgroups
+  // instead of 768 are ~2 % slower, tools/grid_ab.sh — more resident waves hide more latency than full rounds save.)
   {
-    const long long slots = grid * 4;
-    const long long rounds = (prm.P + slots - 1) / slots;
-    if (rounds >= 2 && rounds <= 16) {
-      long long g2 = ((prm.P + rounds - 1) / rounds + 3) / 4;
-      const long long floor_wgs = (long long)h->num_cus * 2;
-      if (g2 < floor_wgs) g2 = floor_wgs;
-      if (g2 < grid) grid = g2;
-    }
-    static const char* cap_env = std::getenv("TOA_MAX_WGS");
+    static const char* cap_env = std::getenv("TOA_MAX_WGS");  // experiments only
     if (cap_env && std::atoll(cap_env) > 0 && grid > std::atoll(cap_env)) grid = std::atoll(cap_env);
   }
   static_assert(sizeof(FusedParams) <= 1024, "parameter block too large");

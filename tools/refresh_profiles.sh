@@ -4,7 +4,7 @@
 set -x
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/refresh
-rm -rf $O; mkdir -p $O
+rm -rf $O; mkdir -p $O   # NOTE: also delete the LOCAL gpurun_out/refresh before calling gpurun (results are merged, not mirrored)
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 python bench.py --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err
