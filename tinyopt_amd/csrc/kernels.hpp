@@ -925,11 +925,35 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
 #ifndef TOA_QUEUE_DRAIN
+  int solved = 0;
   for (;;) {  // one work item = one whole problem
     int p = 0;
     if (lane == 0) p = atomicAdd(queue, 1);
     p = __builtin_amdgcn_readfirstlane(p);
     if (p >= P) break;
+#ifndef TOA_PRIO_SCHEME
+#define TOA_PRIO_SCHEME 1
+#endif
+#if TOA_PRIO_SCHEME != 0
+    // Fairness between the waves of a SIMD.  The issue arbiter serves the OLDEST wave first, and a wave keeps its age for
+    // the whole (persistent) kernel: the launch timeline shows the oldest wave of each SIMD solving a problem in 0.8 ms
+    // while the youngest needs up to 6.9 ms for its first one and is still far from done when the queue runs dry — the
+    // drain is then as long as those starved problems.  Priority outranks age, so the waves that are behind are given
+    // the issue slots.  Scheme 1: a wave drops one level per problem it has finished.  Scheme 2: its level follows how
+    // far it is behind the average wave (p / #resident waves = rounds of problems handed out so far).
+    {
+#if TOA_PRIO_SCHEME == 1
+      const int lag = 1 - solved;
+#else
+      const int lag = p / int(gridDim.x * 4) - solved;
+#endif
+      if (lag >= 1) __builtin_amdgcn_s_setprio(3);
+      else if (lag == 0) __builtin_amdgcn_s_setprio(2);
+      else if (lag == -1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    ++solved;
+#endif
     model.bind(p);
     wave_sync();
     L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
