@@ -32,6 +32,8 @@ WORKLOADS = {
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# dense MFMA peaks of the dtypes this path computes in: f32-input MFMA 157.3 TF (MI355X_MICROARCH.md), f64 78.6 TF (vendor spec)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
 
 
 def log(*a):
@@ -123,9 +125,10 @@ def main():
         e1.record()
         it = out.num_iters.sum(dtype=torch.int64)
         ps = out.counters[0] + out.counters[1]
+        ap = out.counters[0].clone()
         if acc is None:
-            return (it, ps, [(e0, e1)])
-        return (acc[0] + it, acc[1] + ps, acc[2] + [(e0, e1)])
+            return (it, ps, [(e0, e1)], ap)
+        return (acc[0] + it, acc[1] + ps, acc[2] + [(e0, e1)], acc[3] + ap)
 
     wacc = None
     for _ in range(max(args.warmup, 1) if args.warmup else 0):
@@ -148,6 +151,7 @@ def main():
     elapsed = time.perf_counter() - t0
     iters_total = int(acc[0].item())
     passes_total = int(acc[1].item())
+    acc_passes_total = int(acc[3].item())
     kern_ms = [a.elapsed_time(b) for a, b in acc[2]]
 
     # ---- max over ranks, totals over ranks
@@ -200,6 +204,12 @@ def main():
     except Exception as e:  # noqa: BLE001
         log(f"[bench] hbm read probe failed: {e}")
         stream_read = None
+    # secondary ceiling ("MFMA ceiling reported additionally"): matrix-core flops ISSUED by the accumulate
+    # passes (NBM(NBM+1)/2 tiles of v_mfma_*_16x16x4 = 2048 flop per 4 rows) against the dense fp32 / fp64 MFMA peak
+    lay = ta.api.dense_row_layout(tdt, n, m)
+    mfma_flop_per_pass = (lay["rows_padded"] // 4) * (lay["nb"] * (lay["nb"] + 1) // 2) * 2048
+    mfma_tflops = mfma_flop_per_pass * (acc_passes_total / args.steps) / kern_avg_s / 1e12
+    mfma_peak = MFMA_PEAK_TFLOPS[tag]
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_file):
@@ -229,7 +239,10 @@ def main():
                      "measured_read_ceiling_GBps": stream_read,
                      "frac_of_measured_ceiling": (achieved / stream_read) if stream_read else None,
                      "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_per_launch,
-                     "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_all": kern_ms},
+                     "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_all": kern_ms,
+                     "mfma_secondary": {"achieved": mfma_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
+                                        "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
+                                        "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
     if not args.no_cpu:
         np_dtype = np.float32 if tdt == torch.float32 else np.float64

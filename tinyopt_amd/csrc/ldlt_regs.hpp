@@ -24,7 +24,7 @@
 // chunk when they are pinned; slower than this version in the fused kernel both ways.)
 //
 // Layout in registers after factor():  row[j], j < lane : L[lane][j]
-//                                       row[lane]        : d_lane (also kept in `dvec`)
+//                                       row[lane]        : d_lane (its reciprocal is kept in `dinv`)
 //                                       row[j], j > lane : d_lane * L[j][lane]  (the un-scaled Schur row
 //                                                          of step `lane`), which is exactly what the
 //                                                          back substitution of  D L^T x = y  needs.
@@ -64,7 +64,7 @@ template <typename T, int NPAD>
 struct LdltRegs {
   static_assert(NPAD % 8 == 0, "columns are processed in chunks of 8");
   RowRegs<T, NPAD> row;
-  T dvec;
+  T dinv;  // lane k: 1 / d_k
 
   // Lane i loads row i of the symmetric n×n LDS image (LD-strided); everything beyond n is zero.
   __device__ __forceinline__ void load(const T* __restrict__ M, const int LD, const int n_in, const int lane) {
@@ -82,7 +82,7 @@ struct LdltRegs {
         static_for<8>([&](auto jjc) __attribute__((always_inline)) { row.template set<jb + decltype(jjc)::value>(T(0)); });
       }
     });
-    dvec = T(1);
+    dinv = T(1);
   }
 
   // One 8-column chunk of the right-looking update  S[i][j] -= l_i * S[j][k],  j in [JB, JB + 8), j > K.
@@ -125,23 +125,55 @@ struct LdltRegs {
     }
   }
 
-  // Returns true iff every pivot was finite and > min_normal (then the factorisation is complete).
-  __device__ __forceinline__ bool factor(const int n_in, const int lane) {
+  // Pivot gate of the fast path, on the scalar unit: the bit pattern of a positive, normal, not-huge value lies in
+  // (lo, hi) as an unsigned integer (negative values and NaN have larger patterns), so one s_sub + s_cmp replaces two
+  // vector compares and their s_nops.  The upper bound is below max() so that 1/d is still a NORMAL number for
+  // v_rcp; anything outside falls back to the exact LDS routine, which carries the reference's acceptance rule.
+  static __device__ __forceinline__ bool pivot_in_range(const T d) {
+    if constexpr (sizeof(T) == 4) {
+      const unsigned b = __builtin_amdgcn_readfirstlane(__float_as_uint(d));
+      return (b - 0x00800001u) < (0x7E000000u - 0x00800001u);
+    } else {
+      const unsigned b = __builtin_amdgcn_readfirstlane(unsigned(__double_as_longlong(d) >> 32));
+      return (b - 0x00100001u) < (0x7FC00000u - 0x00100001u);
+    }
+  }
+  // 1/d for d accepted by pivot_in_range: hardware reciprocal + Newton steps (3 / 5 instructions, error < 1 ulp)
+  // instead of the 12- / 22-instruction IEEE division sequence on the critical path of every pivot.
+  static __device__ __forceinline__ T recip(const T d) {
+    if constexpr (sizeof(T) == 4) {
+      float r = __builtin_amdgcn_rcpf(d);
+      r = fmaf(r, fmaf(-d, r, 1.0f), r);
+      return r;
+    } else {
+      double r = __builtin_amdgcn_rcp(d);
+      r = fma(r, fma(-d, r, 1.0), r);
+      r = fma(r, fma(-d, r, 1.0), r);
+      return r;
+    }
+  }
+
+  // Returns true iff every pivot passed pivot_in_range (then the factorisation is complete).
+  __device__ __forceinline__ bool factor(const int n_in, const int lane_in) {
     const int n = opaque_uniform(n_in);
+    // opaque for the same reason as n: `lane > k` is one v_cmp here, but loop-invariant for the kernel's problem and
+    // iteration loops, and LICM would park all 2 x NPAD masks in VGPR lanes (v_writelane / 2 v_readlane per use)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     bool ok = true;
     static_for<NPAD>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       if (k < n && ok) {  // wave-uniform
         const T c = row.template get<k>();  // lane i > k: S[i][k]
         const T d = wave_bcast(c, k);
-        if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
+        if (!pivot_in_range(d)) {
           ok = false;
         } else {
-          const T inv = T(1) / d;
+          const T inv = recip(d);
           const bool below = lane > k;
           const T l = below ? c * inv : T(0);
           row.template set<k>(below ? l : c);  // lane k keeps d_k, lanes < k keep their Schur row entry
-          dvec = (lane == k) ? d : dvec;
+          dinv = (lane == k) ? inv : dinv;
           constexpr int jb0 = ((k + 1) / 8);
           static_for<NPAD / 8 - jb0>([&](auto jbc) __attribute__((always_inline)) {
             constexpr int jb = (jb0 + decltype(jbc)::value) * 8;
@@ -154,8 +186,10 @@ struct LdltRegs {
   }
 
   // x = A^-1 b using the factors above.  b_lane / return: element `lane` (lanes >= n: 0).
-  __device__ __forceinline__ T solve(const int n_in, const int lane, const T b_lane) const {
+  __device__ __forceinline__ T solve(const int n_in, const int lane_in, const T b_lane) const {
     const int n = opaque_uniform(n_in);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     T y = lane < n ? b_lane : T(0);
     static_for<NPAD - 1>([&](auto kc) __attribute__((always_inline)) {  // L y' = b   (unit lower, column sweep)
       constexpr int k = decltype(kc)::value;
@@ -164,7 +198,7 @@ struct LdltRegs {
         y = (lane > k) ? fma(-row.template get<k>(), s, y) : y;
       }
     });
-    const T invd = T(1) / dvec;
+    const T invd = dinv;
     // D L^T x = y' with the rows stored un-scaled: x_i = (y_i - sum_{j>i} row_i[j] x_j) / d_i
     static_for<NPAD - 1>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = NPAD - 1 - decltype(jc)::value;
