@@ -193,6 +193,7 @@ int toa_inst_misc_accumulate(int dtag, int model, int npad, toa_handle h, int n,
 int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok) {
   return dtag == 0 ? toa_inst_inv_cov_0_0(npad, h, n, P, H, C, ok) : toa_inst_inv_cov_1_0(npad, h, n, P, H, C, ok);
 }
+int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok) {
   return dtag == 0 ? toa_inst_solve_0_0(npad, h, n, P, H, g, scale, dx, ok)
@@ -272,6 +273,7 @@ int toa_destroy(toa_handle h) {
   if (h->queue) (void)hipFree(h->queue);
   if (h->params_dev) (void)hipFree(h->params_dev);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->blas && h->blas_destroy) (void)h->blas_destroy(h->blas);
   for (int i = 0; i < h->nwgraphs; ++i) (void)hipGraphExecDestroy(h->wgraphs[i].exec);
   delete h;
   return TOA_OK;
@@ -480,10 +482,21 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
                      int32_t* ok) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  if (int rc = check_shape(dtype, n, 1, P)) return rc;
+  // n <= 63: one wavefront per matrix (register / LDS LDL^T); 64 <= n <= 4096: rocSOLVER batched Cholesky (large_n.hip).
+  // TOA_FORCE_ROCSOLVER=1 sends small matrices down the library path too (tools/k3_crossover.py measures both).
+  static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+  const bool large = n > 63 || force_lib;
+  if (large) {
+    if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+    if (n < 1 || n > 4096) return fail(TOA_E_ARG, "toa_solve_damped: n must be in [1, 4096]");
+    if (P < 0 || P > 0x7fffffff) return fail(TOA_E_ARG, "P out of range");
+  } else if (int rc = check_shape(dtype, n, 1, P)) {
+    return rc;
+  }
   if (!H || !g || !dx || !ok) return fail(TOA_E_ARG, "toa_solve_damped: null pointer");
   if (P == 0) return TOA_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (large) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   return toa_inst_solve(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, g, scale, dx, ok);
 }
 

@@ -1557,6 +1557,9 @@ struct toa_context {
   struct Cfg { const void* fn; size_t lds; int wg_per_cu; };
   Cfg cfg[256];
   int ncfg = 0;
+  // large-n K3 (large_n.hip): rocBLAS handle created on the first n > 63 solve, and how to destroy it
+  void* blas = nullptr;
+  int (*blas_destroy)(void*) = nullptr;
 };
 
 // error reporting lives in capi.hip (one thread_local message for the whole library)
