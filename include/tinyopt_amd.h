@@ -62,6 +62,10 @@ extern "C" {
  * differentiated on the device by dual numbers over the right perturbation; n == m == 6; x: [P][12] poses;
  * data_dev: [P][12] = prior_inv (rotation matrix row-major, translation) */
 #define TOA_MODEL_SE3_PRIOR 9
+/* DenseRow beyond one wavefront (n up to 1024): rows in natural layout, J^T J by a batched library
+ * GEMM (at this width the residual block is a real dense contraction), the solve by rocSOLVER's batched Cholesky,
+ * the LM state machine in small kernels between them (tinyopt_amd/csrc/large_n.hip).  toa_lm_run only. */
+#define TOA_MODEL_DENSE_ROW_NATURAL 10
 
 /* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
 #define TOA_LOSS_L2 0
@@ -195,7 +199,8 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  *                           a point is an inlier when ||r||^2 <= th2 (results: final_inlier_ratio).
  * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
- * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6]. */
+ * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6].
+ * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024, P <= 65535; data_dev: [P][m][n+1] = (a_i, b_i) rows; x: [P][n]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).

@@ -63,3 +63,73 @@ def test_library_path_agrees_with_wavefront_path_below_64(monkeypatch):
     a, b = np.array(outs[0]["dx"]), np.array(outs[1]["dx"])
     assert outs[0]["ok"] == outs[1]["ok"] == [1] * 5
     assert np.abs(a - b).max() / np.abs(a).max() < 1e-10
+
+
+# ---- the LM loop beyond one wavefront (TOA_MODEL_DENSE_ROW_NATURAL): parity with the CPU restatement of
+#      optimizer.h:242-539 on the same seeded problems, and with the fused one-wavefront kernel where both apply
+def _run_natural(A, b, x0, opts, history=False):
+    import tinyopt_amd as ta
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0).cuda()
+    out = ta.Optimize(x, model, opts, history=history)
+    torch.cuda.synchronize()
+    return x.cpu().numpy(), out
+
+
+@pytest.mark.parametrize("dtype,n,m,xtol", [(np.float64, 64, 300, 1e-8), (np.float64, 100, 400, 1e-8),
+                                             (np.float32, 96, 400, 2e-3), (np.float64, 12, 100, 1e-8)])
+def test_large_n_lm_matches_oracle(dtype, n, m, xtol):
+    import tinyopt_amd as ta
+    from oracle import pyoracle
+    P = 5
+    A, b, x0, xs = pyoracle.synth_dense_row(P, n, m, dtype)
+    for opts in (ta.Options.benchmark(), ta.Options()):
+        ref = pyoracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+        xg, out = _run_natural(A, b, x0, opts, history=True)
+        assert np.abs(xg - ref["x"]).max() < xtol
+        assert np.abs(xg - xs).max() < 2e-2  # planted solution recovered
+        assert (out.stop_reason.cpu().numpy() >= 0).all()
+        if dtype == np.float64:  # well-conditioned fixtures: identical StopReason and iteration counts
+            assert (out.stop_reason.cpu().numpy() == ref["stop"]).all()
+            assert (out.num_iters.cpu().numpy() == ref["iters"]).all()
+            k = int(ref["iters"].min())
+            np.testing.assert_allclose(out.errs.cpu().numpy()[:, :k], ref["errs"][:, :k], rtol=1e-9)
+            np.testing.assert_allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-9)
+
+
+def test_large_n_lm_agrees_with_fused_kernel_at_n50():
+    import tinyopt_amd as ta
+    from oracle import pyoracle
+    P, n, m = 6, 50, 400
+    A, b, x0, _ = pyoracle.synth_dense_row(P, n, m, np.float64)
+    opts = ta.Options()
+    xg, out = _run_natural(A, b, x0, opts)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0).cuda()
+    out2 = ta.Optimize(x, model, opts)
+    torch.cuda.synchronize()
+    assert np.abs(xg - x.cpu().numpy()).max() < 1e-9
+    assert (out.stop_reason == out2.stop_reason).all() and (out.num_iters == out2.num_iters).all()
+    Hn, Hf = out.final_hessian.cpu().numpy(), out2.final_hessian.cpu().numpy()
+    assert np.abs(Hn - Hf).max() / np.abs(Hf).max() < 1e-10
+
+
+def test_large_n_lm_failure_modes():
+    """NaN in the data -> kSystemHasNaNOrInf; a rank-deficient Jacobian with damping disabled -> kSolverFailed
+    (optimizer.h:370-399), like the small-n path."""
+    import tinyopt_amd as ta
+    from oracle import pyoracle
+    P, n, m = 3, 70, 200
+    A, b, x0, _ = pyoracle.synth_dense_row(P, n, m, np.float64)
+    A2 = A.copy()
+    A2[1, 5, 3] = np.nan
+    _, out = _run_natural(A2, b, x0, ta.Options())
+    stop = out.stop_reason.cpu().numpy()
+    assert stop[1] == int(ta.StopReason.kSystemHasNaNOrInf) and stop[0] >= 0 and stop[2] >= 0
+    A3 = A.copy()
+    A3[2, :, 7] = 0.0  # a zero column: J^T J singular; Gauss-Newton has no damping to repair it
+    o = ta.Options()
+    o.solver_type = ta.Options.GaussNewton
+    _, out = _run_natural(A3, b, x0, o)
+    stop = out.stop_reason.cpu().numpy()
+    assert stop[2] == int(ta.StopReason.kSolverFailed) and stop[0] >= 0

@@ -18,6 +18,7 @@ MODEL_DENSE_ROW, MODEL_GAUSSIAN_PRIOR, MODEL_SQRT2, MODEL_SE3_REPROJ, MODEL_CIRC
 MODEL_TESTFN = 7
 MODEL_MAHA_PRIOR = 8
 MODEL_SE3_PRIOR = 9
+MODEL_DENSE_ROW_NATURAL = 10
 
 # StopReason, same integers as include/tinyopt/stop_reasons.h:14-43
 STOP_NAMES = {

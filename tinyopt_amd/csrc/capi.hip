@@ -194,6 +194,8 @@ int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const v
   return dtag == 0 ? toa_inst_inv_cov_0_0(npad, h, n, P, H, C, ok) : toa_inst_inv_cov_1_0(npad, h, n, P, H, C, ok);
 }
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                     const toa_results* results, uint64_t* counters);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok) {
   return dtag == 0 ? toa_inst_solve_0_0(npad, h, n, P, H, g, scale, dx, ok)
@@ -513,8 +515,18 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
                        const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
                        int mode = 0, void* state = nullptr, int32_t* active = nullptr) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  if (int rc = check_shape(dtype, n, m, P)) return rc;
-  if (int rc = check_model(model, n, m, data)) return rc;
+  const bool natural = model == TOA_MODEL_DENSE_ROW_NATURAL;  // the library-backed path for n beyond one wavefront
+  if (natural) {
+    if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+    if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");
+    if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
+    if (P < 0 || P > 65535) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: P must be in [0, 65535]");
+    if (!data) return fail(TOA_E_ARG, "null data pointer");
+    if (mode != 0 || splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: toa_lm_run only");
+  } else {
+    if (int rc = check_shape(dtype, n, m, P)) return rc;
+    if (int rc = check_model(model, n, m, data)) return rc;
+  }
   if (!x || !options || !results) return fail(TOA_E_ARG, "toa_lm_run: null pointer");
   if (!results->stop_reason || !results->num_iters || !results->final_cost)
     return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");
@@ -527,6 +539,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");
   if (P == 0) return TOA_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (natural) return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   FusedParams prm;
   std::memset(&prm, 0, sizeof(prm));
   prm.data = data;

@@ -21,6 +21,7 @@ namespace {
 
 using rb_handle = void*;
 constexpr int kFillUpper = 121;  // rocblas_fill_upper (rocblas-types.h)
+constexpr int kOpN = 111, kOpT = 112;  // rocblas_operation_none / _transpose
 
 struct RocApi {
   int (*create)(rb_handle*) = nullptr;
@@ -30,6 +31,14 @@ struct RocApi {
   int (*dpotrf)(rb_handle, int, int, double*, int, int64_t, int*, int) = nullptr;
   int (*spotrs)(rb_handle, int, int, int, float*, int, int64_t, float*, int, int64_t, int) = nullptr;
   int (*dpotrs)(rb_handle, int, int, int, double*, int, int64_t, double*, int, int64_t, int) = nullptr;
+  int (*sgemm)(rb_handle, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t,
+               const float*, float*, int, int64_t, int) = nullptr;
+  int (*dgemm)(rb_handle, int, int, int, int, int, const double*, const double*, int, int64_t, const double*, int, int64_t,
+               const double*, double*, int, int64_t, int) = nullptr;
+  int (*sgemv)(rb_handle, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t, const float*,
+               float*, int, int64_t, int) = nullptr;
+  int (*dgemv)(rb_handle, int, int, int, const double*, const double*, int, int64_t, const double*, int, int64_t,
+               const double*, double*, int, int64_t, int) = nullptr;
   std::string err;
   bool ok = false;
 };
@@ -58,6 +67,10 @@ RocApi& roc_api() {
     api.dpotrf = reinterpret_cast<decltype(api.dpotrf)>(sym(sol, "rocsolver_dpotrf_strided_batched"));
     api.spotrs = reinterpret_cast<decltype(api.spotrs)>(sym(sol, "rocsolver_spotrs_strided_batched"));
     api.dpotrs = reinterpret_cast<decltype(api.dpotrs)>(sym(sol, "rocsolver_dpotrs_strided_batched"));
+    api.sgemm = reinterpret_cast<decltype(api.sgemm)>(sym(blas, "rocblas_sgemm_strided_batched"));
+    api.dgemm = reinterpret_cast<decltype(api.dgemm)>(sym(blas, "rocblas_dgemm_strided_batched"));
+    api.sgemv = reinterpret_cast<decltype(api.sgemv)>(sym(blas, "rocblas_sgemv_strided_batched"));
+    api.dgemv = reinterpret_cast<decltype(api.dgemv)>(sym(blas, "rocblas_dgemv_strided_batched"));
     api.ok = api.err.empty();
   });
   return api;
@@ -139,6 +152,362 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
   return TOA_OK;
 }
 
+
+// =====================================================================================================================
+// The LM / GN loop for n > 63 (TOA_MODEL_DENSE_ROW_NATURAL): same state machine as lm_device.hpp (its scalar pieces are
+// shared: LmState, lm_good_step / lm_bad_step, lm_judge_core), but the vectors of a problem live in HBM, one
+// WORKGROUP owns a problem inside the small kernels, and the two heavy operations are library calls:
+//   rows kernel   r_i, and J = diag(s) A written once (HBM-bound: reads m (n + 1), writes m n)
+//   rocBLAS       H = J^T J (gemm_strided_batched: at n >= 64 the residual block IS a real dense contraction),
+//                 g = J^T r (gemv_strided_batched)
+//   pre kernel    cost, Build (lm.h:59-120): clip, diagonal check, damping; forms the damped copy + right-hand side
+//   rocSOLVER     potrf + potrs strided batched
+//   post kernel   the rest of Step (optimizer.h:354-539) and of OptimizeAcc's loop body (:266-310), finalisation
+// One host loop pass = one Build + Solve attempt of every active problem; a failed solve re-damps and retries in the
+// next pass without advancing the iteration, exactly like the `while` at optimizer.h:358.  The host reads two
+// integers per pass (active problems, problems that want a Jacobian) to stop early and to skip the GEMM.
+template <typename T>
+struct LargeArgs {
+  const T* data;  // [P][m][n + 1]  rows (a_i, b_i)
+  T* x;           // [P][n] in / out
+  int n, m;
+  long long P;
+  toa_options opt;
+  toa_results res;
+  LmState<T>* st;
+  int* active;   // [P]
+  int* built;    // [P]
+  int* summary;  // [2 * passes]: (active, want Jacobian) after each pass
+  T *g, *hd, *dx, *ldx, *H, *Hnew, *gnew, *work, *rhs, *J, *r;
+  int* info;
+  unsigned long long* counters;
+};
+
+template <typename T>
+__device__ __forceinline__ double block_sum(const double v, double* red) {  // fixed-order tree: deterministic
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double out = red[0];
+  __syncthreads();
+  return out;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) large_init_kernel(const LargeArgs<T> a) {
+  const long long p = blockIdx.x * 256ll + threadIdx.x;
+  if (p >= a.P) return;
+  LmState<T>& S = a.st[p];
+  const toa_options& opt = a.opt;
+  S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;  // lm.h:46-52
+  S.final_cost = kDblMax; S.final_nres = 0; S.final_ninl = 0; S.cost_ninl = 0; S.final_rerr = kDblMax;  // output.h:104-117
+  S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
+  S.cost_val = 0; S.cost_nres = 0;
+  S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
+  S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
+  S.acc_passes = S.eval_passes = S.solves = S.problems = 0;
+  a.active[p] = 1;
+  a.built[p] = 0;
+}
+
+// r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1 + 0.1 cos(a_i.x)) a_i   (SURVEY §8d DenseRow family), one wave per row
+template <typename T>
+__global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
+  extern __shared__ char lds_raw[];
+  T* xs = reinterpret_cast<T*>(lds_raw);
+  const long long p = blockIdx.y;
+  if (!a.active[p]) return;
+  const LmState<T>& S = a.st[p];
+  const bool want_j = a.opt.solver_type != 0 || S.rebuild;
+  const int n = a.n, m = a.m;
+  for (int j = threadIdx.x; j < n; j += 256) xs[j] = a.x[p * n + j];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* A = a.data + size_t(p) * m * (n + 1);
+  T* Jp = a.J + size_t(p) * m * n;
+  T* rp = a.r + size_t(p) * m;
+  for (int i = blockIdx.x * 4 + wave; i < m; i += gridDim.x * 4) {
+    const T* row = A + size_t(i) * (n + 1);
+    T t = 0;
+    for (int j = lane; j < n; j += 64) t = fma(row[j], xs[j], t);
+    t = wave_allreduce_sum(t);
+    T sn, cs;
+    sincos_t(t, &sn, &cs);
+    if (lane == 0) rp[i] = t + T(0.1) * sn - row[n];
+    if (want_j) {
+      const T sc = T(1) + T(0.1) * cs;
+      for (int j = lane; j < n; j += 64) Jp[size_t(i) * n + j] = sc * row[j];
+    }
+  }
+}
+
+// cost + Build (lm.h:59-120) up to the damped matrix and right-hand side
+template <typename T>
+__global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
+  __shared__ double red[256];
+  __shared__ int sh_built;
+  const long long p = blockIdx.x;
+  if (!a.active[p]) return;
+  LmState<T>& S = a.st[p];
+  const toa_options& opt = a.opt;
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  const bool is_lm = opt.solver_type == 0;
+  const bool do_acc = !is_lm || S.rebuild;
+  double c = 0;
+  for (int i = tid; i < m; i += 256) { const T r = a.r[p * m + i]; c += double(r * r); }
+  c = block_sum<T>(c, red);
+  const double cost_val = normalize_cost(double(T(c)), m, opt);
+  bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
+  T* g = a.g + p * n;
+  T* hd = a.hd + p * n;
+  T* H = a.H + size_t(p) * n * n;
+  if (built && do_acc) {  // H, g assigned from the fresh accumulation (gn.h:77-81,109-113)
+    const T* Hn = a.Hnew + size_t(p) * n * n;
+    for (size_t e = tid; e < size_t(n) * n; e += 256) H[e] = Hn[e];
+    double low = 0;
+    for (int i = tid; i < n; i += 256) {
+      T gi = a.gnew[p * n + i];
+      if (opt.grad_clipping != 0) { const T mm = opt.grad_clipping; gi = fmin(fmax(gi, -mm), mm); }  // base.h:29-38
+      g[i] = gi;
+      const T d = Hn[size_t(i) * n + i];
+      hd[i] = d;
+      if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
+    }
+    if (block_sum<T>(low, red) > 0) built = false;
+  }
+  __syncthreads();
+  if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double
+    const double s = S.rebuild ? 1.0 + double(S.lambda) : (1.0 + double(S.lambda)) / (1.0 + double(S.prev_lambda));
+    for (int i = tid; i < n; i += 256) hd[i] = T(double(hd[i]) * s);
+  }
+  __syncthreads();
+  if (built) {
+    T* W = a.work + size_t(p) * n * n;
+    for (size_t e = tid; e < size_t(n) * n; e += 256) {
+      const int i = int(e / n), j = int(e % n);
+      W[e] = (i == j) ? hd[i] : H[e];
+    }
+    for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = g[i];
+  }
+  if (tid == 0) {
+    if (do_acc) S.acc_passes++; else S.eval_passes++;
+    S.cost_val = cost_val;
+    S.cost_nres = m;
+    S.cost_ninl = m;
+    a.built[p] = built ? 1 : 0;
+  }
+}
+
+// the rest of Step and of the loop body; finalisation of problems that stop
+template <typename T>
+__global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, int* __restrict__ summary) {
+  __shared__ double red[256];
+  __shared__ int sh_action, sh_cont;
+  const long long p = blockIdx.x;
+  if (!a.active[p]) return;
+  LmState<T>& S = a.st[p];
+  const toa_options& opt = a.opt;
+  const toa_results& res = a.res;
+  const int n = a.n, tid = threadIdx.x;
+  T* x = a.x + p * n;
+  T* g = a.g + p * n;
+  T* dx = a.dx + p * n;
+  T* ldx = a.ldx + p * n;
+  const bool built = a.built[p] != 0;
+  bool solver_failed = true;
+  double dx_norm2 = 0, grad_norm2 = 0;
+  if (built) {  // gn.h:150-171
+    double bad = a.info[p] != 0 ? 1.0 : 0.0, d2 = 0, g2 = 0;
+    for (int i = tid; i < n; i += 256) {
+      const T v = -a.rhs[p * n + i];
+      if (!(fabs(v) <= NumLimits<T>::max())) bad = 1.0;
+      dx[i] = v;
+      d2 += double(v * v);
+      g2 += double(g[i] * g[i]);
+    }
+    bad = block_sum<T>(bad, red);
+    dx_norm2 = double(T(block_sum<T>(d2, red)));
+    if (opt.min_grad_norm2 > 0.0f) grad_norm2 = double(T(block_sum<T>(g2, red)));
+    solver_failed = bad > 0;
+  }
+  if (tid == 0) {
+    const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
+    int rc;  // 0 step, 1 solver failed for good, 2 early stop, -1 retry (same iteration, next pass)
+    if (built) S.solves++;
+    if (!solver_failed) {
+      rc = 0;
+    } else {  // optimizer.h:370-390
+      S.num_consec = (S.num_consec + 1) & 0xff;
+      S.num_failures = (S.num_failures + 1) & 0xff;
+      if (S.cost_nres == 0) { S.stop = TOA_STOP_SKIPPED; rc = 2; }
+      else if (isnan(S.cost_val) || isinf(S.cost_val)) { S.stop = TOA_STOP_NAN_OR_INF; rc = 2; }
+      else if (opt.max_consec_failures > 0 && S.num_consec >= unsigned(opt.max_consec_failures)) {
+        if (S.final_cost < double(NumLimits<T>::max())) S.stop = TOA_STOP_MAX_CONSEC_NO_DECR;
+        rc = 1;
+      } else {
+        lm_bad_step(S, opt);  // FailedStep == BadStep  lm.h:148
+        rc = (S.num_consec <= max_tries) ? -1 : 1;
+      }
+    }
+    int action = 0;  // 1: x += dx, last_dx = dx ; 2: x -= last_dx
+    int cont = 1;
+    if (rc >= 0) {
+      int status = 0;
+      if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399
+      if (rc == 0) status = lm_judge_core<T>(S, opt, res, p, dx_norm2, grad_norm2, true);
+      bool eval_only = false;  // optimizer.h:269-309
+      if (status & 1) {
+        action = 1;
+        S.has_last_dx = 1;
+        S.last_was_success = 1;
+        if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
+      } else {
+        if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
+        else if (status & 2) { action = 1; S.has_last_dx = 1; }
+        eval_only = (S.last_was_success == 0);
+        S.last_was_success = 0;
+      }
+      if (opt.solver_type == 0) S.rebuild = eval_only ? 0 : 1;
+      S.num_iters = S.num_iters + 1;
+      S.iter = S.iter + 1;
+      cont = (S.stop == TOA_STOP_NONE && S.iter < S.max_iters) ? 1 : 0;
+    }
+    sh_action = action;
+    sh_cont = cont;
+  }
+  __syncthreads();
+  const int action = sh_action;
+  if (action == 1) for (int i = tid; i < n; i += 256) { const T d = dx[i]; x[i] += d; ldx[i] = d; }  // traits.h:184-190
+  if (action == 2) for (int i = tid; i < n; i += 256) x[i] -= ldx[i];
+  if (sh_cont) {
+    if (tid == 0) {
+      atomicAdd(&summary[0], 1);
+      if (opt.solver_type != 0 || S.rebuild) atomicAdd(&summary[1], 1);
+    }
+    return;
+  }
+  // ---- optimizer.h:313-327: the problem is done
+  if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
+    double* Hout = res.final_hessian + size_t(p) * n * n;
+    const T* H = a.H + size_t(p) * n * n;
+    const T* hd = a.hd + p * n;
+    for (size_t e = tid; e < size_t(n) * n; e += 256) {
+      const int i = int(e / n), j = int(e % n);
+      T v = H[e];
+      if (i == j) { v = hd[i]; if (opt.solver_type == 0 && S.prev_lambda > T(0)) v = v / (T(1.0f) + S.prev_lambda); }
+      Hout[e] = double(v);
+    }
+  }
+  if (tid == 0) {
+    if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
+    res.stop_reason[p] = S.stop;
+    res.num_iters[p] = S.num_iters;
+    res.final_cost[p] = S.final_cost;
+    if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+    if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+    if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+    if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+    a.active[p] = 0;
+    if (a.counters) {
+      atomicAdd(&a.counters[0], S.acc_passes);
+      atomicAdd(&a.counters[1], S.eval_passes);
+      atomicAdd(&a.counters[2], S.solves);
+      atomicAdd(&a.counters[3], 1ull);
+    }
+  }
+}
+
+template <typename T>
+int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
+                   const toa_results& res, uint64_t* counters) {
+  const size_t nn = size_t(n) * n;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
+  const long long max_passes = (long long)(opt.max_iters + 2 + (opt.check_final_cost ? 1 : 0)) * (long long)(max_tries + 1);
+  const size_t b_st = al(size_t(P) * sizeof(LmState<T>)), b_i = al(size_t(P) * sizeof(int));
+  const size_t b_vec = al(size_t(P) * n * sizeof(T)), b_mat = al(size_t(P) * nn * sizeof(T));
+  const size_t b_J = al(size_t(P) * m * n * sizeof(T)), b_r = al(size_t(P) * m * sizeof(T));
+  const size_t b_sum = al(size_t(2) * sizeof(int) * size_t(max_passes + 1));
+  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum;
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    if (hipMalloc(&h->scratch, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return toa_fail(TOA_E_NOMEM, "large-n LM: cannot allocate " + std::to_string(need >> 20) + " MiB of workspace (J scratch is P*m*n)");
+    }
+    h->scratch_bytes = need;
+  }
+  char* q = static_cast<char*>(h->scratch);
+  auto take = [&](size_t b) { char* r = q; q += b; return r; };
+  LargeArgs<T> a;
+  a.data = data; a.x = x; a.n = n; a.m = m; a.P = P; a.opt = opt; a.res = res;
+  a.counters = reinterpret_cast<unsigned long long*>(counters);
+  a.st = reinterpret_cast<LmState<T>*>(take(b_st));
+  a.active = reinterpret_cast<int*>(take(b_i));
+  a.built = reinterpret_cast<int*>(take(b_i));
+  a.info = reinterpret_cast<int*>(take(b_i));
+  a.g = reinterpret_cast<T*>(take(b_vec)); a.hd = reinterpret_cast<T*>(take(b_vec)); a.dx = reinterpret_cast<T*>(take(b_vec));
+  a.ldx = reinterpret_cast<T*>(take(b_vec)); a.gnew = reinterpret_cast<T*>(take(b_vec)); a.rhs = reinterpret_cast<T*>(take(b_vec));
+  a.H = reinterpret_cast<T*>(take(b_mat)); a.Hnew = reinterpret_cast<T*>(take(b_mat)); a.work = reinterpret_cast<T*>(take(b_mat));
+  a.J = reinterpret_cast<T*>(take(b_J)); a.r = reinterpret_cast<T*>(take(b_r));
+  a.summary = reinterpret_cast<int*>(take(b_sum));
+  if (!h->blas) {
+    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
+    h->blas_destroy = api.destroy;
+  }
+  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
+  HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
+  HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
+  if (counters) HIP_TRY(hipMemsetAsync(counters, 0, 4 * sizeof(uint64_t), st));
+  hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
+  const unsigned row_blocks = unsigned(std::max<long long>(1, std::min<long long>((m + 3) / 4, (long long)h->num_cus * 16 / std::max<long long>(1, P) + 1)));
+  const T one = 1, zero = 0;
+  int active = int(P), want_j = int(P);
+  for (long long pass = 0; pass < max_passes && active > 0; ++pass) {
+    hipLaunchKernelGGL(large_rows_kernel<T>, dim3(row_blocks, unsigned(P)), dim3(256), size_t(n) * sizeof(T), st, a);
+    if (want_j > 0) {
+      int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
+      if constexpr (sizeof(T) == 4) {
+        rc = api.sgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
+        if (rc == 0) rc = api.sgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+      } else {
+        rc = api.dgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
+        if (rc == 0) rc = api.dgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+      }
+      if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
+    }
+    hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
+    int rc;
+    if constexpr (sizeof(T) == 4) {
+      rc = api.spotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
+      if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
+    } else {
+      rc = api.dpotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
+      if (rc == 0) rc = api.dpotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
+    }
+    if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER potrf/potrs returned status " + std::to_string(rc));
+    int* sum_dev = a.summary + 2 * pass;
+    hipLaunchKernelGGL(large_post_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a, sum_dev);
+    HIP_TRY(hipGetLastError());
+    int sum_host[2];
+    HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, sizeof(sum_host), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    active = sum_host[0];
+    want_j = sum_host[1];
+  }
+  if (active > 0) return toa_fail(TOA_E_HIP, "large-n LM: pass budget exhausted with active problems (internal error)");
+  return TOA_OK;
+}
+
 }  // namespace
 }  // namespace toa
 
@@ -151,4 +520,15 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                                      static_cast<float*>(dx), ok);
   return toa::large_solve_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale,
                                     static_cast<double*>(dx), ok);
+}
+
+int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                     const toa_results* results, uint64_t* counters) {
+  toa::RocApi& api = toa::roc_api();
+  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
+  if (dtype == TOA_F32)
+    return toa::large_lm_run_t<float>(h, api, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options,
+                                      *results, counters);
+  return toa::large_lm_run_t<double>(h, api, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options,
+                                     *results, counters);
 }

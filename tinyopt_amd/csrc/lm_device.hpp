@@ -231,22 +231,13 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
   return 1;
 }
 
-// ---- the rest of Step (optimizer.h:401-539).  Returns bit0 = good step, bit1 = has dx.
+// ---- the rest of Step (optimizer.h:401-539) once |dx|^2 and |g|^2 are known: scalar, shared by the one-wavefront
+//      state machine below and the large-n path (large_n.hip).  Returns bit0 = good step, bit1 = has dx.
 template <typename T>
-__device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const int lane, const long long p) {
-  LmState<T>& S = *L.st;
-  const toa_options& opt = *L.opt;
-  const toa_results& res = *L.res;
-  const bool in_n = lane < n;
+__device__ __forceinline__ int lm_judge_core(LmState<T>& S, const toa_options& opt, const toa_results& res, const long long p,
+                                             const double dx_norm2, const double grad_norm2, const bool writer) {
   const double err = S.cost_val;
   if (isnan(err) || isinf(err)) { S.stop = TOA_STOP_NAN_OR_INF; return 0; }  // :405-409
-  const T dxl = in_n ? L.dx[lane] : T(0);
-  const double dx_norm2 = double(wave_allreduce_sum(dxl * dxl));  // :412
-  double grad_norm2 = 0.0;
-  if (opt.min_grad_norm2 > 0.0f) {  // :413-415
-    const T gl = in_n ? L.g[lane] : T(0);
-    grad_norm2 = double(wave_allreduce_sum(gl * gl));
-  }
   if (isnan(dx_norm2) || isinf(dx_norm2)) { S.stop = TOA_STOP_NAN_OR_INF; return 0; }  // :416-425
   const double final_cost = S.final_cost;
   const double derr = err - final_cost;             // :428
@@ -255,7 +246,7 @@ __device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const i
                               ? (final_cost - err) / final_cost
                               : 0.0;                // :431-434
   const int hs = res.hist_stride;
-  if (lane == 0 && S.num_iters < hs) {              // :436-438
+  if (writer && S.num_iters < hs) {                 // :436-438
     if (res.errs) res.errs[p * hs + S.num_iters] = err;
     if (res.deltas2) res.deltas2[p * hs + S.num_iters] = dx_norm2;
     if (res.successes) res.successes[p * hs + S.num_iters] = is_good_step ? 1 : 0;
@@ -286,6 +277,23 @@ __device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const i
   else if (opt.min_step_norm2 > 0 && dx_norm2 < double(opt.min_step_norm2)) S.stop = TOA_STOP_MIN_DELTA_NORM;
   else if (opt.min_grad_norm2 > 0 && grad_norm2 < double(opt.min_grad_norm2)) S.stop = TOA_STOP_MIN_GRAD_NORM;
   return (is_good_step ? 1 : 0) | 2;
+}
+
+template <typename T>
+__device__ __forceinline__ int lm_judge_step(WaveLds<T>& L, const int n, const int lane, const long long p) {
+  LmState<T>& S = *L.st;
+  const toa_options& opt = *L.opt;
+  const bool in_n = lane < n;
+  const double err = S.cost_val;
+  if (isnan(err) || isinf(err)) { S.stop = TOA_STOP_NAN_OR_INF; return 0; }  // :405-409 (before the norms are formed)
+  const T dxl = in_n ? L.dx[lane] : T(0);
+  const double dx_norm2 = double(wave_allreduce_sum(dxl * dxl));  // :412
+  double grad_norm2 = 0.0;
+  if (opt.min_grad_norm2 > 0.0f) {  // :413-415
+    const T gl = in_n ? L.g[lane] : T(0);
+    grad_norm2 = double(wave_allreduce_sum(gl * gl));
+  }
+  return lm_judge_core<T>(S, opt, *L.res, p, dx_norm2, grad_norm2, lane == 0);
 }
 
 // ---- the three stages of OptimizeAcc (optimizer.h:242-327), separable so that the same state machine runs either
