@@ -229,17 +229,32 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
   const T* A = a.data + size_t(p) * m * (n + 1);
   T* Jp = a.J + size_t(p) * m * n;
   T* rp = a.r + size_t(p) * m;
-  for (int i = blockIdx.x * 4 + wave; i < m; i += gridDim.x * 4) {
-    const T* row = A + size_t(i) * (n + 1);
-    T t = 0;
-    for (int j = lane; j < n; j += 64) t = fma(row[j], xs[j], t);
-    t = wave_allreduce_sum(t);
-    T sn, cs;
-    sincos_t(t, &sn, &cs);
-    if (lane == 0) rp[i] = t + T(0.1) * sn - row[n];
-    if (want_j) {
-      const T sc = T(1) + T(0.1) * cs;
-      for (int j = lane; j < n; j += 64) Jp[size_t(i) * n + j] = sc * row[j];
+  // four consecutive rows per wave and trip: their loads and reduction chains are independent, which is what hides
+  // the HBM latency here (one row at a time left the kernel at a third of the streaming rate)
+  constexpr int R = 4;
+  for (int i0 = (blockIdx.x * 4 + wave) * R; i0 < m; i0 += gridDim.x * 4 * R) {
+    T t[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      t[k] = 0;
+      if (i0 + k < m) {
+        const T* row = A + size_t(i0 + k) * (n + 1);
+        for (int j = lane; j < n; j += 64) t[k] = fma(row[j], xs[j], t[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) t[k] = wave_allreduce_sum(t[k]);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (i0 + k >= m) break;
+      const T* row = A + size_t(i0 + k) * (n + 1);
+      T sn, cs;
+      sincos_t(t[k], &sn, &cs);
+      if (lane == 0) rp[i0 + k] = t[k] + T(0.1) * sn - row[n];
+      if (want_j) {
+        const T sc = T(1) + T(0.1) * cs;
+        for (int j = lane; j < n; j += 64) Jp[size_t(i0 + k) * n + j] = sc * row[j];
+      }
     }
   }
 }
