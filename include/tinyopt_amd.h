@@ -200,7 +200,8 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6].
- * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024, P <= 65535; data_dev: [P][m][n+1] = (a_i, b_i) rows; x: [P][n]. */
+ * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024, P <= 65535; data_dev: per problem A row-major [m][n] then b [m]
+ *                           (problem stride m (n + 1) elements); x: [P][n]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).

@@ -387,13 +387,14 @@ class DenseRowAD6:
 class DenseRowNatural:
     """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout,
     J^T J through a batched rocBLAS GEMM, the damped solve through rocSOLVER's batched Cholesky, the LM state machine of
-    optimizer.h:242-539 in small kernels between them.  A: [P, m, n], b: [P, m]."""
+    optimizer.h:242-539 in small kernels between them.  A: [P, m, n], b: [P, m]; stored per problem as A then b."""
     model_id = MODEL_DENSE_ROW_NATURAL
 
     def __init__(self, A: torch.Tensor, b: torch.Tensor):
         assert A.dim() == 3 and b.shape == A.shape[:2] and A.is_cuda
         self.P, self.m, self.n, self.dtype = A.shape[0], A.shape[1], A.shape[2], A.dtype
-        self.packed = torch.cat([A, b[..., None]], dim=2).contiguous()
+        # per problem: A row-major [m][n] followed by b [m] (SURVEY §8d layout; rows stay 16-byte aligned when n % 4 == 0)
+        self.packed = torch.cat([A.reshape(self.P, -1), b], dim=1).contiguous()
 
     @classmethod
     def from_arrays(cls, A: torch.Tensor, b: torch.Tensor) -> "DenseRowNatural":

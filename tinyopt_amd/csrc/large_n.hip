@@ -168,7 +168,7 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
 // integers per pass (active problems, problems that want a Jacobian) to stop early and to skip the GEMM.
 template <typename T>
 struct LargeArgs {
-  const T* data;  // [P][m][n + 1]  rows (a_i, b_i)
+  const T* data;  // per problem: A row-major [m][n], then b [m]   (SURVEY §8d layout)
   T* x;           // [P][n] in / out
   int n, m;
   long long P;
@@ -179,6 +179,8 @@ struct LargeArgs {
   int* built;    // [P]
   int* summary;  // [2 * passes]: (active, want Jacobian) after each pass
   T *g, *hd, *dx, *ldx, *H, *Hnew, *gnew, *work, *rhs, *J, *r;
+  T* gpart;    // [P][gslots][n] per-wave partial J^T r of the vectorised rows kernel (0 slots: g comes from the GEMV)
+  int gslots;
   int* info;
   unsigned long long* counters;
 };
@@ -213,7 +215,8 @@ __global__ void __launch_bounds__(256) large_init_kernel(const LargeArgs<T> a) {
   a.built[p] = 0;
 }
 
-// r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1 + 0.1 cos(a_i.x)) a_i   (SURVEY §8d DenseRow family), one wave per row
+// r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1 + 0.1 cos(a_i.x)) a_i   (SURVEY §8d DenseRow family).
+// General form (any n): a wave per row, four rows per trip; J^T r is left to a library GEMV.
 template <typename T>
 __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
   extern __shared__ char lds_raw[];
@@ -227,10 +230,9 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* A = a.data + size_t(p) * m * (n + 1);
+  const T* bv = A + size_t(m) * n;
   T* Jp = a.J + size_t(p) * m * n;
   T* rp = a.r + size_t(p) * m;
-  // four consecutive rows per wave and trip: their loads and reduction chains are independent, which is what hides
-  // the HBM latency here (one row at a time left the kernel at a third of the streaming rate)
   constexpr int R = 4;
   for (int i0 = (blockIdx.x * 4 + wave) * R; i0 < m; i0 += gridDim.x * 4 * R) {
     T t[R];
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
     for (int k = 0; k < R; ++k) {
       t[k] = 0;
       if (i0 + k < m) {
-        const T* row = A + size_t(i0 + k) * (n + 1);
+        const T* row = A + size_t(i0 + k) * n;
         for (int j = lane; j < n; j += 64) t[k] = fma(row[j], xs[j], t[k]);
       }
     }
@@ -247,13 +249,94 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (i0 + k >= m) break;
-      const T* row = A + size_t(i0 + k) * (n + 1);
+      const T* row = A + size_t(i0 + k) * n;
       T sn, cs;
       sincos_t(t[k], &sn, &cs);
-      if (lane == 0) rp[i0 + k] = t[k] + T(0.1) * sn - row[n];
+      if (lane == 0) rp[i0 + k] = t[k] + T(0.1) * sn - bv[i0 + k];
       if (want_j) {
         const T sc = T(1) + T(0.1) * cs;
         for (int j = lane; j < n; j += 64) Jp[size_t(i0 + k) * n + j] = sc * row[j];
+      }
+    }
+  }
+}
+
+// Vectorised form (n a multiple of the 16-byte vector, problem base 16-byte aligned): LPR = 2^k lanes share a row with
+// 16-byte loads / stores, 64 / LPR rows per wave and trip, and each lane keeps the partial J^T r of its own columns in
+// registers across all its rows — written once per wave and summed in fixed order by the pre kernel, so the GEMV and
+// its second pass over J disappear.  KV = 16-byte vectors per lane and row.
+template <typename T, int KV>
+__global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> a, const int LPR) {
+  constexpr int VEC = 16 / sizeof(T);
+  using V = T __attribute__((ext_vector_type(VEC)));
+  extern __shared__ char lds_raw[];
+  T* xs = reinterpret_cast<T*>(lds_raw);
+  const long long p = blockIdx.y;
+  if (!a.active[p]) return;
+  const LmState<T>& S = a.st[p];
+  const bool want_j = a.opt.solver_type != 0 || S.rebuild;
+  const int n = a.n, m = a.m, nv = n / VEC;
+  for (int j = threadIdx.x; j < n; j += 256) xs[j] = a.x[p * n + j];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rl = lane & (LPR - 1), rg = lane / LPR, RPW = 64 / LPR;  // lane in row, row group, rows per wave
+  const T* A = a.data + size_t(p) * m * (n + 1);
+  const T* bv = A + size_t(m) * n;
+  T* Jp = a.J + size_t(p) * m * n;
+  T* rp = a.r + size_t(p) * m;
+  V xv[KV], gacc[KV];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int c = rl + k * LPR;
+    gacc[k] = V(0);
+    xv[k] = V(0);
+    if (c < nv) xv[k] = *reinterpret_cast<const V*>(xs + c * VEC);
+  }
+  const int slot = blockIdx.x * 4 + wave;
+  for (int i0 = slot * RPW; i0 < m; i0 += gridDim.x * 4 * RPW) {
+    const int i = i0 + rg;
+    const bool live = i < m;
+    V av[KV];
+    T t = 0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int c = rl + k * LPR;
+      av[k] = V(0);
+      if (live && c < nv) av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A + size_t(i) * n) + c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) t = fma(av[k][e], xv[k][e], t);
+    }
+    for (int off = 1; off < LPR; off <<= 1) t += __shfl_xor(t, off);
+    T sn, cs;
+    sincos_t(t, &sn, &cs);
+    const T ri = live ? t + T(0.1) * sn - bv[live ? i : 0] : T(0);
+    if (live && rl == 0) rp[i] = ri;
+    if (want_j) {
+      const T sc = T(1) + T(0.1) * cs;
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const int c = rl + k * LPR;
+        const V jv = av[k] * sc;
+        gacc[k] += jv * ri;
+        if (live && c < nv) __builtin_nontemporal_store(jv, reinterpret_cast<V*>(Jp + size_t(i) * n) + c);
+      }
+    }
+  }
+  if (want_j) {  // fold the row groups of the wave (fixed order), then one partial vector per wave
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        T v = gacc[k][e];
+        for (int off = LPR; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        gacc[k][e] = v;
+      }
+    if (rg == 0) {
+      T* gp = a.gpart + (size_t(p) * a.gslots + slot) * n;
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const int c = rl + k * LPR;
+        if (c < nv) *reinterpret_cast<V*>(gp + c * VEC) = gacc[k];
       }
     }
   }
@@ -284,7 +367,13 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
     for (size_t e = tid; e < size_t(n) * n; e += 256) H[e] = Hn[e];
     double low = 0;
     for (int i = tid; i < n; i += 256) {
-      T gi = a.gnew[p * n + i];
+      T gi;
+      if (a.gslots > 0) {  // fixed-order sum of the per-wave partials of the vectorised rows kernel
+        gi = 0;
+        for (int sl = 0; sl < a.gslots; ++sl) gi += a.gpart[(size_t(p) * a.gslots + sl) * n + i];
+      } else {
+        gi = a.gnew[p * n + i];
+      }
       if (opt.grad_clipping != 0) { const T mm = opt.grad_clipping; gi = fmin(fmax(gi, -mm), mm); }  // base.h:29-38
       g[i] = gi;
       const T d = Hn[size_t(i) * n + i];
@@ -447,7 +536,19 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const size_t b_vec = al(size_t(P) * n * sizeof(T)), b_mat = al(size_t(P) * nn * sizeof(T));
   const size_t b_J = al(size_t(P) * m * n * sizeof(T)), b_r = al(size_t(P) * m * sizeof(T));
   const size_t b_sum = al(size_t(2) * sizeof(int) * size_t(max_passes + 1));
-  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum;
+  // vectorised rows kernel (see large_rows_vec_kernel): geometry and the per-wave J^T r partials
+  constexpr int VEC = 16 / int(sizeof(T));
+  const bool vec_ok = n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
+  const int nv = n / VEC;
+  int LPR = 1;
+  while (LPR * 2 <= std::min(64, nv)) LPR *= 2;
+  const int KV = vec_ok ? (nv + LPR - 1) / LPR : 0;
+  const int RPW = 64 / LPR;
+  const long long wg_target = (long long)h->num_cus * 16 / std::max<long long>(1, P) + 1;
+  const unsigned row_blocks = unsigned(std::max<long long>(1, std::min<long long>((m + 4 * (vec_ok ? RPW : 4) - 1) / (4 * (vec_ok ? RPW : 4)), wg_target)));
+  const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
+  const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
+  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum + b_gpart;
   if (need > h->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->scratch) (void)hipFree(h->scratch);
@@ -473,6 +574,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.H = reinterpret_cast<T*>(take(b_mat)); a.Hnew = reinterpret_cast<T*>(take(b_mat)); a.work = reinterpret_cast<T*>(take(b_mat));
   a.J = reinterpret_cast<T*>(take(b_J)); a.r = reinterpret_cast<T*>(take(b_r));
   a.summary = reinterpret_cast<int*>(take(b_sum));
+  a.gpart = reinterpret_cast<T*>(take(b_gpart));
+  a.gslots = gslots;
   if (!h->blas) {
     if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
     h->blas_destroy = api.destroy;
@@ -484,19 +587,33 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
   if (counters) HIP_TRY(hipMemsetAsync(counters, 0, 4 * sizeof(uint64_t), st));
   hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
-  const unsigned row_blocks = unsigned(std::max<long long>(1, std::min<long long>((m + 3) / 4, (long long)h->num_cus * 16 / std::max<long long>(1, P) + 1)));
   const T one = 1, zero = 0;
   int active = int(P), want_j = int(P);
   for (long long pass = 0; pass < max_passes && active > 0; ++pass) {
-    hipLaunchKernelGGL(large_rows_kernel<T>, dim3(row_blocks, unsigned(P)), dim3(256), size_t(n) * sizeof(T), st, a);
+    const dim3 rgrid(row_blocks, unsigned(P));
+    const size_t xs_bytes = size_t(n) * sizeof(T);
+    if (!vec_ok) {
+      hipLaunchKernelGGL(large_rows_kernel<T>, rgrid, dim3(256), xs_bytes, st, a);
+    } else {
+      switch (KV) {
+        case 1: hipLaunchKernelGGL((large_rows_vec_kernel<T, 1>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 2: hipLaunchKernelGGL((large_rows_vec_kernel<T, 2>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 3: hipLaunchKernelGGL((large_rows_vec_kernel<T, 3>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 4: hipLaunchKernelGGL((large_rows_vec_kernel<T, 4>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 5: hipLaunchKernelGGL((large_rows_vec_kernel<T, 5>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 6: hipLaunchKernelGGL((large_rows_vec_kernel<T, 6>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 7: hipLaunchKernelGGL((large_rows_vec_kernel<T, 7>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        default: hipLaunchKernelGGL((large_rows_vec_kernel<T, 8>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+      }
+    }
     if (want_j > 0) {
       int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
       if constexpr (sizeof(T) == 4) {
         rc = api.sgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
-        if (rc == 0) rc = api.sgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+        if (rc == 0 && !vec_ok) rc = api.sgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
       } else {
         rc = api.dgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
-        if (rc == 0) rc = api.dgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+        if (rc == 0 && !vec_ok) rc = api.dgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
       }
       if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
     }
