@@ -234,6 +234,14 @@ struct CircleFit : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT> {
   CircleFit(const Context& ctx, int64_t P, int npts, const Scalar* obs)
       : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT>(ctx, P, 3, npts, 3, obs, size_t(P) * npts * 2) {}
 };
+// The DenseRow residual r_i = a_i.x + 0.1 sin(a_i.x) - b_i for parameter blocks beyond one wavefront (1 <= n <= 1024;
+// `Dims == Dynamic` in the reference, optimize.h:27-33): batched library GEMM + rocSOLVER Cholesky under the same LM state
+// machine.  data: per problem A row-major [m][n] followed by b [m].
+template <typename Scalar>
+struct DenseRowNatural : PlainModel<Scalar, TOA_MODEL_DENSE_ROW_NATURAL> {
+  DenseRowNatural(const Context& ctx, int64_t P, int n, int m, const Scalar* A_then_b)
+      : PlainModel<Scalar, TOA_MODEL_DENSE_ROW_NATURAL>(ctx, P, n, m, n, A_then_b, size_t(P) * m * (size_t(n) + 1)) {}
+};
 // SE3 pinhole reprojection (3rdparty/traits/sophus.h:13-27 update); x: [P][12] = R (row-major) | t; n = 6.
 // data: [P][8 + 5*npts] = [f cx cy 0 0 0 0 0 | x y z u v ...].
 // Optional M-estimator on each point's squared reprojection error: data[3] = TOA_LOSS_*, data[4] = th^2

@@ -51,6 +51,31 @@ static void run(int P, int n, int m, double tol) {
   REQUIRE(threw);
 }
 
+// Parameter blocks beyond one wavefront (Dims == Dynamic, n = 96): same call, the library-backed path underneath
+static void large_block() {
+  const int P = 3, n = 96, m = 400;
+  std::mt19937 rng(11);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<double> data(size_t(P) * m * (n + 1)), x(size_t(P) * n), xs(size_t(P) * n);
+  for (int p = 0; p < P; ++p) {
+    double* A = data.data() + size_t(p) * m * (n + 1);
+    double* b = A + size_t(m) * n;
+    for (int j = 0; j < n; ++j) { xs[p * n + j] = U(rng); x[p * n + j] = xs[p * n + j] + 0.3 * U(rng); }
+    for (int i = 0; i < m; ++i) {
+      double t = 0;
+      for (int j = 0; j < n; ++j) { A[size_t(i) * n + j] = U(rng); t += A[size_t(i) * n + j] * xs[p * n + j]; }
+      b[i] = t + 0.1 * std::sin(t);
+    }
+  }
+  Context ctx(0);
+  DenseRowNatural<double> cost(ctx, P, n, m, data.data());
+  const auto out = Optimize(x, cost, Options());
+  for (int p = 0; p < P; ++p) {
+    REQUIRE(out.Succeeded(p));
+    for (int j = 0; j < n; ++j) REQUIRE(std::abs(x[p * n + j] - xs[p * n + j]) < 1e-7);
+  }
+}
+
 // tests/sqrt2.cpp:106-112 — x0 in {1, -0.3, 3.2}: Succeeded && Converged && |x| == sqrt(2) +- 1e-5
 template <typename T>
 static void sqrt2() {
@@ -150,6 +175,7 @@ int main() {
   prior_cov();
   run<double>(5, 12, 200, 1e-7);
   run<float>(3, 50, 600, 2e-3);
+  large_block();
   std::printf("test_header_adaptor: %s\n", fails ? "FAILED" : "ok");
   return fails ? 1 : 0;
 }
