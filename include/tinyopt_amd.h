@@ -214,7 +214,8 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
 /* ---- K3: damped solve (replaces SolverLM::Build's damping lm.h:108-117 + SolverGN::Solve gn.h:150-171
  *      -> SolveLDLT math.h:232-240).  H_ii <- H_ii * scale (double, Marquardt multiplicative), then
  *      dx = -H^-1 g by pivoted LDL^T with Eigen's acceptance rule (info()==Success && isPositive()).
- *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure). */
+ *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure).
+ *      n <= 63: one wavefront per matrix.  64 <= n <= 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs). */
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);
 
@@ -225,7 +226,8 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
 
 /* ---- covariance seam (replaces tinyopt::InvCov / DenseInvCov, math.h:41-91, used by Output::Covariance
  *      output.h:80-94 and SolverLM::Covariance lm.h:174): C = H^-1 by LDL^T against the identity, same acceptance
- *      rule as SolveLDLT.  H_dev, C_dev: [P][n*n] T; ok_dev: [P] int32 (0 = "not invertible" => std::nullopt). */
+ *      rule as SolveLDLT.  H_dev, C_dev: [P][n*n] T; ok_dev: [P] int32 (0 = "not invertible" => std::nullopt).
+ *      n > 63 (up to 4096, P <= 65535): Cholesky against the identity through rocSOLVER. */
 int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, void* C_dev, int32_t* ok_dev);
 
 /* ---- fused batched solve (replaces Optimizer_::OptimizeAcc optimizer.h:242-327 + Step :331-539 +

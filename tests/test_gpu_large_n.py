@@ -133,3 +133,22 @@ def test_large_n_lm_failure_modes():
     _, out = _run_natural(A3, b, x0, o)
     stop = out.stop_reason.cpu().numpy()
     assert stop[2] == int(ta.StopReason.kSolverFailed) and stop[0] >= 0
+
+
+def test_large_n_covariance():
+    """Output.Covariance() (output.h:80-94) beyond one wavefront: inverse of the final undamped Hessian."""
+    import tinyopt_amd as ta
+    from oracle import pyoracle
+    P, n, m = 3, 80, 300
+    A, b, x0, _ = pyoracle.synth_dense_row(P, n, m, np.float64)
+    _, out = _run_natural(A, b, x0, ta.Options())
+    C, ok = out.Covariance()
+    torch.cuda.synchronize()
+    assert ok.cpu().numpy().tolist() == [1] * P
+    H = out.final_hessian.cpu().numpy()
+    ref = np.linalg.inv(H)
+    assert np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-9
+    Hbad = out.final_hessian.clone()
+    Hbad[1, 4, 4] = -1.0
+    _, ok2 = ta.inv_cov(Hbad)
+    assert ok2.cpu().numpy().tolist() == [1, 0, 1]

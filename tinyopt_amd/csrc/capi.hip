@@ -194,6 +194,7 @@ int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const v
   return dtag == 0 ? toa_inst_inv_cov_0_0(npad, h, n, P, H, C, ok) : toa_inst_inv_cov_1_0(npad, h, n, P, H, C, ok);
 }
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_large_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok);
 int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                      const toa_results* results, uint64_t* counters);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
@@ -491,7 +492,7 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
   if (large) {
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
     if (n < 1 || n > 4096) return fail(TOA_E_ARG, "toa_solve_damped: n must be in [1, 4096]");
-    if (P < 0 || P > 0x7fffffff) return fail(TOA_E_ARG, "P out of range");
+    if (P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_solve_damped: P must be in [0, 65535] on the library path");
   } else if (int rc = check_shape(dtype, n, 1, P)) {
     return rc;
   }
@@ -504,6 +505,15 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
 
 int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok) {
   if (!h) return fail(TOA_E_ARG, "null handle");
+  if (n > 63) {  // beyond one wavefront: Cholesky against the identity through rocSOLVER (large_n.hip)
+    if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+    if (n > 4096) return fail(TOA_E_ARG, "toa_inv_cov: n must be in [1, 4096]");
+    if (P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_inv_cov: P must be in [0, 65535] for n > 63");
+    if (!H || !C || !ok) return fail(TOA_E_ARG, "toa_inv_cov: null pointer");
+    if (P == 0) return TOA_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    return toa_large_inv_cov(h, dtype, n, P, H, C, ok);
+  }
   if (int rc = check_shape(dtype, n, 1, P)) return rc;
   if (!H || !C || !ok) return fail(TOA_E_ARG, "toa_inv_cov: null pointer");
   if (P == 0) return TOA_OK;

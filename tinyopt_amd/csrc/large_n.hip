@@ -153,6 +153,63 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
 }
 
 
+// C = H^-1 for n > 63 (tinyopt::InvCov, math.h:41-91): Cholesky against the identity.
+template <typename T>
+__global__ void __launch_bounds__(256) large_identity_kernel(T* __restrict__ C, const int n) {
+  const size_t p = blockIdx.y, nn = size_t(n) * n;
+  for (size_t e = size_t(blockIdx.x) * 256 + threadIdx.x; e < nn; e += size_t(gridDim.x) * 256) C[p * nn + e] = (e / n == e % n) ? T(1) : T(0);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) large_inv_finish_kernel(T* __restrict__ C, const int* __restrict__ info, int32_t* __restrict__ ok, const int n) {
+  __shared__ int bad;
+  const size_t p = blockIdx.x, nn = size_t(n) * n;
+  if (threadIdx.x == 0) bad = info[p] != 0;
+  __syncthreads();
+  for (size_t e = threadIdx.x; e < nn; e += 256)
+    if (!(fabs(C[p * nn + e]) <= NumLimits<T>::max())) bad = 1;
+  __syncthreads();
+  if (bad) for (size_t e = threadIdx.x; e < nn; e += 256) C[p * nn + e] = T(0);
+  if (threadIdx.x == 0) ok[p] = bad ? 0 : 1;
+}
+
+template <typename T>
+int large_inv_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, T* Cm, int32_t* ok) {
+  const size_t nn = size_t(n) * n;
+  const size_t b_work = (size_t(P) * nn * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_info = (size_t(P) * sizeof(int) + 255) & ~size_t(255);
+  const size_t need = b_work + b_info;
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->scratch, need));
+    h->scratch_bytes = need;
+  }
+  T* work = reinterpret_cast<T*>(h->scratch);
+  int* info = reinterpret_cast<int*>(static_cast<char*>(h->scratch) + b_work);
+  if (!h->blas) {
+    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
+    h->blas_destroy = api.destroy;
+  }
+  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  HIP_TRY(hipMemcpyAsync(work, H, size_t(P) * nn * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
+  hipLaunchKernelGGL(large_identity_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, Cm, n);
+  int rc;
+  if constexpr (sizeof(T) == 4) {
+    rc = api.spotrf(h->blas, kFillUpper, n, work, n, int64_t(nn), info, int(P));
+    if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, n, work, n, int64_t(nn), Cm, n, int64_t(nn), int(P));
+  } else {
+    rc = api.dpotrf(h->blas, kFillUpper, n, work, n, int64_t(nn), info, int(P));
+    if (rc == 0) rc = api.dpotrs(h->blas, kFillUpper, n, n, work, n, int64_t(nn), Cm, n, int64_t(nn), int(P));
+  }
+  if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER potrf/potrs returned status " + std::to_string(rc));
+  hipLaunchKernelGGL(large_inv_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, Cm, info, ok, n);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 // =====================================================================================================================
 // The LM / GN loop for n > 63 (TOA_MODEL_DENSE_ROW_NATURAL): same state machine as lm_device.hpp (its scalar pieces are
 // shared: LmState, lm_good_step / lm_bad_step, lm_judge_core), but the vectors of a problem live in HBM, one
@@ -663,4 +720,11 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
                                       *results, counters);
   return toa::large_lm_run_t<double>(h, api, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options,
                                      *results, counters);
+}
+
+int toa_large_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok) {
+  toa::RocApi& api = toa::roc_api();
+  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n covariance needs rocSOLVER: " + api.err);
+  if (dtype == TOA_F32) return toa::large_inv_t<float>(h, api, n, P, static_cast<const float*>(H), static_cast<float*>(C), ok);
+  return toa::large_inv_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<double*>(C), ok);
 }
