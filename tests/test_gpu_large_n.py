@@ -152,3 +152,36 @@ def test_large_n_covariance():
     Hbad[1, 4, 4] = -1.0
     _, ok2 = ta.inv_cov(Hbad)
     assert ok2.cpu().numpy().tolist() == [1, 0, 1]
+
+
+def test_large_n_option_variants():
+    """Every option branch of the state machine (same list as test_gpu_dense_row.py::test_option_variants) through the
+    library-backed path at n = 72, against the oracle."""
+    import tinyopt_amd as ta
+    from oracle import pyoracle
+    A, b, x0, xs = pyoracle.synth_dense_row(8, 72, 300, np.float64, seed=3)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    variants = []
+    o = ta.Options(); o.solver_type = ta.Options.GaussNewton; variants.append(o)
+    o = ta.Options(); o.cost.downscale_by_2 = True; variants.append(o)
+    o = ta.Options(); o.cost.normalize = True; variants.append(o)
+    o = ta.Options(); o.cost.use_squared_norm = False; variants.append(o)
+    o = ta.Options(); o.check_final_cost = True; o.max_iters = 3; variants.append(o)
+    o = ta.Options(); o.max_iters = 1; variants.append(o)
+    o = ta.Options(); o.lm.damping_init = 10.0; variants.append(o)
+    o = ta.Options(); o.use_step_quality_approx = True; variants.append(o)
+    o = ta.Options(); o.grad_clipping = 0.5; o.max_iters = 5; variants.append(o)
+    o = ta.Options(); o.hessian.check_min_H_diag = 1e9; variants.append(o)   # forces Build failure -> kSolverFailed
+    o = ta.Options(); o.min_error = 1e3; variants.append(o)                  # immediate kMinError
+    for i, o in enumerate(variants):
+        ref = pyoracle.dense_row_lm(A, b, x0, o.to_pod(), history=True)
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, o, history=True)
+        torch.cuda.synchronize()
+        stop, iters = out.stop_reason.cpu().numpy(), out.num_iters.cpu().numpy()
+        agree = ((stop == ref["stop"]) & (iters == ref["iters"])).mean()
+        assert agree >= 0.75, f"variant {i}: {stop} vs {ref['stop']}, {iters} vs {ref['iters']}"
+        assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6, f"variant {i}"
+        fc, rc = out.final_cost.cpu().numpy(), ref["cost"]
+        assert np.abs(fc - rc).max() <= 1e-8 * max(1.0, np.abs(rc).max()), f"variant {i}"
+        assert (out.num_failures.cpu().numpy() == ref["fails"]).mean() >= 0.75, f"variant {i}"
