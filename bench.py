@@ -244,7 +244,7 @@ def main():
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
                                         "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # the CPU baseline leg runs on rank 0 at N = 1 only
         np_dtype = np.float32 if tdt == torch.float32 else np.float64
         est = 4e-4 * (n * n * m) / (50 * 50 * 2000) * 8  # rough seconds per problem (8 iterations)
         sample = args.cpu_problems or int(max(16, min(P, 15.0 / max(est, 1e-6))))
