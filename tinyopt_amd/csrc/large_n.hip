@@ -76,6 +76,31 @@ RocApi& roc_api() {
   return api;
 }
 
+// Grow the context's scratch block (shared with the row-split path; contents are per-call) to at least `need` bytes.
+int ensure_scratch(toa_handle h, size_t need, const char* what) {
+  if (need <= h->scratch_bytes) return TOA_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->scratch) (void)hipFree(h->scratch);
+  h->scratch = nullptr;
+  h->scratch_bytes = 0;
+  if (hipMalloc(&h->scratch, need) != hipSuccess) {
+    (void)hipGetLastError();
+    return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace");
+  }
+  h->scratch_bytes = need;
+  return TOA_OK;
+}
+
+// The context's rocBLAS handle (created on first use), bound to the context's stream.
+int ensure_blas(toa_handle h, RocApi& api) {
+  if (!h->blas) {
+    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
+    h->blas_destroy = api.destroy;
+  }
+  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  return TOA_OK;
+}
+
 // work[p] = H[p] with the diagonal scaled (in double, like lm.h:108-117); rhs[p] = g[p]
 template <typename T>
 __global__ void __launch_bounds__(256) large_damp_kernel(const T* __restrict__ H, const T* __restrict__ g, T* __restrict__ work,
@@ -118,23 +143,12 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
   const size_t b_rhs = (size_t(P) * n * sizeof(T) + 255) & ~size_t(255);
   const size_t b_info = (size_t(P) * sizeof(int) + 255) & ~size_t(255);
   const size_t need = b_work + b_rhs + b_info;
-  if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->scratch) (void)hipFree(h->scratch);
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
-    HIP_TRY(hipMalloc(&h->scratch, need));
-    h->scratch_bytes = need;
-  }
+  if (int rc = ensure_scratch(h, need, "large-n solve")) return rc;
   char* base = static_cast<char*>(h->scratch);
   T* work = reinterpret_cast<T*>(base);
   T* rhs = reinterpret_cast<T*>(base + b_work);
   int* info = reinterpret_cast<int*>(base + b_work + b_rhs);
-  if (!h->blas) {
-    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
-    h->blas_destroy = api.destroy;
-  }
-  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  if (int rc = ensure_blas(h, api)) return rc;
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, work, rhs, n, scale);
   HIP_TRY(hipGetLastError());
@@ -178,21 +192,10 @@ int large_inv_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, T* Cm, 
   const size_t b_work = (size_t(P) * nn * sizeof(T) + 255) & ~size_t(255);
   const size_t b_info = (size_t(P) * sizeof(int) + 255) & ~size_t(255);
   const size_t need = b_work + b_info;
-  if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->scratch) (void)hipFree(h->scratch);
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
-    HIP_TRY(hipMalloc(&h->scratch, need));
-    h->scratch_bytes = need;
-  }
+  if (int rc = ensure_scratch(h, need, "large-n solve")) return rc;
   T* work = reinterpret_cast<T*>(h->scratch);
   int* info = reinterpret_cast<int*>(static_cast<char*>(h->scratch) + b_work);
-  if (!h->blas) {
-    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
-    h->blas_destroy = api.destroy;
-  }
-  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  if (int rc = ensure_blas(h, api)) return rc;
   HIP_TRY(hipMemcpyAsync(work, H, size_t(P) * nn * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_identity_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, Cm, n);
@@ -606,17 +609,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
   const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum + b_gpart;
-  if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->scratch) (void)hipFree(h->scratch);
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
-    if (hipMalloc(&h->scratch, need) != hipSuccess) {
-      (void)hipGetLastError();
-      return toa_fail(TOA_E_NOMEM, "large-n LM: cannot allocate " + std::to_string(need >> 20) + " MiB of workspace (J scratch is P*m*n)");
-    }
-    h->scratch_bytes = need;
-  }
+  if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
   LargeArgs<T> a;
@@ -633,11 +626,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.summary = reinterpret_cast<int*>(take(b_sum));
   a.gpart = reinterpret_cast<T*>(take(b_gpart));
   a.gslots = gslots;
-  if (!h->blas) {
-    if (api.create(&h->blas) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
-    h->blas_destroy = api.destroy;
-  }
-  if (api.set_stream(h->blas, h->stream) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+  if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
   HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
