@@ -264,7 +264,9 @@ int toa_lm_step(toa_handle h, int model, int dtype, int n, int m, int64_t P, con
  *      `splits` chunks (0 = choose automatically) whose partial (H, g, cost) are folded in a fixed order before
  *      each LM iteration, nothing read back by the host: ONE persistent launch when P * chunks <= #CUs (the chunk waves
  *      hand over through generation counters in HBM), else one (partial, step) kernel pair per iteration.
- *      toa_lm_run selects this path by itself when P*4 <= #CUs and m >= 512.  DenseRow and SE3Reproj only. */
+ *      toa_lm_run selects this path by itself when P*4 <= #CUs and m >= 512, and — team form: the chunk waves of a
+ *      problem are the waves of one workgroup, hand-over through LDS and workgroup barriers — for batches of small
+ *      problems (n <= 15, 512 <= m <= 4096) up to one or two problems per compute unit.  DenseRow and SE3Reproj only. */
 int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                      const void* data_dev, void* x_dev, const toa_options* options,
                      const toa_results* results, uint64_t* counters_dev, int splits);

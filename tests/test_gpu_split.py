@@ -94,3 +94,31 @@ def test_split_failure_paths(ta, oracle):
 def test_split_rejected_for_other_models(ta):
     with pytest.raises(ta.ToaError):
         ta.Optimize(torch.ones(2, 1, dtype=torch.float64, device="cuda"), ta.Sqrt2(2, torch.float64), splits=2)
+
+
+@pytest.mark.parametrize("dtype,n,m,P", [(np.float64, 6, 1000, 100), (np.float64, 15, 600, 37), (np.float32, 12, 2000, 200)])
+def test_team_form_for_batches_of_small_problems(ta, oracle, dtype, n, m, P):
+    """Automatic selection for batches of SMALL problems (n <= 15, 512..4096 rows, up to 1-2 per CU): one workgroup per
+    problem, the chunk partials folded through LDS.  Same results as the oracle; the problems of a batch are independent
+    (a sub-batch reproduces its rows bit for bit: the fold order depends only on the shape)."""
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=77)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    for opts in (ta.Options.benchmark(), ta.Options()):
+        ref = oracle.dense_row_lm(A, b, x0, opts.to_pod())
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, opts)
+        torch.cuda.synchronize()
+        assert (out.stop_reason.cpu().numpy() >= 0).all()
+        assert np.abs(x.cpu().numpy() - ref["x"]).max() < (1e-8 if dtype == np.float64 else 2e-3)
+        if dtype == np.float64:
+            assert np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"])
+            assert np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+            assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-9)
+        cnt = out.counters.cpu().numpy()
+        assert cnt[3] == P and cnt[2] >= P
+        K = 11
+        sub_model = ta.DenseRow.from_arrays(torch.from_numpy(A[5:5 + K]).cuda(), torch.from_numpy(b[5:5 + K]).cuda())
+        xsub = torch.from_numpy(x0[5:5 + K].copy()).cuda()
+        ta.Optimize(xsub, sub_model, opts)
+        torch.cuda.synchronize()
+        assert torch.equal(xsub, x[5:5 + K])

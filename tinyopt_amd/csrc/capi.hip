@@ -574,7 +574,18 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   const bool splittable = model == TOA_MODEL_DENSE_ROW || model == TOA_MODEL_SE3_REPROJ;
   // splits < 0: automatic — row-split when one-wave-per-problem would leave most of the chip idle
   // (fewer problems than CUs and enough rows to give every chunk >= 256 of them)
-  if (splits == -1) splits = (splittable && P * 4 <= h->num_cus && m >= 512) ? 0 : -1;
+  //   or, for small problems (n <= 15, 512..4096 rows), the team form: one workgroup per problem has no co-residency
+  //   requirement, so it also pays for whole batches of them — measured (tests/tools/team_probe.py, C2-sized problems):
+  //   89-100 us for 1..256 problems against 131-144 us with one wavefront per problem; the crossover is one problem per
+  //   compute unit at n = 6 x 1000 rows and two at n = 12 x 2000.  TOA_TEAM_MAX_PER_CU overrides, TOA_NO_AUTOSPLIT disables.
+  if (splits == -1) {
+    static const bool no_auto = std::getenv("TOA_NO_AUTOSPLIT") != nullptr;
+    static const long long team_env = [] { const char* e = std::getenv("TOA_TEAM_MAX_PER_CU"); return e ? atoll(e) : 0ll; }();
+    const long long team_per_cu = team_env > 0 ? team_env : ((long long)m * (n + 1) >= 20000 ? 2 : 1);
+    const bool few = P * 4 <= h->num_cus && m >= 512;
+    const bool team = n <= 15 && m >= 512 && m <= 4096 && P <= team_per_cu * h->num_cus;
+    splits = (splittable && !no_auto && (few || team)) ? 0 : -1;
+  }
   if (splits >= 0) {
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);

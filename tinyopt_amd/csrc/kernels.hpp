@@ -1417,6 +1417,91 @@ __device__ __forceinline__ bool persistent_wait(unsigned* addr, const unsigned t
   return true;
 }
 
+// Team form for ONE SMALL problem per workgroup (BASELINE config C2: n = 6, 1000 residuals, 56 KB): the S chunk-waves
+// of a problem are the waves of ONE workgroup, their partials and the leader's x / flags live in LDS, and the two
+// hand-overs of an iteration are workgroup barriers (~1 us) instead of release / acquire round trips through HBM
+// (~10 us each across XCDs).  Same arithmetic in the same order as the persistent form (fixed-order fold of S partials).
+template <typename Model, int NPAD, typename Manifold>
+__global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __restrict__ prm) {
+  using T = typename Model::Scalar;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = prm->n, S = prm->splits;  // S == blockDim.x / 64
+  const long long p = blockIdx.x;
+  const bool leader = wave == 0;
+  const size_t pw = size_t(prm->lds_per_wave);
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * pw, n);
+  const int stride = n * n + n + 2;
+  T* parts = reinterpret_cast<T*>(smem + size_t(S) * pw);
+  T* xshare = parts + size_t(S) * stride;
+  int* flags = reinterpret_cast<int*>(xshare + 64);  // [0] stopped, [1] rebuild
+  const int xd = Manifold::kXdim ? Manifold::kXdim : n;
+
+  const int m4 = (prm->m + 3) & ~3;
+  const int row0 = wave * prm->chunk_rows;
+  const int rows = min(prm->chunk_rows, m4 - row0);
+  Model model;
+  model.init(n, prm->m, prm->data);
+  model.bind_chunk(p, row0, rows, n);
+  T* part = parts + size_t(wave) * stride;
+
+  PartialSumModel<T, NPAD, Manifold> fold;
+  fold.S = S; fold.n_ = n; fold.m = prm->m;
+  fold.part = parts;
+  fold.hsum = (n * n <= 64) ? L.aux : static_cast<T*>(prm->hsum) + size_t(p) * n * n;
+
+  if (leader) {
+    wide_copy_pods(L, prm, lane);
+    wave_sync();
+    const T* X = static_cast<const T*>(prm->x);
+    L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+    L.g[lane] = T(0);
+    L.hd[lane] = T(0);
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    lm_init<T>(L, lane);
+    xshare[lane] = L.xs[lane];
+    if (lane == 0) { flags[0] = 0; flags[1] = L.st->rebuild; }
+  }
+  __syncthreads();
+  for (;;) {
+    if (flags[0] != 0) break;  // workgroup-uniform: written before the barrier every wave has just passed
+    if (!leader) { L.xs[lane] = xshare[lane]; wave_sync(); }
+    const bool do_acc = prm->opt.solver_type != 0 || flags[1] != 0;
+    T c;
+    int nr;
+    if (do_acc) {
+      model.accumulate(L, n, lane, c, nr);
+      model.write_sym(part, n, n, lane);
+      wave_sync();
+      if (lane < n) {
+        part[lane * n + lane] = L.hd[lane];
+        part[n * n + lane] = L.g[lane];
+      }
+    } else {
+      model.evaluate(L, n, lane, c, nr);
+    }
+    if (lane == 0) { part[n * n + n] = c; part[n * n + n + 1] = T(model_inliers(model, -1, 0)); }
+    __syncthreads();
+    if (leader) {
+      const bool more = lm_iteration<T>(fold, L, n, lane, p);
+      if (!more) {
+        lm_finalize<T>(fold, L, n, lane, p);
+        T* X = static_cast<T*>(prm->x);
+        if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
+        if (prm->counters && lane == 0) {
+          atomicAdd(&prm->counters[0], L.st->acc_passes);
+          atomicAdd(&prm->counters[1], L.st->eval_passes);
+          atomicAdd(&prm->counters[2], L.st->solves);
+          atomicAdd(&prm->counters[3], L.st->problems);
+        }
+      }
+      xshare[lane] = L.xs[lane];
+      if (lane == 0) { flags[0] = more ? 0 : 1; flags[1] = L.st->rebuild; }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename Model, int NPAD, typename Manifold>
 __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* __restrict__ prm) {
   using T = typename Model::Scalar;
@@ -1811,7 +1896,27 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   // Instantiated for the small systems only (n <= 15: BASELINE configs C2 / C5 are n = 6): the kernel carries a whole
   // lm_iteration with the NPAD-unrolled register LDL^T per residual-model layout, and 40 copies of it tripled the build.
   static const bool multilaunch = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
+  static const bool noteam = std::getenv("TOA_WIDE_NOTEAM") != nullptr;
   if constexpr (NPAD <= 16) {
+    // Team form: a small problem (<= 4096 rows) is cheaper on ONE compute unit with barrier hand-overs than on 16-64
+    // of them with HBM hand-overs.  Up to 8 waves (512 threads: two waves per SIMD keep the whole register file usable).
+    if (!multilaunch && !noteam && splits_req <= 0 && m4 <= 4096 && m4 >= 32) {
+      long long St = std::min<long long>(8, m4 / 16);
+      int chunk_t = int((m4 + St - 1) / St);
+      chunk_t = (chunk_t + 15) & ~15;
+      St = (m4 + chunk_t - 1) / chunk_t;
+      const size_t lds_team = size_t(St) * pw + (size_t(St) * stride + 64) * sizeof(T) + 16;
+      if (lds_team <= size_t(h->max_lds)) {
+        wp.splits = int(St);
+        wp.chunk_rows = chunk_t;
+        HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+        auto k_team = wide_team_kernel<Model, NPAD, Manifold>;
+        if (int rc = ensure_lds_attr(h, (const void*)k_team, lds_team)) return rc;
+        hipLaunchKernelGGL(k_team, dim3(unsigned(P)), dim3(unsigned(64 * St)), lds_team, h->stream, dp);
+        HIP_TRY(hipGetLastError());
+        return TOA_OK;
+      }
+    }
     if (!multilaunch && P * S <= (long long)h->num_cus && pw <= 64 * 1024) {
       auto k_pers = wide_persistent_kernel<Model, NPAD, Manifold>;
       if (int rc = ensure_lds_attr(h, (const void*)k_pers, pw)) return rc;
