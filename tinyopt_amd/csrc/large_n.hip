@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   T* A = reinterpret_cast<T*>(lds_raw);
   __shared__ int fail_at;
-  __shared__ T diag[128];
+  __shared__ T diag[128];  // 1 / sqrt(d_k)
   const size_t p = blockIdx.x;
   if (!a.active[p] || !a.built[p]) return;
   const int n = a.n, LD = n + 1, tid = threadIdx.x;
@@ -484,27 +484,26 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
   if (tid == 0) fail_at = 0;
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
+  // ONE barrier per column: the trailing update uses the UNSCALED column, A[i][j] -= A[i][k] A[j][k] / d_k, so column k never
+  // has to be rescaled in place; L[i][k] = A[i][k] * rs[k] with rs[k] = 1 / sqrt(d_k) is applied inside the substitutions.
   for (int k = 0; k < n; ++k) {
     const T d = A[k * LD + k];  // the same value in every thread: the branch below is workgroup-uniform
     if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
       if (tid == 0) fail_at = k + 1;
       break;
     }
-    const T lkk = sqrt(d);
-    const T inv = T(1) / lkk;
-    for (int i = k + 1 + tid; i < n; i += 256) A[i * LD + k] *= inv;  // A[k][k] itself stays: L's diagonal lives in diag[]
-    if (tid == 0) diag[k] = lkk;
-    __syncthreads();
+    const T dinv = T(1) / d;
+    if (tid == 0) diag[k] = T(1) / sqrt(d);
     const int r = n - k - 1, tiles = (r + 15) >> 4;
     for (int ti = 0; ti < tiles; ++ti) {
       const int i = k + 1 + ti * 16 + ty;
-      const T li = i < n ? A[i * LD + k] : T(0);
+      const T li = i < n ? A[i * LD + k] * dinv : T(0);
       for (int tj = 0; tj <= ti; ++tj) {
         const int j = k + 1 + tj * 16 + tx;
         if (i < n && j <= i) A[i * LD + j] = fma(-li, A[j * LD + k], A[i * LD + j]);
       }
     }
-    __syncthreads();  // the next pivot A[k+1][k+1] is final
+    __syncthreads();  // the next pivot A[k+1][k+1] and column k+1 are final
   }
   __syncthreads();
   if (fail_at != 0) {
@@ -515,19 +514,22 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
     const int lane = tid;
     T* rp = a.rhs + p * n;
     T y0 = lane < n ? rp[lane] : T(0), y1 = lane + 64 < n ? rp[lane + 64] : T(0);
-    for (int k = 0; k < n; ++k) {  // L y = b, column sweep
+    const T rs0 = lane < n ? diag[lane] : T(0), rs1 = lane + 64 < n ? diag[lane + 64] : T(0);
+    for (int k = 0; k < n; ++k) {  // L y = b, column sweep;  L[i][k] = A[i][k] rs[k],  L[k][k] = 1 / rs[k]
       const int ku = __builtin_amdgcn_readfirstlane(k);
-      const T yk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) / diag[ku];
+      const T rk = diag[ku];
+      const T yk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) * rk;
       if (lane == (ku & 63)) { if (ku < 64) y0 = yk; else y1 = yk; }
-      if (lane > ku && lane < n) y0 = fma(-A[lane * LD + ku], yk, y0);
-      if (lane + 64 > ku && lane + 64 < n) y1 = fma(-A[(lane + 64) * LD + ku], yk, y1);
+      const T s = yk * rk;
+      if (lane > ku && lane < n) y0 = fma(-A[lane * LD + ku], s, y0);
+      if (lane + 64 > ku && lane + 64 < n) y1 = fma(-A[(lane + 64) * LD + ku], s, y1);
     }
-    for (int k = n - 1; k >= 0; --k) {  // L^T x = y: row k of L is column k of L^T
+    for (int k = n - 1; k >= 0; --k) {  // L^T x = y: row k of L is column k of L^T;  L[k][i] = A[k][i] rs[i]
       const int ku = __builtin_amdgcn_readfirstlane(k);
-      const T xk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) / diag[ku];
+      const T xk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) * diag[ku];
       if (lane == (ku & 63)) { if (ku < 64) y0 = xk; else y1 = xk; }
-      if (lane < ku) y0 = fma(-A[ku * LD + lane], xk, y0);
-      if (lane + 64 < ku) y1 = fma(-A[ku * LD + lane + 64], xk, y1);
+      if (lane < ku) y0 = fma(-A[ku * LD + lane] * rs0, xk, y0);
+      if (lane + 64 < ku) y1 = fma(-A[ku * LD + lane + 64] * rs1, xk, y1);
     }
     if (lane < n) rp[lane] = y0;
     if (lane + 64 < n) rp[lane + 64] = y1;
