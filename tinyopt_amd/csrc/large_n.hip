@@ -35,6 +35,10 @@ struct RocApi {
                const float*, float*, int, int64_t, int) = nullptr;
   int (*dgemm)(rb_handle, int, int, int, int, int, const double*, const double*, int, int64_t, const double*, int, int64_t,
                const double*, double*, int, int64_t, int) = nullptr;
+  int (*sgemm_b)(rb_handle, int, int, int, int, int, const float*, const float* const*, int, const float* const*, int, const float*,
+                 float* const*, int, int) = nullptr;
+  int (*dgemm_b)(rb_handle, int, int, int, int, int, const double*, const double* const*, int, const double* const*, int,
+                 const double*, double* const*, int, int) = nullptr;
   int (*sgemv)(rb_handle, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t, const float*,
                float*, int, int64_t, int) = nullptr;
   int (*dgemv)(rb_handle, int, int, int, const double*, const double*, int, int64_t, const double*, int, int64_t,
@@ -69,6 +73,8 @@ RocApi& roc_api() {
     api.dpotrs = reinterpret_cast<decltype(api.dpotrs)>(sym(sol, "rocsolver_dpotrs_strided_batched"));
     api.sgemm = reinterpret_cast<decltype(api.sgemm)>(sym(blas, "rocblas_sgemm_strided_batched"));
     api.dgemm = reinterpret_cast<decltype(api.dgemm)>(sym(blas, "rocblas_dgemm_strided_batched"));
+    api.sgemm_b = reinterpret_cast<decltype(api.sgemm_b)>(sym(blas, "rocblas_sgemm_batched"));
+    api.dgemm_b = reinterpret_cast<decltype(api.dgemm_b)>(sym(blas, "rocblas_dgemm_batched"));
     api.sgemv = reinterpret_cast<decltype(api.sgemv)>(sym(blas, "rocblas_sgemv_strided_batched"));
     api.dgemv = reinterpret_cast<decltype(api.dgemv)>(sym(blas, "rocblas_dgemv_strided_batched"));
     api.ok = api.err.empty();
@@ -239,6 +245,8 @@ struct LargeArgs {
   int* built;    // [P]
   int* summary;  // [2 * passes]: (active, want Jacobian) after each pass
   T *g, *hd, *dx, *ldx, *H, *Hnew, *gnew, *work, *rhs, *J, *r;
+  const T** jptr;  // [P] J of the problems that want a Jacobian this pass, in index order (large_compact_kernel)
+  T** hptr;        // [P] their Hnew
   T* gpart;    // [P][gslots][n] per-wave partial J^T r of the vectorised rows kernel (0 slots: g comes from the GEMV)
   int gslots;
   int* info;
@@ -400,6 +408,29 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
       }
     }
   }
+}
+
+// Pointer lists for the batched GEMM: only the problems that are still running AND rebuild their Hessian this pass
+// (index order: deterministic).  The host knows their count from the previous pass's read-back.
+template <typename T>
+__global__ void __launch_bounds__(256) large_compact_kernel(const LargeArgs<T> a) {
+  __shared__ int cnt[256];
+  const int tid = threadIdx.x;
+  const long long per = (a.P + 255) / 256, lo = tid * per, hi = lo + per < a.P ? lo + per : a.P;
+  auto want = [&](long long p) { return a.active[p] && (a.opt.solver_type != 0 || a.st[p].rebuild); };
+  int c = 0;
+  for (long long p = lo; p < hi; ++p) c += want(p) ? 1 : 0;
+  cnt[tid] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int v = cnt[t]; cnt[t] = run; run += v; }
+  }
+  __syncthreads();
+  int off = cnt[tid];
+  const size_t sj = size_t(a.m) * a.n, sh = size_t(a.n) * a.n;
+  for (long long p = lo; p < hi; ++p)
+    if (want(p)) { a.jptr[off] = a.J + p * sj; a.hptr[off] = a.Hnew + p * sh; ++off; }
 }
 
 // cost + Build (lm.h:59-120) up to the damped matrix and right-hand side
@@ -680,7 +711,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const unsigned row_blocks = unsigned(std::max<long long>(1, std::min<long long>((m + 4 * (vec_ok ? RPW : 4) - 1) / (4 * (vec_ok ? RPW : 4)), wg_target)));
   const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
-  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum + b_gpart;
+  const size_t b_ptr = al(size_t(P) * sizeof(void*));
+  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum + b_gpart + 2 * b_ptr;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
@@ -698,6 +730,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.summary = reinterpret_cast<int*>(take(b_sum));
   a.gpart = reinterpret_cast<T*>(take(b_gpart));
   a.gslots = gslots;
+  a.jptr = reinterpret_cast<const T**>(take(b_ptr));
+  a.hptr = reinterpret_cast<T**>(take(b_ptr));
   if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
   // 64 <= n <= 128: the LDS-resident Cholesky above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
@@ -731,12 +765,13 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
       }
     }
     if (want_j > 0) {
+      hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
       int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
       if constexpr (sizeof(T) == 4) {
-        rc = api.sgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
+        rc = api.sgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, a.jptr, n, a.jptr, n, &zero, a.hptr, n, want_j);
         if (rc == 0 && !vec_ok) rc = api.sgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
       } else {
-        rc = api.dgemm(h->blas, kOpN, kOpT, n, n, m, &one, a.J, n, int64_t(m) * n, a.J, n, int64_t(m) * n, &zero, a.Hnew, n, int64_t(nn), int(P));
+        rc = api.dgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, a.jptr, n, a.jptr, n, &zero, a.hptr, n, want_j);
         if (rc == 0 && !vec_ok) rc = api.dgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
       }
       if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
