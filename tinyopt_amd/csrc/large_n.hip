@@ -496,45 +496,82 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   }
 }
 
-// (H + lambda diag H) sol = g for 64 <= n <= 128 without the library: one workgroup per problem, the matrix resident in
-// LDS (n (n + 1) elements: 66 KB fp32 / 132 KB fp64 at n = 128), right-looking Cholesky on 16 x 16 thread tiles of the
-// lower triangle, then both triangular solves inside wave 0 with the unknowns in registers (two per lane) and the pivot
-// value broadcast by v_readlane — no barrier per row.  Skips problems that have stopped or whose Build failed, which the
-// library calls cannot.  ~4x faster than potrf + potrs strided batched at these sizes.
-template <typename T>
+// (H + lambda diag H) sol = g for n <= 128 without the library: one workgroup per problem, the matrix REGISTER-resident in
+// a 16 x 16 block-cyclic distribution (thread (ty, tx) owns rows 16a + ty, columns 16b + tx of the lower block triangle:
+// NB (NB + 1) / 2 values), right-looking Cholesky with ONE barrier per column: the owners of column k publish it
+// (unscaled) to a double-buffered LDS vector and into the LDS image the substitutions read, everybody updates its own
+// elements with A_ij -= A_ik A_jk / d_k.  L = A diag(1 / sqrt d) is applied inside the two triangular solves, which run in
+// wave 0 with the unknowns in registers (two per lane) and the pivot value broadcast by v_readlane.  Skips problems that
+// have stopped or whose Build failed, which the library calls cannot.
+template <typename T, int NB>
 __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  T* A = reinterpret_cast<T*>(lds_raw);
+  T* A = reinterpret_cast<T*>(lds_raw);  // n x LD image of the unscaled columns of L
+  __shared__ T col[2][NB * 16];
+  __shared__ T diag[NB * 16];  // 1 / sqrt(d_k)
   __shared__ int fail_at;
-  __shared__ T diag[128];  // 1 / sqrt(d_k)
   const size_t p = blockIdx.x;
   if (!a.active[p] || !a.built[p]) return;
   const int n = a.n, LD = n + 1, tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
   const T* Wp = a.work + p * size_t(n) * n;
-  for (int e = tid; e < n * n; e += 256) A[(e / n) * LD + (e % n)] = Wp[e];
+  T e[NB][NB];
+  static_for<NB>([&](auto ac) __attribute__((always_inline)) {
+    static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int ab = decltype(ac)::value, bb = decltype(bc)::value;
+      if constexpr (bb <= ab) {
+        const int i = 16 * ab + ty, j = 16 * bb + tx;
+        e[ab][bb] = (i < n && j < n) ? Wp[size_t(i) * n + j] : T(0);
+      }
+    });
+  });
   if (tid == 0) fail_at = 0;
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  // ONE barrier per column: the trailing update uses the UNSCALED column, A[i][j] -= A[i][k] A[j][k] / d_k, so column k never
-  // has to be rescaled in place; L[i][k] = A[i][k] * rs[k] with rs[k] = 1 / sqrt(d_k) is applied inside the substitutions.
   for (int k = 0; k < n; ++k) {
-    const T d = A[k * LD + k];  // the same value in every thread: the branch below is workgroup-uniform
+    const int kb = k >> 4, kx = k & 15, buf = k & 1;
+    if (tx == kx) {  // the owners of column k publish it
+      static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int bb = decltype(bc)::value;
+        if (bb == kb) {  // workgroup-uniform
+          static_for<NB>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int ab = decltype(ac)::value;
+            if constexpr (ab >= bb) {
+              const int i = 16 * ab + ty;
+              const T v = e[ab][bb];
+              col[buf][i] = v;
+              if (i >= k && i < n) A[i * LD + k] = v;
+            }
+          });
+        }
+      });
+    }
+    __syncthreads();
+    const T d = col[buf][k];  // the same value in every thread: the branch below is workgroup-uniform
     if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
       if (tid == 0) fail_at = k + 1;
       break;
     }
     const T dinv = T(1) / d;
     if (tid == 0) diag[k] = T(1) / sqrt(d);
-    const int r = n - k - 1, tiles = (r + 15) >> 4;
-    for (int ti = 0; ti < tiles; ++ti) {
-      const int i = k + 1 + ti * 16 + ty;
-      const T li = i < n ? A[i * LD + k] * dinv : T(0);
-      for (int tj = 0; tj <= ti; ++tj) {
-        const int j = k + 1 + tj * 16 + tx;
-        if (i < n && j <= i) A[i * LD + j] = fma(-li, A[j * LD + k], A[i * LD + j]);
+    T li[NB], lj[NB];
+    static_for<NB>([&](auto ac) __attribute__((always_inline)) {
+      constexpr int ab = decltype(ac)::value;
+      li[ab] = T(0);
+      lj[ab] = T(0);
+      if (ab >= kb) {  // uniform
+        const int i = 16 * ab + ty, j = 16 * ab + tx;
+        li[ab] = i > k ? col[buf][i] * dinv : T(0);
+        lj[ab] = j > k ? col[buf][j] : T(0);
       }
-    }
-    __syncthreads();  // the next pivot A[k+1][k+1] and column k+1 are final
+    });
+    static_for<NB>([&](auto ac) __attribute__((always_inline)) {
+      static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int ab = decltype(ac)::value, bb = decltype(bc)::value;
+        if constexpr (bb <= ab) {
+          if (bb >= kb) e[ab][bb] = fma(-li[ab], lj[bb], e[ab][bb]);  // uniform gate; zero factors mask rows / columns <= k
+        }
+      });
+    });
   }
   __syncthreads();
   if (fail_at != 0) {
@@ -737,9 +774,11 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // 64 <= n <= 128: the LDS-resident Cholesky above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
-  const bool own_chol = !force_lib && n <= 128 && chol_lds + 1024 <= size_t(h->max_lds);
-  if (own_chol)
-    if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T>, chol_lds)) return rc;
+  const bool own_chol = !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);
+  if (own_chol) {
+    const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
+    if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
+  }
   HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
@@ -779,7 +818,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
     int rc = 0;
     if (own_chol) {
-      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(256), chol_lds, st, a);
+      if (n <= 64) hipLaunchKernelGGL((large_chol_solve_kernel<T, 4>), dim3(unsigned(P)), dim3(256), chol_lds, st, a);
+      else hipLaunchKernelGGL((large_chol_solve_kernel<T, 8>), dim3(unsigned(P)), dim3(256), chol_lds, st, a);
     } else if constexpr (sizeof(T) == 4) {
       rc = api.spotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
       if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
