@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   }
 }
 
-// (H + lambda diag H) sol = g for n <= 128 without the library: one workgroup per problem, the matrix REGISTER-resident in
+// (H + lambda diag H) sol = g for n <= 128 (fp32) / 96 (fp64: the measured crossover) without the library: one workgroup per problem, the matrix REGISTER-resident in
 // a 16 x 16 block-cyclic distribution (thread (ty, tx) owns rows 16a + ty, columns 16b + tx of the lower block triangle:
 // NB (NB + 1) / 2 values), right-looking Cholesky with ONE barrier per column: the owners of column k publish it
 // (unscaled) to a double-buffered LDS vector and into the LDS image the substitutions read, everybody updates its own
@@ -774,7 +774,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // 64 <= n <= 128: the LDS-resident Cholesky above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
-  const bool own_chol = !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);
+  const bool own_chol = !force_lib && n <= (sizeof(T) == 4 ? 128 : 96) && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
   if (own_chol) {
     const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
     if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
@@ -841,11 +841,55 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   return TOA_OK;
 }
 
+
+// The K3 seam (toa_solve_damped) for 64 <= n <= 128 on the workgroup Cholesky above instead of the library.
+template <typename T>
+__global__ void __launch_bounds__(256) large_fill_ones_kernel(int* __restrict__ v, const long long count) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < count) v[i] = 1;
+}
+
+template <typename T>
+int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, double scale, T* dx, int32_t* ok) {
+  const size_t nn = size_t(n) * n;
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_work = al(size_t(P) * nn * sizeof(T)), b_rhs = al(size_t(P) * n * sizeof(T)), b_i = al(size_t(P) * sizeof(int));
+  if (int rc = ensure_scratch(h, b_work + b_rhs + 2 * b_i, "large-n solve")) return rc;
+  char* base = static_cast<char*>(h->scratch);
+  LargeArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.n = n;
+  a.P = P;
+  a.work = reinterpret_cast<T*>(base);
+  a.rhs = reinterpret_cast<T*>(base + b_work);
+  a.info = reinterpret_cast<int*>(base + b_work + b_rhs);
+  a.active = reinterpret_cast<int*>(base + b_work + b_rhs + b_i);  // every matrix is solved
+  a.built = a.active;
+  const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
+  const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
+  if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
+  hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P);
+  const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
+  hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
+  if (n <= 64) hipLaunchKernelGGL((large_chol_solve_kernel<T, 4>), dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
+  else hipLaunchKernelGGL((large_chol_solve_kernel<T, 8>), dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
+  hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 }  // namespace
 }  // namespace toa
 
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
                     int32_t* ok) {
+  static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+  const size_t chol_lds = size_t(n) * (n + 1) * (dtype == TOA_F32 ? 4 : 8);
+  if (!force_lib && n <= (dtype == TOA_F32 ? 128 : 96) && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup Cholesky, up to its measured crossover with the library
+    if (dtype == TOA_F32)
+      return toa::large_solve_own_t<float>(h, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
+    return toa::large_solve_own_t<double>(h, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);
+  }
   toa::RocApi& api = toa::roc_api();
   if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n solve needs rocSOLVER: " + api.err);
   if (dtype == TOA_F32)

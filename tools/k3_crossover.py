@@ -46,9 +46,9 @@ def run(force, ns):
 def main():
     small = [8, 12, 16, 24, 32, 48, 50, 63]
     large = [64, 96, 128, 256]
-    wave = run("0", small)
+    wave = run("0", small + [64, 96, 128])   # 64..128: the workgroup Cholesky of large_n.hip
     lib = run("1", small + large)
-    print("| dtype | n | matrices | one wavefront per matrix: ns / solve | rocSOLVER potrf+potrs batched: ns / solve | ratio |")
+    print("| dtype | n | matrices | own kernel (n <= 63: one wavefront per matrix; 64..128: one workgroup): ns / solve | rocSOLVER potrf+potrs batched: ns / solve | ratio |")
     print("|---|---|---|---|---|---|")
     for dt in ("f32", "f64"):
         for n in small + large:
