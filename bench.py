@@ -30,6 +30,8 @@ WORKLOADS = {
     # name: (P per GPU, n, m, torch dtype, dtype tag, description)
     "c4": (12500, 50, 2000, torch.float32, "f32", "C4 shard: 12500 problems/GPU x n=50 x m=2000 DenseRow fp32 (8 GPUs = 100k-problem C4)"),
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
+    # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
+    "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, library-backed path (n > 63)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # dense MFMA peaks of the dtypes this path computes in: f32-input MFMA 157.3 TF (MI355X_MICROARCH.md), f64 78.6 TF (vendor spec)
@@ -108,7 +110,18 @@ def main():
     pod = opts.to_pod()
 
     # ---- inputs resident in HBM before the timed region (weak scaling: rank r owns problems [r*P, (r+1)*P))
-    model, x0, xstar = ta.DenseRow.synthetic(P, n, m, tdt, problem0=rank * P)
+    large = n > 63
+    if not large:
+        model, x0, xstar = ta.DenseRow.synthetic(P, n, m, tdt, problem0=rank * P)
+    else:  # natural layout (A then b), generated on the device with the same distributions
+        gen = torch.Generator(device="cuda").manual_seed(0x7194 + rank)
+        A = torch.rand(P, m, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        xstar = torch.rand(P, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        t = torch.einsum("pmn,pn->pm", A, xstar)
+        bvec = t + 0.1 * torch.sin(t) + 1e-3 * (torch.rand(P, m, dtype=tdt, device="cuda", generator=gen) * 2 - 1)
+        x0 = xstar + 0.5 * (torch.rand(P, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1) / (n / 50) ** 0.5
+        model = ta.DenseRowNatural(A, bvec)
+        del A, bvec, t
     x = x0.clone()
     out = ta.Optimize(x, model, opts)  # allocates result buffers once
     torch.cuda.synchronize()
@@ -200,14 +213,17 @@ def main():
     achieved = bytes_per_pass * passes_per_launch / kern_avg_s / 1e9
     # measured STREAM-like read ceiling over the same packed buffer, next to the nominal peak
     try:
-        stream_read = ctx.hbm_read_GBps(model.packed, reps=5)
+        stream_read = ctx.hbm_read_GBps(model.packed[: min(model.packed.shape[0], 64)].contiguous() if large else model.packed, reps=5)
     except Exception as e:  # noqa: BLE001
         log(f"[bench] hbm read probe failed: {e}")
         stream_read = None
     # secondary ceiling ("MFMA ceiling reported additionally"): matrix-core flops ISSUED by the accumulate
     # passes (NBM(NBM+1)/2 tiles of v_mfma_*_16x16x4 = 2048 flop per 4 rows) against the dense fp32 / fp64 MFMA peak
-    lay = ta.api.dense_row_layout(tdt, n, m)
-    mfma_flop_per_pass = (lay["rows_padded"] // 4) * (lay["nb"] * (lay["nb"] + 1) // 2) * 2048
+    if large:  # the library GEMM computes the full n x n square: 2 m n^2 flop per accumulate pass
+        mfma_flop_per_pass = 2 * m * n * n
+    else:
+        lay = ta.api.dense_row_layout(tdt, n, m)
+        mfma_flop_per_pass = (lay["rows_padded"] // 4) * (lay["nb"] * (lay["nb"] + 1) // 2) * 2048
     mfma_tflops = mfma_flop_per_pass * (acc_passes_total / args.steps) / kern_avg_s / 1e12
     mfma_peak = MFMA_PEAK_TFLOPS[tag]
     traffic = None
@@ -221,7 +237,7 @@ def main():
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
-        "metric": "LM iterations/s (batched dense n<=50)",
+        "metric": "LM iterations/s (batched dense n<=50)" if not large else f"LM iterations/s (batched dense n={n}, library-backed path)",
         "value": iters_all / elapsed,
         "unit": "LM iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,7 +250,8 @@ def main():
                    "gather_ms": gather_ms, "lm_iterations_per_step_all_gpus": iters_all / args.steps,
                    "lm_iterations_per_step_per_gpu_min_max": rank_iters,
                    "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else "large_rows_vec_kernel + rocBLAS gemm_batched + large_chol_solve_kernel (whole pass)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "measured_read_ceiling_GBps": stream_read,
                      "frac_of_measured_ceiling": (achieved / stream_read) if stream_read else None,
@@ -244,6 +261,16 @@ def main():
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
                                         "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
+    if large:  # AI = 2 m n^2 / (m (n + 1) sizeof) = 64 flop/B at n = 128 fp32, beyond the 19.7 flop/B ridge: the MFMA roof bounds this path
+        r = result["roofline"]
+        sec = r.pop("mfma_secondary")
+        result["roofline"] = {"bound": "mfma", "kernel": r["kernel"], "achieved": sec["achieved"], "peak": sec["peak"], "unit": "TFLOP/s",
+                              "frac": sec["frac"], "traffic": None, "flop_per_accumulate_pass": sec["issued_flop_per_accumulate_pass"],
+                              "accumulate_passes_per_launch": sec["accumulate_passes_per_launch"],
+                              "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_all": r["kernel_ms_all"],
+                              "hbm_secondary": {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"],
+                                                "algorithmic_bytes_per_pass": r["algorithmic_bytes_per_pass"],
+                                                "passes_per_launch": r["passes_per_launch"]}}
     if not args.no_cpu and world == 1:  # the CPU baseline leg runs on rank 0 at N = 1 only
         np_dtype = np.float32 if tdt == torch.float32 else np.float64
         est = 4e-4 * (n * n * m) / (50 * 50 * 2000) * 8  # rough seconds per problem (8 iterations)

@@ -31,7 +31,9 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for name in ("bench_c4", "bench_c3", "bench_under_rocprof"):
+    for name in ("bench_c4", "bench_c3", "bench_under_rocprof", "bench_large128"):
+        if not os.path.exists(os.path.join(SRC, name + ".json")):
+            continue
         with open(os.path.join(SRC, name + ".json")) as f:
             line = [l for l in f.read().splitlines() if l.startswith("{")][-1]
         with open(os.path.join(DST, f"{tag}_{name}.json"), "w") as f:

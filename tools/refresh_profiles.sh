@@ -9,6 +9,7 @@ cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 python bench.py > $O/bench_c4.json 2> $O/bench_c4.err
 python bench.py --workload c3 > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
 for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA"; do
