@@ -48,5 +48,11 @@ Box-to-box spread of the same binary is about +-3 %.  SQ counters of the same ke
 (GRBM_GUI_ACTIVE / 8 XCDs / duration), MFMA busy ~45 % + VALU active ~43 % of the SIMD cycles (they do not overlap for f32 MFMA).
 `{tag}_large_n_kernel_stats.csv`: kernel split of the n > 63 path (tools/prof_large_n.py; DESIGN.md §4b).
 """
+lp = os.path.join(ROOT, "profiles", f"{tag}_bench_large128.json")
+if os.path.exists(lp):
+    d = json.load(open(lp))
+    s += (f"`{tag}_bench_large128.json`: the same bench line for the n > 63 path (`python bench.py --workload large128`): {d['value']/1e3:.0f} k LM it/s,\n"
+          f"{d['ms_per_step']:.1f} ms per batched solve, {d['roofline']['achieved']:.1f} TFLOP/s of GEMM work = {100*d['roofline']['frac']:.0f} % of the f32 MFMA peak over the whole pass, "
+          f"x{d['config']['speedup_vs_cpu_1thread']:.0f} the CPU oracle.\n")
 open(PR, "w").write(s)
 print("[sync_docs] done:", f"C4 {b['value']/1e6:.2f} M it/s {100*rf['frac']:.1f} %; C3 {c3['value']/1e6:.1f} M it/s {100*r3['frac']:.1f} %")
