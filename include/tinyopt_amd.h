@@ -215,7 +215,7 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
  *      -> SolveLDLT math.h:232-240).  H_ii <- H_ii * scale (double, Marquardt multiplicative), then
  *      dx = -H^-1 g by pivoted LDL^T with Eigen's acceptance rule (info()==Success && isPositive()).
  *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure).
- *      n <= 63: one wavefront per matrix.  64 <= n <= 128 (fp32) / 96 (fp64): one workgroup per matrix (register-resident
+ *      n <= 63: one wavefront per matrix.  64 <= n <= 128: one workgroup per matrix (register-resident
  *      Cholesky).  Beyond, up to 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs) — the measured crossover. */
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);

@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   }
 }
 
-// (H + lambda diag H) sol = g for n <= 128 (fp32) / 96 (fp64: the measured crossover) without the library: one workgroup per problem, the matrix REGISTER-resident in
+// (H + lambda diag H) sol = g for n <= 128 (the measured crossover with rocSOLVER) without the library: one workgroup per problem, the matrix REGISTER-resident in
 // a 16 x 16 block-cyclic distribution (thread (ty, tx) owns rows 16a + ty, columns 16b + tx of the lower block triangle:
 // NB (NB + 1) / 2 values), right-looking Cholesky with ONE barrier per column: the owners of column k publish it
 // (unscaled) to a double-buffered LDS vector and into the LDS image the substitutions read, everybody updates its own
@@ -527,49 +527,43 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
   });
   if (tid == 0) fail_at = 0;
   __syncthreads();
-  for (int k = 0; k < n; ++k) {
+  bool failed = false;
+  for (int k = 0; k < n && !failed; ++k) {
     const int kb = k >> 4, kx = k & 15, buf = k & 1;
-    if (tx == kx) {  // the owners of column k publish it
-      static_for<NB>([&](auto bc) __attribute__((always_inline)) {
-        constexpr int bb = decltype(bc)::value;
-        if (bb == kb) {  // workgroup-uniform
-          static_for<NB>([&](auto ac) __attribute__((always_inline)) {
-            constexpr int ab = decltype(ac)::value;
-            if constexpr (ab >= bb) {
-              const int i = 16 * ab + ty;
-              const T v = e[ab][bb];
-              col[buf][i] = v;
-              if (i >= k && i < n) A[i * LD + k] = v;
-            }
-          });
-        }
-      });
-    }
-    __syncthreads();
-    const T d = col[buf][k];  // the same value in every thread: the branch below is workgroup-uniform
-    if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
-      if (tid == 0) fail_at = k + 1;
-      break;
-    }
-    const T dinv = T(1) / d;
-    if (tid == 0) diag[k] = T(1) / sqrt(d);
-    T li[NB], lj[NB];
-    static_for<NB>([&](auto ac) __attribute__((always_inline)) {
-      constexpr int ab = decltype(ac)::value;
-      li[ab] = T(0);
-      lj[ab] = T(0);
-      if (ab >= kb) {  // uniform
-        const int i = 16 * ab + ty, j = 16 * ab + tx;
-        li[ab] = i > k ? col[buf][i] * dinv : T(0);
-        lj[ab] = j > k ? col[buf][j] : T(0);
+    // one specialisation of the column step per block column KB: every block loop below has compile-time bounds
+    static_for<NB>([&](auto kbc) __attribute__((always_inline)) {
+      constexpr int KB = decltype(kbc)::value;
+      if (KB != kb) return;  // workgroup-uniform
+      if (tx == kx) {  // the owners of column k publish it
+        static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
+          constexpr int ab = KB + decltype(ac)::value;
+          const int i = 16 * ab + ty;
+          const T v = e[ab][KB];
+          col[buf][i] = v;
+          if (i >= k && i < n) A[i * LD + k] = v;
+        });
       }
-    });
-    static_for<NB>([&](auto ac) __attribute__((always_inline)) {
-      static_for<NB>([&](auto bc) __attribute__((always_inline)) {
-        constexpr int ab = decltype(ac)::value, bb = decltype(bc)::value;
-        if constexpr (bb <= ab) {
-          if (bb >= kb) e[ab][bb] = fma(-li[ab], lj[bb], e[ab][bb]);  // uniform gate; zero factors mask rows / columns <= k
-        }
+      __syncthreads();
+      const T d = col[buf][k];  // the same value in every thread: the branch below is workgroup-uniform
+      if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
+        if (tid == 0) fail_at = k + 1;
+        failed = true;
+        return;
+      }
+      const T dinv = T(1) / d;
+      if (tid == 0) diag[k] = T(1) / sqrt(d);
+      T li[NB], lj[NB];
+      static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int ab = KB + decltype(ac)::value;
+        const int i = 16 * ab + ty, j = 16 * ab + tx;
+        li[ab] = i > k ? col[buf][i] * dinv : T(0);  // zero factors mask the rows / columns <= k of block column KB
+        lj[ab] = j > k ? col[buf][j] : T(0);
+      });
+      static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
+        static_for<NB - KB>([&](auto bc) __attribute__((always_inline)) {
+          constexpr int ab = KB + decltype(ac)::value, bb = KB + decltype(bc)::value;
+          if constexpr (bb <= ab) e[ab][bb] = fma(-li[ab], lj[bb], e[ab][bb]);
+        });
       });
     });
   }
@@ -774,7 +768,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // 64 <= n <= 128: the LDS-resident Cholesky above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
-  const bool own_chol = !force_lib && n <= (sizeof(T) == 4 ? 128 : 96) && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
+  const bool own_chol = !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
   if (own_chol) {
     const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
     if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
@@ -885,7 +879,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                     int32_t* ok) {
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = size_t(n) * (n + 1) * (dtype == TOA_F32 ? 4 : 8);
-  if (!force_lib && n <= (dtype == TOA_F32 ? 128 : 96) && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup Cholesky, up to its measured crossover with the library
+  if (!force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup Cholesky, up to its measured crossover with the library
     if (dtype == TOA_F32)
       return toa::large_solve_own_t<float>(h, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
     return toa::large_solve_own_t<double>(h, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);
