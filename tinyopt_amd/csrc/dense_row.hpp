@@ -530,8 +530,20 @@ struct DenseRowGram {
             }
           }
           if constexpr (NBM & 1) {
+#ifndef TOA_NO_THIN_PAIR_LAST
+            // the odd block against the thin columns two at a time: (v[j], v[j+1]) is an aligned pair of the load tuple
+#pragma unroll
+            for (int j = 0; j + 1 < THIN; j += 2) {
+              f2 a = {accT[ti(NBM - 1, j)], accT[ti(NBM - 1, j + 1)]};
+              a += f2{w[NBM - 1], w[NBM - 1]} * f2{v[j], v[j + 1]};
+              accT[ti(NBM - 1, j)] = a[0];
+              accT[ti(NBM - 1, j + 1)] = a[1];
+            }
+            if constexpr (THIN & 1) accT[ti(NBM - 1, THIN - 1)] += w[NBM - 1] * v[THIN - 1];
+#else
 #pragma unroll
             for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
+#endif
           }
           // thin x thin corner, column j2 at a time: (j, j+1) pairs against a splat of v[j2] in one packed FMA
 #pragma unroll
