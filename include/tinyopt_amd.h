@@ -235,8 +235,10 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      SolverLM lm.h:46-171 for P independent problems).  x_dev: [P][n] T, updated in place
  *      (reference: `x` by non-const ref).  One launch; no host round trips; each wavefront runs whole
  *      problems to their StopReason.  counters_dev (optional, [4] uint64): {accumulate passes,
- *      evaluate-only passes, linear solves, problems} summed over the batch — the units the roofline
- *      accounting in bench.py multiplies by the algorithmic bytes per pass. */
+ *      evaluate-only passes, linear solves, problems} ADDED to by every path (the caller zeroes them) — the units the
+ *      roofline accounting in bench.py multiplies by the algorithmic bytes per pass.
+ *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL: that path reads two integers back per
+ *      pass (it blocks the host and cannot be captured in a hipGraph). */
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                const void* data_dev, void* x_dev, const toa_options* options,
                const toa_results* results, uint64_t* counters_dev);
@@ -259,6 +261,21 @@ int toa_lm_begin(toa_handle h, int model, int dtype, int n, int m, int64_t P, co
 int toa_lm_step(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,
                 const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
                 int32_t* active_dev);
+
+/* ---- host-side stop controls through the stepping form (replaces Options::stop_callback / stop_callback2,
+ *      include/tinyopt/optimizers/options.h:97-106, consulted at optimizer.h:529-534 when no numeric stop test fired, and
+ *      Options::max_duration_ms -> kTimedOut, optimizer.h:302-305).  Host callables cannot run on the device, so the
+ *      adaptors run the loop of toa_lm_step calls themselves:
+ *        toa_lm_step_info  after a step: err (the iteration's cost), |dx|^2, |g|^2 [P] double and, optionally, the dx and
+ *                          g vectors [P][n] of T of every problem's last iteration (any pointer may be NULL);
+ *        toa_lm_stop       ends the still-running problems p with stop_request_dev[p] != 0 with that StopReason
+ *                          (TOA_STOP_USER_STOPPED / TOA_STOP_TIMED_OUT): results written exactly as toa_lm_step writes
+ *                          them for a problem that stops by itself (final undamped Hessian included). */
+int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state_dev, double* err_dev, double* dx_norm2_dev,
+                     double* grad_norm2_dev, void* dx_dev, void* g_dev);
+int toa_lm_stop(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,
+                const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
+                const int32_t* stop_request_dev);
 
 /* ---- row-split execution of the same solve, for FEW, HUGE problems (BASELINE configs C2 / C5: P = 1,
  *      m = 10^3 .. 5*10^4).  Same contract and results as toa_lm_run; the rows of each problem are split into

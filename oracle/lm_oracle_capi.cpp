@@ -281,9 +281,21 @@ double oracle_dense_row_lm(int dtype, int64_t P, int n, int m, const void* A, co
 }
 
 // Batched LM on GaussianPrior problems (benchmarks/dense.cpp manual-callback semantics).
+double oracle_gaussian_prior_lm_hist(int dtype, int64_t P, int n, const void* y, const void* sigma, void* x,
+                                     const toa_options* opts, int32_t* stop, int32_t* iters, int32_t* fails,
+                                     double* cost, double* finalH, double* errs, double* deltas2, uint8_t* succ,
+                                     int hist_stride);
 double oracle_gaussian_prior_lm(int dtype, int64_t P, int n, const void* y, const void* sigma, void* x,
                                 const toa_options* opts, int32_t* stop, int32_t* iters, int32_t* fails,
                                 double* cost, double* finalH) {
+  return oracle_gaussian_prior_lm_hist(dtype, P, n, y, sigma, x, opts, stop, iters, fails, cost, finalH, nullptr, nullptr,
+                                       nullptr, 0);
+}
+// the same with the per-iteration history (Output::errs / deltas2 / successes) for the trajectory comparator
+double oracle_gaussian_prior_lm_hist(int dtype, int64_t P, int n, const void* y, const void* sigma, void* x,
+                                     const toa_options* opts, int32_t* stop, int32_t* iters, int32_t* fails,
+                                     double* cost, double* finalH, double* errs, double* deltas2, uint8_t* succ,
+                                     int hist_stride) {
   const Options o = from_pod(*opts);
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t p = 0; p < P; ++p) {
@@ -307,6 +319,12 @@ double oracle_gaussian_prior_lm(int dtype, int64_t P, int n, const void* y, cons
     if (cost) cost[p] = out.final_cost.cost;
     if (finalH && !out.final_hessian.empty())
       std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
+    if (errs)
+      for (size_t k = 0; k < out.errs.size() && int(k) < hist_stride; ++k) {
+        errs[size_t(p) * hist_stride + k] = out.errs[k];
+        if (deltas2) deltas2[size_t(p) * hist_stride + k] = out.deltas2[k];
+        if (succ) succ[size_t(p) * hist_stride + k] = out.successes[k];
+      }
   }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -55,6 +55,9 @@ def load(path: str | None = None):
                                         vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int]
     lib.oracle_gaussian_prior_lm.restype = C.c_double
     lib.oracle_gaussian_prior_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
+    lib.oracle_gaussian_prior_lm_hist.restype = C.c_double
+    lib.oracle_gaussian_prior_lm_hist.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp,
+                                                  vp, vp, vp, C.c_int]
     lib.oracle_sqrt2_lm.argtypes = [C.c_int, C.c_int64, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_se3_reproj_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp]
     lib.oracle_se3_prior_lm.argtypes = [C.c_int, C.c_int64, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
@@ -142,8 +145,9 @@ def synth_gaussian_prior(P, n, dtype, seed=0x71940917, problem0=0):
     return y, sigma, x0
 
 
-def gaussian_prior_lm(y, sigma, x0, pod: ToaOptions):
-    """benchmarks/dense.cpp manual-callback semantics; returns dict(x, stop, iters, fails, cost, H, seconds)."""
+def gaussian_prior_lm(y, sigma, x0, pod: ToaOptions, history=False):
+    """benchmarks/dense.cpp manual-callback semantics; returns dict(x, stop, iters, fails, cost, H, seconds
+    [, errs, deltas2, succ])."""
     lib = load()
     P, n = y.shape
     x = np.array(x0, copy=True)
@@ -152,9 +156,14 @@ def gaussian_prior_lm(y, sigma, x0, pod: ToaOptions):
     fails = np.zeros(P, np.int32)
     cost = np.zeros(P, np.float64)
     Hf = np.zeros((P, n, n), np.float64) if pod.save_last else None
-    secs = lib.oracle_gaussian_prior_lm(_code(y.dtype), P, n, _p(np.ascontiguousarray(y)), _p(np.ascontiguousarray(sigma)),
-                                        _p(x), C.byref(pod), _p(stop), _p(iters), _p(fails), _p(cost), _p(Hf))
-    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, H=Hf, seconds=secs)
+    hs = pod.max_iters + 2
+    errs = np.zeros((P, hs), np.float64) if history else None
+    d2 = np.zeros((P, hs), np.float64) if history else None
+    succ = np.zeros((P, hs), np.uint8) if history else None
+    secs = lib.oracle_gaussian_prior_lm_hist(_code(y.dtype), P, n, _p(np.ascontiguousarray(y)), _p(np.ascontiguousarray(sigma)),
+                                             _p(x), C.byref(pod), _p(stop), _p(iters), _p(fails), _p(cost), _p(Hf),
+                                             _p(errs), _p(d2), _p(succ), hs)
+    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, H=Hf, seconds=secs, errs=errs, deltas2=d2, succ=succ)
 
 
 def sqrt2_lm(x0, pod: ToaOptions, history=True):

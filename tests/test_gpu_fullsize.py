@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import check_trajectories
+
 pytestmark = pytest.mark.gpu
 
 CONFIGS = [
@@ -68,12 +70,43 @@ def test_full_size_properties(ta, oracle, tag, P, n, m, dtype, tdt, tol_star, to
         assert torch.equal(sub.stop_reason, out.stop_reason[first:first + S])
         assert torch.equal(sub.num_iters, out.num_iters[first:first + S])
         assert torch.equal(sub.final_cost, out.final_cost[first:first + S])
-        K = 8    # oracle on the first K of them
+
+    # ---- sampled oracle parity on the headline dtype too: 3 x 176 = 528 problem ids cut out of the full
+    # batch, the whole trajectory (cost, accept / reject, StopReason, iteration count) against the oracle's with the
+    # tie-aware comparator, and the iteration-count DISTRIBUTION bounded: `value` of bench.py counts LM iterations, so
+    # the device may not buy throughput with extra floor-thrashing iterations the reference algorithm would not make.
+    K = 176
+    it_gpu, it_ref, ties, full = [], [], 0, 0
+    errs_all, succ_all = out.errs.cpu().numpy(), out.successes.cpu().numpy()
+    fails_all, d2_all = out.num_failures.cpu().numpy(), out.deltas2.cpu().numpy()
+    cost_all, x_all = out.final_cost.cpu().numpy(), x.cpu().numpy()
+    for first in (0, P // 2 + 37, P - K):
         A, b, x0h, _ = oracle.synth_dense_row(K, n, m, dtype, problem0=first)
-        ref = oracle.dense_row_lm(A, b, x0h, opts.to_pod())
+        ref = oracle.dense_row_lm(A, b, x0h, opts.to_pod(), history=True, nthreads=oracle.load().oracle_num_threads_max())
         assert (ref["stop"] >= 0).all()
-        assert np.abs(xs[:K].cpu().numpy() - ref["x"]).max() < tol_oracle
-        if dtype == np.float64:
-            assert np.array_equal(sub.stop_reason[:K].cpu().numpy(), ref["stop"])
-            assert np.array_equal(sub.num_iters[:K].cpu().numpy(), ref["iters"])
-            assert np.allclose(sub.final_cost[:K].cpu().numpy(), ref["cost"], rtol=1e-9)
+        sl = slice(first, first + K)
+        g = dict(errs=errs_all[sl], succ=succ_all[sl], iters=iters[sl], stop=stop[sl], x=x_all[sl], cost=cost_all[sl],
+                 fails=fails_all[sl], deltas2=d2_all[sl])
+        refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                    fails=ref["fails"], deltas2=ref["deltas2"])
+        st = check_trajectories(g, refd, dtype, opts.to_pod(), label=f"{tag} ids {first}..")
+        assert all(j >= 2 for j in st["tie_iters"]), st       # the pre-floor prefix is identical for every problem
+        ties += st["ties"]
+        full += st["full"]
+        it_gpu.append(iters[sl])
+        it_ref.append(ref["iters"])
+        assert np.abs(x_all[sl] - ref["x"]).max() < tol_oracle
+    it_gpu, it_ref = np.concatenate(it_gpu), np.concatenate(it_ref)
+    assert full + ties == 3 * K
+    if dtype == np.float64:
+        # C3 stops on |dx|^2 < min_step_norm2 before any cost comparison can tie: identical counts (a |dx|^2 that sits
+        # on the threshold to round-off is the only way to part, and check_trajectories has proven any such case)
+        assert np.array_equal(it_gpu, it_ref) or ties > 0
+        assert abs(it_gpu.mean() - it_ref.mean()) <= 0.01
+    else:
+        # fp32: the device's blocked sums resolve slightly smaller cost decreases than the oracle's sequential float
+        # sum, so it takes a few more last-bit steps; bound the mean (measured round 1: 7.44 vs 7.25 it/problem)
+        assert abs(it_gpu.mean() - it_ref.mean()) <= 0.5, (it_gpu.mean(), it_ref.mean())
+        assert np.abs(it_gpu.astype(int) - it_ref.astype(int)).max() <= opts.max_iters + 1
+    print(f"[{tag}] sampled parity: {full} identical to the end, {ties} proven ties; iterations/problem "
+          f"GPU {it_gpu.mean():.3f} oracle {it_ref.mean():.3f}")

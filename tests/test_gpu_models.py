@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import check_trajectories, gpu_dict
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -68,10 +70,10 @@ def test_gaussian_prior_matches_oracle(ta, oracle, dtype, tdt, n):
     y, sigma, x0 = oracle.synth_gaussian_prior(P, n, dtype, seed=5)
     o = ta.Options.benchmark()
     o.hessian.save_last = True
-    ref = oracle.gaussian_prior_lm(y, sigma, x0, o.to_pod())
+    ref = oracle.gaussian_prior_lm(y, sigma, x0, o.to_pod(), history=True)
     model = ta.GaussianPrior(torch.from_numpy(y).cuda(), torch.from_numpy(sigma).cuda())
     x = torch.from_numpy(x0.copy()).cuda()
-    out = ta.Optimize(x, model, o)
+    out = ta.Optimize(x, model, o, history=True)
     torch.cuda.synchronize()
     xg = x.cpu().numpy()
     stop = out.stop_reason.cpu().numpy()
@@ -79,8 +81,19 @@ def test_gaussian_prior_matches_oracle(ta, oracle, dtype, tdt, n):
     tol = 1e-12 if dtype == np.float64 else 1e-5
     assert np.abs(xg - y).max() < (1e-9 if dtype == np.float64 else 1e-4)       # known answer: x -> y
     assert np.abs(xg - ref["x"]).max() < tol * 10
-    agree = ((stop == ref["stop"]) & (out.num_iters.cpu().numpy() == ref["iters"])).mean()
-    assert agree >= 0.8, (stop, ref["stop"], out.num_iters.cpu().numpy(), ref["iters"])
+    # the whole trajectory against the oracle's.  This solve converges in one Gauss-Newton step, after which every
+    # cost is a sum of round-off residues (~eps^2 of the first cost): the floor of THIS problem is absolute, so costs
+    # below eps * (first cost) are clamped onto one floor value before the comparison (tests/parity.py).
+    refd = dict(errs=ref["errs"].copy(), succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
+                cost=ref["cost"].copy(), fails=ref["fails"], deltas2=ref["deltas2"])
+    g = gpu_dict(out, x)
+    scale = np.maximum(ref["errs"][:, :1], 1e-300)
+    eps = 1e-15 if dtype == np.float64 else 1e-6
+    for d in (g, refd):
+        d["errs"] = np.where(d["errs"] / scale < eps, 0.0, d["errs"]) + eps * scale
+        d["cost"] = np.where(d["cost"] / scale[:, 0] < eps, 0.0, d["cost"]) + eps * scale[:, 0]
+    st = check_trajectories(g, refd, dtype, o.to_pod(), label=f"gaussian prior n={n}")
+    assert st["full"] + st["ties"] == P, st
     # tests/cov.cpp:20-47: covariance from the final UNDAMPED Hessian recovers the prior stdevs
     Hf = out.final_hessian.cpu().numpy()
     idx = np.arange(n)

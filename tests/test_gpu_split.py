@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import check_trajectories, gpu_dict
+
 pytestmark = pytest.mark.gpu
 
 
@@ -37,15 +39,14 @@ def test_split_dense_row_matches_oracle_and_fused(ta, oracle, dtype, n, m, P, sp
         stop = out.stop_reason.cpu().numpy()
         iters = out.num_iters.cpu().numpy()
         assert (stop >= 0).all()
+        refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                    fails=ref["fails"], deltas2=ref["deltas2"])
+        st = check_trajectories(gpu_dict(out, x), refd, dtype, opts.to_pod(), label=f"split {n}x{m}/{splits}")
+        assert st["full"] + st["ties"] == P and all(j >= 2 for j in st["tie_iters"]), st
         if dtype == np.float64:
             assert np.abs(xg - ref["x"]).max() < 1e-8
             assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-9)
-            errs = out.errs.cpu().numpy()
-            for p in range(P):
-                k = min(3, iters[p], ref["iters"][p])
-                assert np.allclose(errs[p, :k], ref["errs"][p, :k], rtol=1e-9)
             assert np.allclose(out.final_hessian.cpu().numpy(), ref["H"], rtol=1e-9, atol=1e-9 * np.abs(ref["H"]).max())
-            assert ((stop == ref["stop"]) & (iters == ref["iters"])).mean() >= 0.6
         else:
             assert np.abs(xg - ref["x"]).max() < 2e-3
             assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-3)

@@ -61,8 +61,10 @@ class _LM:  # options.h:127-141
 
 @dataclass
 class Options:
-    """tinyopt::Options (options.h:18-156).  log.*, stop_callback*, max_duration_ms are host-side
-    features of the reference that the device path does not take."""
+    """tinyopt::Options (options.h:18-156).  ``max_duration_ms``, ``stop_callback`` and ``stop_callback2`` are
+    host-side controls: when any of them is set, ``Optimize`` runs the loop through the stepping form and evaluates
+    them between iterations (optimizer.h:302-305, 529-534) — per problem: ``stop_callback(err, dx_norm2, grad_norm2)``
+    / ``stop_callback2(err, dx, g)`` with numpy vectors.  log.* is not mirrored."""
     LevenbergMarquardt = 0
     GaussNewton = 1
     solver_type: int = 0
@@ -78,7 +80,13 @@ class Options:
     min_grad_norm2: float = 1e-18
     max_total_failures: int = 0
     max_consec_failures: int = 5
+    max_duration_ms: float = 0.0               # options.h:96; 0 = no limit
+    stop_callback: Optional[object] = None     # options.h:97-101  bool(err, |dx|^2, |g|^2)
+    stop_callback2: Optional[object] = None    # options.h:102-106 bool(err, dx, g)
     lm: _LM = field(default_factory=_LM)
+
+    def has_host_controls(self) -> bool:
+        return self.max_duration_ms > 0 or self.stop_callback is not None or self.stop_callback2 is not None
 
     @staticmethod
     def benchmark() -> "Options":
@@ -501,12 +509,18 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
     cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
-    asynchronous on torch's current stream.
+    asynchronous on torch's current stream — except ``DenseRowNatural`` (n > 63), whose host loop reads two integers
+    back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
+    library (every path accumulates).
     """
     options = options or Options()
     _check_call(x, cost)
     P, n = x.shape[0], cost.n
     ctx = ctx or default_context(x.device.index)
+    if options.has_host_controls():
+        if splits is not None or out is not None:
+            raise ValueError("stop callbacks / max_duration_ms run through the stepping form: splits / out are not taken")
+        return _optimize_with_host_controls(x, cost, options, history, ctx)
     pod = options.to_pod()
     if out is None:
         out = _alloc_output(P, n, options, history, x.device)
@@ -561,6 +575,78 @@ class Optimizer:
             if self.Step() == 0:
                 break
         return self.out
+
+    def step_info(self, vectors: bool = False):
+        """What the reference hands its stop callbacks after an iteration (optimizer.h:529-534): per problem the cost
+        ``err``, ``dx_norm2``, ``grad_norm2`` (float64 tensors [P]) and, with vectors=True, ``dx`` and ``g`` [P, n]."""
+        x, cost = self.x, self.cost
+        P, n = x.shape[0], cost.n
+        f64 = dict(dtype=torch.float64, device=x.device)
+        err, dx2, g2 = torch.zeros(P, **f64), torch.zeros(P, **f64), torch.zeros(P, **f64)
+        dx = torch.zeros(P, n, dtype=x.dtype, device=x.device) if vectors else None
+        g = torch.zeros(P, n, dtype=x.dtype, device=x.device) if vectors else None
+        check(self.ctx.lib.toa_lm_step_info(self.ctx.h, _dtype_code(x.dtype), n, P, self._state.data_ptr(), err.data_ptr(),
+                                            dx2.data_ptr(), g2.data_ptr(), dx.data_ptr() if vectors else None,
+                                            g.data_ptr() if vectors else None))
+        return err, dx2, g2, dx, g
+
+    def stop(self, request: torch.Tensor) -> None:
+        """End the still-running problems p with request[p] != 0 (int32, a StopReason such as kUserStopped / kTimedOut):
+        their Output rows are finalised exactly as for a problem that stops by itself."""
+        x, cost = self.x, self.cost
+        request = request.to(device=x.device, dtype=torch.int32).contiguous()
+        check(self.ctx.lib.toa_lm_stop(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
+                                       cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
+                                       self.out.counters.data_ptr(), self._state.data_ptr(), request.data_ptr()))
+
+
+def _optimize_with_host_controls(x, cost, options: Options, history: bool, ctx: Context) -> Output:
+    """Optimize() when Options carries host-side stop controls: the loop of OptimizeAcc (optimizer.h:266-310) driven
+    from the host over the stepping form.  After every pass: the callbacks see (err, |dx|^2, |g|^2) / (err, dx, g) of
+    each problem that no numeric stop test has ended (the else-if chain of optimizer.h:519-534), and the accumulated
+    wall time is checked against max_duration_ms (one clock for the batch) — kTimedOut overrides whatever reason a
+    problem picked up in that same pass, as the unconditional assignment at optimizer.h:303-305 does."""
+    import time
+    opt = Optimizer(x, cost, options, history=history, ctx=ctx)
+    out = opt.out
+    P = x.shape[0]
+    want_vec = options.stop_callback2 is not None
+    duration_ms = 0.0
+    running_before = torch.ones(P, dtype=torch.bool, device=x.device)
+    for _ in range(options.max_iters + 2):
+        t0 = time.perf_counter()
+        active = opt.Step()
+        running = out.stop_reason == int(StopReason.kNone)
+        running &= running_before          # a row reports kNone until its problem stops
+        req = torch.zeros(P, dtype=torch.int32)
+        if active and (options.stop_callback is not None or options.stop_callback2 is not None):
+            err, dx2, g2, dxv, gv = opt.step_info(vectors=want_vec)
+            err_h, dx2_h, g2_h = err.cpu().numpy(), dx2.cpu().numpy(), g2.cpu().numpy()
+            dx_h = dxv.cpu().numpy() if want_vec else None
+            g_h = gv.cpu().numpy() if want_vec else None
+            for p in torch.nonzero(running).flatten().tolist():
+                stop = False
+                if options.stop_callback is not None:
+                    stop = bool(options.stop_callback(float(err_h[p]), float(dx2_h[p]), float(g2_h[p])))
+                if not stop and options.stop_callback2 is not None:
+                    stop = bool(options.stop_callback2(float(err_h[p]), dx_h[p].astype("float32"), g_h[p].astype("float32")))
+                if stop:
+                    req[p] = int(StopReason.kUserStopped)
+        torch.cuda.synchronize(x.device)
+        duration_ms += (time.perf_counter() - t0) * 1e3
+        timed_out = options.max_duration_ms > 0 and duration_ms > options.max_duration_ms
+        if timed_out:
+            req[running.cpu()] = int(StopReason.kTimedOut)
+        if bool(req.any()):
+            opt.stop(req)
+        if timed_out:   # problems that stopped by themselves in this very pass: the reference overwrites their reason too
+            just = running_before & ~running
+            out.stop_reason[just] = int(StopReason.kTimedOut)
+            break
+        running_before = running & (req.to(x.device) == 0)
+        if not bool(running_before.any()):
+            break
+    return out
 
 
 def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Context] = None):

@@ -249,7 +249,7 @@ int toa_create(toa_handle* out, int device, void* stream) {
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
   if (device < 0 || device >= count) return fail(TOA_E_ARG, "toa_create: no such device");
-  HIP_TRY(hipSetDevice(device));
+  TOA_ON_DEVICE(device);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -272,7 +272,7 @@ int toa_create(toa_handle* out, int device, void* stream) {
 
 int toa_destroy(toa_handle h) {
   if (!h) return TOA_OK;
-  (void)hipSetDevice(h->device);
+  toa::DeviceGuard guard_(h->device);
   if (h->queue) (void)hipFree(h->queue);
   if (h->params_dev) (void)hipFree(h->params_dev);
   if (h->scratch) (void)hipFree(h->scratch);
@@ -292,55 +292,57 @@ int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size
 
 int toa_malloc(toa_handle h, void** dev_ptr, size_t bytes) {
   if (!h || !dev_ptr) return fail(TOA_E_ARG, "toa_malloc: null argument");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
   return TOA_OK;
 }
 int toa_free(toa_handle h, void* dev_ptr) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipFree(dev_ptr));
   return TOA_OK;
 }
 int toa_memcpy_h2d(toa_handle h, void* dst, const void* src, size_t bytes) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return TOA_OK;
 }
 int toa_memcpy_d2h(toa_handle h, void* dst, const void* src, size_t bytes) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return TOA_OK;
 }
 int toa_memset(toa_handle h, void* dst, int value, size_t bytes) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipMemsetAsync(dst, value, bytes, h->stream));
   return TOA_OK;
 }
 int toa_hbm_read_probe(toa_handle h, const void* src_dev, size_t bytes, int reps, double* gb_per_s) {
   if (!h || !src_dev || !gb_per_s || reps < 1 || bytes < 16) return fail(TOA_E_ARG, "toa_hbm_read_probe: bad argument");
-  HIP_TRY(hipSetDevice(h->device));
+  if (reinterpret_cast<uintptr_t>(src_dev) & 15) return fail(TOA_E_ARG, "toa_hbm_read_probe: src_dev must be 16-byte aligned");
+  TOA_ON_DEVICE(h->device);
   const size_t n16 = bytes / 16;
   const int grid = h->num_cus * 16;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  struct Events {  // destroyed on every exit path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
   uint32_t* sink = reinterpret_cast<uint32_t*>(h->queue) + 60;  // unused tail of the 256-byte queue block
   hipLaunchKernelGGL(toa::hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const toa::u32x4*)src_dev, n16, sink);  // warm
-  HIP_TRY(hipEventRecord(e0, h->stream));
+  HIP_TRY(hipEventRecord(ev.e0, h->stream));
   for (int r = 0; r < reps; ++r)
     hipLaunchKernelGGL(toa::hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, (const toa::u32x4*)src_dev, n16, sink);
-  HIP_TRY(hipEventRecord(e1, h->stream));
-  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventRecord(ev.e1, h->stream));
+  HIP_TRY(hipEventSynchronize(ev.e1));
   float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   HIP_TRY(hipGetLastError());
   *gb_per_s = double(n16) * 16.0 * reps / (double(ms) * 1e-3) * 1e-9;
   return TOA_OK;
@@ -351,7 +353,7 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
   if (kind < TOA_LOSS_L2 || kind > TOA_LOSS_BLAKE_ZISSERMAN) return fail(TOA_E_ARG, "toa_robust_norm: unknown loss kind");
   if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "toa_robust_norm: dtype must be TOA_F32 or TOA_F64");
   if (count == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   const unsigned grid = unsigned((count + 255) / 256);
   if (dtype == TOA_F32)
     hipLaunchKernelGGL(toa::robust_norm_kernel<float>, dim3(grid), dim3(256), 0, h->stream, kind, (long long)count,
@@ -365,7 +367,7 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
 
 int toa_synchronize(toa_handle h) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return TOA_OK;
 }
@@ -436,7 +438,8 @@ int toa_dense_row_pack(toa_handle h, int dtype, int n, int m, int64_t P, const v
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  if (!A || !b || !packed) return fail(TOA_E_ARG, "toa_dense_row_pack: null pointer");
+  TOA_ON_DEVICE(h->device);
   const DenseRowLayout L = DenseRowLayout::make(n, m);
   const int grid = h->num_cus * 8;
   if (dtype == TOA_F32)
@@ -454,7 +457,8 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  if (!packed) return fail(TOA_E_ARG, "toa_dense_row_synth: packed_dev is null");
+  TOA_ON_DEVICE(h->device);
   const DenseRowLayout L = DenseRowLayout::make(n, m);
   const int grid = h->num_cus * 16;
   if (dtype == TOA_F32)
@@ -474,7 +478,7 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
   if (int rc = check_model(model, n, m, data)) return rc;
   if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   const int dtag = dtype == TOA_F32 ? 0 : 1;
   if (model != TOA_MODEL_DENSE_ROW)
     return toa_inst_misc_accumulate(dtag, model, 16 * ((n + 15) / 16), h, n, m, P, data, x, want_grad, g, H, cost, nres);
@@ -498,7 +502,7 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
   }
   if (!H || !g || !dx || !ok) return fail(TOA_E_ARG, "toa_solve_damped: null pointer");
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   if (large) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   return toa_inst_solve(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, g, scale, dx, ok);
 }
@@ -511,19 +515,19 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* 
     if (P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_inv_cov: P must be in [0, 65535] for n > 63");
     if (!H || !C || !ok) return fail(TOA_E_ARG, "toa_inv_cov: null pointer");
     if (P == 0) return TOA_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    TOA_ON_DEVICE(h->device);
     return toa_large_inv_cov(h, dtype, n, P, H, C, ok);
   }
   if (int rc = check_shape(dtype, n, 1, P)) return rc;
   if (!H || !C || !ok) return fail(TOA_E_ARG, "toa_inv_cov: null pointer");
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   return toa_inst_inv_cov(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, C, ok);
 }
 
 static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                        const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
-                       int mode = 0, void* state = nullptr, int32_t* active = nullptr) {
+                       int mode = 0, void* state = nullptr, int32_t* active = nullptr, const int32_t* stop_request = nullptr) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   const bool natural = model == TOA_MODEL_DENSE_ROW_NATURAL;  // the library-backed path for n beyond one wavefront
   if (natural) {
@@ -548,7 +552,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     return fail(TOA_E_ARG, "toa_lm_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");
   if (P == 0) return TOA_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  TOA_ON_DEVICE(h->device);
   if (natural) return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   FusedParams prm;
   std::memset(&prm, 0, sizeof(prm));
@@ -563,6 +567,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   prm.mode = mode;
   prm.state = state;
   prm.active = active;
+  prm.stop_request = stop_request;
   if (mode != 0) {
     if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
     // the stepping form runs on the launch-per-iteration kernels with one chunk per problem (launch_stepping)
@@ -614,6 +619,30 @@ int toa_lm_step(toa_handle h, int model, int dtype, int n, int m, int64_t P, con
                 const toa_options* options, const toa_results* results, uint64_t* counters, void* state_dev,
                 int32_t* active_dev) {
   return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1, 2, state_dev, active_dev);
+}
+
+int toa_lm_stop(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
+                const toa_options* options, const toa_results* results, uint64_t* counters, void* state_dev,
+                const int32_t* stop_request_dev) {
+  if (!stop_request_dev) return fail(TOA_E_ARG, "toa_lm_stop: stop_request_dev is null");
+  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1, 3, state_dev, nullptr, stop_request_dev);
+}
+
+int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state_dev, double* err_dev, double* dx_norm2_dev,
+                     double* grad_norm2_dev, void* dx_dev, void* g_dev) {
+  if (!h || !state_dev) return fail(TOA_E_ARG, "toa_lm_step_info: null argument");
+  if (int rc = check_shape(dtype, n, 1, P)) return rc;
+  if (P == 0) return TOA_OK;
+  TOA_ON_DEVICE(h->device);
+  const unsigned grid = unsigned((P + 3) / 4);
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::step_info_kernel<float>, dim3(grid), dim3(256), 0, h->stream, state_dev, (long long)P, n, err_dev,
+                       dx_norm2_dev, grad_norm2_dev, (float*)dx_dev, (float*)g_dev);
+  else
+    hipLaunchKernelGGL(toa::step_info_kernel<double>, dim3(grid), dim3(256), 0, h->stream, state_dev, (long long)P, n, err_dev,
+                       dx_norm2_dev, grad_norm2_dev, (double*)dx_dev, (double*)g_dev);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
 }
 
 int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,

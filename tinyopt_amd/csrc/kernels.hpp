@@ -891,9 +891,11 @@ struct FusedParams {
   void* park;                    // WideState<T>[P]: the state of a problem between two of its work items
   unsigned long long* timeline;  // debug (TOA_TIMELINE=file): [P][2] start / end of every problem in 100 MHz ticks
   int lds_per_wave;
-  int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form)
-  void* state;                   // modes 1, 2: caller's state block (see launch_wide)
+  int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form);
+                                 // 3: finalise the problems named in stop_request with that StopReason (host-side stop controls)
+  void* state;                   // modes 1, 2, 3: caller's state block (see launch_wide)
   int* active;                   // mode 2 (optional): += 1 per problem that is still running after this pass
+  const int* stop_request;       // mode 3: [P] StopReason to impose on a still-running problem (0 = leave it running)
 };
 
 // (An occupancy request via __launch_bounds__'s second argument is NOT usable here: under the tighter register budget
@@ -1153,6 +1155,8 @@ __global__ void __launch_bounds__(256) inv_cov_kernel(const void* H_, long long 
           if (lane < n) C[size_t(j) * n + lane] = x;
         }
     }
+    if (!ok)  // rejected (std::nullopt in the reference): define the output instead of leaving caller memory untouched
+      for (int e = lane; e < n * n; e += 64) C[e] = T(0);
     if (lane == 0) ok_[p] = ok ? 1 : 0;
   }
 }
@@ -1180,6 +1184,7 @@ struct WideParams {
   void* hsum;      // T[P][n*n]
   int step_mode;   // stepping form: publish x and the running results at every pass
   int* active;     // stepping form (optional): += 1 per problem still running after the pass
+  const int* stop_request;  // stepping form, wide_stop_kernel: [P] StopReason to impose (0 = none)
   unsigned* sync;  // persistent form: [P][2] = (arrive, go) generation counters, then [1] abort flag; zeroed per launch
   int lds_per_wave;
 };
@@ -1387,6 +1392,66 @@ __global__ void __launch_bounds__(256) wide_step_kernel(const WideParams* __rest
     }
   }
   wide_store_state(L, ws, lane);
+}
+
+// Host-side stop controls of the stepping form (`Options::stop_callback`, `stop_callback2`, `max_duration_ms`;
+// optimizer.h:302-305, 529-534): the host evaluates them between two toa_lm_step calls on what toa_lm_step_info reads
+// back and names the problems to stop; this kernel ends those problems exactly as the loop would have — StopReason set,
+// then the finalisation of OptimizeAcc (undamped final Hessian, Output fields; optimizer.h:313-321).  x already holds
+// the iterate the reference would return: its Step sets the StopReason first and OptimizeAcc still applies the step
+// before leaving the loop (optimizer.h:271-309), which is what the completed toa_lm_step has done.
+template <typename T, int NPAD, typename Manifold>
+__global__ void __launch_bounds__(256) wide_stop_kernel(const WideParams* __restrict__ prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p = (long long)blockIdx.x * 4 + wave;
+  if (p >= prm->P) return;
+  const int req = prm->stop_request[p];
+  if (req == TOA_STOP_NONE) return;
+  const int n = prm->n;
+  WideState<T>* ws = static_cast<WideState<T>*>(prm->state) + p;
+  if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) return;  // already finished on its own
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm->lds_per_wave, n);
+  wide_copy_pods(L, prm, lane);
+  wide_load_state(L, ws, lane);
+  PartialSumModel<T, NPAD, Manifold> model;
+  model.S = prm->splits;
+  model.n_ = n;
+  model.m = prm->m;
+  model.part = static_cast<const T*>(prm->partials) + size_t(p) * prm->splits * (n * n + n + 2);
+  model.hsum = static_cast<T*>(prm->hsum) + size_t(p) * n * n;
+  L.st->stop = req;
+  wave_sync();
+  lm_finalize<T>(model, L, n, lane, p);
+  if (prm->counters && lane == 0) {
+    atomicAdd(&prm->counters[0], L.st->acc_passes);
+    atomicAdd(&prm->counters[1], L.st->eval_passes);
+    atomicAdd(&prm->counters[2], L.st->solves);
+    atomicAdd(&prm->counters[3], L.st->problems);
+  }
+  wide_store_state(L, ws, lane);
+}
+
+// What the host-side stop controls look at after a step (optimizer.h:529-534: `stop_callback(err, |dx|^2, |g|^2)`,
+// `stop_callback2(err, dx, g)`): the cost, step and gradient of each problem's LAST iteration, out of the state block.
+template <typename T>
+__global__ void __launch_bounds__(256) step_info_kernel(const void* state_, long long P, int n, double* err, double* dx2,
+                                                        double* g2, T* dx_out, T* g_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p = (long long)blockIdx.x * 4 + wave;
+  if (p >= P) return;
+  const WideState<T>* ws = static_cast<const WideState<T>*>(state_) + p;
+  const T d = lane < n ? ws->dx[lane] : T(0);
+  const T g = lane < n ? ws->g[lane] : T(0);
+  const double sd = double(wave_allreduce_sum(d * d));   // same arithmetic as lm_judge_step (optimizer.h:412-415)
+  const double sg = double(wave_allreduce_sum(g * g));
+  if (lane == 0) {
+    if (err) err[p] = ws->st.cost_val;
+    if (dx2) dx2[p] = sd;
+    if (g2) g2[p] = sg;
+  }
+  if (dx_out && lane < n) dx_out[size_t(p) * n + lane] = d;
+  if (g_out && lane < n) g_out[size_t(p) * n + lane] = g;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1658,6 +1723,28 @@ int toa_fail(int code, const std::string& msg);
   } while (0)
 
 namespace toa {
+// Every C entry point runs on its handle's GPU and leaves the CALLER's current device as it found it: torch (and any
+// other HIP user of the process) reads its "current device" through hipGetDevice, so a library that switched it as a
+// side effect would silently redirect the caller's later allocations in a single-process multi-GPU program.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    int cur = -1;
+    err = hipGetDevice(&cur);
+    if (err == hipSuccess && cur != dev) {
+      err = hipSetDevice(dev);
+      if (err == hipSuccess) prev = cur;
+    }
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define TOA_ON_DEVICE(dev)          \
+  toa::DeviceGuard guard_(dev);     \
+  HIP_TRY(guard_.err)
+
 // Raise a kernel's dynamic-LDS limit once per (kernel, size): hipFuncSetAttribute costs ~1 ms per call.
 inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
   for (int i = 0; i < h->ncfg; ++i)
@@ -1809,6 +1896,7 @@ inline int launch_stepping(toa_handle h, const FusedParams& fp) {
   wp.hsum = static_cast<char*>(fp.state) + o_hsum;
   wp.step_mode = 1;
   wp.active = fp.active;
+  wp.stop_request = fp.stop_request;
   wp.lds_per_wave = int(pw);
   HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
   const WideParams* dp = static_cast<const WideParams*>(h->params_dev);
@@ -1817,6 +1905,10 @@ inline int launch_stepping(toa_handle h, const FusedParams& fp) {
     auto k_init = wide_init_kernel<T, Manifold::kXdim>;
     if (int rc = ensure_lds_attr(h, (const void*)k_init, pwg)) return rc;
     hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
+  } else if (fp.mode == 3) {
+    auto k_stop = wide_stop_kernel<T, NPAD, Manifold>;
+    if (int rc = ensure_lds_attr(h, (const void*)k_stop, pwg)) return rc;
+    hipLaunchKernelGGL(k_stop, dim3(g_p), dim3(256), pwg, h->stream, dp);
   } else {
     auto k_part = wide_partial_kernel<Model>;
     auto k_step = wide_step_kernel<T, NPAD, Manifold>;

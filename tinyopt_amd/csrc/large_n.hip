@@ -776,7 +776,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
-  if (counters) HIP_TRY(hipMemsetAsync(counters, 0, 4 * sizeof(uint64_t), st));
+  // counters ACCUMULATE on every path (fused, row-split, stepping, here): the caller zeroes them (include/tinyopt_amd.h)
   hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
   const T one = 1, zero = 0;
   int active = int(P), want_j = int(P);
