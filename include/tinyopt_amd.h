@@ -35,6 +35,7 @@ extern "C" {
 #define TOA_E_HIP (-2)     /* HIP runtime error */
 #define TOA_E_NOMEM (-3)   /* device allocation failed (reference: bad_alloc -> kOutOfMemory) */
 #define TOA_E_UNSUPPORTED (-4)
+#define TOA_E_RCCL (-5)    /* RCCL (collective) error */
 
 /* scalar type of x / H / g (the solver `Scalar`, solvers/lm.h:27) */
 #define TOA_F32 0
@@ -288,6 +289,28 @@ int toa_lm_stop(toa_handle h, int model, int dtype, int n, int m, int64_t P, con
 int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                      const void* data_dev, void* x_dev, const toa_options* options,
                      const toa_results* results, uint64_t* counters_dev, int splits);
+
+/* ---- C1: the result gather of a sharded batch (SURVEY §8(b) export list `gather(handle_group...)`, §8(e)).
+ *      Problems are independent (the reference optimises exactly one x per call, docs/API.md:12), so a batch of P_total
+ *      problems shards across the GPUs of a node with no data-path communication: one process per GPU, rank g solves the
+ *      contiguous id block toa_shard_range(P_total, g, nranks) with toa_lm_run.  Exactly ONE collective ends the job:
+ *      toa_gather = pack -> ncclGather (RCCL over xGMI) -> unpack on the root, in problem-id order, native types
+ *      (xdim scalars of x, stop_reason, num_iters, final_cost per problem: 216 B at C4 = 2.7 MB per GPU).
+ *        toa_comm_unique_id  called by ONE rank; the host program hands the 128 bytes to every rank (MPI_Bcast, a file,
+ *                            torch.distributed's store ...) — the library has no side channel of its own;
+ *        toa_comm_init_rank  collective over the ranks of that id (ncclCommInitRank on the handle's GPU);
+ *        toa_gather          stream-ordered on the handle's stream.  local: the rank's result arrays — stop_reason,
+ *                            num_iters and final_cost are required; all / x_all_dev: destination arrays of P_total entries on
+ *                            the root (ignored elsewhere; NULL members are skipped).
+ *      RCCL is opened with dlopen on first use (TOA_E_UNSUPPORTED if absent); single-problem configs (C2, C5) do not shard. */
+#define TOA_COMM_ID_BYTES 128
+typedef struct toa_comm_s* toa_comm;
+int toa_shard_range(int64_t P_total, int rank, int nranks, int64_t* lo, int64_t* hi);
+int toa_comm_unique_id(void* id_bytes_out);
+int toa_comm_init_rank(toa_handle h, const void* id_bytes, int nranks, int rank, toa_comm* out);
+int toa_comm_destroy(toa_comm c);
+int toa_gather(toa_handle h, toa_comm c, int dtype, int xdim, int64_t P_total, const void* x_dev, const toa_results* local,
+               int root, void* x_all_dev, const toa_results* all);
 
 #ifdef __cplusplus
 }

@@ -19,10 +19,14 @@
 #pragma once
 
 #include <array>
+#include <chrono>
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../tinyopt_amd.h"
@@ -58,6 +62,12 @@ struct Options {  // include/tinyopt/optimizers/options.h:18-156 (numeric knobs)
   float min_grad_norm2 = 1e-18f;
   uint8_t max_total_failures = 0;
   uint8_t max_consec_failures = 5;
+  // Host-side stop controls (options.h:96-106).  When any is set, Optimize() drives the loop through the stepping form
+  // and evaluates them between iterations (optimizer.h:302-305, 529-534); per problem of the batch.
+  double max_duration_ms = 0;                                          // 0 = no limit -> kTimedOut
+  std::function<bool(double, double, double)> stop_callback;           // (err, |dx|^2, |g|^2) -> kUserStopped
+  std::function<bool(float, const std::vector<float>&, const std::vector<float>&)> stop_callback2;   // (err, dx, g)
+  bool has_host_controls() const { return max_duration_ms > 0 || stop_callback || stop_callback2; }
   struct LM {
     float damping_init = 1e-4f;
     std::array<float, 2> damping_range{{1e-9f, 1e9f}};
@@ -228,6 +238,18 @@ template <typename Scalar>
 struct Sqrt2 : PlainModel<Scalar, TOA_MODEL_SQRT2> {
   Sqrt2(const Context& ctx, int64_t P) : PlainModel<Scalar, TOA_MODEL_SQRT2>(ctx, P, 1, 1, 1, nullptr, 0) {}
 };
+// The analytic functions of the reference's optimizer tests as manual Accumulate callbacks (tests/optimize_easy.cpp,
+// optimize_hard.cpp, basic.cpp:41-87): fn = 0 Rosenbrock, 1 plateau, 2 Powell (n = 4), 3 Beale, 4 Himmelblau, 5 `x - 2` (n = 1).
+template <typename Scalar>
+struct TestFn : PlainModel<Scalar, TOA_MODEL_TESTFN> {
+  static int dims(int fn) { return fn == 5 ? 1 : (fn == 2 ? 4 : 2); }
+  static int residuals(int fn) { return fn == 3 ? 3 : (fn == 4 ? 2 : 1); }
+  TestFn(const Context& ctx, int64_t P, int fn) : PlainModel<Scalar, TOA_MODEL_TESTFN>(ctx, P, dims(fn), residuals(fn), dims(fn), id(fn), 1) {}
+
+ private:
+  const Scalar* id(int fn) { fn_ = Scalar(fn); return &fn_; }
+  Scalar fn_ = 0;
+};
 // tests/circle.cpp:32-68, differentiated on the device by dual numbers.  obs: [P][npts][2]; x = (cx, cy, radius).
 template <typename Scalar>
 struct CircleFit : PlainModel<Scalar, TOA_MODEL_CIRCLE_FIT> {
@@ -265,6 +287,23 @@ struct BatchOutput {
   bool Converged(size_t p) const { return stop_reason[p] >= kMinError && stop_reason[p] < kMaxIters; } // output.h:33-35
 };
 
+// include/tinyopt/output.h:26-145 for ONE problem — what the P == 1 overload of Optimize returns, so that a call site of
+// the reference (`const auto& out = Optimize(x, loss, options); REQUIRE(out.Succeeded());`) keeps compiling.
+struct Output {
+  int32_t stop_reason = kNone;
+  int32_t num_iters = 0, num_failures = 0, num_consec_failures = 0;
+  struct Cost_ { double cost = 0; int32_t num_resisuals = 0; float inlier_ratio = 1; } final_cost;   // cost.h:18-97
+  double final_rerr_dec = 0;
+  std::vector<double> final_hessian;   // n*n, undamped; empty unless options.hessian.save_last
+  std::vector<double> errs, deltas2;   // one entry per iteration (only with history = true)
+  std::vector<bool> successes;
+  bool Succeeded() const { return stop_reason >= kNone; }
+  bool Converged() const { return stop_reason >= kMinError && stop_reason < kMaxIters; }
+};
+
+template <typename Scalar, typename Cost>
+BatchOutput OptimizeWithHostControls(std::vector<Scalar>& x, const Cost& cost, const Options& options, bool history);
+
 // tinyopt::Optimize(x, cost, options) for a batch.  x: [P][n] contiguous host scalars, updated in place.
 template <typename Scalar, typename Cost>
 BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& options = {}, bool history = false) {
@@ -272,6 +311,7 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   const int n = cost.n();
   if (int64_t(x.size()) != P * cost.xdim())
     throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P * (parameters per problem) scalars");
+  if (options.has_host_controls()) return OptimizeWithHostControls(x, cost, options, history);
   const Context& ctx = cost.ctx();
   DeviceBuffer<Scalar> dx(ctx, x.size());
   dx.upload(x.data());
@@ -313,7 +353,7 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
 template <typename Scalar, typename Cost>
 class Optimizer {
  public:
-  Optimizer(std::vector<Scalar>& x, const Cost& cost, const Options& options = {})
+  Optimizer(std::vector<Scalar>& x, const Cost& cost, const Options& options = {}, bool history = false)
       : x_(&x), cost_(&cost), options_(options), pod_(options.to_pod()), P_(cost.P()), n_(cost.n()),
         dx_(cost.ctx(), x.size()), stop_(cost.ctx(), P_), iters_(cost.ctx(), P_), fails_(cost.ctx(), P_), cfails_(cost.ctx(), P_),
         nres_(cost.ctx(), P_), fc_(cost.ctx(), P_), fr_(cost.ctx(), P_), inl_(cost.ctx(), P_), active_(cost.ctx(), 1),
@@ -327,6 +367,13 @@ class Optimizer {
     r_.num_consec_failures = cfails_.data(); r_.final_cost = fc_.data(); r_.final_num_residuals = nres_.data();
     r_.final_rerr_dec = fr_.data(); r_.final_inlier_ratio = inl_.data();
     if (options.hessian.save_last) { fH_ = DeviceBuffer<double>(cost.ctx(), size_t(P_) * n_ * n_); fH_.zero(); r_.final_hessian = fH_.data(); }
+    if (history) {
+      hist_stride_ = options.max_iters + 2;
+      errs_ = DeviceBuffer<double>(cost.ctx(), size_t(P_) * hist_stride_); errs_.zero();
+      d2_ = DeviceBuffer<double>(cost.ctx(), size_t(P_) * hist_stride_); d2_.zero();
+      succ_ = DeviceBuffer<uint8_t>(cost.ctx(), size_t(P_) * hist_stride_); succ_.zero();
+      r_.errs = errs_.data(); r_.deltas2 = d2_.data(); r_.successes = succ_.data(); r_.hist_stride = hist_stride_;
+    }
     check(toa_lm_begin(cost.ctx().get(), Cost::model_id, dtype_of<Scalar>(), n_, cost.m(), P_, cost.data(), dx_.data(), &pod_, &r_,
                        state_.data()));
   }
@@ -356,8 +403,37 @@ class Optimizer {
     get(out.num_consec_failures, cfails_); get(out.final_num_residuals, nres_); get(out.final_cost, fc_);
     get(out.final_rerr_dec, fr_); get(out.final_inlier_ratio, inl_);
     if (options_.hessian.save_last) get(out.final_hessian, fH_);
+    if (hist_stride_) { out.hist_stride = hist_stride_; get(out.errs, errs_); get(out.deltas2, d2_); get(out.successes, succ_); }
     return out;
   }
+  // What the reference hands its stop callbacks after an iteration (optimizer.h:529-534), per problem: the cost, |dx|^2,
+  // |g|^2 and — when dx / g are given — the step and gradient vectors ([P][n]).
+  void StepInfo(std::vector<double>& err, std::vector<double>& dx2, std::vector<double>& g2, std::vector<Scalar>* dx = nullptr,
+                std::vector<Scalar>* g = nullptr) const {
+    const Context& ctx = cost_->ctx();
+    DeviceBuffer<double> de(ctx, P_), dd(ctx, P_), dg(ctx, P_);
+    DeviceBuffer<Scalar> vdx, vg;
+    if (dx) vdx = DeviceBuffer<Scalar>(ctx, size_t(P_) * n_);
+    if (g) vg = DeviceBuffer<Scalar>(ctx, size_t(P_) * n_);
+    check(toa_lm_step_info(ctx.get(), dtype_of<Scalar>(), n_, P_, state_.data(), de.data(), dd.data(), dg.data(),
+                           dx ? vdx.data() : nullptr, g ? vg.data() : nullptr));
+    check(toa_synchronize(ctx.get()));
+    err.resize(P_); dx2.resize(P_); g2.resize(P_);
+    de.download(err.data()); dd.download(dx2.data()); dg.download(g2.data());
+    if (dx) { dx->resize(size_t(P_) * n_); vdx.download(dx->data()); }
+    if (g) { g->resize(size_t(P_) * n_); vg.download(g->data()); }
+  }
+  // Ends the still-running problems p with request[p] != 0 with that StopReason (kUserStopped, kTimedOut).
+  void Stop(const std::vector<int32_t>& request) {
+    if (int64_t(request.size()) != P_) throw std::invalid_argument("tinyopt_amd::Optimizer::Stop: one request per problem");
+    const Context& ctx = cost_->ctx();
+    DeviceBuffer<int32_t> dr(ctx, P_);
+    dr.upload(request.data());
+    check(toa_lm_stop(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
+                      nullptr, state_.data(), dr.data()));
+    check(toa_synchronize(ctx.get()));
+  }
+  void SetStopReason(const std::vector<int32_t>& stop) { stop_.upload(stop.data()); }
 
  private:
   std::vector<Scalar>* x_;
@@ -372,9 +448,183 @@ class Optimizer {
   DeviceBuffer<float> inl_;
   DeviceBuffer<int32_t> active_;
   DeviceBuffer<unsigned char> state_;
-  DeviceBuffer<double> fH_;
+  DeviceBuffer<double> fH_, errs_, d2_;
+  DeviceBuffer<uint8_t> succ_;
+  int hist_stride_ = 0;
   toa_results r_;
 };
+
+// Optimize() when Options carries host-side stop controls: the loop of OptimizeAcc (optimizer.h:266-310) driven from the
+// host over the stepping form.  After every pass the callbacks see (err, |dx|^2, |g|^2) / (err, dx, g) of each problem no
+// numeric stop test has ended (the else-if chain of optimizer.h:519-534); the accumulated wall time is checked against
+// max_duration_ms (one clock for the batch) and kTimedOut overrides whatever reason a problem picked up in that same
+// pass, as the unconditional assignment at optimizer.h:303-305 does.
+template <typename Scalar, typename Cost>
+BatchOutput OptimizeWithHostControls(std::vector<Scalar>& x, const Cost& cost, const Options& options, bool history) {
+  Optimizer<Scalar, Cost> opt(x, cost, options, history);
+  const int64_t P = cost.P();
+  const int n = cost.n();
+  std::vector<char> running_before(P, 1);
+  std::vector<double> err, dx2, g2;
+  std::vector<Scalar> dxv, gv;
+  std::vector<float> dxf(n), gf(n);
+  double duration_ms = 0;
+  for (int it = 0; it < int(options.max_iters) + 2; ++it) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t active = opt.Step();
+    BatchOutput now = opt.output();
+    std::vector<char> running(P);
+    for (int64_t p = 0; p < P; ++p) running[p] = running_before[p] && now.stop_reason[p] == kNone;
+    std::vector<int32_t> req(P, 0);
+    bool any = false;
+    if (active > 0 && (options.stop_callback || options.stop_callback2)) {
+      opt.StepInfo(err, dx2, g2, options.stop_callback2 ? &dxv : nullptr, options.stop_callback2 ? &gv : nullptr);
+      for (int64_t p = 0; p < P; ++p) {
+        if (!running[p]) continue;
+        bool stop = options.stop_callback && options.stop_callback(err[p], dx2[p], g2[p]);
+        if (!stop && options.stop_callback2) {
+          for (int j = 0; j < n; ++j) { dxf[j] = float(dxv[size_t(p) * n + j]); gf[j] = float(gv[size_t(p) * n + j]); }
+          stop = options.stop_callback2(float(err[p]), dxf, gf);
+        }
+        if (stop) { req[p] = kUserStopped; any = true; }
+      }
+    }
+    duration_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const bool timed_out = options.max_duration_ms > 0 && duration_ms > options.max_duration_ms;
+    if (timed_out)
+      for (int64_t p = 0; p < P; ++p)
+        if (running[p]) { req[p] = kTimedOut; any = true; }
+    if (any) opt.Stop(req);
+    if (timed_out) {
+      BatchOutput fin = opt.output();
+      bool changed = false;
+      for (int64_t p = 0; p < P; ++p)
+        if (running_before[p] && !running[p]) { fin.stop_reason[p] = kTimedOut; changed = true; }
+      if (changed) opt.SetStopReason(fin.stop_reason);
+      break;
+    }
+    bool left = false;
+    for (int64_t p = 0; p < P; ++p) { running_before[p] = running[p] && req[p] == 0; left = left || running_before[p]; }
+    if (!left) break;
+  }
+  return opt.output();
+}
+
+// ---- C1: a batch sharded over the GPUs of a node, one process per GPU ---------------------------------------
+// RAII over toa_comm.  The 128-byte id comes from ONE rank (`Communicator::UniqueId()`) and is handed to the others by the
+// host program (MPI_Bcast, a file, a socket): the library has no side channel of its own.
+class Communicator {
+ public:
+  using Id = std::array<char, TOA_COMM_ID_BYTES>;
+  static Id UniqueId() { Id id; check(toa_comm_unique_id(id.data())); return id; }
+  Communicator(const Context& ctx, const Id& id, int nranks, int rank) : ctx_(&ctx), nranks_(nranks), rank_(rank) {
+    check(toa_comm_init_rank(ctx.get(), id.data(), nranks, rank, &c_));
+  }
+  ~Communicator() { toa_comm_destroy(c_); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  toa_comm get() const { return c_; }
+  int nranks() const { return nranks_; }
+  int rank() const { return rank_; }
+  const Context& ctx() const { return *ctx_; }
+  // this rank's contiguous block [lo, hi) of the P_total problem ids
+  std::pair<int64_t, int64_t> shard(int64_t P_total) const {
+    int64_t lo = 0, hi = 0;
+    check(toa_shard_range(P_total, rank_, nranks_, &lo, &hi));
+    return {lo, hi};
+  }
+
+ private:
+  const Context* ctx_;
+  toa_comm c_ = nullptr;
+  int nranks_, rank_;
+};
+
+// Optimize() of this rank's shard followed by the ONE collective of the path: x_local / local_cost hold the problems
+// comm.shard(P_total) of a batch of P_total.  On the root the returned BatchOutput carries stop_reason / num_iters /
+// final_cost of ALL P_total problems in problem-id order and *x_all their parameters; the other ranks get their local
+// Output (x_all untouched).  No communication happens during the solve.
+template <typename Scalar, typename Cost>
+BatchOutput ShardedOptimize(std::vector<Scalar>& x_local, const Cost& local_cost, const Options& options, const Communicator& comm,
+                            int64_t P_total, std::vector<Scalar>* x_all, int root = 0) {
+  const auto range = comm.shard(P_total);
+  if (local_cost.P() != range.second - range.first)
+    throw std::invalid_argument("tinyopt_amd::ShardedOptimize: the local model must hold this rank's shard of P_total problems");
+  BatchOutput local = Optimize(x_local, local_cost, options);
+  const Context& ctx = local_cost.ctx();
+  const int xd = local_cost.xdim();
+  const int64_t Pl = local_cost.P();
+  DeviceBuffer<Scalar> dx(ctx, x_local.size() ? x_local.size() : 1);
+  DeviceBuffer<int32_t> ds(ctx, Pl ? Pl : 1), di(ctx, Pl ? Pl : 1);
+  DeviceBuffer<double> dc(ctx, Pl ? Pl : 1);
+  if (Pl) { dx.upload(x_local.data()); ds.upload(local.stop_reason.data()); di.upload(local.num_iters.data()); dc.upload(local.final_cost.data()); }
+  toa_results lr{}, ar{};
+  lr.stop_reason = ds.data(); lr.num_iters = di.data(); lr.final_cost = dc.data();
+  const bool is_root = comm.rank() == root;
+  DeviceBuffer<Scalar> ax;
+  DeviceBuffer<int32_t> as, ai;
+  DeviceBuffer<double> ac;
+  if (is_root) {
+    ax = DeviceBuffer<Scalar>(ctx, size_t(P_total) * xd); as = DeviceBuffer<int32_t>(ctx, P_total); ai = DeviceBuffer<int32_t>(ctx, P_total);
+    ac = DeviceBuffer<double>(ctx, P_total);
+    ar.stop_reason = as.data(); ar.num_iters = ai.data(); ar.final_cost = ac.data();
+  }
+  check(toa_gather(ctx.get(), comm.get(), dtype_of<Scalar>(), xd, P_total, dx.data(), &lr, root, is_root ? ax.data() : nullptr, &ar));
+  check(toa_synchronize(ctx.get()));
+  if (!is_root) return local;
+  BatchOutput all;
+  all.stop_reason.resize(P_total); all.num_iters.resize(P_total); all.final_cost.resize(P_total);
+  as.download(all.stop_reason.data()); ai.download(all.num_iters.data()); ac.download(all.final_cost.data());
+  if (x_all) { x_all->resize(size_t(P_total) * xd); ax.download(x_all->data()); }
+  return all;
+}
+
+// ---- the reference's own call shape: ONE parameter block, `Output out = Optimize(x, cost, options)` --------------------
+// (include/tinyopt/optimize.h:16-17 takes any `T& x`).  x: a scalar, or any contiguous container with data() / size()
+// (std::array, std::vector of another scalar type is excluded by the batch overload above, an Eigen::Matrix, ...) holding
+// the parameters of the single problem of `cost` (cost.P() == 1).  Updated in place; returns one Output.
+namespace detail {
+template <typename X, typename = void> struct is_container : std::false_type {};
+template <typename X> struct is_container<X, std::void_t<decltype(std::declval<X&>().data()), decltype(std::declval<X&>().size())>> : std::true_type {};
+template <typename S> struct is_std_vector : std::false_type {};
+template <typename S, typename A> struct is_std_vector<std::vector<S, A>> : std::true_type {};
+inline Output single(const BatchOutput& b, int n, bool history) {
+  Output o;
+  o.stop_reason = b.stop_reason[0]; o.num_iters = b.num_iters[0]; o.num_failures = b.num_failures[0];
+  o.num_consec_failures = b.num_consec_failures[0];
+  o.final_cost.cost = b.final_cost[0]; o.final_cost.num_resisuals = b.final_num_residuals[0];
+  o.final_cost.inlier_ratio = b.final_inlier_ratio.empty() ? 1.0f : b.final_inlier_ratio[0];
+  o.final_rerr_dec = b.final_rerr_dec[0];
+  if (!b.final_hessian.empty()) o.final_hessian.assign(b.final_hessian.begin(), b.final_hessian.begin() + size_t(n) * n);
+  if (history && b.hist_stride > 0) {
+    const int k = std::min<int>(o.num_iters, b.hist_stride);
+    o.errs.assign(b.errs.begin(), b.errs.begin() + k);
+    o.deltas2.assign(b.deltas2.begin(), b.deltas2.begin() + k);
+    for (int i = 0; i < k; ++i) o.successes.push_back(b.successes[i] != 0);
+  }
+  return o;
+}
+}  // namespace detail
+
+template <typename X, typename Cost, typename Scalar = std::decay_t<decltype(*std::declval<const Cost&>().data())>,
+          std::enable_if_t<!detail::is_std_vector<X>::value && (detail::is_container<X>::value || std::is_arithmetic<X>::value), int> = 0>
+Output Optimize(X& x, const Cost& cost, const Options& options = {}, bool history = false) {
+  if (cost.P() != 1) throw std::invalid_argument("tinyopt_amd::Optimize(x, cost): this overload solves ONE problem (cost.P() == 1)");
+  std::vector<Scalar> xv;
+  if constexpr (std::is_arithmetic<X>::value) {
+    xv.assign(1, Scalar(x));
+  } else {
+    xv.resize(x.size());
+    for (size_t i = 0; i < xv.size(); ++i) xv[i] = Scalar(x.data()[i]);
+  }
+  const BatchOutput b = Optimize(xv, cost, options, history);   // throws std::invalid_argument on a size mismatch
+  if constexpr (std::is_arithmetic<X>::value) {
+    x = X(xv[0]);
+  } else {
+    for (size_t i = 0; i < xv.size(); ++i) x.data()[i] = static_cast<std::decay_t<decltype(x.data()[0])>>(xv[i]);
+  }
+  return detail::single(b, cost.n(), history);
+}
 
 // The Accumulate-callback seam `acc(x, grad, H) -> Cost` (docs/API.md:37-57) for a batch; grad == nullptr
 // (cost only) when g / H are null.  g: [P][n], H: [P][n*n], cost: [P] (= ||r||^2), all host.

@@ -1,6 +1,7 @@
 // Exercises the header-only C++ adaptor (include/tinyopt_amd/tinyopt.hpp) the way a tinyopt user would:
 // build a cost model, call Optimize(x, cost, options), read the Output.  Reads like the reference's
 // tests (tests/sqrt2.cpp:30-56: Succeeded && Converged && answer within a margin).  Needs a GPU.
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -167,8 +168,133 @@ static void stepping() {
   }
 }
 
+// The reference's own call shape: ONE parameter block of any contiguous type, `Output out = Optimize(x, cost, options)`
+// (optimize.h:16-17; tests/sqrt2.cpp:30-56 `double x = 1; const auto& out = Optimize(x, loss); REQUIRE(out.Succeeded());`)
+static void single_problem_overload() {
+  Context ctx(0);
+  {
+    Sqrt2<double> cost(ctx, 1);
+    double x = 1;                                    // a scalar parameter, as in tests/sqrt2.cpp
+    const Output out = Optimize(x, cost);
+    REQUIRE(out.Succeeded());
+    REQUIRE(out.Converged());
+    REQUIRE(std::abs(x - std::sqrt(2.0)) < 1e-5);
+    REQUIRE(out.final_cost.cost < 1e-10 && out.final_cost.num_resisuals == 1);
+    REQUIRE(out.final_hessian.size() == 1 && out.final_hessian[0] > 0);
+    float xf = 3.2f;                                 // scalar of another type than the model's: converted both ways
+    Sqrt2<float> costf(ctx, 1);
+    const Output outf = Optimize(xf, costf, Options(), /*history=*/true);
+    REQUIRE(outf.Converged() && std::abs(double(xf) - std::sqrt(2.0)) < 1e-5);
+    REQUIRE(int(outf.errs.size()) == outf.num_iters && outf.errs.front() > outf.errs.back());
+  }
+  {
+    const int n = 6, m = 200;
+    std::mt19937_64 rng(3);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::vector<double> A(size_t(m) * n), b(m);
+    std::array<double, 6> xs{}, x{};                 // a fixed-size contiguous container (what an Eigen::Matrix<double,6,1> is)
+    for (int j = 0; j < n; ++j) { xs[j] = U(rng); x[j] = xs[j] + 0.5 * U(rng); }
+    for (auto& v : A) v = U(rng);
+    for (int i = 0; i < m; ++i) {
+      double t = 0;
+      for (int j = 0; j < n; ++j) t += A[size_t(i) * n + j] * xs[j];
+      b[i] = t + 0.1 * std::sin(t);
+    }
+    DenseRow<double> cost(ctx, 1, n, m, A.data(), b.data());
+    const Output out = Optimize(x, cost);
+    REQUIRE(out.Succeeded() && out.num_iters >= 2);
+    for (int j = 0; j < n; ++j) REQUIRE(std::abs(x[j] - xs[j]) < 1e-7);
+    Sqrt2<double> batch(ctx, 3);                     // a batch model through the single-problem overload: misuse
+    bool threw = false;
+    try { Optimize(x, batch); } catch (const std::invalid_argument&) { threw = true; }
+    REQUIRE(threw);
+  }
+}
+
+// Host-side stop controls (options.h:96-106) evaluated between the iterations of the stepping form
+static void stop_controls() {
+  Context ctx(0);
+  {  // tests/basic.cpp:126-143 "User stop callback": x - 2 from x = 1, min_error / min_grad_norm2 disabled,
+     // stop_callback2 = [](float, const VecXf&, const VecXf& g) { return g.norm() < 2.0; }  ->  kUserStopped
+    TestFn<double> cost(ctx, 1, 5);
+    double x = 1;
+    Options options;
+    options.min_error = 0;
+    options.min_grad_norm2 = 0;
+    int calls = 0;
+    options.stop_callback2 = [&](float, const std::vector<float>& dx, const std::vector<float>& g) {
+      ++calls;
+      return dx.size() == 1 && std::abs(g[0]) < 2.0f;
+    };
+    const Output out = Optimize(x, cost, options);
+    REQUIRE(out.stop_reason == kUserStopped);
+    REQUIRE(out.Succeeded() && !out.Converged());
+    REQUIRE(calls == 1 && out.num_iters == 1);       // |g| = |x - 2| = 1 < 2 at the very first iteration
+    REQUIRE(std::abs(x - 2.0) < 1e-3);               // the step of that iteration is still applied (optimizer.h:271-279)
+    // after ONE iteration prev_lambda is still 0: Hessian() returns the damped diagonal as is (lm.h:157-171), reproduced
+    REQUIRE(out.final_hessian.size() == 1 && std::abs(out.final_hessian[0] - 1.0001) < 1e-7);
+  }
+  {  // stop_callback(err, |dx|^2, |g|^2), per problem of a batch: only the problems it names stop, the others converge
+    Sqrt2<double> cost(ctx, 3);
+    std::vector<double> x{1.0, -0.3, 3.2}, xr = x;
+    Options options;
+    options.max_iters = 20;
+    options.max_consec_failures = 0;
+    const auto ref = Optimize(xr, cost, options);
+    // names exactly one problem: x0 = 3.2 has r^2 = (10.24 - 2)^2 = 67.9 at iteration 0 (x0 = -0.3 overshoots to a cost of
+    // ~102 at iteration 1 and must NOT be stopped)
+    options.stop_callback = [](double err, double, double) { return err > 67.0 && err < 69.0; };
+    const auto out = Optimize(x, cost, options);
+    REQUIRE(out.stop_reason[2] == kUserStopped && out.num_iters[2] == 1);
+    for (int p = 0; p < 2; ++p) {
+      REQUIRE(out.stop_reason[p] == ref.stop_reason[p] && out.num_iters[p] == ref.num_iters[p]);
+      REQUIRE(std::abs(x[p] - xr[p]) < 1e-14);
+    }
+  }
+  {  // tests/basic.cpp:88-106 "Timing out": max_duration_ms exceeded -> kTimedOut (a success, not a convergence)
+    Sqrt2<double> cost(ctx, 2);
+    std::vector<double> x{1.0, 3.2};
+    Options options;
+    options.max_duration_ms = 1e-6;
+    const auto out = Optimize(x, cost, options);
+    for (int p = 0; p < 2; ++p) {
+      REQUIRE(out.stop_reason[p] == kTimedOut && out.num_iters[p] == 1);
+      REQUIRE(out.Succeeded(p) && !out.Converged(p));
+    }
+    REQUIRE(x[0] != 1.0);                            // the first iteration's step was applied before the clock was read
+  }
+}
+
+// C1: the sharded form with a one-rank communicator (all a single-GPU box can run): Optimize + the ONE collective of the
+// path; the gathered rows must be the local rows, in order, in their native types
+static void sharded() {
+  Context ctx(0);
+  const Communicator::Id id = Communicator::UniqueId();
+  Communicator comm(ctx, id, /*nranks=*/1, /*rank=*/0);
+  const auto range = comm.shard(7);
+  REQUIRE(range.first == 0 && range.second == 7);
+  Sqrt2<float> cost(ctx, 7);
+  std::vector<float> x{1.f, -0.3f, 3.2f, 0.5f, 2.f, -4.f, 1.4f}, xa = x, all_x;
+  Options options;
+  options.max_iters = 20;
+  options.max_consec_failures = 0;
+  const auto ref = Optimize(xa, cost, options);
+  const auto out = ShardedOptimize(x, cost, options, comm, 7, &all_x);
+  REQUIRE(all_x.size() == 7);
+  for (int p = 0; p < 7; ++p) {
+    REQUIRE(all_x[p] == xa[p] && x[p] == xa[p]);
+    REQUIRE(out.stop_reason[p] == ref.stop_reason[p] && out.num_iters[p] == ref.num_iters[p] && out.final_cost[p] == ref.final_cost[p]);
+  }
+  int64_t lo = -1, hi = -1;   // the block partition of SURVEY §8e: contiguous, sizes differ by at most one
+  REQUIRE(toa_shard_range(100000, 3, 8, &lo, &hi) == 0 && lo == 37500 && hi == 50000);
+  REQUIRE(toa_shard_range(11, 1, 2, &lo, &hi) == 0 && lo == 6 && hi == 11);
+}
+
 int main() {
+  if (const char* e = std::getenv("TOA_TEST_SHARDED"); !e || e[0] != '0') sharded();
   stepping();
+  single_problem_overload();
+  stop_controls();
   huber();
   sqrt2<double>();
   sqrt2<float>();

@@ -66,3 +66,18 @@ def test_gather_single_process_passthrough():
     x = torch.zeros(4, 2)
     out = gather_output(x, {"stop_reason": torch.ones(4, dtype=torch.int32)}, P_total=4)
     assert out["x"] is x and out["stop_reason"].sum() == 4
+
+
+def test_c_abi_shard_range_matches_python(built):
+    """toa_shard_range (the C-ABI's block partition, used by toa_gather's unpack) == tinyopt_amd.dist.shard_range."""
+    import ctypes as C
+    from tinyopt_amd import _capi
+    from tinyopt_amd.dist import shard_range
+    lib = _capi.load()
+    lo, hi = C.c_int64(), C.c_int64()
+    for P in (0, 1, 7, 8, 100000, 12501):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert lib.toa_shard_range(P, r, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_range(P, r, world)
+    assert lib.toa_shard_range(5, 2, 2, C.byref(lo), C.byref(hi)) != 0

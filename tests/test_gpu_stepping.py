@@ -81,3 +81,78 @@ def test_bounded_run_and_in_place_updates(ta, oracle):
     torch.cuda.synchronize()
     assert (out.stop_reason.cpu().numpy() > 0).all()
     assert float((x - torch.from_numpy(xs).cuda()).abs().max()) < min(err2, 1e-2)
+
+
+def test_stop_callback2_reference_test(ta):
+    """tests/basic.cpp:126-143 "User stop callback": x - 2 from x = 1, min_error / min_grad_norm2 disabled,
+    stop_callback2 = g.norm() < 2 -> kUserStopped; the callback sees (err, dx, g) of the iteration."""
+    seen = []
+
+    def cb(err, dx, g):
+        seen.append((err, dx.copy(), g.copy()))
+        return float(np.linalg.norm(g)) < 2.0
+
+    o = ta.Options()
+    o.min_error = 0.0
+    o.min_grad_norm2 = 0.0
+    o.stop_callback2 = cb
+    x = torch.ones(1, 1, dtype=torch.float64, device="cuda")
+    out = ta.Optimize(x, ta.TestFn("x_minus_2", 1), o)
+    torch.cuda.synchronize()
+    assert int(out.stop_reason[0]) == int(ta.StopReason.kUserStopped)
+    assert bool(out.Succeeded()[0]) and not bool(out.Converged()[0])
+    assert len(seen) == 1 and int(out.num_iters[0]) == 1
+    err, dx, g = seen[0]
+    assert err == 1.0 and abs(float(g[0]) + 1.0) < 1e-6 and abs(float(dx[0]) - 1.0 / 1.0001) < 1e-6   # grad = res = -1, H = 1
+    assert abs(float(x[0, 0]) - (1.0 + 1.0 / 1.0001)) < 1e-9         # the step of that iteration is still applied
+    # finalised like a problem that stops by itself: after ONE iteration prev_lambda is still 0, so Hessian() returns the
+    # damped diagonal as is (lm.h:157-171) — the reference's own quirk, reproduced
+    assert abs(float(out.final_hessian[0, 0, 0]) - 1.0001) < 1e-7
+
+
+def test_stop_callback_per_problem_and_timeout(ta, oracle):
+    """stop_callback(err, |dx|^2, |g|^2) per problem of a batch: the named problems stop with kUserStopped after that
+    iteration, every other problem runs exactly as without the callback; max_duration_ms -> kTimedOut for everything
+    still running (tests/basic.cpp:88-106)."""
+    A, b, x0, xs = oracle.synth_dense_row(12, 12, 500, np.float64, seed=21)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    o = ta.Options()
+    xr = torch.from_numpy(x0.copy()).cuda()
+    ref = ta.Optimize(xr, model, o, history=True)
+    e1 = ref.errs.cpu().numpy()[:, 1]                 # cost seen at iteration 1
+    thr = float(np.sort(e1)[6])
+    calls = []
+
+    def cb(err, dx2, g2):
+        calls.append((err, dx2, g2))
+        return len(calls) > 12 and err > thr          # from the second pass on: stop the problems whose cost is above thr
+
+    o2 = ta.Options()
+    o2.stop_callback = cb
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o2, history=True)
+    torch.cuda.synchronize()
+    stop, iters = out.stop_reason.cpu().numpy(), out.num_iters.cpu().numpy()
+    user = e1 > thr
+    assert user.sum() == 5
+    assert (stop[user] == int(ta.StopReason.kUserStopped)).all() and (iters[user] == 2).all()
+    assert np.array_equal(stop[~user], ref.stop_reason.cpu().numpy()[~user])
+    assert np.array_equal(iters[~user], ref.num_iters.cpu().numpy()[~user])
+    keep = torch.from_numpy(~user).cuda()
+    assert float((x[keep] - xr[keep]).abs().max()) < 1e-9      # stepping form vs fused kernel: equal up to the fold order of H
+    # the callback saw the same (err, |dx|^2) the history records
+    assert np.allclose(sorted(c[0] for c in calls[:12]), sorted(out.errs.cpu().numpy()[:, 0]), rtol=1e-12)
+    assert np.allclose(sorted(c[1] for c in calls[:12]), sorted(out.deltas2.cpu().numpy()[:, 0]), rtol=1e-12)
+    assert all(c[2] > 0 for c in calls)               # |g|^2 is formed for the callbacks even with min_grad_norm2 == 0 (optimizer.h:413-415)
+    # stopped problems still carry a finalised Output row
+    assert (out.final_cost.cpu().numpy()[user] > 0).all() and out.final_hessian[torch.from_numpy(user).cuda()].abs().sum() > 0
+
+    o3 = ta.Options()
+    o3.max_duration_ms = 1e-6
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o3)
+    torch.cuda.synchronize()
+    assert (out.stop_reason.cpu().numpy() == int(ta.StopReason.kTimedOut)).all()
+    assert (out.num_iters.cpu().numpy() == 1).all()
+    assert bool(out.Succeeded().all()) and not bool(out.Converged().any())
+    assert float((x - torch.from_numpy(x0).cuda()).abs().max()) > 1e-3       # the first step was applied

@@ -7,7 +7,7 @@ Host-side mirror (Python flavour) of the reference's user API for the LM hot pat
 """
 from ._capi import (F32, F64, MODEL_DENSE_ROW, STOP_NAMES, ToaError, ToaOptions, ToaResults, load)  # noqa: F401
 from .api import (Context, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowNatural, TestFn, MahaPrior, SE3Prior, Options, Output, Optimize, Optimizer, StopReason, accumulate, solve_damped, inv_cov, robust_norm, LOSS_KINDS)  # noqa: F401
-from .dist import gather_output, shard_range  # noqa: F401
+from .dist import Communicator, gather_native, gather_output, shard_range  # noqa: F401
 
 __all__ = ["Context", "DenseRow", "GaussianPrior", "Sqrt2", "SE3Reproj", "CircleFit", "DenseRowAD6", "DenseRowNatural", "TestFn", "MahaPrior", "SE3Prior", "Options", "Output", "Optimize", "Optimizer", "StopReason", "accumulate", "solve_damped", "inv_cov", "robust_norm", "LOSS_KINDS",
-           "gather_output", "shard_range", "F32", "F64"]
+           "gather_output", "gather_native", "Communicator", "shard_range", "F32", "F64"]
