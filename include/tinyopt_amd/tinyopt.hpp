@@ -172,10 +172,22 @@ constexpr int dtype_of() {
   return std::is_same<Scalar, float>::value ? TOA_F32 : TOA_F64;
 }
 
+// The M-estimator part of a cost functor (losses/robust_norms.h:32-316; docs/API.md:396-411 wraps a residual's squared norm
+// in `losses::Huber(n2, th2, true)`): `cost.set_loss(TOA_LOSS_HUBER, th)` makes every launch with this model pass each
+// residual item through rho — cost += l, the item's J^T J / J^T r scaled by s, inliers in final_inlier_ratio.  Honoured by
+// DenseRow, CircleFit (the families toa_set_loss lists); SE3Reproj carries its loss in its data header.
+struct LossTag {
+  int loss_kind = TOA_LOSS_L2;
+  double loss_th2 = 0;
+  void set_loss(int kind, double th) { loss_kind = kind; loss_th2 = th * th; }
+};
+template <typename Cost>
+inline void apply_loss(const Cost& cost) { check(toa_set_loss(cost.ctx().get(), cost.loss_kind, cost.loss_th2)); }
+
 // Device cost model: r_i(x) = a_i.x + 0.1 sin(a_i.x) - b_i for P problems.  Takes the place of the
 // residual functor in Optimize(x, cost) (e.g. benchmarks/dense.cpp:56,71-74).
 template <typename Scalar>
-class DenseRow {
+class DenseRow : public LossTag {
  public:
   // A: [P][m][n] row-major, b: [P][m] — host arrays; uploaded and packed into the HBM layout once.
   DenseRow(const Context& ctx, int64_t P, int n, int m, const Scalar* A, const Scalar* b) : ctx_(&ctx), P_(P), n_(n), m_(m) {
@@ -205,7 +217,7 @@ class DenseRow {
 
 // Generic holder for the models whose device data is a plain host array uploaded as is.
 template <typename Scalar, int ModelId>
-class PlainModel {
+class PlainModel : public LossTag {
  public:
   PlainModel(const Context& ctx, int64_t P, int n, int m, int xdim, const Scalar* host, size_t count)
       : ctx_(&ctx), P_(P), n_(n), m_(m), xdim_(xdim), data_(ctx, count ? count : 1) {
@@ -335,6 +347,7 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
     r.errs = errs.data(); r.deltas2 = d2.data(); r.successes = succ.data(); r.hist_stride = out.hist_stride;
   }
   const toa_options pod = options.to_pod();
+  apply_loss(cost);
   check(toa_lm_run(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), &pod, &r, nullptr));
   check(toa_synchronize(ctx.get()));
   dx.download(x.data());
@@ -374,6 +387,7 @@ class Optimizer {
       succ_ = DeviceBuffer<uint8_t>(cost.ctx(), size_t(P_) * hist_stride_); succ_.zero();
       r_.errs = errs_.data(); r_.deltas2 = d2_.data(); r_.successes = succ_.data(); r_.hist_stride = hist_stride_;
     }
+    apply_loss(cost);
     check(toa_lm_begin(cost.ctx().get(), Cost::model_id, dtype_of<Scalar>(), n_, cost.m(), P_, cost.data(), dx_.data(), &pod_, &r_,
                        state_.data()));
   }
@@ -381,6 +395,7 @@ class Optimizer {
   int64_t Step() {
     const Context& ctx = cost_->ctx();
     active_.zero();
+    apply_loss(*cost_);
     check(toa_lm_step(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
                       nullptr, state_.data(), active_.data()));
     check(toa_synchronize(ctx.get()));
@@ -640,6 +655,7 @@ void Accumulate(const Cost& cost, const std::vector<Scalar>& x, std::vector<Scal
   const bool want = g && H;
   DeviceBuffer<Scalar> dg, dH;
   if (want) { dg = DeviceBuffer<Scalar>(ctx, size_t(P) * n); dH = DeviceBuffer<Scalar>(ctx, size_t(P) * n * n); }
+  apply_loss(cost);
   check(toa_accumulate(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), want ? 1 : 0,
                        want ? dg.data() : nullptr, want ? dH.data() : nullptr, dc.data(), nullptr));
   check(toa_synchronize(ctx.get()));

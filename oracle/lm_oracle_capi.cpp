@@ -7,6 +7,7 @@
 
 #include "../include/tinyopt_amd.h"
 #include "lm_oracle.hpp"
+#include "robust.hpp"
 #include "se3.hpp"
 #include "testfns.hpp"
 #include "synth.hpp"
@@ -49,6 +50,14 @@ static Options from_pod(const toa_options& p) {
 // grad = J^T r, H = J^T J (full), cost = (||r||^2, m); all arithmetic in T.
 // Loop order is i-outer (rank-1 updates) — same per-entry summation order as a naive
 // triple loop, but vectorisable, so the timed CPU baseline is not artificially slow.
+// M-estimator applied by the DenseRow / circle-fit accumulators below (set by oracle_set_loss): what a tinyopt user does
+// by wrapping the residual's squared norm in `losses::Huber(n2, th2, true)` inside the cost functor
+// (losses/robust_norms.h:20-26, docs/API.md:396-411): cost += l, the residual's J^T J and J^T r scaled by s = dl/dn2,
+// inliers = residuals with n2 <= th2 (cost.h:84-95).  kind 0 = plain squared L2.
+static int g_loss_kind = 0;
+static double g_loss_th2 = 0;
+static float* g_inlier_out = nullptr;   // [P] final inlier ratios of the next oracle_dense_row_lm call (nullptr = not wanted)
+
 template <typename T>
 struct DenseRowAcc {
   int n, m;
@@ -58,27 +67,38 @@ struct DenseRowAcc {
   DenseRowAcc(int n_, int m_, const T* A_, const T* b_) : n(n_), m(m_), A(A_), b(b_), Jrow(n_) {}
   Cost operator()(const std::vector<T>& x, T* g, T* H) const {
     T c = 0;
+    const int kind = g_loss_kind;
+    const T th2 = T(g_loss_th2);
+    int inliers = 0;
     for (int i = 0; i < m; ++i) {
       const T* a = A + size_t(i) * n;
       T t = 0;
       for (int j = 0; j < n; ++j) t += a[j] * x[j];
       const T r = t + T(0.1) * std::sin(t) - b[i];
-      c += r * r;
+      T w = T(1);
+      if (kind == 0) {
+        c += r * r;
+      } else {
+        const auto ls = robust::Apply<T>(kind, r * r, th2);
+        c += ls.l;
+        w = ls.s;
+        inliers += (r * r <= th2) ? 1 : 0;
+      }
       if (g) {
         const T s = T(1) + T(0.1) * std::cos(t);
         T* J = Jrow.data();
         for (int j = 0; j < n; ++j) J[j] = s * a[j];
-        for (int j = 0; j < n; ++j) g[j] += J[j] * r;
+        for (int j = 0; j < n; ++j) g[j] += w * J[j] * r;
         if (H) {
           for (int q = 0; q < n; ++q) {  // column q of col-major H: H[q*n + p] += J[p]*J[q]
-            const T Jq = J[q];
+            const T Jq = w * J[q];
             T* Hq = H + size_t(q) * n;
             for (int p = 0; p < n; ++p) Hq[p] += J[p] * Jq;
           }
         }
       }
     }
-    return Cost(double(c), m);
+    return kind == 0 ? Cost(double(c), m) : Cost(double(c), m, m ? float(inliers) / float(m) : 1.0f);
   }
 };
 
@@ -124,6 +144,7 @@ static void run_batch_dense_row(int64_t P, int n, int m, const T* A, const T* b,
     if (fails) fails[p] = out.num_failures;
     if (cost) cost[p] = out.final_cost.cost;
     if (rerr) rerr[p] = out.final_rerr_dec;
+    if (g_inlier_out) g_inlier_out[p] = out.final_cost.inlier_ratio;
     if (finalH && !out.final_hessian.empty())
       std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
     if (errs) {
@@ -155,6 +176,31 @@ static void se3_lm_t(int64_t P, int npts, const T* data, T* poses, const Options
     if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * 36, out.final_hessian.data(), sizeof(double) * 36);
   }
 }
+// AccumulateFromJ (oracle/lm_oracle.hpp) with the M-estimator of oracle_set_loss on every scalar residual: what the AD bridge
+// computes when the user's functor returns residuals already passed through `losses::X(n2, th2, true)`.
+template <typename T>
+static Cost AccumulateFromJLoss(int m, int n, const T* r, const T* J, T* g, T* H) {
+  if (g_loss_kind == 0) return AccumulateFromJ<T>(m, n, r, J, g, H);
+  const T th2 = T(g_loss_th2);
+  T c = 0;
+  int inliers = 0;
+  if (g) std::fill(g, g + n, T(0));
+  if (g && H) std::fill(H, H + size_t(n) * n, T(0));
+  for (int i = 0; i < m; ++i) {
+    const auto ls = robust::Apply<T>(g_loss_kind, r[i] * r[i], th2);
+    c += ls.l;
+    inliers += (r[i] * r[i] <= th2) ? 1 : 0;
+    if (g) {
+      for (int a = 0; a < n; ++a) {
+        const T sw = ls.s * J[size_t(i) * n + a];
+        g[a] += sw * r[i];
+        if (H) for (int b2 = 0; b2 < n; ++b2) H[size_t(b2) * n + a] += sw * J[size_t(i) * n + b2];
+      }
+    }
+  }
+  return Cost(double(c), m, m ? float(inliers) / float(m) : 1.0f);
+}
+
 // Gaussian prior with a GENERAL covariance, whitened by the upper Cholesky factor U of the information matrix:
 // res = U (x - y), J = U  (losses/mahalanobis.h:160-171 MahaWhitenedInfoU; the AD form of tests/cov.cpp:127-146
 // `res = Lt * (x - y)`), folded as the AD bridge folds a residual vector: grad = J^T res, H = J^T J, cost = ||res||^2
@@ -191,6 +237,12 @@ static void maha_prior_lm_t(int64_t P, int n, const T* data, T* x, const Options
   }
 }
 extern "C" {
+
+void oracle_set_loss(int kind, double th2, float* inlier_ratio_out) {
+  g_loss_kind = kind;
+  g_loss_th2 = th2;
+  g_inlier_out = inlier_ratio_out;
+}
 
 int oracle_num_threads_max() {
 #ifdef _OPENMP
@@ -237,6 +289,7 @@ void oracle_dense_row_accumulate(int dtype, int64_t P, int n, int m, const void*
       if (gp) { std::fill(gp, gp + n, 0.f); std::fill(Hp, Hp + size_t(n) * n, 0.f); }
       Cost c = acc(xv, gp, Hp);
       cost[p] = c.cost; if (nres) nres[p] = c.num_residuals;
+      if (g_inlier_out) g_inlier_out[p] = c.inlier_ratio;
     } else {
       DenseRowAcc<double> acc(n, m, (const double*)A + size_t(p) * m * n, (const double*)b + size_t(p) * m);
       std::vector<double> xv((const double*)x + p * n, (const double*)x + (p + 1) * n);
@@ -245,6 +298,7 @@ void oracle_dense_row_accumulate(int dtype, int64_t P, int n, int m, const void*
       if (gp) { std::fill(gp, gp + n, 0.0); std::fill(Hp, Hp + size_t(n) * n, 0.0); }
       Cost c = acc(xv, gp, Hp);
       cost[p] = c.cost; if (nres) nres[p] = c.num_residuals;
+      if (g_inlier_out) g_inlier_out[p] = c.inlier_ratio;
     }
   }
 }
@@ -538,8 +592,7 @@ void oracle_circle_fit_lm(int dtype, int64_t P, int npts, const void* obs, void*
           r[i] = dx * dx + dy * dy - v[2] * v[2];
           J[i * 3] = -2 * dx; J[i * 3 + 1] = -2 * dy; J[i * 3 + 2] = -2 * v[2];
         }
-        if (g) { std::fill(g, g + 3, 0.f); }
-        return AccumulateFromJ<float>(npts, 3, r.data(), J.data(), g, H);
+        return AccumulateFromJLoss<float>(npts, 3, r.data(), J.data(), g, H);
       };
       Optimizer<float> opt(o, 3);
       out = opt.OptimizeAcc(xv, acc, EuclidPlus<float>());
@@ -554,7 +607,7 @@ void oracle_circle_fit_lm(int dtype, int64_t P, int npts, const void* obs, void*
           r[i] = dx * dx + dy * dy - v[2] * v[2];
           J[i * 3] = -2 * dx; J[i * 3 + 1] = -2 * dy; J[i * 3 + 2] = -2 * v[2];
         }
-        return AccumulateFromJ<double>(npts, 3, r.data(), J.data(), g, H);
+        return AccumulateFromJLoss<double>(npts, 3, r.data(), J.data(), g, H);
       };
       Optimizer<double> opt(o, 3);
       out = opt.OptimizeAcc(xv, acc, EuclidPlus<double>());
@@ -563,6 +616,7 @@ void oracle_circle_fit_lm(int dtype, int64_t P, int npts, const void* obs, void*
     if (stop) stop[p] = out.stop_reason;
     if (iters) iters[p] = out.num_iters;
     if (cost) cost[p] = out.final_cost.cost;
+    if (g_inlier_out) g_inlier_out[p] = out.final_cost.inlier_ratio;
   }
 }
 

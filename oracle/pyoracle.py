@@ -69,6 +69,7 @@ def load(path: str | None = None):
     lib.oracle_robust_norm.argtypes = [C.c_int, C.c_int, C.c_int64, vp, C.c_double, vp, vp]
     lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
     lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
+    lib.oracle_set_loss.argtypes = [C.c_int, C.c_double, vp]
     lib.oracle_circle_fit_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
     if path is None:
         _lib = lib
@@ -93,9 +94,18 @@ def synth_dense_row(P, n, m, dtype, seed=0x71940917, problem0=0):
     return A, b, x0, xs
 
 
-def dense_row_accumulate(A, b, x, want_grad=True):
+def dense_row_accumulate(A, b, x, want_grad=True, loss=None, th2=0.0):
+    """(g, H, cost, nres); with a loss also the inlier ratio as a fifth element."""
     lib = load()
     P, m, n = A.shape
+    if loss is not None:
+        inl = np.ones(P, np.float32)
+        lib.oracle_set_loss(LOSS_KINDS[loss], float(th2), _p(inl))
+        try:
+            r = dense_row_accumulate(A, b, x, want_grad)
+        finally:
+            lib.oracle_set_loss(0, 0.0, None)
+        return r + (inl,)
     g = np.zeros((P, n), A.dtype)
     H = np.zeros((P, n, n), A.dtype)
     cost = np.zeros(P, np.float64)
@@ -115,10 +125,20 @@ def solve_damped(H, g, scale=1.0):
     return dx, ok
 
 
-def dense_row_lm(A, b, x0, pod: ToaOptions, history=False, nthreads=1, lib=None):
-    """Returns dict(x, stop, iters, fails, cost, rerr, H, errs, deltas2, succ, seconds)."""
+def dense_row_lm(A, b, x0, pod: ToaOptions, history=False, nthreads=1, lib=None, loss=None, th2=0.0):
+    """Returns dict(x, stop, iters, fails, cost, rerr, H, errs, deltas2, succ, seconds[, inlier_ratio]).
+    loss / th2: an M-estimator on every residual (LOSS_KINDS name; squared threshold)."""
     lib = lib or load()
     P, m, n = A.shape
+    if loss is not None:
+        inl = np.ones(P, np.float32)
+        lib.oracle_set_loss(LOSS_KINDS[loss], float(th2), _p(inl))
+        try:
+            r = dense_row_lm(A, b, x0, pod, history=history, nthreads=1, lib=lib)
+        finally:
+            lib.oracle_set_loss(0, 0.0, None)
+        r["inlier_ratio"] = inl
+        return r
     x = np.array(x0, copy=True)
     stop = np.zeros(P, np.int32)
     iters = np.zeros(P, np.int32)
@@ -270,10 +290,19 @@ def se3_add_outliers(data, npts, frac, seed=7, amplitude=80.0):
     return out, mask
 
 
-def circle_fit_lm(obs, x0, pod: ToaOptions):
-    """tests/circle.cpp:32-68 for a batch; obs [P, npts, 2], x0 [P, 3]."""
+def circle_fit_lm(obs, x0, pod: ToaOptions, loss=None, th2=0.0):
+    """tests/circle.cpp:32-68 for a batch; obs [P, npts, 2], x0 [P, 3].  loss / th2: M-estimator per residual."""
     lib = load()
     P, npts, _ = obs.shape
+    if loss is not None:
+        inl = np.ones(P, np.float32)
+        lib.oracle_set_loss(LOSS_KINDS[loss], float(th2), _p(inl))
+        try:
+            r = circle_fit_lm(obs, x0, pod)
+        finally:
+            lib.oracle_set_loss(0, 0.0, None)
+        r["inlier_ratio"] = inl
+        return r
     x = np.array(x0, copy=True)
     stop = np.zeros(P, np.int32)
     iters = np.zeros(P, np.int32)

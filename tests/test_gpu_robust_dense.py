@@ -1,0 +1,137 @@
+"""M-estimators on the dense families (VERDICT r1 missing #4): `model.with_loss(kind, th)` =
+wrapping every residual's squared norm in the reference's `losses::X(n2, th2, true)` inside the cost functor
+(losses/robust_norms.h:20-26 "JtJ * dx = Jt*res*s", docs/API.md:396-411): cost += l, the residual's J^T J and J^T r
+scaled by s, inliers reported through Cost::inlier_ratio (cost.h:84-95).  DenseRow (MFMA path: sqrt(s) folded into the
+row [J | r] in front of the Gram) and the Jet models against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from parity import check_trajectories, gpu_dict
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["truncated", "huber", "tukey", "arctan", "cauchy", "geman_mcclure", "blake_zisserman"]
+
+
+def _with_outliers(oracle, P, n, m, dtype, frac=0.1, seed=5):
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=seed)
+    rng = np.random.default_rng(seed)
+    mask = rng.uniform(size=(P, m)) < frac
+    off = rng.uniform(1, 3, (P, m)) * np.where(rng.uniform(size=(P, m)) < 0.5, -1.0, 1.0)
+    b = b + (mask * off).astype(dtype)     # gross outliers, |offset| in [1, 3]: a thousand sigmas (noise 1e-3), a clean gap to the inliers
+    return A, b.astype(dtype), x0, xs, mask
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 12, 203), (np.float64, 50, 130), (np.float32, 50, 402), (np.float64, 16, 77),
+                                       (np.float32, 6, 1000)])
+def test_dense_row_robust_accumulate_matches_oracle(ta, oracle, kind, dtype, n, m):
+    """(g, H, cost, inlier ratio) and the cost-only form, every loss kind, b in the main block (THIN = 0: n = 12, 6) and in
+    the thin tail (n = 50, 16), ragged row counts (padding rows must count neither as residuals nor as inliers)."""
+    P = 5
+    A, b, x0, xs, _ = _with_outliers(oracle, P, n, m, dtype)
+    x = (xs + 0.02 * np.random.default_rng(1).uniform(-1, 1, xs.shape)).astype(dtype)   # near the solution: inliers AND outliers
+    # fp64: a threshold INSIDE the cloud of inlier residuals (|r| up to ~0.08 here) exercises both branches of every loss
+    # on neighbouring rows.  fp32: hardware sin / cos move r in its last bits, and the branch of a row that sits on the
+    # threshold to 1e-6 is not reproducible — for the discontinuous losses (truncated) one flipped row changes g by r J —
+    # so the fp32 fixture keeps the threshold in the gap between the inliers and the gross outliers.
+    th = 0.05 if dtype == np.float64 else 0.3
+    g_ref, H_ref, c_ref, nres_ref, inl_ref = oracle.dense_row_accumulate(A, b, x, loss=kind, th2=th * th)
+    r_all = np.einsum("pmn,pn->pm", A.astype(np.float64), x.astype(np.float64))
+    r_all = r_all + 0.1 * np.sin(r_all) - b
+    if dtype == np.float32:
+        assert (np.abs(np.abs(r_all) - th) > 1e-3).all()      # nothing near the threshold
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()).with_loss(kind, th)
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    assert np.abs(g.cpu().numpy() - g_ref).max() <= tol * np.abs(g_ref).max()
+    assert np.abs(H.cpu().numpy() - H_ref).max() <= tol * np.abs(H_ref).max()
+    assert np.allclose(c.cpu().numpy(), c_ref, rtol=tol) and (nres.cpu().numpy() == m).all()
+    c0 = ta.accumulate(model, torch.from_numpy(x).cuda(), want_grad=False)[2]
+    assert np.allclose(c0.cpu().numpy(), c_ref, rtol=tol)
+    assert 0.5 < inl_ref.min() and inl_ref.max() < 1.0          # the fixture really has both kinds of residuals
+    # the plain model on the same data is NOT the same system (the loss is active) ...
+    g2 = ta.accumulate(ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()), torch.from_numpy(x).cuda())[0]
+    assert np.abs(g2.cpu().numpy() - g_ref).max() > 1e-3 * np.abs(g_ref).max()
+    # ... and "l2" / no loss is bit-identical to the untouched path
+    g3 = ta.accumulate(model.with_loss(None), torch.from_numpy(x).cuda())[0]
+    assert torch.equal(g3, g2)
+
+
+@pytest.mark.parametrize("kind", ["huber", "cauchy", "tukey"])
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 12, 500), (np.float32, 50, 2000), (np.float64, 18, 300)])
+def test_dense_row_robust_lm_recovers_planted_solution(ta, oracle, kind, dtype, n, m):
+    """10 % gross outliers in b: the plain L2 solve is dragged away from the planted x*, the robust solve lands on it;
+    trajectory, StopReason / iterations and the inlier ratio against the oracle (tie-aware, tests/parity.py)."""
+    P = 8
+    A, b, x0, xs, mask = _with_outliers(oracle, P, n, m, dtype, frac=0.1)
+    x0 = (xs + 0.05 * np.random.default_rng(2).uniform(-1, 1, xs.shape)).astype(dtype)   # inside the basin of the redescending losses
+    # huber / cauchy keep a gradient on every row: a tight threshold.  tukey's weight vanishes beyond the threshold: it must
+    # enclose the inlier residuals of the START (|r| ~ 0.2 here), else the first normal matrix is all but empty
+    th = 0.5 if kind == "tukey" else 0.02
+    opts = ta.Options()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True, loss=kind, th2=th * th)
+    base = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, base.with_loss(kind, th), opts, history=True)
+    xl2 = torch.from_numpy(x0.copy()).cuda()
+    ta.Optimize(xl2, base, opts)
+    torch.cuda.synchronize()
+    err_rob = np.abs(x.cpu().numpy() - xs).max()
+    err_l2 = np.abs(xl2.cpu().numpy() - xs).max()
+    assert err_rob < 5e-3 and err_l2 > 5 * err_rob, (err_rob, err_l2)
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    st = check_trajectories(gpu_dict(out, x), refd, dtype, opts.to_pod(), label=f"{kind} {n}x{m}")
+    assert st["full"] + st["ties"] == P
+    inl = out.final_inlier_ratio.cpu().numpy()
+    assert np.abs(inl - ref["inlier_ratio"]).max() <= (2.0 / m if dtype == np.float64 else 6.0 / m)
+    assert np.abs(inl - (1.0 - mask.mean(1))).max() < 0.05     # ~ the fraction of rows left untouched
+    # the row-split form (team kernel: chunk partials of cost AND inliers folded) agrees with the fused kernel
+    if n <= 15:
+        x2 = torch.from_numpy(x0.copy()).cuda()
+        out2 = ta.Optimize(x2, base.with_loss(kind, th), opts, splits=3)
+        torch.cuda.synchronize()
+        assert float((x2 - x).abs().max()) < (1e-9 if dtype == np.float64 else 2e-3)
+        assert np.abs(out2.final_inlier_ratio.cpu().numpy() - inl).max() <= 2.0 / m
+
+
+@pytest.mark.parametrize("tdt,dtype", [(torch.float64, np.float64), (torch.float32, np.float32)])
+def test_circle_fit_with_outliers(ta, oracle, tdt, dtype):
+    """The Jet family: tests/circle.cpp's fit with a fifth of the points thrown far off the circle; Cauchy on each residual."""
+    P, npts = 6, 40
+    rng = np.random.default_rng(3)
+    ang = np.linspace(0, 2 * np.pi, npts)[None, :] + rng.uniform(0, 1, (P, 1))
+    obs = np.stack([2 + 2 * np.cos(ang), 7 + 2 * np.sin(ang)], -1) + 1e-4 * rng.uniform(-1, 1, (P, npts, 2))
+    bad = rng.uniform(size=(P, npts)) < 0.2
+    obs = (obs + bad[..., None] * rng.uniform(1.0, 2.0, (P, npts, 2))).astype(dtype)
+    x0 = np.tile(np.array([1.8, 7.3, 1.7], dtype), (P, 1))
+    o = ta.Options()
+    th = 0.05
+    ref = oracle.circle_fit_lm(obs, x0, o.to_pod(), loss="cauchy", th2=th * th)
+    model = ta.CircleFit(torch.from_numpy(obs).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model.with_loss("cauchy", th), o)
+    xl2 = torch.from_numpy(x0.copy()).cuda()
+    ta.Optimize(xl2, model, o)
+    torch.cuda.synchronize()
+    xg = x.cpu().numpy()
+    truth = np.array([2.0, 7.0, 2.0])
+    assert np.abs(np.abs(xg) - truth).max() < 5e-3
+    assert np.abs(np.abs(xl2.cpu().numpy()) - truth).max() > 0.1       # plain least squares is pulled by the outliers
+    assert np.abs(xg - ref["x"]).max() < (1e-7 if dtype == np.float64 else 2e-3)
+    if dtype == np.float64:
+        assert np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"]) and np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+    assert np.abs(out.final_inlier_ratio.cpu().numpy() - ref["inlier_ratio"]).max() <= 1.5 / npts
+
+
+def test_loss_argument_errors(ta):
+    model, x0, _ = ta.DenseRow.synthetic(4, 12, 50, torch.float64)
+    with pytest.raises(ValueError):
+        model.with_loss("not-a-loss", 1.0)
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(x0.clone(), model.with_loss("huber", 0.0))          # a loss needs a positive threshold
+    out = ta.Optimize(x0.clone(), model)                                 # and the handle is back to plain L2 afterwards
+    assert float(out.final_inlier_ratio.min()) == 1.0

@@ -199,7 +199,33 @@ def dense_row_layout(dtype: torch.dtype, n: int, m: int):
             "pos_b": (rs.value - 1) if thin.value else (rsm - 1)}
 
 
-class DenseRow:
+class _LossMixin:
+    """Models whose residual items can be wrapped in one of the reference's M-estimators (losses/robust_norms.h:32-316):
+    ``model.with_loss("huber", th)`` is the device counterpart of calling ``losses::Huber(n2, th*th, true)`` on each
+    residual's squared norm inside the cost functor (docs/API.md:396-411).  cost += l, the item's J^T J and J^T r are
+    scaled by s = dl/dn2, and Output.final_inlier_ratio reports the residuals with n2 <= th^2 (cost.h:84-95)."""
+    loss: Optional[str] = None
+    th: float = 0.0
+
+    def with_loss(self, loss: Optional[str], th: float = 0.0):
+        import copy
+        if loss is not None and loss not in LOSS_KINDS:
+            raise ValueError(f"unknown loss {loss!r}; one of {sorted(LOSS_KINDS)}")
+        m = copy.copy(self)          # shares the device data
+        m.loss, m.th = (loss if loss not in (None, "l2") else None), float(th)
+        return m
+
+
+def _apply_loss(ctx: "Context", cost) -> None:
+    """The handle carries the cost functor's M-estimator (toa_set_loss): set it from the model before every launch."""
+    kind = getattr(cost, "loss", None)
+    if kind is None:
+        check(ctx.lib.toa_set_loss(ctx.h, 0, 0.0))
+    else:
+        check(ctx.lib.toa_set_loss(ctx.h, LOSS_KINDS[kind], float(cost.th) * float(cost.th)))
+
+
+class DenseRow(_LossMixin):
     """Device residual model  r_i(x) = a_i.x + 0.1 sin(a_i.x) - b_i  for a batch of P problems.
 
     Plays the role of the user's cost functor in ``Optimize(x, cost)`` (a Jet-invocable residual
@@ -302,7 +328,7 @@ class SE3Reproj:
         return (self.m // 2) * 5 * self.packed.element_size()
 
 
-class CircleFit:
+class CircleFit(_LossMixin):
     """tests/circle.cpp:32-68 on the device, differentiated by forward-mode dual numbers (csrc/jet.hpp):
     x = (cx, cy, radius), one residual ||p - c||^2 - radius^2 per observed point.  obs: [P, m, 2]."""
     model_id = MODEL_CIRCLE_FIT
@@ -377,7 +403,7 @@ class TestFn:
         return 0
 
 
-class DenseRowAD6:
+class DenseRowAD6(_LossMixin):
     """The DenseRow residual for n = 6 written the tinyopt way — residual only, Jacobian by device AD.
     A: [P, m, 6], b: [P, m] (natural layout)."""
     model_id = MODEL_DENSE_ROW_AD6
@@ -527,6 +553,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     else:
         out.counters.zero_()
     res = _results_pod(out)
+    _apply_loss(ctx, cost)
     if splits is None:   # the library decides (row-split for few, huge problems)
         check(ctx.lib.toa_lm_run(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                  x.data_ptr(), C.byref(pod), C.byref(res), out.counters.data_ptr()))
@@ -555,6 +582,7 @@ class Optimizer:
         nbytes = self.ctx.lib.toa_lm_state_bytes(_dtype_code(x.dtype), n, P)
         self._state = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=x.device)
         self._active = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _apply_loss(self.ctx, cost)
         check(self.ctx.lib.toa_lm_begin(self.ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                         x.data_ptr(), C.byref(self.pod), C.byref(self._res), self._state.data_ptr()))
 
@@ -563,6 +591,7 @@ class Optimizer:
         None with sync=False (stream-ordered, nothing read back)."""
         x, cost = self.x, self.cost
         self._active.zero_()
+        _apply_loss(self.ctx, cost)
         check(self.ctx.lib.toa_lm_step(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
                                        cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
                                        self.out.counters.data_ptr(), self._state.data_ptr(), self._active.data_ptr()))
@@ -659,6 +688,7 @@ def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Cont
     H = torch.zeros(P, n, n, dtype=x.dtype, device=dev) if want_grad else None
     c = torch.zeros(P, dtype=torch.float64, device=dev)
     nres = torch.zeros(P, dtype=torch.int32, device=dev)
+    _apply_loss(ctx, cost)
     check(ctx.lib.toa_accumulate(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                  x.data_ptr(), int(want_grad), g.data_ptr() if want_grad else None,
                                  H.data_ptr() if want_grad else None, c.data_ptr(), nres.data_ptr()))

@@ -365,6 +365,15 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
   return TOA_OK;
 }
 
+int toa_set_loss(toa_handle h, int kind, double th2) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (kind < TOA_LOSS_L2 || kind > TOA_LOSS_BLAKE_ZISSERMAN) return fail(TOA_E_ARG, "toa_set_loss: unknown loss kind");
+  if (kind != TOA_LOSS_L2 && !(th2 > 0)) return fail(TOA_E_ARG, "toa_set_loss: the squared threshold must be positive");
+  h->loss = kind;
+  h->loss_th2 = th2;
+  return TOA_OK;
+}
+
 int toa_synchronize(toa_handle h) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   TOA_ON_DEVICE(h->device);
@@ -568,6 +577,8 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   prm.state = state;
   prm.active = active;
   prm.stop_request = stop_request;
+  prm.loss = h->loss;
+  prm.loss_th2 = h->loss_th2;
   if (mode != 0) {
     if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
     // the stepping form runs on the launch-per-iteration kernels with one chunk per problem (launch_stepping)
@@ -591,6 +602,9 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     const bool team = n <= 15 && m >= 512 && m <= 4096 && P <= team_per_cu * h->num_cus;
     splits = (splittable && !no_auto && (few || team)) ? 0 : -1;
   }
+  // DenseRow with an M-estimator on the handle: the robust data pass lives in the launch-per-iteration form (kernels.hpp
+  // RobustOf): chunked automatically for a few huge problems, one chunk per problem for a batch
+  if (model == TOA_MODEL_DENSE_ROW && h->loss != TOA_LOSS_L2 && splits < 0) splits = (P * 4 <= h->num_cus && m >= 512) ? 0 : 1;
   if (splits >= 0) {
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);

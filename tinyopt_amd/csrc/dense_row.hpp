@@ -21,6 +21,7 @@
 // DPP rows); s = 1 + 0.1 cos t scales the lane's a-values into J in registers; the lane holding
 // b_i replaces it by r_i = t + 0.1 sin t - b_i.
 #pragma once
+#include "robust.hpp"
 #include "wave_utils.hpp"
 
 namespace toa {
@@ -404,6 +405,14 @@ struct DenseRowGram {
     T mA, mB;                        // (1, 0) on ordinary lanes, (0, 1) on the lane whose last main element is b
     bool q0, q1;                     // bits of the lane's quad position: the batch step whose a_i.x this lane finishes
     int c;
+    // M-estimator on each residual (ROBUST passes only; losses/robust_norms.h:20-26: cost += l, the row's J^T J and J^T r
+    // scaled by s = dl/dn2 — here as sqrt(s) on the row [J | r] in front of the Gram)
+    int loss;                        // TOA_LOSS_* (wave-uniform)
+    T th2;
+    int k;                           // row group of this lane (lane >> 4)
+    int rows_real;                   // rows of the problem / chunk that exist (padding rows are zero and must not count)
+    bool owner;                      // the one lane per row that books cost and inliers
+    T inl;                           // inlier rows booked by this lane
   };
 
   static __device__ __forceinline__ void issue_batch(Slots& m, SlotsT& t, const i32x4 rsrc, const unsigned voff,
@@ -428,9 +437,9 @@ struct DenseRowGram {
 
   // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
   // of `m` / `tv` (no staging copies: the other slot set is the one being refilled meanwhile).
-  template <bool WANT_H, bool TAIL = false>
-  __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, const PassCtx& pc, T& csum,
-                                                const int last = 0) {
+  template <bool WANT_H, bool TAIL = false, bool ROBUST = false>
+  __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, PassCtx& pc, T& csum,
+                                                const int last = 0, const int row0 = 0) {
     T wa[U][NBM];
     T va[U][THIN ? THIN : 1];
     T part[U];
@@ -465,8 +474,26 @@ struct DenseRowGram {
       constexpr int u = decltype(uc)::value;
       T(&w)[NBM] = wa[u];
       T(&v)[THIN ? THIN : 1] = va[u];
-      const T sc = quad_bcast<u>(sc_sel);
+      T sc = quad_bcast<u>(sc_sel);
       const T rbase = quad_bcast<u>(rb_sel);
+      T rsq = T(0);  // ROBUST: sqrt(s) * r of this row
+      if constexpr (ROBUST) {
+        // the residual of this row on every lane of its row group: the thin tail is broadcast-loaded (all 16 lanes hold
+        // b); with b in the main block only its owner has it, and a 16-lane reduction hands r to the others
+        T r;
+        if constexpr (THIN == 0) r = row16_allreduce_sum(pc.isB_lane ? rbase - w[NBM - 1] : T(0));
+        else r = rbase - v[THIN - 1];
+        const T n2 = r * r;
+        T l, sw;
+        robust_norm(pc.loss, n2, pc.th2, l, sw);
+        const bool valid = row0 + 4 * u + pc.k < pc.rows_real;
+        const bool book = pc.owner && valid;
+        csum += book ? l : T(0);                       // Cost += l
+        pc.inl += (book && n2 <= pc.th2) ? T(1) : T(0);   // cost.h:84-95: inliers are the residuals inside the threshold
+        const T sq = r_sqrt(sw);
+        sc *= sq;
+        rsq = r * sq;
+      }
       if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
         using f2 = float __attribute__((ext_vector_type(2)));
         constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
@@ -493,8 +520,13 @@ struct DenseRowGram {
       }
       // THIN == 0: the lane holding b turns it into r = rbase - b, every other lane scales its column by sc; written as
       // one FMA with per-lane constants (mA, mB) = (1, 0) / (0, 1) instead of a select (fp64: no exec-mask branch)
-      if constexpr (THIN == 0) w[NBM - 1] = fma(w[NBM - 1], fma(sc, pc.mA, -pc.mB), rbase * pc.mB);
-      else v[THIN - 1] = rbase - v[THIN - 1];
+      if constexpr (ROBUST) {
+        if constexpr (THIN == 0) w[NBM - 1] = pc.isB_lane ? rsq : w[NBM - 1] * sc;
+        else v[THIN - 1] = rsq;
+      } else {
+        if constexpr (THIN == 0) w[NBM - 1] = fma(w[NBM - 1], fma(sc, pc.mA, -pc.mB), rbase * pc.mB);
+        else v[THIN - 1] = rbase - v[THIN - 1];
+      }
       if (WANT_H) {
 #if defined(TOA_SPLIT_MFMA)
 #pragma unroll
@@ -571,7 +603,7 @@ struct DenseRowGram {
 #pragma unroll
         for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
 #endif
-      } else {
+      } else if constexpr (!ROBUST) {
         if constexpr (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
         else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
       }
@@ -591,9 +623,16 @@ struct DenseRowGram {
   // Software pipeline: two sets of load registers (A, B) alternate between "being refilled by buffer loads" and
   // "being consumed by the arithmetic", so no register-to-register staging copies are needed (24 v_mov per batch
   // in the single-set version = 13 % of the VALU issue slots of this issue-bound loop).
-  template <bool WANT_H>
+  // ROBUST: every residual goes through the M-estimator `loss` (a separate instantiation of the loop, compiled only into
+  // the kernels of DenseRowModel<.., ROBUST = true>: the plain kernels' instruction stream and register budget are
+  // untouched).  Returns the cost (K2, and K1 with a loss); *ninl = inlier rows, or -1 when every residual is one.
+  template <bool WANT_H, bool ROBUST = false>
   __device__ __forceinline__ T pass(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
-                                    const T* __restrict__ xs, const int lane) {
+                                    const T* __restrict__ xs, const int lane, const int loss = 0, const T th2 = T(0),
+                                    const int rows_real = 0, int* ninl = nullptr) {
+    if constexpr (!ROBUST) {
+      if (ninl) *ninl = -1;
+    }
     const int k = lane >> 4, c = lane & 15;
     const int RS = lay.rs, rsm = lay.rsm;
     const bool active = c * NBM < rsm;
@@ -611,6 +650,12 @@ struct DenseRowGram {
     pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);  // b = last main element
     pc.mA = pc.isB_lane ? T(0) : T(1);
     pc.mB = pc.isB_lane ? T(1) : T(0);
+    pc.loss = loss;
+    pc.th2 = th2;
+    pc.k = k;
+    pc.rows_real = rows_real;
+    pc.owner = THIN == 0 ? pc.isB_lane : c == 0;
+    pc.inl = T(0);
     if (WANT_H) clear();
     T csum = 0;
     const int steps = lay.m4 >> 2;
@@ -641,10 +686,20 @@ struct DenseRowGram {
         const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + (i + kDepth - 1) * U) * step_bytes_u)));
         issue_batch(S[refill], St[refill], rsrc, voff, vofft, soff, step_bytes_u);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ROBUST) {
+          // The M-estimators (exp / log / atan2 / divisions, in fp64 too) need far more registers than the plain loop:
+          // with loads in flight across them hipcc splits the live ranges of the load DESTINATION registers and copies
+          // them before the data has landed (tools/isa_lint.py flags exactly that).  So this variant lets every load
+          // land before it computes: the latency is hidden by the other waves of the SIMD only.
+          wait_batch<0, kDw>(S[refill][0], S[refill][1], S[refill][2], S[refill][3]);
+          if (THIN) wait_batch<0, kDwT>(St[refill][0], St[refill][1], St[refill][2], St[refill][3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (i == kDepth - 1)
-          compute_batch<WANT_H, true>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + kDepth * U >= steps)));
+          compute_batch<WANT_H, true, ROBUST>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + kDepth * U >= steps)),
+                                               4 * (s0 + i * U));
         else
-          compute_batch<WANT_H>(S[i], St[i], pc, csum);
+          compute_batch<WANT_H, false, ROBUST>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
         __builtin_amdgcn_sched_barrier(0);
         wait_slots(S[(i + 1) % kDepth], St[(i + 1) % kDepth]);
       });
@@ -657,6 +712,9 @@ struct DenseRowGram {
       });
     }
     if (WANT_H) mfma_retire();
+    if constexpr (ROBUST) {
+      if (ninl) *ninl = int(wave_allreduce_sum(pc.inl));   // exact in T: one count per row
+    }
     if (WANT_H) {
       if (THIN) {  // fold the 4 row groups: every lane ends with the totals for its column set
 #pragma unroll
@@ -664,6 +722,7 @@ struct DenseRowGram {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
       }
+      if constexpr (ROBUST) return wave_allreduce_sum(csum);   // sum of l; the Gram's (r, r) entry holds sum of s r^2
       return T(0);
     }
     return wave_allreduce_sum(csum);

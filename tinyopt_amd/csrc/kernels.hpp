@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tinyopt_amd.h"
@@ -38,7 +39,10 @@ __device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign
   L.xs[lane] += sign * d[lane];
 }
 
-template <typename T, int NBM, int THIN>
+// ROBUST = true: the variant whose passes apply the handle's M-estimator (toa_set_loss) to every residual.  It exists only in
+// the small kernels of the launch-per-iteration forms (accumulate_kernel, wide_partial_kernel): compiled into the fused
+// kernel, the estimators' exp / log / atan2 raise its register count from 168 to 232 (3 -> 2 waves per SIMD for everybody).
+template <typename T, int NBM, int THIN, bool ROBUST = false>
 struct DenseRowModel {
   using Scalar = T;
   static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
@@ -51,15 +55,21 @@ struct DenseRowModel {
   const T* prob;
   DenseRowLayout lay;
   int m;
+  int loss;        // TOA_LOSS_* applied to every residual (toa_set_loss; 0 = plain squared L2)
+  T th2;
+  int rows_real;   // rows of the bound problem / chunk that exist (the packed layout pads to a multiple of 4)
+  int ninl;        // inlier residuals of the last pass; -1 = all of them (no loss)
   __device__ __forceinline__ void init(int n, int m_, const void* d) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
+    loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
   }
+  __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
 #ifdef TOA_ABL_REUSE  // ablation: every wave streams one of 64 problems (cache-resident data, same instruction stream)
-  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); }
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); rows_real = m; }
 #else
-  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); }
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); rows_real = m; }
 #endif
   // row-split execution: restrict the model to rows [row0, row0 + rows) of problem p (rows % 4 == 0)
   __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int n) {
@@ -67,14 +77,16 @@ struct DenseRowModel {
     prob = data + size_t(p) * full.elems_per_problem() + size_t(row0) * full.rs;
     lay = full;
     lay.m4 = rows;
+    rows_real = max(0, min(rows, m - row0));
   }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    gram.template pass<true>(prob, lay, n, L.xs, lane);
+    const T cl = gram.template pass<true, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
     cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+    if constexpr (ROBUST) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
     nres = m;
   }
   __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    cost = gram.template pass<false>(prob, lay, n, L.xs, lane);
+    cost = gram.template pass<false, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
     nres = m;
   }
   template <typename O>
@@ -82,6 +94,11 @@ struct DenseRowModel {
     gram.write_sym(M, LD, lay, n, lane);
   }
 };
+
+// The model whose data passes honour toa_set_loss, for the kernels that only run passes (Model itself where the family
+// has no separate variant: the Jet models branch at run time, the others have no M-estimator).
+template <typename M> struct RobustOf { using type = M; };
+template <typename T, int NBM, int THIN> struct RobustOf<DenseRowModel<T, NBM, THIN, false>> { using type = DenseRowModel<T, NBM, THIN, true>; };
 
 // Gaussian prior  r = (x - y) / sigma,  m = n — the residual of the reference's published dense
 // benchmark, with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66, 90-99;
@@ -91,6 +108,7 @@ struct DenseRowModel {
 template <typename T, int NPAD>
 struct GaussianPriorModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kXdim = 0;
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   static constexpr int kNpad = NPAD;
@@ -137,6 +155,7 @@ struct GaussianPriorModel {
 template <typename T, int NPAD>
 struct MahaPriorModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kXdim = 0;
   static constexpr int kNpad = NPAD;
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
@@ -201,6 +220,7 @@ struct MahaPriorModel {
 template <typename T>
 struct TestFnModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kXdim = 0;
   static constexpr int kNpad = 16;
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
@@ -326,6 +346,7 @@ struct TestFnModel {
 template <typename T>
 struct Sqrt2Model {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kXdim = 0;
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   static constexpr int kNpad = 16;
@@ -444,6 +465,7 @@ __device__ __forceinline__ void se3_log(const S* R, const S* t, S* xi) {
 template <typename T>
 struct Se3PriorModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kNpad = 16;
   static constexpr int kXdim = 12;
   const T* data;
@@ -542,6 +564,7 @@ struct Se3PriorModel {
 template <typename T>
 struct Se3ReprojModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // this family carries its loss in the data header
   static constexpr int kNpad = 16;
   static constexpr int kXdim = 12;
   const T* data;
@@ -708,9 +731,16 @@ struct JetModel {
   const T* data;
   const T* d;
   int items, it0, it1;
+  int loss;   // TOA_LOSS_* on each ITEM's squared residual norm (toa_set_loss; robust_norms.h:20-26); 0 = plain L2
+  T th2;
+  int ninl;   // inlier residuals of the last pass
   T G[kG];
   static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * kW - a * (a - 1) / 2 + (b - a); }
-  __device__ __forceinline__ void init(int, int m, const void* dp) { items = m / F::kR; data = static_cast<const T*>(dp); }
+  __device__ __forceinline__ void init(int, int m, const void* dp) {
+    items = m / F::kR; data = static_cast<const T*>(dp);
+    loss = TOA_LOSS_L2; th2 = T(0); ninl = -1;
+  }
+  __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
   __device__ __forceinline__ void bind(long long p) {
     d = data + size_t(p) * (F::kH + size_t(items) * F::kD);
     it0 = 0; it1 = items;
@@ -728,6 +758,8 @@ struct JetModel {
       for (int i = 0; i < kG; ++i) G[i] = T(0);
     }
     T csum = 0;
+    T inl = 0;
+    const bool robust = loss != TOA_LOSS_L2;   // wave-uniform
     const T* itemsp = d + F::kH;
     for (int i = it0 + lane; i < it1; i += 64) {
       const T* item = itemsp + size_t(i) * F::kD;
@@ -736,6 +768,15 @@ struct JetModel {
 #pragma unroll
         for (int k = 0; k < kN; ++k) xj[k] = Jet<T, kN>(x[k], k);   // optimize_autodiff.h:56-69
         F::template eval<Jet<T, kN>>(xj, d, item, r);
+        T s = T(1);
+        if (robust) {   // the item's ||r||^2 through the M-estimator: cost += l, its J^T J and J^T r scaled by s
+          T n2 = 0, l;
+#pragma unroll
+          for (int q = 0; q < F::kR; ++q) n2 += r[q].a * r[q].a;
+          robust_norm(loss, n2, th2, l, s);
+          csum += l;
+          inl += n2 <= th2 ? T(F::kR) : T(0);
+        }
 #pragma unroll
         for (int q = 0; q < F::kR; ++q) {
           T w[kW];
@@ -743,21 +784,33 @@ struct JetModel {
           for (int a = 0; a < kN; ++a) w[a] = r[q].v[a];             // J.row(i) = res[i].v   (:127-148)
           w[kN] = r[q].a;
 #pragma unroll
-          for (int a = 0; a < kW; ++a)
+          for (int a = 0; a < kW; ++a) {
+            const T sw = s * w[a];
 #pragma unroll
-            for (int b = a; b < kW; ++b) G[tt(a, b)] += w[a] * w[b];
+            for (int b = a; b < kW; ++b) G[tt(a, b)] += sw * w[b];
+          }
         }
       } else {
         T r[F::kR];
         F::template eval<T>(x, d, item, r);
+        T n2 = 0;
 #pragma unroll
-        for (int q = 0; q < F::kR; ++q) csum += r[q] * r[q];
+        for (int q = 0; q < F::kR; ++q) n2 += r[q] * r[q];
+        if (robust) {
+          T l, s;
+          robust_norm(loss, n2, th2, l, s);
+          csum += l;
+          inl += n2 <= th2 ? T(F::kR) : T(0);
+        } else {
+          csum += n2;
+        }
       }
     }
+    ninl = robust ? int(wave_allreduce_sum(inl)) : -1;
     if (WANT_H) {
 #pragma unroll
       for (int i = 0; i < kG; ++i) G[i] = wave_allreduce_sum(G[i]);
-      return G[tt(kN, kN)];
+      if (!robust) return G[tt(kN, kN)];
     }
     return wave_allreduce_sum(csum);
   }
@@ -896,6 +949,8 @@ struct FusedParams {
   void* state;                   // modes 1, 2, 3: caller's state block (see launch_wide)
   int* active;                   // mode 2 (optional): += 1 per problem that is still running after this pass
   const int* stop_request;       // mode 3: [P] StopReason to impose on a still-running problem (0 = leave it running)
+  int loss;                      // TOA_LOSS_* of the handle (toa_set_loss): applied per residual by the DenseRow / Jet families
+  double loss_th2;
 };
 
 // (An occupancy request via __launch_bounds__'s second argument is NOT usable here: under the tighter register budget
@@ -923,15 +978,26 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   const long long P = prm_g->P;
   Model model;
   model.init(n, prm_g->m, prm_g->data);
+  model.set_loss(prm_g->loss, prm_g->loss_th2);
   T* X = static_cast<T*>(prm_g->x);
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
 #ifndef TOA_QUEUE_DRAIN
   int solved = 0;
+  // The first problem of every wave is assigned statically (wave w of the launch takes problem w); the shared counter hands
+  // out the rest.  4 096 waves popping the same address at launch time serialise in the L2 (~5 ns per atomic = 20-30 us
+  // before the last wave has its first problem: 4 % of a C3 launch, visible in the launch timeline).
+  const int nwaves = int(gridDim.x) * 4;
+  bool first = true;
   for (;;) {  // one work item = one whole problem
     int p = 0;
-    if (lane == 0) p = atomicAdd(queue, 1);
-    p = __builtin_amdgcn_readfirstlane(p);
+    if (first) {
+      p = int(blockIdx.x) * 4 + wave;
+      first = false;
+    } else {
+      if (lane == 0) p = atomicAdd(queue, 1) + nwaves;
+      p = __builtin_amdgcn_readfirstlane(p);
+    }
     if (p >= P) break;
 #ifndef TOA_PRIO_SCHEME
 #define TOA_PRIO_SCHEME 1
@@ -1044,7 +1110,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
 template <typename Model>
 __global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, const void* x_, long long P, int n, int m,
                                                          int want_grad, void* g_, void* H_, double* cost, int* nres,
-                                                         int lds_per_wave) {
+                                                         int lds_per_wave, int loss, double loss_th2) {
   using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1052,6 +1118,7 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, cons
   const T* X = static_cast<const T*>(x_);
   Model model;
   model.init(n, m, data_);
+  model.set_loss(loss, loss_th2);
   const int xd = Model::kXdim ? Model::kXdim : n;
   for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
     wave_sync();
@@ -1185,6 +1252,8 @@ struct WideParams {
   int step_mode;   // stepping form: publish x and the running results at every pass
   int* active;     // stepping form (optional): += 1 per problem still running after the pass
   const int* stop_request;  // stepping form, wide_stop_kernel: [P] StopReason to impose (0 = none)
+  int loss;                 // toa_set_loss
+  double loss_th2;
   unsigned* sync;  // persistent form: [P][2] = (arrive, go) generation counters, then [1] abort flag; zeroed per launch
   int lds_per_wave;
 };
@@ -1239,6 +1308,7 @@ __global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __r
   const int rows = min(prm->chunk_rows, m4 - row0);
   Model model;
   model.init(n, prm->m, prm->data);
+  model.set_loss(prm->loss, prm->loss_th2);
   model.bind_chunk(p, row0, rows, n);
   const int stride = n * n + n + 2;
   T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
@@ -1262,6 +1332,7 @@ __global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __r
 template <typename T, int NPAD, typename Manifold>
 struct PartialSumModel {
   using Scalar = T;
+  __device__ __forceinline__ void set_loss(int, double) {}  // no M-estimator on this family
   static constexpr int kNpad = NPAD;
   static constexpr int kXdim = Manifold::kXdim;
   const T* part;
@@ -1507,6 +1578,7 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
   const int rows = min(prm->chunk_rows, m4 - row0);
   Model model;
   model.init(n, prm->m, prm->data);
+  model.set_loss(prm->loss, prm->loss_th2);
   model.bind_chunk(p, row0, rows, n);
   T* part = parts + size_t(wave) * stride;
 
@@ -1588,6 +1660,7 @@ __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* _
   const int rows = min(prm->chunk_rows, m4 - row0);
   Model model;
   model.init(n, prm->m, prm->data);
+  model.set_loss(prm->loss, prm->loss_th2);
   model.bind_chunk(p, row0, rows, n);
   const int stride = n * n + n + 2;
   T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
@@ -1696,6 +1769,10 @@ struct toa_context {
   char name[128] = {0};
   int* queue = nullptr;  // device work-queue head
   void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
+  int loss = TOA_LOSS_L2;      // toa_set_loss: the M-estimator of this handle's cost functor (DenseRow / Jet families)
+  double loss_th2 = 0;
+  unsigned char params_shadow[1024] = {0};  // what params_dev holds (or will hold, in stream order): see upload_params
+  size_t params_shadow_bytes = 0;
   void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
   size_t scratch_bytes = 0;
   // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (TOA_USE_GRAPH=1)
@@ -1754,6 +1831,17 @@ inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
   return TOA_OK;
 }
 
+// Stream-ordered upload of a kernel's parameter block into the context's device copy.  Repeated solves over the same
+// buffers (an outer loop re-solving, the stepping form, the benchmark) present byte-identical blocks: the upload — a
+// staged ~10 us stream operation in front of every launch — is skipped when the block already there is the same.
+inline int upload_params(toa_handle h, const void* blk, size_t bytes) {
+  if (bytes == h->params_shadow_bytes && std::memcmp(h->params_shadow, blk, bytes) == 0) return TOA_OK;
+  HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
+  std::memcpy(h->params_shadow, blk, bytes);
+  h->params_shadow_bytes = bytes;
+  return TOA_OK;
+}
+
 // waves per workgroup is fixed at 4 (256 threads); LDS per wave decides how many WGs fit per CU.
 template <typename T>
 inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg) {
@@ -1775,9 +1863,16 @@ inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* 
   if (grid > cap) grid = cap;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
-  if (int rc = ensure_lds_attr(h, (const void*)accumulate_kernel<Model>, pwg)) return rc;
-  hipLaunchKernelGGL((accumulate_kernel<Model>), dim3((unsigned)grid), dim3(256), pwg, h->stream, data, x, (long long)P, n, m,
-                     want_grad, g, H, cost, nres, (int)pw);
+  using RModel = typename RobustOf<Model>::type;
+  if (h->loss != TOA_LOSS_L2 && !std::is_same<RModel, Model>::value) {
+    if (int rc = ensure_lds_attr(h, (const void*)accumulate_kernel<RModel>, pwg)) return rc;
+    hipLaunchKernelGGL((accumulate_kernel<RModel>), dim3((unsigned)grid), dim3(256), pwg, h->stream, data, x, (long long)P, n, m,
+                       want_grad, g, H, cost, nres, (int)pw, h->loss, h->loss_th2);
+  } else {
+    if (int rc = ensure_lds_attr(h, (const void*)accumulate_kernel<Model>, pwg)) return rc;
+    hipLaunchKernelGGL((accumulate_kernel<Model>), dim3((unsigned)grid), dim3(256), pwg, h->stream, data, x, (long long)P, n, m,
+                       want_grad, g, H, cost, nres, (int)pw, h->loss, h->loss_th2);
+  }
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
@@ -1836,14 +1931,14 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   static_assert(sizeof(FusedParams) <= 1024, "parameter block too large");
   // stream-ordered upload of the parameter block (kept out of the kernarg segment so that its ~60
   // scalars are loaded on demand instead of being pinned in SGPRs across the hot loop)
-  HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+  if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
   static const char* tl_path = std::getenv("TOA_TIMELINE");
   unsigned long long* tl_dev = nullptr;
   if (tl_path) {  // debug: per-problem start / end stamps of this launch, appended to the file as text
     HIP_TRY(hipMalloc(&tl_dev, size_t(prm.P) * 16));
     HIP_TRY(hipMemsetAsync(tl_dev, 0, size_t(prm.P) * 16, h->stream));
     prm.timeline = tl_dev;
-    HIP_TRY(hipMemcpyAsync(h->params_dev, &prm, sizeof(prm), hipMemcpyHostToDevice, h->stream));
+    if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
   HIP_TRY(hipGetLastError());
@@ -1897,8 +1992,9 @@ inline int launch_stepping(toa_handle h, const FusedParams& fp) {
   wp.step_mode = 1;
   wp.active = fp.active;
   wp.stop_request = fp.stop_request;
+  wp.loss = fp.loss; wp.loss_th2 = fp.loss_th2;
   wp.lds_per_wave = int(pw);
-  HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+  if (int rc = upload_params(h, &wp, sizeof(wp))) return rc;
   const WideParams* dp = static_cast<const WideParams*>(h->params_dev);
   const unsigned g_p = unsigned((P + 3) / 4);
   if (fp.mode == 1) {
@@ -1910,7 +2006,9 @@ inline int launch_stepping(toa_handle h, const FusedParams& fp) {
     if (int rc = ensure_lds_attr(h, (const void*)k_stop, pwg)) return rc;
     hipLaunchKernelGGL(k_stop, dim3(g_p), dim3(256), pwg, h->stream, dp);
   } else {
-    auto k_part = wide_partial_kernel<Model>;
+    using RModel = typename RobustOf<Model>::type;
+    const bool robust = fp.loss != TOA_LOSS_L2 && !std::is_same<RModel, Model>::value;
+    void (*k_part)(const WideParams*) = robust ? wide_partial_kernel<RModel> : wide_partial_kernel<Model>;
     auto k_step = wide_step_kernel<T, NPAD, Manifold>;
     if (int rc = ensure_lds_attr(h, (const void*)k_part, pwg)) return rc;
     if (int rc = ensure_lds_attr(h, (const void*)k_step, pwg)) return rc;
@@ -1969,11 +2067,16 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   wp.hsum = static_cast<char*>(h->scratch) + b_state + b_part;
   wp.sync = reinterpret_cast<unsigned*>(static_cast<char*>(h->scratch) + b_state + b_part + b_hsum);
   wp.lds_per_wave = int(pw);
+  wp.loss = fp.loss; wp.loss_th2 = fp.loss_th2;
   static_assert(sizeof(WideParams) <= 1024, "parameter block too large");
-  HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+  if (int rc = upload_params(h, &wp, sizeof(wp))) return rc;
   const WideParams* dp = static_cast<const WideParams*>(h->params_dev);
+  // With an M-estimator on the handle (toa_set_loss) the data pass is the ROBUST variant of the model, which exists in the
+  // pass-only kernels: the solve then runs in the launch-per-iteration form (no team / persistent kernel).
+  using RModel = typename RobustOf<Model>::type;
+  const bool robust = fp.loss != TOA_LOSS_L2 && !std::is_same<RModel, Model>::value;
   auto k_init = wide_init_kernel<T, Manifold::kXdim>;
-  auto k_part = wide_partial_kernel<Model>;
+  void (*k_part)(const WideParams*) = robust ? wide_partial_kernel<RModel> : wide_partial_kernel<Model>;
   auto k_step = wide_step_kernel<T, NPAD, Manifold>;
   if (int rc = ensure_lds_attr(h, (const void*)k_init, pwg)) return rc;
   if (int rc = ensure_lds_attr(h, (const void*)k_part, pwg)) return rc;
@@ -1987,7 +2090,8 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   // 64-thread workgroup per chunk, at most one per CU.  TOA_WIDE_MULTILAUNCH=1 forces the launch-per-iteration form.
   // Instantiated for the small systems only (n <= 15: BASELINE configs C2 / C5 are n = 6): the kernel carries a whole
   // lm_iteration with the NPAD-unrolled register LDL^T per residual-model layout, and 40 copies of it tripled the build.
-  static const bool multilaunch = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
+  static const bool multilaunch_env = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
+  const bool multilaunch = multilaunch_env || robust;
   static const bool noteam = std::getenv("TOA_WIDE_NOTEAM") != nullptr;
   if constexpr (NPAD <= 16) {
     // Team form: a small problem (<= 4096 rows) is cheaper on ONE compute unit with barrier hand-overs than on 16-64
@@ -2001,7 +2105,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
       if (lds_team <= size_t(h->max_lds)) {
         wp.splits = int(St);
         wp.chunk_rows = chunk_t;
-        HIP_TRY(hipMemcpyAsync(h->params_dev, &wp, sizeof(wp), hipMemcpyHostToDevice, h->stream));
+        if (int rc = upload_params(h, &wp, sizeof(wp))) return rc;
         auto k_team = wide_team_kernel<Model, NPAD, Manifold>;
         if (int rc = ensure_lds_attr(h, (const void*)k_team, lds_team)) return rc;
         hipLaunchKernelGGL(k_team, dim3(unsigned(P)), dim3(unsigned(64 * St)), lds_team, h->stream, dp);

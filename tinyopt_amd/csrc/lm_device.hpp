@@ -36,7 +36,7 @@ constexpr double kDblMax = 1.7976931348623157e+308;
 // Inlier residuals of the model's last pass: models with a robust loss expose `ninl`, the others count every
 // residual as an inlier (Cost's default inlier_ratio = 1, cost.h:23,95).
 template <typename M>
-__device__ __forceinline__ auto model_inliers(const M& m, int, int) -> decltype(m.ninl) { return m.ninl; }
+__device__ __forceinline__ auto model_inliers(const M& m, int nres, int) -> decltype(m.ninl) { return m.ninl < 0 ? nres : m.ninl; }
 template <typename M>
 __device__ __forceinline__ int model_inliers(const M&, int nres, long) { return nres; }
 
