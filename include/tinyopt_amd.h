@@ -68,6 +68,12 @@ extern "C" {
  * the LM state machine in small kernels between them (tinyopt_amd/csrc/large_n.hip).  toa_lm_run only. */
 #define TOA_MODEL_DENSE_ROW_NATURAL 10
 
+/* The DenseRow residual written as r(x) ONLY and differentiated on the device for wide parameter blocks (13 <= n <= 63,
+ * "chunked Jets": the 16 lanes of a row group evaluate the functor on Jet chunks seeded on the columns each feeds to the
+ * matrix cores; csrc/kernels.hpp JetRowModel).  Instantiated for n = 12 and n = 50 (BASELINE shapes C3 / C4);
+ * data_dev: [P][m][n + 1] = (a_i, b_i) rows in natural layout; x: [P][n]. */
+#define TOA_MODEL_DENSE_ROW_AD 11
+
 /* robust norms / M-estimators (include/tinyopt/losses/robust_norms.h:32-316) */
 #define TOA_LOSS_L2 0
 #define TOA_LOSS_TRUNCATED 1
@@ -234,6 +240,15 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
  *      = off, the default); th2 = squared threshold.  TOA_MODEL_SE3_REPROJ keeps its loss in its data header; the other
  *      families have none. */
 int toa_set_loss(toa_handle h, int kind, double th2);
+
+/* ---- the dual numbers alone (replaces ceres::Jet<T, N>, include/tinyopt/3rdparty/ceres/jet.h:216-1400, as the residual
+ *      functors of the device-AD families use it): out[i] = (f, df/da, df/db) of function `fn` at (a[i], b[i]), evaluated on
+ *      Jet<T, 2> seeded on (a, b).  fn: 0 + 1 - 2 * 3 / 4 abs 5 log 6 exp 7 sqrt 8 cos 9 sin 10 tan 11 atan 12 tanh
+ *      13 atan2(a,b) 14 pow(a,2.5) 15 acos 16 asin 17 sinh 18 cosh 19 cbrt 20 exp2 21 log2 22 log10 23 log1p 24 expm1
+ *      25 hypot(a,b) 26 fmax 27 fmin 28 erf 29 erfc 30 pow(a,b) 31 pow(scalar a, b) 32 fma(a,b,a) 33 fdim 34 floor 35 ceil
+ *      36 norm 37 copysign(a,b) 38 mixed scalar/Jet arithmetic 2/a + a/4 - 3b  39 hypot(a, b, a*b).  a, b: [count] of T;
+ *      out: [count][3] of T. */
+int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a_dev, const void* b_dev, void* out_dev);
 
 /* ---- covariance seam (replaces tinyopt::InvCov / DenseInvCov, math.h:41-91, used by Output::Covariance
  *      output.h:80-94 and SolverLM::Covariance lm.h:174): C = H^-1 by LDL^T against the identity, same acceptance

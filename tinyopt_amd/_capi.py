@@ -19,6 +19,7 @@ MODEL_TESTFN = 7
 MODEL_MAHA_PRIOR = 8
 MODEL_SE3_PRIOR = 9
 MODEL_DENSE_ROW_NATURAL = 10
+MODEL_DENSE_ROW_AD = 11
 
 # StopReason, same integers as include/tinyopt/stop_reasons.h:14-43
 STOP_NAMES = {
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "toa_comm_init_rank": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "toa_comm_destroy": (C.c_int, [_P]),
     "toa_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P, C.POINTER(ToaResults), C.c_int, _P, C.POINTER(ToaResults)]),
+    "toa_jet_eval": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "toa_set_loss": (C.c_int, [_P, C.c_int, C.c_double]),
     "toa_robust_norm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_double, _P, _P]),
     "toa_hbm_read_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),

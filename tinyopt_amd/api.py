@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from ._capi import (F32, F64, MODEL_DENSE_ROW_NATURAL, MODEL_TESTFN, MODEL_MAHA_PRIOR, MODEL_SE3_PRIOR, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
+from ._capi import (F32, F64, MODEL_DENSE_ROW_AD, MODEL_DENSE_ROW_NATURAL, MODEL_TESTFN, MODEL_MAHA_PRIOR, MODEL_SE3_PRIOR, MODEL_CIRCLE_FIT, MODEL_DENSE_ROW, MODEL_DENSE_ROW_AD6, MODEL_GAUSSIAN_PRIOR, MODEL_SE3_REPROJ,
                     MODEL_SQRT2, ToaOptions, ToaResults, check)
 
 
@@ -418,6 +418,22 @@ class DenseRowAD6(_LossMixin):
         return self.m * 7 * self.packed.element_size()
 
 
+class DenseRowAD:
+    """The DenseRow residual for a WIDE parameter block written the tinyopt way — residual only, the Jacobian by device
+    AD in the matrix cores' operand layout (csrc/kernels.hpp JetRowModel, "chunked Jets").  n = 12 or n = 50.
+    A: [P, m, n], b: [P, m] (natural layout)."""
+    model_id = MODEL_DENSE_ROW_AD
+
+    def __init__(self, A: torch.Tensor, b: torch.Tensor):
+        assert A.dim() == 3 and A.shape[2] in (12, 50) and b.shape == A.shape[:2] and A.is_cuda
+        self.P, self.m, self.n, self.dtype = A.shape[0], A.shape[1], A.shape[2], A.dtype
+        self.packed = torch.cat([A, b[..., None]], dim=2).contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return self.m * (self.n + 1) * self.packed.element_size()
+
+
 class DenseRowNatural:
     """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout,
     J^T J through a batched rocBLAS GEMM, the damped solve through rocSOLVER's batched Cholesky, the LM state machine of
@@ -439,7 +455,7 @@ class DenseRowNatural:
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
-_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowNatural)
+_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural)
 
 
 @dataclass

@@ -32,6 +32,36 @@ __global__ void __launch_bounds__(256) robust_norm_kernel(int kind, long long co
   scale[i] = s;
 }
 
+// ceres::Jet on the device, function by function (tests/test_gpu_jet.py pins every one against closed-form
+// derivatives): out[i] = (f, df/da, df/db) of function `fn` at (a[i], b[i]) through Jet<T, 2> seeded on (a, b).
+template <typename T>
+__global__ void __launch_bounds__(256) jet_eval_kernel(int fn, long long count, const T* __restrict__ a, const T* __restrict__ b,
+                                                       T* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  using J = Jet<T, 2>;
+  const J x(a[i], 0), y(b[i], 1);
+  J r;
+  switch (fn) {
+    case 0: r = x + y; break;           case 1: r = x - y; break;            case 2: r = x * y; break;
+    case 3: r = x / y; break;           case 4: r = abs(x); break;           case 5: r = log(x); break;
+    case 6: r = exp(x); break;          case 7: r = sqrt(x); break;          case 8: r = cos(x); break;
+    case 9: r = sin(x); break;          case 10: r = tan(x); break;          case 11: r = atan(x); break;
+    case 12: r = tanh(x); break;        case 13: r = atan2(x, y); break;     case 14: r = pow(x, 2.5); break;
+    case 15: r = acos(x); break;        case 16: r = asin(x); break;         case 17: r = sinh(x); break;
+    case 18: r = cosh(x); break;        case 19: r = cbrt(x); break;         case 20: r = exp2(x); break;
+    case 21: r = log2(x); break;        case 22: r = log10(x); break;        case 23: r = log1p(x); break;
+    case 24: r = expm1(x); break;       case 25: r = hypot(x, y); break;     case 26: r = fmax(x, y); break;
+    case 27: r = fmin(x, y); break;     case 28: r = erf(x); break;          case 29: r = erfc(x); break;
+    case 30: r = pow(x, y); break;      case 31: r = pow(a[i], y); break;    case 32: r = fma(x, y, x); break;
+    case 33: r = fdim(x, y); break;     case 34: r = floor(x); break;        case 35: r = ceil(x); break;
+    case 36: r = norm(x); break;        case 37: r = copysign(x, y); break;  case 38: r = T(2) / x + x / T(4) - T(3) * y; break;
+    case 39: r = hypot(x, y, x * y); break;
+    default: r = J(T(NAN)); break;
+  }
+  out[3 * i] = r.a; out[3 * i + 1] = r.v[0]; out[3 * i + 2] = r.v[1];
+}
+
 // Natural (A [P][m][n], b [P][m]) -> packed [P][m4][RS] (layout: DenseRowLayout).
 template <typename T>
 __global__ void dense_row_pack_kernel(const T* __restrict__ A, const T* __restrict__ b, T* __restrict__ out,
@@ -140,6 +170,12 @@ int toa_inst_wide_1_2(int thin, toa_handle h, const toa::FusedParams& prm, int s
 int toa_inst_wide_1_3(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 
+int toa_inst_jetrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_jetrow_fused_1_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_jetrow_wide_0_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_jetrow_wide_1_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_jetrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+int toa_inst_jetrow_accumulate_1_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_inv_cov_0_0(int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
 int toa_inst_inv_cov_1_0(int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
 
@@ -365,6 +401,23 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
   return TOA_OK;
 }
 
+int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a, const void* b, void* out) {
+  if (!h || !a || !b || !out || count < 0) return fail(TOA_E_ARG, "toa_jet_eval: null argument");
+  if (fn < 0 || fn > 39) return fail(TOA_E_ARG, "toa_jet_eval: unknown function id");
+  if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+  if (count == 0) return TOA_OK;
+  TOA_ON_DEVICE(h->device);
+  const unsigned grid = unsigned((count + 255) / 256);
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::jet_eval_kernel<float>, dim3(grid), dim3(256), 0, h->stream, fn, (long long)count, (const float*)a,
+                       (const float*)b, (float*)out);
+  else
+    hipLaunchKernelGGL(toa::jet_eval_kernel<double>, dim3(grid), dim3(256), 0, h->stream, fn, (long long)count, (const double*)a,
+                       (const double*)b, (double*)out);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 int toa_set_loss(toa_handle h, int kind, double th2) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (kind < TOA_LOSS_L2 || kind > TOA_LOSS_BLAKE_ZISSERMAN) return fail(TOA_E_ARG, "toa_set_loss: unknown loss kind");
@@ -413,6 +466,10 @@ static int check_model(int model, int n, int m, const void* data) {
     case TOA_MODEL_DENSE_ROW_AD6:
       if (n != 6) return fail(TOA_E_ARG, "DenseRowAD6: n must be 6");
       if (!data) return fail(TOA_E_ARG, "DenseRowAD6: data pointer ([P][m][7] = a_i, b_i) is null");
+      return TOA_OK;
+    case TOA_MODEL_DENSE_ROW_AD:
+      if (n != 12 && n != 50) return fail(TOA_E_UNSUPPORTED, "DenseRowAD: instantiated for n = 12 and n = 50 (a functor's parameter count is a compile-time constant)");
+      if (!data) return fail(TOA_E_ARG, "DenseRowAD: data pointer ([P][m][n + 1] = a_i, b_i) is null");
       return TOA_OK;
     case TOA_MODEL_SE3_REPROJ:
       if (n != 6 || m < 2 || (m & 1)) return fail(TOA_E_ARG, "SE3Reproj: n must be 6 and m an even count of residuals");
@@ -489,6 +546,9 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   const int dtag = dtype == TOA_F32 ? 0 : 1;
+  if (model == TOA_MODEL_DENSE_ROW_AD)
+    return dtag == 0 ? toa_inst_jetrow_accumulate_0_0(h, n, m, P, data, x, want_grad, g, H, cost, nres)
+                     : toa_inst_jetrow_accumulate_1_0(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   if (model != TOA_MODEL_DENSE_ROW)
     return toa_inst_misc_accumulate(dtag, model, 16 * ((n + 15) / 16), h, n, m, P, data, x, want_grad, g, H, cost, nres);
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
@@ -583,6 +643,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
     // the stepping form runs on the launch-per-iteration kernels with one chunk per problem (launch_stepping)
     const DenseRowLayout lay_s = DenseRowLayout::make(n, m);
+    if (model == TOA_MODEL_DENSE_ROW_AD) return dtype == TOA_F32 ? toa_inst_jetrow_wide_0_0(n, h, prm) : toa_inst_jetrow_wide_1_0(n, h, prm);
     return toa_inst_wide(dtype == TOA_F32 ? 0 : 1, model, lay_s.nbm, lay_s.thin, h, prm, 1);
   }
   const int dtag = dtype == TOA_F32 ? 0 : 1;
@@ -609,6 +670,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);
   }
+  if (model == TOA_MODEL_DENSE_ROW_AD) return dtag == 0 ? toa_inst_jetrow_fused_0_0(n, h, prm) : toa_inst_jetrow_fused_1_0(n, h, prm);
   if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtag, model, 16 * ((n + 15) / 16), h, prm);
   return toa_inst_fused(dtag, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");

@@ -610,6 +610,34 @@ struct DenseRowGram {
     });
   }
 
+  // One step (4 residual rows, one per row group) handed in as operands instead of being loaded: w = this lane's NBM main
+  // columns of W = [J | r], v = the thin columns (every lane of the row group holds the same values).  For the models
+  // that PRODUCE their rows (JetRowModel: forward-mode AD of a user functor) rather than stream them; the hot streaming
+  // loop above keeps its own hand-scheduled copy of this arithmetic.  last != 0: final step of the pass (see run_tail).
+  __device__ __forceinline__ void add_step(T (&w)[NBM], T (&v)[THIN ? THIN : 1], const int last) {
+    GramStep<T, NBM>::run_tail(acc, w, last);
+    if constexpr (THIN > 0) {
+#pragma unroll
+      for (int cb = 0; cb < NBM; ++cb)
+#pragma unroll
+        for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
+#pragma unroll
+      for (int j = 0; j < THIN; ++j)
+#pragma unroll
+        for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
+    }
+  }
+  // End of a pass made of add_step calls: retire the matrix pipe and fold the four row groups of the thin products.
+  __device__ __forceinline__ void finish_steps() {
+    mfma_retire();
+    if (THIN) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+    }
+  }
+
   // Belt and braces after the loop (the final step already waited inside its own asm statement, see
   // GramStep::run_tail); tools/isa_lint.py checks the built objects for accumulator reads that could overtake an MFMA.
   __device__ __forceinline__ void mfma_retire() {

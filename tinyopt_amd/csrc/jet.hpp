@@ -3,8 +3,9 @@
 // OptimizeWithAutoDiff (include/tinyopt/diff/optimize_autodiff.h:21-169) evaluates user residuals on.
 //
 // Same algebra, same formulas (each operator cites the reference line it restates); what differs is the
-// storage: the infinitesimal part is a plain T[N] that lives in VGPRs (N is a compile-time constant <= 12
-// here; the reference's N = Dynamic heap vectors have no place in a kernel).  With it a user writes only
+// storage: the infinitesimal part is a plain T[N] that lives in VGPRs (N is a compile-time constant; the
+// reference's N = Dynamic heap vectors have no place in a kernel — wide parameter blocks are differentiated
+// in chunks instead, JetRowModel in kernels.hpp).  With it a user writes only
 // `r(x)` as a template over the scalar type, exactly like a tinyopt residual functor, and JetModel
 // (kernels.hpp) turns it into the Accumulate contract on the device.
 #pragma once
@@ -18,6 +19,9 @@ namespace toa {
 // call sin(t), sqrt(t), ... unqualified; the Jet overloads below would otherwise hide ::sin inside toa::)
 using ::sqrt; using ::sin; using ::cos; using ::tan; using ::atan; using ::atan2; using ::tanh;
 using ::exp; using ::log; using ::pow; using ::fabs; using std::abs;
+using ::acos; using ::asin; using ::sinh; using ::cosh; using ::cbrt; using ::exp2; using ::log2; using ::log10;
+using ::log1p; using ::expm1; using ::hypot; using ::erf; using ::erfc; using ::floor; using ::ceil; using ::fmax;
+using ::fmin; using ::fdim; using ::fma; using ::copysign;
 
 template <typename T, int N>
 struct Jet {
@@ -122,6 +126,90 @@ TOA_JET_FN Jet<T, N> atan2(const Jet<T, N>& g, const Jet<T, N>& f) {            
 TOA_JET_FN Jet<T, N> pow(const Jet<T, N>& f, double g) {                                             // :1258
   const T tmp = T(g) * T(::pow(f.a, T(g) - T(1.0)));
   return jet_chain(f, T(::pow(f.a, T(g))), tmp);
+}
+
+// ---- the rest of jet.h:557-1340 (same formulas; the line cited is the reference's) -------------------------------------
+TOA_JET_FN bool operator<=(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a <= g.a; }           // :426-460 scalar part
+TOA_JET_FN bool operator>=(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a >= g.a; }
+TOA_JET_FN bool operator==(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a == g.a; }
+TOA_JET_FN bool operator!=(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a != g.a; }
+TOA_JET_FN bool operator<=(const Jet<T, N>& f, T s) { return f.a <= s; }
+TOA_JET_FN bool operator>=(const Jet<T, N>& f, T s) { return f.a >= s; }
+TOA_JET_FN bool operator==(const Jet<T, N>& f, T s) { return f.a == s; }
+TOA_JET_FN Jet<T, N> copysign(const Jet<T, N>& f, const Jet<T, N>& g) {                             // :584-604
+  const T d = g.a == T(0) ? T(INFINITY) : T(0);   // Dirac delta of the sign flip
+  const T sa = T(::copysign(T(1), f.a)), sb = T(::copysign(T(1), g.a));
+  Jet<T, N> r; r.a = T(::copysign(f.a, g.a));
+  TOA_JET_LOOP r.v[i] = sa * sb * f.v[i] + T(::fabs(f.a)) * d * g.v[i];
+  return r;
+}
+TOA_JET_FN Jet<T, N> log10(const Jet<T, N>& f) { return jet_chain(f, T(::log10(f.a)), T(1.0) / (f.a * T(::log(T(10.0))))); }   // :613
+TOA_JET_FN Jet<T, N> log1p(const Jet<T, N>& f) { return jet_chain(f, T(::log1p(f.a)), T(1.0) / (T(1.0) + f.a)); }             // :621
+TOA_JET_FN Jet<T, N> expm1(const Jet<T, N>& f) { const T e = T(::expm1(f.a)); return jet_chain(f, e, e + T(1.0)); }           // :635
+TOA_JET_FN Jet<T, N> acos(const Jet<T, N>& f) { return jet_chain(f, T(::acos(f.a)), -T(1.0) / jsqrt(T(1.0) - f.a * f.a)); }   // :657
+TOA_JET_FN Jet<T, N> asin(const Jet<T, N>& f) { return jet_chain(f, T(::asin(f.a)), T(1.0) / jsqrt(T(1.0) - f.a * f.a)); }    // :670
+TOA_JET_FN Jet<T, N> sinh(const Jet<T, N>& f) { return jet_chain(f, T(::sinh(f.a)), T(::cosh(f.a))); }                        // :692
+TOA_JET_FN Jet<T, N> cosh(const Jet<T, N>& f) { return jet_chain(f, T(::cosh(f.a)), T(::sinh(f.a))); }                        // :698
+TOA_JET_FN Jet<T, N> floor(const Jet<T, N>& f) { return Jet<T, N>(T(::floor(f.a))); }                                         // :715 zero derivative
+TOA_JET_FN Jet<T, N> ceil(const Jet<T, N>& f) { return Jet<T, N>(T(::ceil(f.a))); }                                           // :724
+TOA_JET_FN Jet<T, N> cbrt(const Jet<T, N>& f) { return jet_chain(f, T(::cbrt(f.a)), T(1.0) / (T(3.0) * T(::cbrt(f.a * f.a)))); }   // :732
+TOA_JET_FN Jet<T, N> exp2(const Jet<T, N>& f) { const T e = T(::exp2(f.a)); return jet_chain(f, e, e * T(::log(T(2)))); }     // :739
+TOA_JET_FN Jet<T, N> log2(const Jet<T, N>& f) { return jet_chain(f, T(::log2(f.a)), T(1.0) / (f.a * T(::log(T(2))))); }       // :747
+TOA_JET_FN Jet<T, N> hypot(const Jet<T, N>& x, const Jet<T, N>& y) {                                                          // :757
+  const T h = T(::hypot(x.a, y.a));
+  Jet<T, N> r; r.a = h; TOA_JET_LOOP r.v[i] = x.a / h * x.v[i] + y.a / h * y.v[i]; return r;
+}
+TOA_JET_FN Jet<T, N> hypot(const Jet<T, N>& x, const Jet<T, N>& y, const Jet<T, N>& z) {                                      // :772
+  const T h = jsqrt(x.a * x.a + y.a * y.a + z.a * z.a);
+  Jet<T, N> r; r.a = h; TOA_JET_LOOP r.v[i] = x.a / h * x.v[i] + y.a / h * y.v[i] + z.a / h * z.v[i]; return r;
+}
+TOA_JET_FN Jet<T, N> fma(const Jet<T, N>& x, const Jet<T, N>& y, const Jet<T, N>& z) {                                        // :789
+  Jet<T, N> r; r.a = T(::fma(x.a, y.a, z.a)); TOA_JET_LOOP r.v[i] = y.a * x.v[i] + x.a * y.v[i] + z.v[i]; return r;
+}
+// fmax / fmin: the larger / smaller scalar part wins; on equality the two Jets are averaged; NaN = missing data (:800-880)
+TOA_JET_FN Jet<T, N> fmax(const Jet<T, N>& x, const Jet<T, N>& y) {
+  if (x.a != x.a || y.a != y.a || x.a < y.a || x.a > y.a) return (x.a != x.a || x.a < y.a) ? y : x;
+  return (x + y) * T(0.5);
+}
+TOA_JET_FN Jet<T, N> fmin(const Jet<T, N>& x, const Jet<T, N>& y) {
+  if (x.a != x.a || y.a != y.a || x.a < y.a || x.a > y.a) return (x.a != x.a || x.a > y.a) ? y : x;
+  return (x + y) * T(0.5);
+}
+TOA_JET_FN Jet<T, N> fmax(const Jet<T, N>& x, T s) { return fmax(x, Jet<T, N>(s)); }
+TOA_JET_FN Jet<T, N> fmax(T s, const Jet<T, N>& x) { return fmax(Jet<T, N>(s), x); }
+TOA_JET_FN Jet<T, N> fmin(const Jet<T, N>& x, T s) { return fmin(x, Jet<T, N>(s)); }
+TOA_JET_FN Jet<T, N> fmin(T s, const Jet<T, N>& x) { return fmin(Jet<T, N>(s), x); }
+TOA_JET_FN Jet<T, N> fdim(const Jet<T, N>& f, const Jet<T, N>& g) {                                                           // :878-888
+  if (f.a != f.a || g.a != g.a) return Jet<T, N>(T(NAN));
+  return f.a > g.a ? f - g : Jet<T, N>();
+}
+TOA_JET_FN Jet<T, N> erf(const Jet<T, N>& x) {                                                                                // :890  2/sqrt(pi) exp(-x^2)
+  return jet_chain(x, T(::erf(x.a)), T(1.1283791670955125739) * T(::exp(-x.a * x.a)));
+}
+TOA_JET_FN Jet<T, N> erfc(const Jet<T, N>& x) {                                                                               // :904
+  return jet_chain(x, T(::erfc(x.a)), -T(1.1283791670955125739) * T(::exp(-x.a * x.a)));
+}
+TOA_JET_FN Jet<T, N> norm(const Jet<T, N>& f) { return jet_chain(f, f.a * f.a, T(2) * f.a); }                                 // :1251
+TOA_JET_FN Jet<T, N> pow(T f, const Jet<T, N>& g) {                                                                           // :1275-1300
+  if (f == T(0) && g.a > T(0)) return Jet<T, N>(T(0));
+  if (f < T(0) && g.a == T(::floor(g.a))) {
+    Jet<T, N> r(T(::pow(f, g.a)));
+    TOA_JET_LOOP if (g.v[i] != T(0)) r.v[i] = T(NAN);
+    return r;
+  }
+  const T p = T(::pow(f, g.a));
+  return jet_chain(g, p, T(::log(f)) * p);
+}
+TOA_JET_FN Jet<T, N> pow(const Jet<T, N>& f, const Jet<T, N>& g) {                                                            // :1338-1400
+  if (f.a == T(0) && g.a >= T(1)) return g.a > T(1) ? Jet<T, N>(T(0)) : f;
+  if (f.a < T(0) && g.a == T(::floor(g.a))) {
+    const T t = g.a * T(::pow(f.a, g.a - T(1.0)));
+    Jet<T, N> r = jet_chain(f, T(::pow(f.a, g.a)), t);
+    TOA_JET_LOOP if (g.v[i] != T(0)) r.v[i] = T(NAN);
+    return r;
+  }
+  const T t1 = T(::pow(f.a, g.a)), t2 = g.a * T(::pow(f.a, g.a - T(1.0))), t3 = t1 * T(::log(f.a));
+  Jet<T, N> r; r.a = t1; TOA_JET_LOOP r.v[i] = t2 * f.v[i] + t3 * g.v[i]; return r;
 }
 
 #undef TOA_JET_FN

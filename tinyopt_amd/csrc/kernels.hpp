@@ -842,8 +842,8 @@ struct JetModel {
 template <typename T>
 struct CircleFitFunctor {
   static constexpr int kN = 3, kR = 1, kD = 2, kH = 0;
-  template <class S>
-  static __device__ __forceinline__ void eval(const S* x, const T*, const T* p, S* r) {
+  template <class S, class X>
+  static __device__ __forceinline__ void eval(const X& x, const T*, const T* p, S* r) {
     const S dx = p[0] - x[0];
     const S dy = p[1] - x[1];
     r[0] = dx * dx + dy * dy - x[2] * x[2];
@@ -854,13 +854,112 @@ struct CircleFitFunctor {
 template <typename T, int NN>
 struct DenseRowAdFunctor {
   static constexpr int kN = NN, kR = 1, kD = NN + 1, kH = 0;
-  template <class S>
-  static __device__ __forceinline__ void eval(const S* x, const T*, const T* item, S* r) {
+  template <class S, class X>
+  static __device__ __forceinline__ void eval(const X& x, const T*, const T* item, S* r) {
     S t = x[0] * item[0];
-#pragma unroll
+    // wide blocks: a rolled loop (fully unrolled, 50 seeded Jets are live at once: 370 VGPRs)
+    constexpr int kUnroll = NN <= 12 ? NN : 2;
+#pragma unroll kUnroll
     for (int j = 1; j < NN; ++j) t = t + x[j] * item[j];
     r[0] = t + T(0.1) * sin(t) - item[NN];
   }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Device AD for WIDE parameter blocks (13 <= kN <= 63; SURVEY §8f rank 1 "chunked Jets"; optimize_autodiff.h:91-166).
+// JetModel above keeps the (kN+1)(kN+2)/2 Gram of one item per lane in registers, which stops at kN = 12.  Here the
+// Jacobian row of an item is produced directly in the operand layout of DenseRowGram: the 16 lanes of a row group
+// evaluate the SAME residual, each on Jet<T, W> dual numbers seeded on the W = NBM + THIN - 1 columns that lane feeds to
+// the matrix cores (its NBM main columns + the thin columns every lane of the group carries) — the 16 chunks of the full
+// ceres::Jet<T, kN> evaluated side by side, r.v landing in MFMA operand order, no transposition, and the same Gram /
+// LDL^T / state machine as the hand-derived DenseRowModel from there on.  The parameters are handed to the functor
+// through SeededX: x[j] materialises parameter j as a Jet whose partials are 1 on the slot (if any) this lane owns for j.
+// One residual per item (kR == 1); cost-only passes evaluate the functor on plain T, one item per lane.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int W>
+struct SeededX {
+  const T* xs;   // the parameters (LDS)
+  int col[W];    // parameter index of each partial slot of this lane (-1: the slot is unused)
+  __device__ __forceinline__ Jet<T, W> operator[](int j) const {
+    Jet<T, W> r;
+    r.a = xs[j];
+#pragma unroll
+    for (int s = 0; s < W; ++s) r.v[s] = (col[s] == j) ? T(1) : T(0);   // optimize_autodiff.h:56-69 seeding, per chunk
+    return r;
+  }
+};
+
+template <typename T, int NBM, int THIN, typename F>
+struct JetRowModel {
+  using Scalar = T;
+  static constexpr int kXdim = 0;
+  static constexpr int kNmax = THIN > 0 ? 16 * NBM + THIN - 1 : 16 * NBM - 1;
+  static constexpr int kNpad = (kNmax + 7) & ~7;
+  static constexpr int kW = NBM + (THIN ? THIN - 1 : 0);
+  static_assert(F::kR == 1, "one residual per item");
+  static_assert(F::kN <= kNmax, "functor has more parameters than this layout holds");
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
+  __device__ __forceinline__ void set_loss(int, double) {}
+  DenseRowGram<T, NBM, THIN> gram;
+  const T* data;
+  const T* d;
+  DenseRowLayout lay;
+  int m;
+  __device__ __forceinline__ void init(int n, int m_, const void* dp) {
+    m = m_;
+    lay = DenseRowLayout::make(n, m_);
+    data = static_cast<const T*>(dp);
+  }
+  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (F::kH + size_t(m) * F::kD); }
+  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }   // one chunk (stepping form)
+  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    const int k = lane >> 4, c = lane & 15;
+    SeededX<T, kW> X;
+    X.xs = L.xs;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      const int q = NBM * c + cb;
+      X.col[cb] = (q < lay.nmr && q < n) ? q : -1;
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < THIN; ++j) X.col[NBM + j] = lay.nmr + j;
+    const bool isB = (THIN == 0) && ((c + 1) * NBM == lay.rsm);
+    gram.clear();
+    const T* items = d + F::kH;
+    const int steps = lay.m4 >> 2;
+    for (int s = 0; s < steps; ++s) {
+      const int row = 4 * s + k;
+      Jet<T, kW> r[1];
+      if (row < m) F::template eval<Jet<T, kW>>(X, d, items + size_t(row) * F::kD, r);   // padding rows stay all-zero
+      T w[NBM], v[THIN ? THIN : 1];
+#pragma unroll
+      for (int cb = 0; cb < NBM; ++cb) w[cb] = r[0].v[cb];                              // J.row(i) = res[i].v (:127-148)
+      if constexpr (THIN == 0) {
+        if (isB) w[NBM - 1] = r[0].a;
+      } else {
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; ++j) v[j] = r[0].v[NBM + j];
+        v[THIN - 1] = r[0].a;
+      }
+      gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == steps)));
+    }
+    gram.finish_steps();
+    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+    nres = m;
+  }
+  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
+    T csum = 0;
+    const T* items = d + F::kH;
+    for (int i = lane; i < m; i += 64) {
+      T r[1];
+      F::template eval<T>(L.xs, d, items + size_t(i) * F::kD, r);   // the same functor on plain scalars (grad == nullptr)
+      csum += r[0] * r[0];
+    }
+    cost = wave_allreduce_sum(csum);
+    nres = m;
+  }
+  template <typename O>
+  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const { gram.write_sym(M, LD, lay, n, lane); }
 };
 
 // Per-problem LM state parked in HBM between launches: the stepping form (`Optimizer_::Step`, optimizer.h:331-539, one
