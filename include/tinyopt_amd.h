@@ -314,6 +314,20 @@ int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P
                      const void* data_dev, void* x_dev, const toa_options* options,
                      const toa_results* results, uint64_t* counters_dev, int splits);
 
+/* ---- bundle adjustment with the points eliminated (SURVEY §8f rank 4 "block-sparse / Schur"; replaces running
+ *      tinyopt::Optimize on ONE parameter object x = (C SE3 poses, N points) with the full (6C + 3N)^2 Hessian — dense
+ *      LDL^T, math.h:232-240, or Eigen's SimplicialLDLT on the sparse matrix, math.h:266-277, README.md:30,165-167).
+ *      Same Levenberg-Marquardt state machine, StopReasons and Output fields; the linear step uses the block structure:
+ *      per-point 3x3 blocks eliminated, the reduced camera system (6C <= 60 unknowns) accumulated on the matrix cores and
+ *      solved by the one-wavefront LDL^T, points recovered by back-substitution; Marquardt damping on every diagonal
+ *      entry.  One workgroup per scene, one launch per solve, P independent scenes per call (P <= 65535).
+ *        x_dev:    [P][12 C + 3 N] of T = C poses (rotation matrix row-major, translation), then N points; updated in
+ *                  place: pose <- pose * exp(delta) (3rdparty/traits/sophus.h:24-26), point += delta (traits.h:184-190)
+ *        data_dev: [P][8 + 3 C N] of T = [f cx cy 0 0 0 0 0 | uv: C x N x 2 | vis: C x N (1 observed, 0 not)]
+ *      results->final_hessian is not written (the block Hessian is not exported). */
+int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t P, const void* data_dev, void* x_dev,
+               const toa_options* options, const toa_results* results, uint64_t* counters_dev);
+
 /* ---- C1: the result gather of a sharded batch (SURVEY §8(b) export list `gather(handle_group...)`, §8(e)).
  *      Problems are independent (the reference optimises exactly one x per call, docs/API.md:12), so a batch of P_total
  *      problems shards across the GPUs of a node with no data-path communication: one process per GPU, rank g solves the

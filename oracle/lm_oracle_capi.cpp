@@ -8,6 +8,7 @@
 #include "../include/tinyopt_amd.h"
 #include "lm_oracle.hpp"
 #include "robust.hpp"
+#include "ba.hpp"
 #include "se3.hpp"
 #include "testfns.hpp"
 #include "synth.hpp"
@@ -234,6 +235,32 @@ static void maha_prior_lm_t(int64_t P, int n, const T* data, T* x, const Options
     if (iters) iters[p] = out.num_iters;
     if (cost) cost[p] = out.final_cost.cost;
     if (finalH && !out.final_hessian.empty()) std::memcpy(finalH + size_t(p) * n * n, out.final_hessian.data(), sizeof(double) * n * n);
+  }
+}
+// Bundle adjustment through the reference's own route: the FULL dense (6C + 3N)^2 system + dense LDL^T (oracle/ba.hpp).
+// x: [P][12 C + 3 N] in place; data: [P][8 + 3 C N]; history arrays as for the other families.
+template <typename T>
+static void ba_lm_t(int64_t P, int C, int N, const T* data, T* x, const Options& o, int32_t* stop, int32_t* iters, int32_t* fails,
+                    double* cost, int32_t* nres, double* errs, double* deltas2, uint8_t* succ, int hs) {
+  const size_t xs = size_t(12) * C + size_t(3) * N, ds = size_t(8) + size_t(3) * C * N;
+  for (int64_t p = 0; p < P; ++p) {
+    ba::Params<T> X;
+    X.C = C; X.N = N;
+    X.v.assign(x + p * xs, x + (p + 1) * xs);
+    Optimizer<T> opt(o, 6 * C + 3 * N);
+    Output out = opt.OptimizeAcc(X, ba::Acc<T>{C, N, data + p * ds}, ba::Plus<T>());
+    std::memcpy(x + p * xs, X.v.data(), sizeof(T) * xs);
+    if (stop) stop[p] = out.stop_reason;
+    if (iters) iters[p] = out.num_iters;
+    if (fails) fails[p] = out.num_failures;
+    if (cost) cost[p] = out.final_cost.cost;
+    if (nres) nres[p] = out.final_cost.num_residuals;
+    if (errs)
+      for (size_t k = 0; k < out.errs.size() && int(k) < hs; ++k) {
+        errs[size_t(p) * hs + k] = out.errs[k];
+        if (deltas2) deltas2[size_t(p) * hs + k] = out.deltas2[k];
+        if (succ) succ[size_t(p) * hs + k] = out.successes[k];
+      }
   }
 }
 extern "C" {
@@ -618,6 +645,13 @@ void oracle_circle_fit_lm(int dtype, int64_t P, int npts, const void* obs, void*
     if (cost) cost[p] = out.final_cost.cost;
     if (g_inlier_out) g_inlier_out[p] = out.final_cost.inlier_ratio;
   }
+}
+
+void oracle_ba_lm(int dtype, int64_t P, int C, int N, const void* data, void* x, const toa_options* opts, int32_t* stop,
+                  int32_t* iters, int32_t* fails, double* cost, int32_t* nres, double* errs, double* deltas2, uint8_t* succ, int hs) {
+  const Options o = from_pod(*opts);
+  if (dtype == TOA_F32) ba_lm_t<float>(P, C, N, (const float*)data, (float*)x, o, stop, iters, fails, cost, nres, errs, deltas2, succ, hs);
+  else ba_lm_t<double>(P, C, N, (const double*)data, (double*)x, o, stop, iters, fails, cost, nres, errs, deltas2, succ, hs);
 }
 
 }  // extern "C"

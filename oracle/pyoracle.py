@@ -70,6 +70,7 @@ def load(path: str | None = None):
     lib.oracle_se3_reproj_accumulate.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp]
     lib.oracle_se3_plus.argtypes = [C.c_int, C.c_int64, vp, vp]
     lib.oracle_set_loss.argtypes = [C.c_int, C.c_double, vp]
+    lib.oracle_ba_lm.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.oracle_circle_fit_lm.argtypes = [C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(ToaOptions), vp, vp, vp]
     if path is None:
         _lib = lib
@@ -412,3 +413,55 @@ def run_pin_tests() -> subprocess.CompletedProcess:
     if not os.path.exists(PIN):
         build()
     return subprocess.run([PIN], capture_output=True, text=True)
+
+
+def synth_ba(P, ncam, npts, dtype, seed=0x71940917, noise_px=0.5, pose_pert=0.02, point_pert=0.05, invisible=0.0):
+    """Synthetic bundle-adjustment scenes: ncam cameras on an arc looking at a cloud of npts points around the origin,
+    pinhole f = 500, c = (320, 240), pixel noise noise_px * U(-1, 1); the start is the planted scene perturbed by
+    exp(pose_pert * U(-1,1)^6) on every pose and point_pert * U(-1,1)^3 on every point.  `invisible`: fraction of the
+    observations dropped (vis = 0).  Returns (data [P, 8 + 3*ncam*npts], x0 [P, 12*ncam + 3*npts], xstar)."""
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 500.0, 320.0, 240.0
+    data = np.zeros((P, 8 + 3 * ncam * npts))
+    x0 = np.zeros((P, 12 * ncam + 3 * npts))
+    xs = np.zeros_like(x0)
+    ident = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+    for p in range(P):
+        pts = rng.uniform(-1, 1, (npts, 3)) * np.array([1.5, 1.0, 1.0])
+        poses = np.zeros((ncam, 12))
+        for c in range(ncam):
+            ang = (c - (ncam - 1) / 2) * 0.25
+            # camera at distance 6 from the origin, rotated about the y axis by `ang`, plus a small random twist
+            Ry = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+            base = np.concatenate([Ry.ravel(), np.array([0.0, 0.0, 6.0])])[None, :]
+            poses[c] = se3_plus(base, 0.05 * rng.uniform(-1, 1, (1, 6)))[0]
+        R = poses[:, :9].reshape(ncam, 3, 3)
+        pc = np.einsum("cij,nj->cni", R, pts) + poses[:, None, 9:]
+        uv = np.stack([f * pc[..., 0] / pc[..., 2] + cx, f * pc[..., 1] / pc[..., 2] + cy], -1)
+        uv = uv + noise_px * rng.uniform(-1, 1, uv.shape)
+        vis = (rng.uniform(size=(ncam, npts)) >= invisible).astype(np.float64)
+        vis[:2] = 1.0                                   # every point is seen by at least two cameras
+        data[p, 0], data[p, 1], data[p, 2] = f, cx, cy
+        data[p, 8:8 + 2 * ncam * npts] = uv.ravel()
+        data[p, 8 + 2 * ncam * npts:] = vis.ravel()
+        xs[p, :12 * ncam] = poses.ravel()
+        xs[p, 12 * ncam:] = pts.ravel()
+        x0[p, :12 * ncam] = se3_plus(poses, pose_pert * rng.uniform(-1, 1, (ncam, 6))).ravel()
+        x0[p, 12 * ncam:] = (pts + point_pert * rng.uniform(-1, 1, pts.shape)).ravel()
+    return data.astype(dtype), x0.astype(dtype), xs.astype(dtype)
+
+
+def ba_lm(data, x0, ncam, npts, pod: ToaOptions, history=True):
+    """Bundle adjustment solved the reference's way: dense (6C + 3N)^2 Hessian + dense LDL^T (oracle/ba.hpp)."""
+    lib = load()
+    x = np.array(x0, copy=True)
+    P = x.shape[0]
+    stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); fails = np.zeros(P, np.int32)
+    cost = np.zeros(P, np.float64); nres = np.zeros(P, np.int32)
+    hs = pod.max_iters + 2
+    errs = np.zeros((P, hs)) if history else None
+    d2 = np.zeros((P, hs)) if history else None
+    succ = np.zeros((P, hs), np.uint8) if history else None
+    lib.oracle_ba_lm(_code(x.dtype), P, ncam, npts, _p(np.ascontiguousarray(data)), _p(x), C.byref(pod), _p(stop), _p(iters),
+                     _p(fails), _p(cost), _p(nres), _p(errs), _p(d2), _p(succ), hs)
+    return dict(x=x, stop=stop, iters=iters, fails=fails, cost=cost, nres=nres, errs=errs, deltas2=d2, succ=succ)

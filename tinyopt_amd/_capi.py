@@ -77,6 +77,7 @@ PROTOTYPES = {
     "toa_comm_destroy": (C.c_int, [_P]),
     "toa_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, _P, C.POINTER(ToaResults), C.c_int, _P, C.POINTER(ToaResults)]),
     "toa_jet_eval": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
+    "toa_ba_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
     "toa_set_loss": (C.c_int, [_P, C.c_int, C.c_double]),
     "toa_robust_norm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_double, _P, _P]),
     "toa_hbm_read_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),

@@ -434,6 +434,25 @@ class DenseRowAD:
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
+class BundleAdjustment:
+    """C SE3 cameras x N 3-D points, pinhole reprojection residuals: the multi-pose problem behind
+    config C5's single-pose block.  x: [P, 12*C + 3*N] = poses (rotation matrix row-major + translation) then points;
+    data: [P, 8 + 3*C*N] = [f, cx, cy, 0... | uv (C, N, 2) | vis (C, N)].  Solved with the points eliminated (Schur
+    complement on the reduced camera system, `toa_ba_run`); the reference would run Optimize on the full dense /
+    SimplicialLDLT system (math.h:232-277).  Output.final_hessian is not produced."""
+    model_id = None
+
+    def __init__(self, data: torch.Tensor, ncam: int, npts: int):
+        assert data.dim() == 2 and data.shape[1] == 8 + 3 * ncam * npts and data.is_cuda
+        self.P, self.ncam, self.npts, self.dtype = data.shape[0], int(ncam), int(npts), data.dtype
+        self.n, self.m, self.xdim = 6 * self.ncam + 3 * self.npts, 2 * self.ncam * self.npts, 12 * self.ncam + 3 * self.npts
+        self.packed = data.contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return (3 * self.ncam * self.npts + 3 * self.npts) * self.packed.element_size()
+
+
 class DenseRowNatural:
     """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout,
     J^T J through a batched rocBLAS GEMM, the damped solve through rocSOLVER's batched Cholesky, the LM state machine of
@@ -455,7 +474,7 @@ class DenseRowNatural:
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
-_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural)
+_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural, BundleAdjustment)
 
 
 @dataclass
@@ -559,6 +578,22 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     _check_call(x, cost)
     P, n = x.shape[0], cost.n
     ctx = ctx or default_context(x.device.index)
+    if isinstance(cost, BundleAdjustment):
+        if options.has_host_controls() or splits is not None:
+            raise ValueError("BundleAdjustment runs as one launch per solve: no stop callbacks / splits")
+        pod = options.to_pod()
+        pod.save_last = 0
+        if out is None:
+            import copy
+            o2 = copy.deepcopy(options)
+            o2.hessian.save_last = False
+            out = _alloc_output(P, 1, o2, history, x.device)
+        else:
+            out.counters.zero_()
+        res = _results_pod(out)
+        check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
+                                 C.byref(pod), C.byref(res), out.counters.data_ptr()))
+        return out
     if options.has_host_controls():
         if splits is not None or out is not None:
             raise ValueError("stop callbacks / max_duration_ms run through the stepping form: splits / out are not taken")

@@ -1,0 +1,577 @@
+// Bundle adjustment with the points eliminated ("block-sparse / Schur"): C SE3 cameras x N 3-D points,
+// reprojection residuals, the SAME Levenberg-Marquardt state machine as every other path (LmState, lm_judge_core,
+// lm_good_step / lm_bad_step of lm_device.hpp).  The reference has no such path: it would run `Optimize(x, acc)` on the
+// full (6C + 3N)^2 system with a dense LDL^T, or Eigen's SimplicialLDLT on the sparse one (include/tinyopt/math.h:232-240,
+// 266-277; README.md:30,165-167 "sparse is slow") — which is what the oracle does (oracle/ba.hpp).  Here the block
+// structure of H = [[U, W], [W^T, V]] (U: 6x6 per camera, V: 3x3 per point, W: 6x3 per observation) is used:
+//
+//   (U - W V^-1 W^T) dc = -g_c + W V^-1 g_p            reduced camera system, 6C <= 60 unknowns: the one-wavefront LDL^T
+//   dp_j = -V_j^-1 (g_pj + W_j^T dc)                   back-substitution, a 3x3 solve per point
+//
+// with Marquardt's multiplicative damping on EVERY diagonal entry of H (lm.h:108-117), cameras and points alike.
+// The Schur complement is accumulated on the matrix cores: with V_j = R_j R_j^T (Cholesky) and Y_j = [W_1j; ...; W_Cj],
+//   W V^-1 W^T = sum_j Z_j Z_j^T,  W V^-1 g_p = sum_j Z_j q_j,   Z_j = Y_j R_j^-T (6C x 3),  q_j = R_j^-1 g_pj
+// i.e. the Gram of the (3N) x (6C + 1) matrix of rows [Z_j[:, a]^T | q_j[a]] — exactly the [J | r] Gram DenseRowGram
+// computes, fed through add_step (one point = 3 rows of a 4-row MFMA step).
+//
+// One workgroup (4 waves) per scene runs the whole solve in one launch; scenes are independent (grid = P).  Every reduction
+// has a fixed order (per-lane partial sums, wave butterflies, waves folded 0..3), so results are bit-reproducible.
+//   data: [f cx cy 0 0 0 0 0 | uv: C x N x 2 | vis: C x N]     x: [12 C poses (R row-major, t) | 3 N points], in place
+#include "kernels.hpp"
+
+namespace toa {
+
+struct BaParams {
+  const void* data;
+  void* x;
+  void* work;                 // per scene: W blocks, V, g_p, R^-1, q, dp, last dp (see BaWork)
+  long long P;
+  int C, N;
+  toa_options opt;
+  toa_results res;
+  unsigned long long* counters;
+  int lds_wave;               // bytes of the WaveLds carve (wave 0's LDL^T workspace + vectors + LmState)
+};
+
+template <typename T>
+struct BaWork {  // element offsets into a scene's scratch block
+  size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, total;
+  __host__ __device__ BaWork(int C, int N) {
+    size_t o = 0;
+    W = o; o += size_t(C) * N * 18;   // W_cj = J_c^T J_p, 6 x 3 row-major
+    Voff = o; o += size_t(N) * 3;     // V_j off-diagonals (0,1) (0,2) (1,2)
+    hdp = o; o += size_t(N) * 3;      // CURRENT (damped) diagonal of V_j
+    gp = o; o += size_t(N) * 3;
+    Rinv = o; o += size_t(N) * 6;     // R_j^-1, lower: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+    q = o; o += size_t(N) * 3;
+    dp = o; o += size_t(N) * 3;
+    ldp = o; o += size_t(N) * 3;
+    total = (o + 63) & ~size_t(63);
+  }
+};
+
+// fixed-order sum over the 256 threads of the workgroup: wave butterflies, then the four wave totals in index order
+template <typename T>
+__device__ __forceinline__ T ba_block_sum(T v, T* red4) {
+  v = wave_allreduce_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+// pose <- pose * exp(sign * d)  (sophus.h:24-26), one thread, pose = R row-major | t
+template <typename T>
+__device__ __forceinline__ void ba_se3_plus(T* P, const T* dv, T sign) {
+  T d[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d[i] = sign * dv[i];
+  const T wx = d[3], wy = d[4], wz = d[5];
+  const T t2 = wx * wx + wy * wy + wz * wz;
+  const T th = sqrt(t2);
+  T A, B, Cc;
+  if (t2 < T(1e-10)) { A = T(1) - t2 / T(6); B = T(0.5) - t2 / T(24); Cc = T(1) / T(6) - t2 / T(120); }
+  else { T sn, cs; sincos_t(th, &sn, &cs); A = sn / th; B = (T(1) - cs) / t2; Cc = (th - sn) / (t2 * th); }
+  T Rd[9];
+  Rd[0] = T(1) - B * (wy * wy + wz * wz); Rd[1] = -A * wz + B * wx * wy;          Rd[2] = A * wy + B * wx * wz;
+  Rd[3] = A * wz + B * wx * wy;          Rd[4] = T(1) - B * (wx * wx + wz * wz); Rd[5] = -A * wx + B * wy * wz;
+  Rd[6] = -A * wy + B * wx * wz;         Rd[7] = A * wx + B * wy * wz;          Rd[8] = T(1) - B * (wx * wx + wy * wy);
+  const T c1[3] = {wy * d[2] - wz * d[1], wz * d[0] - wx * d[2], wx * d[1] - wy * d[0]};
+  const T c2[3] = {wy * c1[2] - wz * c1[1], wz * c1[0] - wx * c1[2], wx * c1[1] - wy * c1[0]};
+  T td[3], x[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) td[i] = d[i] + B * c1[i] + Cc * c2[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = P[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P[3 * i + j] = x[3 * i] * Rd[j] + x[3 * i + 1] * Rd[3 + j] + x[3 * i + 2] * Rd[6 + j];
+    P[9 + i] = x[3 * i] * td[0] + x[3 * i + 1] * td[1] + x[3 * i + 2] * td[2] + x[9 + i];
+  }
+}
+
+// residual and Jacobians of observation (camera P, point q): r (2), Jc (2 x 6), Jp (2 x 3)
+template <typename T, bool WANT_J>
+__device__ __forceinline__ void ba_obs(const T* P, const T* q, const T f, const T cx, const T cy, const T u, const T v, T* r, T (*Jc)[6],
+                                       T (*Jp)[3]) {
+  const T X = P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + P[9];
+  const T Y = P[3] * q[0] + P[4] * q[1] + P[5] * q[2] + P[10];
+  const T Z = P[6] * q[0] + P[7] * q[1] + P[8] * q[2] + P[11];
+  const T iz = T(1) / Z;
+  r[0] = f * X * iz + cx - u;
+  r[1] = f * Y * iz + cy - v;
+  if constexpr (WANT_J) {
+    const T du0 = f * iz, du2 = -f * X * iz * iz, dv1 = f * iz, dv2 = -f * Y * iz * iz;
+    T D[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      D[a][0] = P[3 * a]; D[a][1] = P[3 * a + 1]; D[a][2] = P[3 * a + 2];
+      D[a][3] = -(P[3 * a + 1] * q[2] - P[3 * a + 2] * q[1]);
+      D[a][4] = -(-P[3 * a] * q[2] + P[3 * a + 2] * q[0]);
+      D[a][5] = -(P[3 * a] * q[1] - P[3 * a + 1] * q[0]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { Jc[0][k] = du0 * D[0][k] + du2 * D[2][k]; Jc[1][k] = dv1 * D[1][k] + dv2 * D[2][k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Jp[0][k] = du0 * P[k] + du2 * P[6 + k]; Jp[1][k] = dv1 * P[3 + k] + dv2 * P[6 + k]; }
+  }
+}
+
+template <typename T, int NBM, int THIN>
+__global__ void __launch_bounds__(256) ba_schur_kernel(const BaParams* __restrict__ prm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = prm->C, N = prm->N, n = 6 * C;
+  const long long p = blockIdx.x;
+  const BaWork<T> wk(C, N);
+  // ---- LDS carve: [ WaveLds of wave 0 | part: n*n | pvec, phd: 64 + 64 | poses: 12 C | U: 36 C | gc, rhs: 64 + 64 | red | flags ]
+  WaveLds<T> L = WaveLds<T>::carve(smem, n);
+  T* part = reinterpret_cast<T*>(smem + prm->lds_wave);
+  T* pvec = part + size_t(n) * n;
+  T* phd = pvec + 64;
+  T* poses = phd + 64;
+  T* U = poses + 12 * C;        // undamped 6 x 6 blocks (row-major); the damped diagonal lives in L.hd
+  T* gc = U + 36 * C;
+  T* red = gc + 64;             // [8]
+  int* flags = reinterpret_cast<int*>(red + 8);   // [0] continue, [1] do_acc, [2] action, [3] build ok, [4] solve ok
+  const T* data = static_cast<const T*>(prm->data) + size_t(p) * (8 + size_t(3) * C * N);
+  const T f = data[0], cx = data[1], cy = data[2];
+  const T* uv = data + 8;
+  const T* vis = uv + size_t(2) * C * N;
+  T* X = static_cast<T*>(prm->x) + size_t(p) * (size_t(12) * C + size_t(3) * N);
+  T* pts = X + 12 * C;
+  T* work = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  T* Wb = work + wk.W; T* Voff = work + wk.Voff; T* hdp = work + wk.hdp; T* gp = work + wk.gp;
+  T* Rinv = work + wk.Rinv; T* qv = work + wk.q; T* dp = work + wk.dp; T* ldp = work + wk.ldp;
+  const DenseRowLayout lay = DenseRowLayout::make(n, 4);
+
+  if (wave == 0) {
+    const int* src_o = reinterpret_cast<const int*>(&prm->opt);
+    int* dst_o = reinterpret_cast<int*>(L.opt);
+    for (int i = lane; i < int(sizeof(toa_options) / 4); i += 64) dst_o[i] = src_o[i];
+    const int* src_r = reinterpret_cast<const int*>(&prm->res);
+    int* dst_r = reinterpret_cast<int*>(L.res);
+    for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    wave_sync();
+    lm_init<T>(L, lane);
+  }
+  for (int i = tid; i < 12 * C; i += 256) poses[i] = X[i];
+  __syncthreads();
+  LmState<T>& S = *L.st;
+  const toa_options& opt = *L.opt;
+  const bool is_lm = opt.solver_type == 0;
+
+  for (;;) {  // one pass = Build (+ Solve) of the loop at optimizer.h:358; a failed solve retries without advancing the iteration
+    const bool do_acc = !is_lm || S.rebuild;
+    // ================= Accumulate / Evaluate (gn.h:97-113) =================
+    T csum = 0, nvis = 0;
+    for (int c = 0; c < C; ++c) {
+      T Pm[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Pm[i] = poses[12 * c + i];
+      T G[28];
+#pragma unroll
+      for (int i = 0; i < 28; ++i) G[i] = T(0);
+      for (int j = tid; j < N; j += 256) {
+        const bool seen = vis[size_t(c) * N + j] != T(0);
+        const T q[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+        T r[2] = {T(0), T(0)};
+        if (do_acc) {
+          T Jc[2][6], Jp[2][3];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Jc[a][k] = T(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Jp[a][k] = T(0);
+          }
+          if (seen) ba_obs<T, true>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, Jc, Jp);
+          // camera block: upper Gram of [Jc | r] (7 x 7), as Se3ReprojModel
+#pragma unroll
+          for (int row = 0; row < 2; ++row) {
+            T w7[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w7[k] = Jc[row][k];
+            w7[6] = r[row];
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < 7; ++a)
+#pragma unroll
+              for (int b = a; b < 7; ++b) G[t++] += w7[a] * w7[b];
+          }
+          // point block V_j += Jp^T Jp, g_pj += Jp^T r (the thread owns point j for every camera: no races), W_cj = Jc^T Jp
+          T v6[6], g3[3];
+          if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v6[k] = T(0); v6[3 + k] = T(0); g3[k] = T(0); }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v6[k] = hdp[3 * j + k]; v6[3 + k] = Voff[3 * j + k]; g3[k] = gp[3 * j + k]; }
+          }
+#pragma unroll
+          for (int row = 0; row < 2; ++row) {
+            v6[0] += Jp[row][0] * Jp[row][0]; v6[1] += Jp[row][1] * Jp[row][1]; v6[2] += Jp[row][2] * Jp[row][2];
+            v6[3] += Jp[row][0] * Jp[row][1]; v6[4] += Jp[row][0] * Jp[row][2]; v6[5] += Jp[row][1] * Jp[row][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g3[k] += Jp[row][k] * r[row];
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { hdp[3 * j + k] = v6[k]; Voff[3 * j + k] = v6[3 + k]; gp[3 * j + k] = g3[k]; }
+          T* Wd = Wb + (size_t(c) * N + j) * 18;
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wd[3 * k + b] = Jc[0][k] * Jp[0][b] + Jc[1][k] * Jp[1][b];
+        } else if (seen) {
+          ba_obs<T, false>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, nullptr, nullptr);
+        }
+        csum += r[0] * r[0] + r[1] * r[1];
+        nvis += seen ? T(2) : T(0);
+      }
+      if (do_acc) {  // fold the camera's 28 sums over the workgroup, fixed order
+#pragma unroll
+        for (int i = 0; i < 28; ++i) G[i] = wave_allreduce_sum(G[i]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 28; ++i) part[wave * 28 + i] = G[i];
+        }
+        __syncthreads();
+        if (tid < 28) {
+          const T tot = (part[tid] + part[28 + tid]) + (part[56 + tid] + part[84 + tid]);
+          // tt(a, b) = a * 7 - a (a - 1) / 2 + (b - a): scatter into the 6 x 6 block, g_c
+          int a = 0, rem = tid;
+          while (rem >= 7 - a) { rem -= 7 - a; ++a; }
+          const int b = a + rem;
+          if (b < 6) { U[36 * c + 6 * a + b] = tot; U[36 * c + 6 * b + a] = tot; }
+          else if (a < 6) gc[6 * c + a] = tot;
+        }
+        __syncthreads();
+      }
+    }
+    const T cost_raw = ba_block_sum<T>(csum, red);
+    const int nres = int(ba_block_sum<T>(nvis, red));
+    __syncthreads();
+    // ================= rest of Build (lm.h:59-120): validity, clipping, diagonal check, Marquardt damping =================
+    if (tid == 0) {
+      if (do_acc) S.acc_passes++; else S.eval_passes++;
+      S.cost_val = normalize_cost(double(cost_raw), nres, opt);
+      S.cost_nres = nres;
+      S.cost_ninl = nres;
+      flags[3] = (nres > 0 && S.cost_val != kDblMax) ? 1 : 0;
+    }
+    __syncthreads();
+    bool built = flags[3] != 0;
+    if (built && do_acc) {
+      if (opt.grad_clipping != 0) {  // base.h:29-38
+        const T mm = opt.grad_clipping;
+        for (int i = tid; i < n; i += 256) gc[i] = fmin(fmax(gc[i], -mm), mm);
+        for (int i = tid; i < 3 * N; i += 256) gp[i] = fmin(fmax(gp[i], -mm), mm);
+      }
+      for (int i = tid; i < n; i += 256) L.hd[i] = U[36 * (i / 6) + 7 * (i % 6)];   // undamped camera diagonal
+      __syncthreads();
+      if (opt.check_min_H_diag > 0) {  // lm.h:82-86, every diagonal entry of H
+        T low = 0;
+        for (int i = tid; i < n; i += 256) low += fabs(L.hd[i]) < T(opt.check_min_H_diag) ? T(1) : T(0);
+        for (int i = tid; i < 3 * N; i += 256) low += fabs(hdp[i]) < T(opt.check_min_H_diag) ? T(1) : T(0);
+        if (ba_block_sum<T>(low, red) > T(0)) built = false;
+      }
+    }
+    __syncthreads();
+    if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double
+      const double s = S.rebuild ? 1.0 + double(S.lambda) : (1.0 + double(S.lambda)) / (1.0 + double(S.prev_lambda));
+      for (int i = tid; i < n; i += 256) L.hd[i] = T(double(L.hd[i]) * s);
+      for (int i = tid; i < 3 * N; i += 256) hdp[i] = T(double(hdp[i]) * s);
+    }
+    __syncthreads();
+    // ================= Solve (gn.h:150-171) through the Schur complement =================
+    T bad = 0;
+    if (built) {
+      // per point: Cholesky of the damped V_j, R^-1, q = R^-1 g_p
+      for (int j = tid; j < N; j += 256) {
+        const T a00 = hdp[3 * j], a11 = hdp[3 * j + 1], a22 = hdp[3 * j + 2];
+        const T a01 = Voff[3 * j], a02 = Voff[3 * j + 1], a12 = Voff[3 * j + 2];
+        // a point no camera sees has V = 0: like the dense LDL^T's zero pivots it takes a zero step (pseudo-inverse)
+        const bool empty = a00 == T(0) && a11 == T(0) && a22 == T(0) && a01 == T(0) && a02 == T(0) && a12 == T(0);
+        T r00 = 0, r10 = 0, r11 = 0, r20 = 0, r21 = 0, r22 = 0;   // R^-1 (lower)
+        if (!empty) {
+          const T l00s = a00;
+          const T l00 = sqrt(l00s);
+          const T l10 = a01 / l00, l20 = a02 / l00;
+          const T l11s = a11 - l10 * l10;
+          const T l11 = sqrt(l11s);
+          const T l21 = (a12 - l20 * l10) / l11;
+          const T l22s = a22 - l20 * l20 - l21 * l21;
+          const T l22 = sqrt(l22s);
+          if (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0))) bad += T(1);   // not positive definite: the solve fails
+          r00 = T(1) / l00; r11 = T(1) / l11; r22 = T(1) / l22;
+          r10 = -l10 * r00 * r11;
+          r21 = -l21 * r11 * r22;
+          r20 = -(l20 * r00 + l21 * r10) * r22;
+        }
+        T* Rj = Rinv + 6 * j;
+        Rj[0] = r00; Rj[1] = r10; Rj[2] = r11; Rj[3] = r20; Rj[4] = r21; Rj[5] = r22;
+        const T g0 = gp[3 * j], g1 = gp[3 * j + 1], g2 = gp[3 * j + 2];
+        qv[3 * j] = r00 * g0;
+        qv[3 * j + 1] = r10 * g0 + r11 * g1;
+        qv[3 * j + 2] = r20 * g0 + r21 * g1 + r22 * g2;
+      }
+      bad = ba_block_sum<T>(bad, red);
+      __syncthreads();
+      // M = U (block diagonal, damped diagonal), rhs = -g_c
+      for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        T v = (i / 6 == j / 6) ? U[36 * (i / 6) + 6 * (i % 6) + (j % 6)] : T(0);
+        if (i == j) v = L.hd[i];
+        L.M[i * L.LD + j] = v;
+      }
+      for (int i = tid; i < 64; i += 256) L.vec[i] = i < n ? -gc[i] : T(0);
+      __syncthreads();
+      // the Schur Gram on the matrix cores: wave w takes points w, w + 4, ...; rows a = 0..2 of a point sit in row groups 0..2
+      {
+        DenseRowGram<T, NBM, THIN> gram;
+        gram.clear();
+        const int k = lane >> 4, c16 = lane & 15;
+        const bool isB = (THIN == 0) && ((c16 + 1) * NBM == lay.rsm);
+        const int npts_w = N > wave ? (N - wave + 3) / 4 : 0;
+        for (int s = 0; s < npts_w; ++s) {
+          const int j = wave + 4 * s;
+          T rk[3] = {T(0), T(0), T(0)};   // row k of R_j^-1 (k == 3: the unused fourth row of the step stays zero)
+          T qk = T(0);
+          if (k < 3) {
+            const T* Rj = Rinv + 6 * j;
+            if (k == 0) rk[0] = Rj[0];
+            else if (k == 1) { rk[0] = Rj[1]; rk[1] = Rj[2]; }
+            else { rk[0] = Rj[3]; rk[1] = Rj[4]; rk[2] = Rj[5]; }
+            qk = qv[3 * j + k];
+          }
+          auto zcol = [&](int col) -> T {  // Z_j[col][k] = sum_b W_{cam,j}[dof][b] R^-1[k][b]
+            if (col >= n || k >= 3) return T(0);
+            const T* Wd = Wb + (size_t(col / 6) * N + j) * 18 + 3 * (col % 6);
+            return Wd[0] * rk[0] + Wd[1] * rk[1] + Wd[2] * rk[2];
+          };
+          T w[NBM], v[THIN ? THIN : 1];
+#pragma unroll
+          for (int cb = 0; cb < NBM; ++cb) {
+            const int qcol = NBM * c16 + cb;
+            w[cb] = qcol < lay.nmr ? zcol(qcol) : T(0);
+          }
+          if constexpr (THIN == 0) {
+            if (isB) w[NBM - 1] = qk;
+          } else {
+#pragma unroll
+            for (int jt = 0; jt + 1 < THIN; ++jt) v[jt] = zcol(lay.nmr + jt);
+            v[THIN - 1] = qk;
+          }
+          gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == npts_w)));
+        }
+        gram.finish_steps();
+        for (int wv = 0; wv < 4; ++wv) {   // fold the four partial Grams in wave order
+          if (wave == wv) {
+            gram.write_sym(part, n, lay, n, lane);
+            (void)gram.extract_g_diag_cost(pvec, phd, lay, n, lane, &red[4]);
+          }
+          __syncthreads();
+          for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e % n;
+            L.M[i * L.LD + j] -= (i == j) ? phd[i] : part[e];
+          }
+          for (int i = tid; i < n; i += 256) L.vec[i] += pvec[i];
+          __syncthreads();
+        }
+      }
+      // reduced camera system: the one-wavefront LDL^T with the reference's acceptance rule
+      if (wave == 0) {
+        bool ok;
+        const T rhs = lane < n ? L.vec[lane] : T(0);
+        {
+          LdltRegs<T, ((16 * NBM + (THIN ? THIN - 1 : -1)) + 7) & ~7> F;
+          F.load(L.M, L.LD, n, lane);
+          ok = F.factor(n, lane);
+          if (ok) L.dx[lane] = F.solve(n, lane, rhs);
+        }
+        if (!ok) {
+          ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
+          if (ok) L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, rhs);
+        }
+        wave_sync();
+        if (lane == 0) { flags[4] = (ok && bad == T(0)) ? 1 : 0; S.solves++; }
+      }
+      __syncthreads();
+    }
+    const bool solved = built && flags[4] != 0;
+    // back-substitution, |dx|^2, |g|^2 (optimizer.h:412-415)
+    T d2 = 0, g2 = 0;
+    if (solved) {
+      for (int j = tid; j < N; j += 256) {
+        T u3[3] = {gp[3 * j], gp[3 * j + 1], gp[3 * j + 2]};
+        g2 += u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];
+        for (int c = 0; c < C; ++c) {
+          const T* Wd = Wb + (size_t(c) * N + j) * 18;
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) {
+            const T dck = L.dx[6 * c + kk];
+            u3[0] += Wd[3 * kk] * dck; u3[1] += Wd[3 * kk + 1] * dck; u3[2] += Wd[3 * kk + 2] * dck;
+          }
+        }
+        const T* Rj = Rinv + 6 * j;
+        const T y0 = Rj[0] * u3[0], y1 = Rj[1] * u3[0] + Rj[2] * u3[1], y2 = Rj[3] * u3[0] + Rj[4] * u3[1] + Rj[5] * u3[2];
+        const T e0 = -(Rj[0] * y0 + Rj[1] * y1 + Rj[3] * y2), e1 = -(Rj[2] * y1 + Rj[4] * y2), e2 = -(Rj[5] * y2);
+        dp[3 * j] = e0; dp[3 * j + 1] = e1; dp[3 * j + 2] = e2;
+        d2 += e0 * e0 + e1 * e1 + e2 * e2;
+      }
+      for (int i = tid; i < n; i += 256) { d2 += L.dx[i] * L.dx[i]; g2 += gc[i] * gc[i]; }
+    }
+    const T d2s = ba_block_sum<T>(d2, red);
+    const T g2s = ba_block_sum<T>(g2, red);
+    __syncthreads();
+    // ================= Step bookkeeping + the loop body of OptimizeAcc (optimizer.h:266-310, 370-399), one thread =================
+    if (tid == 0) {
+      const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
+      int rc;  // 0 step, 1 solver failed for good, 2 early stop, -1 retry (same iteration)
+      if (solved) {
+        rc = 0;
+      } else {
+        S.num_consec = (S.num_consec + 1) & 0xff;
+        S.num_failures = (S.num_failures + 1) & 0xff;
+        if (S.cost_nres == 0) { S.stop = TOA_STOP_SKIPPED; rc = 2; }
+        else if (isnan(S.cost_val) || isinf(S.cost_val)) { S.stop = TOA_STOP_NAN_OR_INF; rc = 2; }
+        else if (opt.max_consec_failures > 0 && S.num_consec >= unsigned(opt.max_consec_failures)) {
+          if (S.final_cost < double(NumLimits<T>::max())) S.stop = TOA_STOP_MAX_CONSEC_NO_DECR;
+          rc = 1;
+        } else {
+          lm_bad_step(S, opt);
+          rc = (S.num_consec <= max_tries) ? -1 : 1;
+        }
+      }
+      int action = 0, cont = 1;
+      if (rc >= 0) {
+        int status = 0;
+        if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;
+        if (rc == 0) status = lm_judge_core<T>(S, opt, *L.res, p, double(d2s), opt.min_grad_norm2 > 0.0f ? double(g2s) : 0.0, true);
+        bool eval_only = false;
+        if (status & 1) {
+          action = 1; S.has_last_dx = 1; S.last_was_success = 1;
+          if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
+        } else {
+          if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
+          else if (status & 2) { action = 1; S.has_last_dx = 1; }
+          eval_only = (S.last_was_success == 0);
+          S.last_was_success = 0;
+        }
+        if (is_lm) S.rebuild = eval_only ? 0 : 1;
+        S.num_iters = S.num_iters + 1;
+        S.iter = S.iter + 1;
+        cont = (S.stop == TOA_STOP_NONE && S.iter < S.max_iters) ? 1 : 0;
+      }
+      flags[0] = cont;
+      flags[2] = action;
+    }
+    __syncthreads();
+    const int action = flags[2];
+    if (action == 1) {  // x (+)= dx: SE3 on the cameras (sophus.h:24-26), Euclidean on the points (traits.h:184-190)
+      if (tid < C) ba_se3_plus<T>(poses + 12 * tid, L.dx + 6 * tid, T(1));
+      if (tid >= 64 && tid < 128) L.ldx[tid - 64] = L.dx[tid - 64];
+      for (int i = tid; i < 3 * N; i += 256) { const T d = dp[i]; pts[i] += d; ldp[i] = d; }
+    } else if (action == 2) {  // roll back the last step
+      if (tid < C) ba_se3_plus<T>(poses + 12 * tid, L.ldx + 6 * tid, T(-1));
+      for (int i = tid; i < 3 * N; i += 256) pts[i] -= ldp[i];
+    }
+    __syncthreads();
+    if (!flags[0]) break;
+  }
+  // ---- optimizer.h:313-327
+  for (int i = tid; i < 12 * C; i += 256) X[i] = poses[i];
+  if (tid == 0) {
+    const toa_results& res = *L.res;
+    if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;
+    res.stop_reason[p] = S.stop;
+    res.num_iters[p] = S.num_iters;
+    res.final_cost[p] = S.final_cost;
+    if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+    if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+    if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+    if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+    if (prm->counters) {
+      atomicAdd(&prm->counters[0], S.acc_passes);
+      atomicAdd(&prm->counters[1], S.eval_passes);
+      atomicAdd(&prm->counters[2], S.solves);
+      atomicAdd(&prm->counters[3], 1ull);
+    }
+  }
+}
+
+template <typename T, int NBM, int THIN>
+int launch_ba(toa_handle h, BaParams& prm) {
+  const int n = 6 * prm.C;
+  size_t pw = WaveLds<T>::bytes(n);
+  pw = (pw + 15) & ~size_t(15);
+  prm.lds_wave = int(pw);
+  const size_t lds = pw + (size_t(n) * n + 64 + 64 + size_t(12) * prm.C + size_t(36) * prm.C + 64 + 8) * sizeof(T) + 64;
+  if (lds > size_t(160 * 1024)) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: LDS footprint exceeds 160 KiB");
+  const BaWork<T> wk(prm.C, prm.N);
+  const size_t need = size_t(prm.P) * wk.total * sizeof(T);
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->scratch, need));
+    h->scratch_bytes = need;
+  }
+  prm.work = h->scratch;
+  static_assert(sizeof(BaParams) <= 1024, "parameter block too large");
+  if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
+  auto kern = ba_schur_kernel<T, NBM, THIN>;
+  if (int rc = ensure_lds_attr(h, (const void*)kern, lds)) return rc;
+  hipLaunchKernelGGL(kern, dim3(unsigned(prm.P)), dim3(256), lds, h->stream, (const BaParams*)h->params_dev);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+template <typename T>
+int launch_ba_any(toa_handle h, BaParams& prm) {
+  const DenseRowLayout lay = DenseRowLayout::make(6 * prm.C, 4);
+  switch (lay.nbm * 8 + lay.thin) {
+    case 8 + 0: return launch_ba<T, 1, 0>(h, prm);    // C = 1, 2
+    case 8 + 3: return launch_ba<T, 1, 3>(h, prm);    // C = 3
+    case 16 + 0: return launch_ba<T, 2, 0>(h, prm);   // C = 4, 5
+    case 24 + 0: return launch_ba<T, 3, 0>(h, prm);   // C = 6, 7
+    case 24 + 1: return launch_ba<T, 3, 1>(h, prm);   // C = 8
+    case 32 + 0: return launch_ba<T, 4, 0>(h, prm);   // C = 9, 10
+  }
+  return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: no kernel for this camera count");
+}
+
+}  // namespace toa
+
+using namespace toa;
+
+extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t P, const void* data_dev, void* x_dev,
+                          const toa_options* options, const toa_results* results, uint64_t* counters_dev) {
+  if (!h) return toa_fail(TOA_E_ARG, "null handle");
+  if (dtype != TOA_F32 && dtype != TOA_F64) return toa_fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+  if (num_cameras < 1 || num_cameras > 10) return toa_fail(TOA_E_ARG, "toa_ba_run: 1 <= num_cameras <= 10 (reduced camera system of one wavefront)");
+  if (num_points < 1 || num_points > (1 << 22)) return toa_fail(TOA_E_ARG, "toa_ba_run: num_points out of range");
+  if (P < 0 || P > 65535) return toa_fail(TOA_E_ARG, "toa_ba_run: P must be in [0, 65535]");
+  if (!data_dev || !x_dev || !options || !results) return toa_fail(TOA_E_ARG, "toa_ba_run: null pointer");
+  if (!results->stop_reason || !results->num_iters || !results->final_cost)
+    return toa_fail(TOA_E_ARG, "toa_ba_run: stop_reason, num_iters and final_cost outputs are required");
+  if (options->solver_type != 0 && options->solver_type != 1) return toa_fail(TOA_E_ARG, "toa_ba_run: solver_type must be 0 (LM) or 1 (GN)");
+  if (!options->use_ldlt) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: use_ldlt=false is not available");
+  if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
+    return toa_fail(TOA_E_ARG, "toa_ba_run: hist_stride must be >= max_iters + 2");
+  if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
+  if (P == 0) return TOA_OK;
+  TOA_ON_DEVICE(h->device);
+  BaParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.data = data_dev; prm.x = x_dev; prm.P = P; prm.C = num_cameras; prm.N = num_points;
+  prm.opt = *options; prm.res = *results;
+  prm.res.final_hessian = nullptr;   // the block Hessian is not exported
+  prm.counters = reinterpret_cast<unsigned long long*>(counters_dev);
+  return dtype == TOA_F32 ? launch_ba_any<float>(h, prm) : launch_ba_any<double>(h, prm);
+}
