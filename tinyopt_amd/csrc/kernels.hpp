@@ -21,6 +21,7 @@
 #include "../../include/tinyopt_amd.h"
 #include "dense_row.hpp"
 #include "jet.hpp"
+#include "ldlt_blocked.hpp"
 #include "ldlt_lds.hpp"
 #include "ldlt_regs.hpp"
 #include "lm_device.hpp"
@@ -1255,22 +1256,25 @@ __global__ void __launch_bounds__(256) solve_damped_kernel(const void* H_, const
     wave_sync();
     const T* H = Hg + size_t(p) * n * n;
     // upper triangle is authoritative (math.h:235 selfadjointView<Upper>): M[i][j] = H(min,max) (col-major)
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e % n;
-      const int a = i < j ? i : j, b = i < j ? j : i;
-      T v = H[size_t(b) * n + a];
-      if (i == j) v = T(double(v) * scale);
-      L.M[i * L.LD + j] = v;
-    }
-    wave_sync();
+    auto fill = [&]() __attribute__((always_inline)) {
+      for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e % n;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        T v = H[size_t(b) * n + a];
+        if (i == j) v = T(double(v) * scale);
+        L.M[i * L.LD + j] = v;
+      }
+      wave_sync();
+    };
+    fill();
     const T gl = lane < n ? gg[size_t(p) * n + lane] : T(0);
     bool ok;
     T dx = 0;
     {
-      LdltRegs<T, NPAD> F;
-      F.load(L.M, L.LD, n, lane);
-      ok = F.factor(n, lane);
-      if (ok) dx = F.solve(n, lane, -gl);
+      LdltFast<T, NPAD> F;
+      ok = F.factor(L.M, L.LD, n, lane);
+      if (ok) dx = F.solve(L.M, L.LD, n, lane, -gl);
+      else if (LdltFast<T, NPAD>::kClobbersM) { wave_sync(); fill(); }
     }
     if (!ok) {
       ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
@@ -1299,21 +1303,24 @@ __global__ void __launch_bounds__(256) inv_cov_kernel(const void* H_, long long 
       if (lane == 0) { C[0] = T(1) / H[0]; ok_[p] = 1; }
       continue;
     }
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e % n;
-      const int a = i < j ? i : j, b = i < j ? j : i;
-      L.M[i * L.LD + j] = H[size_t(b) * n + a];  // upper triangle is authoritative
-    }
-    wave_sync();
-    LdltRegs<T, NPAD> F;
-    F.load(L.M, L.LD, n, lane);
-    bool ok = F.factor(n, lane);
+    auto fill = [&]() __attribute__((always_inline)) {
+      for (int e = lane; e < n * n; e += 64) {
+        const int i = e / n, j = e % n;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        L.M[i * L.LD + j] = H[size_t(b) * n + a];  // upper triangle is authoritative
+      }
+      wave_sync();
+    };
+    fill();
+    LdltFast<T, NPAD> F;
+    bool ok = F.factor(L.M, L.LD, n, lane);
     if (ok) {
       for (int j = 0; j < n; ++j) {
-        const T x = F.solve(n, lane, lane == j ? T(1) : T(0));
+        const T x = F.solve(L.M, L.LD, n, lane, lane == j ? T(1) : T(0));
         if (lane < n) C[size_t(j) * n + lane] = x;  // column j (symmetric: row j)
       }
     } else {
+      if (LdltFast<T, NPAD>::kClobbersM) { wave_sync(); fill(); }
       ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
       if (ok)
         for (int j = 0; j < n; ++j) {

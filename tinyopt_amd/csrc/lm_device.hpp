@@ -18,6 +18,7 @@
 //   write_sym(M, LD, n, lane)           emit the symmetric undamped H into an LD-strided image
 #pragma once
 #include "../../include/tinyopt_amd.h"
+#include "ldlt_blocked.hpp"
 #include "ldlt_lds.hpp"
 #include "ldlt_regs.hpp"
 #include "wave_utils.hpp"
@@ -196,11 +197,17 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
         if (in_n) L.M[lane * L.LD + lane] = L.hd[lane];
         wave_sync();
         const T rhs = in_n ? -L.g[lane] : T(0);
-        {  // fast path: register-resident unpivoted LDL^T (positive-definite case)
-          LdltRegs<T, Model::kNpad> F;
-          F.load(L.M, L.LD, n, lane);
-          ok = F.factor(n, lane);
-          if (ok) L.dx[lane] = F.solve(n, lane, rhs);
+        {  // fast path: unpivoted LDL^T (positive-definite case) — one register panel, or blocked on the matrix cores
+          LdltFast<T, Model::kNpad> F;
+          ok = F.factor(L.M, L.LD, n, lane);
+          if (ok) L.dx[lane] = F.solve(L.M, L.LD, n, lane, rhs);
+          else if (LdltFast<T, Model::kNpad>::kClobbersM) {  // the blocked form works in place: re-create the image
+            wave_sync();
+            model.write_sym(L.M, L.LD, n, lane);
+            wave_sync();
+            if (in_n) L.M[lane * L.LD + lane] = L.hd[lane];
+            wave_sync();
+          }
         }
         if (!ok) {  // not safely positive definite: Eigen's pivoted algorithm + acceptance rule decides
           ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);

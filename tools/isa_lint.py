@@ -17,6 +17,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 MIN_WAIT = 19  # XDL write VGPR -> VALU read, 16-pass op (CDNA3/4 ISA guide, software wait states)
+MIN_WAIT_MEM = 18  # XDL write VGPR -> LDS / VMEM / FLAT read of that register, 16-pass op: one less than for a VALU reader
+                   # (what hipcc itself leaves after a builtin DGEMM MFMA whose result it stores straight from the AGPRs)
+MEM_READER = re.compile(r"^(ds_|buffer_|global_|flat_|scratch_)")
 
 AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -181,8 +184,9 @@ def lint_object(obj):
                 srcs = rest.split(",", 1)[1] if "," in rest else ""
                 if op.startswith("v_accvgpr_write"):
                     srcs = ""
+                need = MIN_WAIT_MEM if MEM_READER.match(op) else MIN_WAIT
                 for r in aregs(srcs):
-                    if r in last_write and last_write[r] < MIN_WAIT:
+                    if r in last_write and last_write[r] < need:
                         problems.append(f"{os.path.basename(obj)}: {func[:90]}: `{ins}` reads a{r} {last_write[r]} wait states after an MFMA wrote it")
                 # any write to an AGPR by a non-MFMA instruction ends the tracking of that register
                 dst = rest.split(",")[0]
