@@ -199,12 +199,12 @@ struct RawVec<1> {
   unsigned a;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>   // IMM: immediate byte offset (12 bits) added to voff + soff
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     } else {
-      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a; }
@@ -214,12 +214,12 @@ struct RawVec<2> {
   u32x2 a;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>   // IMM: immediate byte offset (12 bits) added to voff + soff
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     } else {
-      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; }
@@ -229,12 +229,12 @@ struct RawVec<3> {
   u32x3 a;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>   // IMM: immediate byte offset (12 bits) added to voff + soff
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     } else {
-      asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
@@ -244,12 +244,12 @@ struct RawVec<4> {
   u32x4 a;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>   // IMM: immediate byte offset (12 bits) added to voff + soff
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     } else {
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(a) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(a) : "v"(voff), "s"(r), "s"(soff), "n"(IMM) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; }
@@ -260,14 +260,14 @@ struct RawVec<6> {
   u32x2 b;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
-                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:%6"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff), "n"(IMM), "n"(IMM + 16) : "memory");
     } else {
-      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:16"
-                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx2 %1, %2, %3, %4 offen offset:%6"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff), "n"(IMM), "n"(IMM + 16) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const {
@@ -279,14 +279,14 @@ struct RawVec<8> {
   u32x4 a, b;
   // soff must be wave-uniform (callers readfirstlane it once per batch).  NOP = false: this load directly follows
   // another asm load that already covered the SALU-write -> VMEM-read wait states for the same soff.
-  template <bool NOP = true>
+  template <bool NOP = true, int IMM = 0>
   __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {
     if constexpr (NOP) {
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
-                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:%6"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff), "n"(IMM), "n"(IMM + 16) : "memory");
     } else {
-      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
-                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:%6"
+                 : "=&v"(a), "=&v"(b) : "v"(voff), "s"(r), "s"(soff), "n"(IMM), "n"(IMM + 16) : "memory");
     }
   }
   __device__ __forceinline__ void get(unsigned* o) const {
@@ -415,12 +415,25 @@ struct DenseRowGram {
     T inl;                           // inlier rows booked by this lane
   };
 
+  // A thin-tail layout serves exactly one n (= 16 NBM + THIN - 1), so its row stride is a compile-time constant and the
+  // four steps of a batch are reached through the loads' IMMEDIATE offsets from one scalar offset per batch: no s_add +
+  // s_nop 4 (SALU write -> VMEM read wait states) in front of every load, one in front of the first.
+  static constexpr int kStepBytesImm = THIN > 0 ? 4 * (16 * NBM + THIN) * int(sizeof(T)) : 0;
+  static constexpr bool kImmOffsets = THIN > 0 && (U - 1) * kStepBytesImm + 32 <= 4095;
   static __device__ __forceinline__ void issue_batch(Slots& m, SlotsT& t, const i32x4 rsrc, const unsigned voff,
                                                      const unsigned vofft, const unsigned soff0, const unsigned step_bytes_u) {
+    if constexpr (kImmOffsets) {
+      static_for<U>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        m[u].template issue<u == 0, u * kStepBytesImm>(rsrc, voff, soff0);
+        t[u].template issue<false, u * kStepBytesImm>(rsrc, vofft, soff0);
+      });
+    } else {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      m[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes_u);
-      if (THIN) t[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
+      for (int u = 0; u < U; ++u) {
+        m[u].issue(rsrc, voff, soff0 + unsigned(u) * step_bytes_u);
+        if (THIN) t[u].issue(rsrc, vofft, soff0 + unsigned(u) * step_bytes_u);
+      }
     }
   }
 #ifndef TOA_DEPTH

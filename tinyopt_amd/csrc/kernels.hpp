@@ -1204,6 +1204,17 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     atomicAdd(&counters[2], L.st->solves);
     atomicAdd(&counters[3], L.st->problems);
   }
+#ifndef TOA_QUEUE_DRAIN
+  // The work queue cleans itself: the last wave to leave puts the pop counter (and this exit counter) back to zero, so the
+  // next launch on the stream needs no memset in front of it (one stream operation, ~5 us, per solve: 1 % of a C3 launch).
+  if (lane == 0) {
+    const int gone = atomicAdd(&queue[16], 1);
+    if (gone == int(gridDim.x) * 4 - 1) {
+      __hip_atomic_store(&queue[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&queue[16], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
 }
 
 // K1/K2 seam: one wave per problem (grid-stride), writes g [P][n], H [P][n*n], cost, nres.
@@ -1874,6 +1885,7 @@ struct toa_context {
   int max_lds = 0;
   char name[128] = {0};
   int* queue = nullptr;  // device work-queue head
+  bool queue_dirty = true;  // the queue block needs a memset before the next fused launch (first use, or after a failure)
   void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
   int loss = TOA_LOSS_L2;      // toa_set_loss: the M-estimator of this handle's cost functor (DenseRow / Jet families)
   double loss_th2 = 0;
@@ -1991,7 +2003,16 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
+#ifdef TOA_QUEUE_DRAIN
   HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));  // [0] pops, [16] pushes, [32] finished: one cache line each
+#else
+  // [0] pop counter, [16] waves that have left: zeroed when the handle is created and by the last wave of every launch
+  // (lm_fused_kernel); a launch that failed may have left them dirty, so the next one starts from a memset again
+  if (h->queue_dirty) {
+    HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));
+    h->queue_dirty = false;
+  }
+#endif
 #ifdef TOA_QUEUE_DRAIN
   {  // iteration-granular work queue: park states + ring of re-queued problems in the context's scratch block
     const long long iters_max = (long long)prm.opt.max_iters + 3;
@@ -2047,7 +2068,10 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
-  HIP_TRY(hipGetLastError());
+  if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess) {
+    h->queue_dirty = true;
+    return toa_fail(TOA_E_HIP, std::string("lm_fused_kernel launch: ") + hipGetErrorString(e_));
+  }
   if (tl_path) {
     std::vector<unsigned long long> tl(size_t(prm.P) * 2);
     HIP_TRY(hipMemcpy(tl.data(), tl_dev, tl.size() * 8, hipMemcpyDeviceToHost));

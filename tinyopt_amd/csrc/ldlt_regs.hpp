@@ -111,19 +111,23 @@ struct LdltRegs {
       });
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      T cj[8];
-      static_for<8>([&](auto jjc) __attribute__((always_inline)) {
+      T cj[kChunk];
+      static_for<kChunk>([&](auto jjc) __attribute__((always_inline)) {
         constexpr int j = JB + decltype(jjc)::value;
         if constexpr (j > K) cj[decltype(jjc)::value] = wave_bcast(c, j);  // S[j][k] = S[k][j]
       });
       __builtin_amdgcn_sched_barrier(0);
-      static_for<8>([&](auto jjc) __attribute__((always_inline)) {
+      static_for<kChunk>([&](auto jjc) __attribute__((always_inline)) {
         constexpr int j = JB + decltype(jjc)::value;
         if constexpr (j > K) row.template set<j>(fma(-l, cj[decltype(jjc)::value], row.template get<j>()));
       });
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // Columns per update chunk (a chunk that lies entirely beyond n is skipped by a uniform branch).  fp32 works on
+  // register PAIRS, 8 columns at a time; fp64 broadcasts cost two v_readlane each, so padding columns are dearer and the
+  // chunk is 4: n = 12 updates 12 columns per pivot instead of 16 (C3: a quarter of the factorisation's update work).
+  static constexpr int kChunk = sizeof(T) == 8 ? 4 : 8;
 
   // Pivot gate of the fast path, on the scalar unit: the bit pattern of a positive, normal, not-huge value lies in
   // (lo, hi) as an unsigned integer (negative values and NaN have larger patterns), so one s_sub + s_cmp replaces two
@@ -174,9 +178,9 @@ struct LdltRegs {
           const T l = below ? c * inv : T(0);
           row.template set<k>(below ? l : c);  // lane k keeps d_k, lanes < k keep their Schur row entry
           dinv = (lane == k) ? inv : dinv;
-          constexpr int jb0 = ((k + 1) / 8);
-          static_for<NPAD / 8 - jb0>([&](auto jbc) __attribute__((always_inline)) {
-            constexpr int jb = (jb0 + decltype(jbc)::value) * 8;
+          constexpr int jb0 = ((k + 1) / kChunk);
+          static_for<NPAD / kChunk - jb0>([&](auto jbc) __attribute__((always_inline)) {
+            constexpr int jb = (jb0 + decltype(jbc)::value) * kChunk;
             if (jb < n) update_chunk<k, jb>(c, l);  // wave-uniform: skip column chunks that are entirely padding
           });
         }

@@ -31,7 +31,14 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for name in ("bench_c4", "bench_c3", "bench_under_rocprof", "bench_large128"):
+    for wl in ("c3", "c2", "c5"):
+        hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
+        if hits:
+            shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
+    if os.path.exists(os.path.join(SRC, "ad_ratio.txt")):
+        shutil.copy(os.path.join(SRC, "ad_ratio.txt"), os.path.join(DST, f"{tag}_ad_ratio.txt"))
+    for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
+                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_large128"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
@@ -67,6 +74,28 @@ def main():
     for name in (f"{tag}_pmc.json", "pmc_latest.json"):
         with open(os.path.join(DST, name), "w") as f:
             json.dump(out, f, indent=1)
+    # ---- the same HBM-traffic measurement for the C3 launch (fp64, n = 12)
+    if os.path.isdir(os.path.join(SRC, "pmc_fused_c3")):
+        b3 = json.loads(open(os.path.join(DST, f"{tag}_bench_c3.json")).read())
+        f3 = {}
+        for d in sorted(glob.glob(os.path.join(SRC, "pmc_fused_c3", "*"))):
+            c, durs = counters(d, kern)
+            f3.update(c)
+            f3.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
+        e3, _ = counters(os.path.join(SRC, "pmc_eval_c3", "FETCH_SIZE"), "accumulate_kernel")
+        P3, bpp3 = b3["config"]["problems_per_gpu"], b3["roofline"]["algorithmic_bytes_per_pass"]
+        cal3 = float(P3) * bpp3 / (e3["FETCH_SIZE"] * 1024.0)
+        hbm3 = f3["FETCH_SIZE"] * 1024.0 * cal3 + f3["WRITE_SIZE"] * 1024.0
+        alg3 = b3["roofline"]["passes_per_launch"] * bpp3
+        out3 = {"round": tag, "workload": "c3", "problems": P3, "kernel": "lm_fused_kernel<DenseRowModel<double,1,0>>",
+                "FETCH_SIZE_KB_per_launch": f3["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": f3["WRITE_SIZE"],
+                "fetch_calibration": {"kernel": "accumulate_kernel<DenseRowModel<double,1,0>> want_grad=0", "known_bytes": float(P3) * bpp3,
+                                      "FETCH_SIZE_KB": e3["FETCH_SIZE"], "bytes_per_reported_byte": cal3},
+                "hbm_bytes_per_launch": hbm3, "algorithmic_bytes_per_launch": alg3, "traffic_over_algorithmic": hbm3 / alg3,
+                "kernel_ms_under_pmc": f3["_kernel_ms"]}
+        with open(os.path.join(DST, f"{tag}_pmc_c3.json"), "w") as f:
+            json.dump(out3, f, indent=1)
+        print("c3", json.dumps({k: out3[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
     print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
     print("calibration", cal, "bench value", bench["value"], "frac", bench["roofline"]["frac"])
 
