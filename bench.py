@@ -419,7 +419,7 @@ def main():
     mfma_tflops = mfma_flop_per_pass * (acc_passes_total / args.steps) / kern_avg_s / 1e12
     mfma_peak = MFMA_PEAK_TFLOPS[tag]
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json" if args.workload == "c4" else f"pmc_latest_{args.workload}.json")
     if os.path.exists(pmc_file):
         try:
             with open(pmc_file) as f:
@@ -447,7 +447,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else "large_rows_vec_kernel + rocBLAS gemm_batched + large_chol_solve_kernel (whole pass)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes of the same workload, not this run)" if traffic else None,
+                     "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of the same workload and binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,
                      "measured_read_ceiling_GBps": stream_read,
                      "frac_of_measured_ceiling": (achieved / stream_read) if stream_read else None,
                      "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_per_launch,

@@ -93,8 +93,9 @@ def main():
                                       "FETCH_SIZE_KB": e3["FETCH_SIZE"], "bytes_per_reported_byte": cal3},
                 "hbm_bytes_per_launch": hbm3, "algorithmic_bytes_per_launch": alg3, "traffic_over_algorithmic": hbm3 / alg3,
                 "kernel_ms_under_pmc": f3["_kernel_ms"]}
-        with open(os.path.join(DST, f"{tag}_pmc_c3.json"), "w") as f:
-            json.dump(out3, f, indent=1)
+        for name in (f"{tag}_pmc_c3.json", "pmc_latest_c3.json"):
+            with open(os.path.join(DST, name), "w") as f:
+                json.dump(out3, f, indent=1)
         print("c3", json.dumps({k: out3[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
     print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
     print("calibration", cal, "bench value", bench["value"], "frac", bench["roofline"]["frac"])
