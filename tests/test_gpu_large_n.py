@@ -75,8 +75,15 @@ def _run_natural(ta, A, b, x0, opts, history=False):
     return x.cpu().numpy(), out
 
 
+# 64 <= n <= 128 (fp32) / 96 (fp64): the workgroup-per-problem persistent kernel (large_fused.hip), one case per block
+# count NB = ceil(n / 16) = 4..8 and ragged row counts; the others: the library-backed pipeline (large_n.hip)
 @pytest.mark.parametrize("dtype,n,m,xtol", [(np.float64, 64, 300, 1e-8), (np.float64, 100, 400, 1e-8),
-                                             (np.float32, 96, 400, 2e-3), (np.float64, 12, 100, 1e-8)])
+                                             (np.float32, 96, 400, 2e-3), (np.float64, 12, 100, 1e-8),
+                                             (np.float32, 64, 259, 2e-3), (np.float32, 72, 300, 2e-3),
+                                             (np.float32, 112, 501, 2e-3), (np.float32, 128, 600, 2e-3),
+                                             (np.float32, 127, 514, 2e-3), (np.float64, 80, 333, 1e-8),
+                                             (np.float64, 96, 450, 1e-8), (np.float64, 128, 520, 1e-8),
+                                             (np.float32, 144, 600, 2e-3)])
 def test_large_n_lm_matches_oracle(ta, oracle, dtype, n, m, xtol):
     pyoracle = oracle
     P = 5
@@ -182,3 +189,20 @@ def test_large_n_option_variants(ta, oracle):
         assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6, f"variant {i}"
         fc, rc = out.final_cost.cpu().numpy(), ref["cost"]
         assert np.abs(fc - rc).max() <= 1e-8 * max(1.0, np.abs(rc).max()), f"variant {i}"
+
+
+def test_large_n_fused_kernel_work_queue(ta, oracle):
+    """More problems than resident workgroups (256 CUs x 1): the persistent kernel's work queue hands out the rest, the
+    queue resets itself, and a second launch on the same handle gives bit-identical results."""
+    pyoracle = oracle
+    P, n, m = 700, 64, 128
+    A, b, x0, xs = pyoracle.synth_dense_row(P, n, m, np.float32)
+    opts = ta.Options.benchmark()
+    ref = pyoracle.dense_row_lm(A, b, x0, opts.to_pod())
+    xg, out = _run_natural(ta, A, b, x0, opts)
+    xg2, out2 = _run_natural(ta, A, b, x0, opts)
+    assert np.array_equal(xg, xg2) and np.array_equal(out.num_iters.cpu().numpy(), out2.num_iters.cpu().numpy())
+    assert (out.stop_reason.cpu().numpy() >= 0).all()
+    assert np.abs(xg - ref["x"]).max() < 2e-3
+    assert np.abs(xg - xs).max() < 5e-2
+    assert abs(out.num_iters.cpu().numpy().mean() - ref["iters"].mean()) <= 0.5

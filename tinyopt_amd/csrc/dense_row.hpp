@@ -55,8 +55,32 @@ struct Mfma<double> {
 // rotates the accumulator tuples between the unrolled steps and pays ~100 v_accvgpr_mov/read/write
 // per 40 MFMAs to undo it.  `s_nop 1` covers the VALU-write -> MFMA-operand wait states that hipcc
 // does not insert inside an asm statement (cdna_hip_programming.md §5.7 item 2).
+// Primary template: any NB, one asm statement per tile (used for NB > 4, the workgroup-per-problem kernel of
+// large_fused.hip; NB <= 4 has the hand-ordered single-statement specialisations below).  The accumulator tuples stay tied
+// in place by the "+a" constraints; the s_nop covers VALU write -> MFMA read on the first tile and is hidden behind the
+// matrix pipe on the others.
 template <typename T, int NB>
-struct GramStep;
+struct GramStep {
+  using Acc = typename Mfma<T>::Acc;
+  static __device__ __forceinline__ constexpr int tile(int i, int j) { return i * NB - i * (i - 1) / 2 + (j - i); }
+  template <int I, int J>
+  static __device__ __forceinline__ void from(Acc* acc, const T* w) {
+    if constexpr (I < NB) {
+      if constexpr (sizeof(T) == 4)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+      else
+        asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+      if constexpr (J + 1 < NB) from<I, J + 1>(acc, w);
+      else from<I + 1, I + 1>(acc, w);
+    }
+  }
+  static __device__ __forceinline__ void run(Acc* acc, const T* w) { from<0, 0>(acc, w); }
+  static __device__ __forceinline__ void run_tail(Acc* acc, const T* w, int last_in) {
+    run(acc, w);
+    const int last = __builtin_amdgcn_readfirstlane(last_in);
+    asm volatile("s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 2\n\ts_nop 15\n\ts_nop 15" : : [last] "s"(last) : "scc", "memory");
+  }
+};
 #define TOA_GRAM_STEP(T, TAG, NBV, BODY, ACCS, WS)                                                      \
   template <>                                                                                           \
   struct GramStep<T, NBV> {                                                                             \
@@ -293,6 +317,69 @@ struct RawVec<8> {
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
   }
 };
+// 5 / 7 / 10 / 12 / 14 dwords (NB = 5, 7 in fp32; NB = 5, 6, 7 in fp64): the natural-layout rows of large_fused.hip
+#define TOA_RAWVEC_ISSUE(ASM, OUTS, INS)                                                                   \
+  template <bool NOP = true, int IMM = 0>                                                                  \
+  __device__ __forceinline__ void issue(i32x4 r, unsigned voff, unsigned soff) {                           \
+    if constexpr (NOP) asm volatile("s_nop 4\n\t" ASM : OUTS : INS : "memory");                           \
+    else asm volatile(ASM : OUTS : INS : "memory");                                                        \
+  }
+template <>
+struct RawVec<5> {
+  u32x4 a;
+  unsigned b;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dword %1, %2, %3, %4 offen offset:%6",
+                   "=&v"(a) TOA_C "=&v"(b), "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16))
+  __device__ __forceinline__ void get(unsigned* o) const { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b; }
+};
+template <>
+struct RawVec<7> {
+  u32x4 a;
+  u32x3 b;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx3 %1, %2, %3, %4 offen offset:%6",
+                   "=&v"(a) TOA_C "=&v"(b), "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16))
+  __device__ __forceinline__ void get(unsigned* o) const {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2];
+  }
+};
+template <>
+struct RawVec<10> {
+  u32x4 a, b;
+  u32x2 c;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %3, %4, %5 offen offset:%6\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen offset:%7\n\t"
+                   "buffer_load_dwordx2 %2, %3, %4, %5 offen offset:%8",
+                   "=&v"(a) TOA_C "=&v"(b) TOA_C "=&v"(c),
+                   "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16) TOA_C "n"(IMM + 32))
+  __device__ __forceinline__ void get(unsigned* o) const {
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+    o[8] = c[0]; o[9] = c[1];
+  }
+};
+template <>
+struct RawVec<12> {
+  u32x4 a, b, c;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %3, %4, %5 offen offset:%6\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen offset:%7\n\t"
+                   "buffer_load_dwordx4 %2, %3, %4, %5 offen offset:%8",
+                   "=&v"(a) TOA_C "=&v"(b) TOA_C "=&v"(c),
+                   "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16) TOA_C "n"(IMM + 32))
+  __device__ __forceinline__ void get(unsigned* o) const {
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; o[8 + i] = c[i]; }
+  }
+};
+template <>
+struct RawVec<14> {
+  u32x4 a, b, c;
+  u32x2 d;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %4, %5, %6 offen offset:%7\n\tbuffer_load_dwordx4 %1, %4, %5, %6 offen offset:%8\n\t"
+                   "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:%9\n\tbuffer_load_dwordx2 %3, %4, %5, %6 offen offset:%10",
+                   "=&v"(a) TOA_C "=&v"(b) TOA_C "=&v"(c) TOA_C "=&v"(d),
+                   "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16) TOA_C "n"(IMM + 32) TOA_C "n"(IMM + 48))
+  __device__ __forceinline__ void get(unsigned* o) const {
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; o[8 + i] = c[i]; }
+    o[12] = d[0]; o[13] = d[1];
+  }
+};
+#undef TOA_RAWVEC_ISSUE
 // Wait for every outstanding VMEM load of this wave; the operands make the four batch slots
 // data-dependent on the wait so that no consumer is hoisted above it.
 // kLeave: how many YOUNGER vector-memory accesses may stay outstanding (loads retire in issue order).
@@ -301,14 +388,24 @@ __device__ __forceinline__ void wait_batch(RawVec<kDwords>& v0, RawVec<kDwords>&
   static_assert(kLeave >= 0 && kLeave < 64, "vmcnt is a 6-bit counter");
   if constexpr (kDwords <= 4) {
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a) : [n] "n"(kLeave) : "memory");
-  } else {
+  } else if constexpr (kDwords <= 8) {
     asm volatile("s_waitcnt vmcnt(%[n])"
                  : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a), "+v"(v0.b), "+v"(v1.b), "+v"(v2.b), "+v"(v3.b)
+                 : [n] "n"(kLeave) : "memory");
+  } else if constexpr (kDwords <= 12) {
+    asm volatile("s_waitcnt vmcnt(%[n])"
+                 : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a), "+v"(v0.b), "+v"(v1.b), "+v"(v2.b), "+v"(v3.b),
+                   "+v"(v0.c), "+v"(v1.c), "+v"(v2.c), "+v"(v3.c)
+                 : [n] "n"(kLeave) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%[n])"
+                 : "+v"(v0.a), "+v"(v1.a), "+v"(v2.a), "+v"(v3.a), "+v"(v0.b), "+v"(v1.b), "+v"(v2.b), "+v"(v3.b),
+                   "+v"(v0.c), "+v"(v1.c), "+v"(v2.c), "+v"(v3.c), "+v"(v0.d), "+v"(v1.d), "+v"(v2.d), "+v"(v3.d)
                  : [n] "n"(kLeave) : "memory");
   }
 }
 template <int kDwords>
-constexpr int rawvec_loads() { return kDwords <= 4 ? 1 : 2; }
+constexpr int rawvec_loads() { return (kDwords + 3) / 4; }
 
 // Host+device layout helper.
 //
@@ -764,6 +861,97 @@ struct DenseRowGram {
         for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
       }
       if constexpr (ROBUST) return wave_allreduce_sum(csum);   // sum of l; the Gram's (r, r) entry holds sum of s r^2
+      return T(0);
+    }
+    return wave_allreduce_sum(csum);
+  }
+
+  // The same pass over rows in the NATURAL layout (large_fused.hip, 64 <= n <= 128): `A` = nrows rows of n elements,
+  // `bv` = their nrows right-hand sides (THIN == 1: the thin tail is b alone, fetched through its own descriptor).  A lane
+  // whose NBM columns straddle the end of a row reads the head of the next one: those columns q >= n meet x = 0 in a_i.x,
+  // and the Gram rows / columns they pollute are never read back (extract_g_diag_cost / the caller's fold stop at n).
+  template <bool WANT_H, int D = 3>   // D: slot sets in the ring (D - 1 batches in flight while one computes)
+  __device__ __forceinline__ T pass_natural(const T* __restrict__ A, const T* __restrict__ bv, const int n, const int nrows,
+                                            const T* __restrict__ xs, const int lane) {
+    static_assert(THIN == 1 && D >= 2 && D <= 4, "natural layout: b is the whole thin tail");
+    const int k = lane >> 4, c = lane & 15;
+    PassCtx pc;
+    pc.c = c;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      const int q = NBM * c + cb;
+      pc.xr[cb] = (q < n) ? xs[q] : T(0);
+    }
+    pc.xt[0] = T(0);
+    pc.q0 = (lane & 1) != 0;
+    pc.q1 = (lane & 2) != 0;
+    pc.isB_lane = false;
+    pc.mA = T(1);
+    pc.mB = T(0);
+    pc.loss = 0;
+    pc.th2 = T(0);
+    pc.k = k;
+    pc.rows_real = nrows;
+    pc.owner = c == 0;
+    pc.inl = T(0);
+    if (WANT_H) clear();
+    T csum = 0;
+    const int steps = (nrows + 3) >> 2;
+    const i32x4 rsA = make_rsrc(A, unsigned(nrows) * unsigned(n) * unsigned(sizeof(T)));
+    const i32x4 rsB = make_rsrc(bv, unsigned(nrows) * unsigned(sizeof(T)));
+    const unsigned voff = (NBM * c < n) ? unsigned((k * n + NBM * c) * int(sizeof(T))) : 0x80000000u;
+    const unsigned voffb = unsigned(k * int(sizeof(T)));
+    const unsigned stepA = unsigned(__builtin_amdgcn_readfirstlane(int(4u * unsigned(n) * unsigned(sizeof(T)))));
+    constexpr unsigned stepB = 4u * unsigned(sizeof(T));
+    auto issue_nat = [&](Slots& m, SlotsT& t, const int step0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned sa = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(step0 + u) * stepA)));
+        const unsigned sb = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(step0 + u) * stepB)));
+        m[u].issue(rsA, voff, sa);
+        t[u].issue(rsB, voffb, sb);
+      }
+    };
+    constexpr int kLeaveN = (D - 2) * kLoadsPerBatch;  // younger batches that may stay outstanding at a wait
+    static_assert(kLeaveN < 64, "vmcnt is a 6-bit counter");
+    auto wait_nat = [&](Slots& m, SlotsT& t) __attribute__((always_inline)) {
+      wait_batch<kLeaveN, kDw>(m[0], m[1], m[2], m[3]);
+      wait_batch<kLeaveN, kDwT>(t[0], t[1], t[2], t[3]);
+    };
+    Slots S[D];
+    SlotsT St[D];
+    static_for<D - 1>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      issue_nat(S[i], St[i], i * U);
+    });
+    wait_nat(S[0], St[0]);
+    for (int s0 = 0; s0 < steps; s0 += D * U) {
+      static_for<D>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int refill = (i + D - 1) % D;  // consumed in the previous segment
+        issue_nat(S[refill], St[refill], s0 + (i + D - 1) * U);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i == D - 1)
+          compute_batch<WANT_H, true>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + D * U >= steps)), 4 * (s0 + i * U));
+        else
+          compute_batch<WANT_H, false>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
+        __builtin_amdgcn_sched_barrier(0);
+        wait_nat(S[(i + 1) % D], St[(i + 1) % D]);
+      });
+    }
+    if constexpr (D > 2) {  // drain the prefetches past the end before their registers are reused
+      static_for<D>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        wait_batch<0, kDw>(S[i][0], S[i][1], S[i][2], S[i][3]);
+        wait_batch<0, kDwT>(St[i][0], St[i][1], St[i][2], St[i][3]);
+      });
+    }
+    if (WANT_H) {
+      mfma_retire();
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
       return T(0);
     }
     return wave_allreduce_sum(csum);

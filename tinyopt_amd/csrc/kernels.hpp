@@ -1907,6 +1907,11 @@ struct toa_context {
   int (*blas_destroy)(void*) = nullptr;
 };
 
+// large_fused.hip: the n in [64, 128] loop as one persistent kernel (called by toa_large_lm_run when eligible)
+bool toa_large_fused_eligible(toa_context* h, int dtype, int n, int m);
+int toa_large_fused_lm_run(toa_context* h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                           const toa_results* results, uint64_t* counters);
+
 // error reporting lives in capi.hip (one thread_local message for the whole library)
 int toa_fail(int code, const std::string& msg);
 #define HIP_TRY(expr)                                                                           \

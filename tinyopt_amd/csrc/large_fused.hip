@@ -1,0 +1,421 @@
+// The LM / GN loop for 64 <= n <= 128 (TOA_MODEL_DENSE_ROW_NATURAL) as ONE persistent kernel: a workgroup owns a problem
+// from its first residual evaluation to its StopReason, nothing returns to the host in between.
+//
+// Replaces, for this range of n, the launch-per-phase pipeline of large_n.hip (rows kernel writing J, rocBLAS
+// gemm_batched J^T J, pre / Cholesky / post kernels, two integers read back per pass).  Same reference code
+// (OptimizeAcc optimizer.h:242-327, Step :331-539, SolverLM::Build lm.h:59-120, SolverGN::Solve gn.h:150-171), same
+// state machine pieces (LmState, lm_judge_core, lm_good_step / lm_bad_step from lm_device.hpp).
+//
+//   data pass   the m rows are split into 4 contiguous ranges, one per wavefront; each wave streams its rows ONCE from
+//               HBM in matrix-core operand order and accumulates the Gram of [J | r] for them: J^T J as NB (NB + 1) / 2
+//               tiles of v_mfma_{f32,f64}_16x16x4 in AGPRs (NB = ceil(n / 16) <= 8: 36 tiles = 144 registers), J^T r and
+//               ||r||^2 on the VALU (DenseRowGram<T, NB, 1>::pass_natural).  J is never written, only the lower
+//               block triangle is computed.  The four partial Grams are folded in fixed order through an L2-resident
+//               scratch block (deterministic: the result does not depend on timing).
+//   Build       clip, diagonal check, damping of the diagonal copy in LDS                                    (lm.h:59-120)
+//   Solve       blocked LDL^T of the LDS image by the four waves, trailing updates on the matrix cores, substitutions in
+//               wave 0 (ldlt_wg.hpp).  Acceptance differs from Eigen's LDLT only for singular positive SEMI-definite
+//               matrices, exactly like the library path.
+//   Step / loop thread 0 runs lm_judge_core and the loop bookkeeping; x, g, dx, last_dx live in LDS.
+//
+// HBM traffic per LM iteration: m (n + 1) sizeof(T) — the algorithmic minimum (the library path: 3x that for J alone).
+#include <string>
+
+#include "kernels.hpp"
+#include "ldlt_wg.hpp"
+
+namespace toa {
+namespace {
+
+template <typename T>
+struct LfArgs {
+  const T* data;  // per problem: A row-major [m][n], then b [m]
+  T* x;           // [P][n] in / out
+  int n, m;
+  long long P;
+  toa_options opt;
+  toa_results res;
+  int* queue;                    // [0] pop counter, [16] workgroups that have left (self-cleaning, as lm_fused_kernel)
+  char* scratch;                 // per resident workgroup: 4 partial Grams + the folded H
+  size_t scratch_per_wg;
+  unsigned long long* counters;  // [4] or null
+};
+
+template <typename T>
+__device__ __forceinline__ double wg_sum(const double v, double* red) {  // fixed-order tree: deterministic
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double out = red[0];
+  __syncthreads();
+  return out;
+}
+
+// -DTOA_LF_TIMING: workgroup 0 prints where its time went (100 MHz ticks -> us), phase by phase
+#ifndef TOA_LF_DEPTH
+#define TOA_LF_DEPTH 3
+#endif
+#ifdef TOA_LF_TIMING
+#define LF_TICK_START unsigned long long tk_prev = wall_clock64(); const long long ck0 = clock64();
+#define LF_TICK(i) { const unsigned long long now_ = wall_clock64(); tk[i] += now_ - tk_prev; tk_prev = now_; }
+#else
+#define LF_TICK_START
+#define LF_TICK(i)
+#endif
+
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
+#ifdef TOA_LF_TIMING
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+  long long ck_pass = 0;
+#endif
+  using Gram = DenseRowGram<T, NB, 1>;
+  using Acc = typename Mfma<T>::Acc;
+  constexpr int NT = Gram::NT;
+  constexpr int NV = 16 * NB;  // padded vector length (>= n)
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  T* Aimg = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image of the damped matrix, factored in place
+  __shared__ T xs[NV], g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
+  __shared__ T gfold[4][NV], hdw[4][NV];
+  __shared__ T costw[4];
+  __shared__ double red[256];
+  __shared__ LmState<T> S;
+  __shared__ int sh_p, sh_action, sh_cont;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n, m = a.m;
+  const toa_options& opt = a.opt;
+  const toa_results& res = a.res;
+  const bool is_lm = opt.solver_type == 0;
+  char* my_scratch = a.scratch + size_t(blockIdx.x) * a.scratch_per_wg;
+  Acc* part = reinterpret_cast<Acc*>(my_scratch);                                        // [4][NT][64]
+  T* Hs = reinterpret_cast<T*>(my_scratch + size_t(4) * NT * 64 * sizeof(Acc));          // [n][n] undamped, full
+  // this wave's rows
+  const int rows_per_wave = (((m + 3) / 4 + 3) / 4) * 4;
+  const int row0 = wave * rows_per_wave;
+  const int nrows = row0 >= m ? 0 : (m - row0 < rows_per_wave ? m - row0 : rows_per_wave);
+  DenseRowLayout lay;
+  lay.nbm = NB; lay.thin = 1; lay.nmr = n; lay.rsm = NV; lay.rs = n; lay.m4 = m;
+  unsigned long long n_acc = 0, n_eval = 0, n_solves = 0, n_problems = 0;  // thread 0 only
+
+  bool first = true;
+  for (;;) {
+    if (tid == 0) {
+      int p = first ? int(blockIdx.x) : atomicAdd(a.queue, 1) + int(gridDim.x);
+      sh_p = p;
+    }
+    first = false;
+    __syncthreads();
+    const long long p = sh_p;
+    if (p >= a.P) break;
+    const T* A = a.data + size_t(p) * m * (size_t(n) + 1);
+    const T* bv = A + size_t(m) * n;
+    if (tid == 0) {  // lm_init (lm.h:46-52, output.h:104-117, optimizer.h:248-250)
+      S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;
+      S.final_cost = kDblMax; S.final_nres = 0; S.final_ninl = 0; S.cost_ninl = 0; S.final_rerr = kDblMax;
+      S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
+      S.cost_val = 0; S.cost_nres = 0;
+      S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
+      S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
+      S.acc_passes = S.eval_passes = S.solves = S.problems = 0;
+    }
+    for (int i = tid; i < NV; i += 256) {
+      xs[i] = i < n ? a.x[p * n + i] : T(0);
+      dx[i] = T(0); ldx[i] = T(0); g[i] = T(0); hd[i] = T(0);
+    }
+    __syncthreads();
+
+    for (;;) {  // one Build + Solve attempt per trip (a failed solve re-damps and retries, optimizer.h:358)
+      const bool do_acc = !is_lm || S.rebuild;
+      LF_TICK_START
+      // ---------------- data pass: this wave's rows ----------------
+      {
+        Gram gram;
+        if (do_acc) {
+          gram.template pass_natural<true, TOA_LF_DEPTH>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+          Acc* mine = part + size_t(wave) * NT * 64;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
+          gram.extract_g_diag_cost(gfold[wave], hdw[wave], lay, n, lane, &costw[wave]);
+        } else {
+          const T c = gram.template pass_natural<false, TOA_LF_DEPTH>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+          if (lane == 0) costw[wave] = c;
+        }
+      }
+      __syncthreads();
+      LF_TICK(0)
+#ifdef TOA_LF_TIMING
+      ck_pass += clock64() - ck0;
+#endif
+      // ---------------- fold (fixed order) + Build (lm.h:59-120) ----------------
+      const double cost_val = normalize_cost(double(T((costw[0] + costw[1]) + (costw[2] + costw[3]))), m, opt);
+      bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
+      const int LD = n | 1;
+      if (built && do_acc) {
+        // H = sum of the four partial Grams, to the L2-resident copy Hs (kept undamped for eval-only iterations and the
+        // final export) AND straight into the LDS image the factorisation works on
+#pragma unroll 3
+        for (int idx = tid; idx < NT * 64; idx += 256) {
+          const int t = idx >> 6, l = idx & 63;
+          const Acc v = (part[(0 * NT + t) * 64 + l] + part[(1 * NT + t) * 64 + l]) +
+                        (part[(2 * NT + t) * 64 + l] + part[(3 * NT + t) * 64 + l]);
+          int bi = 0, rem = t;  // tile t = (bi, bj), bi <= bj, row-major over the upper block triangle
+          while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+          const int bj = bi + rem;
+          const int qj = NB * (l & 15) + bj;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = NB * Mfma<T>::out_row(l, r) + bi;
+            if (qi < n && qj < n) {
+              Hs[qi * n + qj] = v[r];
+              Aimg[qi * LD + qj] = v[r];
+              if (bi != bj) { Hs[qj * n + qi] = v[r]; Aimg[qj * LD + qi] = v[r]; }
+            }
+          }
+        }
+        double low = 0;
+        for (int i = tid; i < n; i += 256) {
+          T gi = (gfold[0][i] + gfold[1][i]) + (gfold[2][i] + gfold[3][i]);
+          if (opt.grad_clipping != 0) { const T mm = opt.grad_clipping; gi = fmin(fmax(gi, -mm), mm); }  // base.h:29-38
+          g[i] = gi;
+          const T d = (hdw[0][i] + hdw[1][i]) + (hdw[2][i] + hdw[3][i]);  // == the folded H_ii (same order of additions)
+          hd[i] = d;
+          if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
+        }
+        if (wg_sum<T>(low, red) > 0) built = false;
+      }
+      __syncthreads();
+      if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double
+        const double s = S.rebuild ? 1.0 + double(S.lambda) : (1.0 + double(S.lambda)) / (1.0 + double(S.prev_lambda));
+        for (int i = tid; i < n; i += 256) hd[i] = T(double(hd[i]) * s);
+      }
+      if (tid == 0) {
+        if (do_acc) n_acc++; else n_eval++;
+        S.cost_val = cost_val;
+        S.cost_nres = m;
+        S.cost_ninl = m;
+      }
+      for (int i = tid; i < NV; i += 256) rhs[i] = i < n ? g[i] : T(0);
+      __syncthreads();
+      LF_TICK(1)
+      // ---------------- Solve (gn.h:150-171): blocked LDL^T of H with the damped diagonal (ldlt_wg.hpp) ----------------
+      bool chol_ok = false;
+      if (built) {
+        if (do_acc) {  // the fold has filled the image; only the damped diagonal is missing
+          for (int i = tid; i < n; i += 256) Aimg[i * LD + i] = hd[i];
+        } else {       // H of the last build (the previous factorisation overwrote the image)
+          for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            Aimg[i * LD + j] = (i == j) ? hd[i] : Hs[e];
+          }
+        }
+        __syncthreads();
+        LF_TICK(2)
+        chol_ok = WgLdlt<T, NB>::factor(Aimg, LD, n, diag, tid);
+        LF_TICK(3)
+        if (chol_ok && tid < 64) WgLdlt<T, NB>::solve(Aimg, LD, n, diag, rhs, lane);
+        __syncthreads();
+        LF_TICK(4)
+      }
+      // ---------------- the rest of Step (optimizer.h:354-539) and of the loop body (:266-310) ----------------
+      bool solver_failed = true;
+      double dx_norm2 = 0, grad_norm2 = 0;
+      if (built) {
+        double bad = chol_ok ? 0.0 : 1.0, d2 = 0, g2 = 0;
+        for (int i = tid; i < n; i += 256) {
+          const T v = -rhs[i];
+          if (!(fabs(v) <= NumLimits<T>::max())) bad = 1.0;
+          dx[i] = v;
+          d2 += double(v * v);
+          g2 += double(g[i] * g[i]);
+        }
+        bad = wg_sum<T>(bad, red);
+        dx_norm2 = double(T(wg_sum<T>(d2, red)));
+        if (opt.min_grad_norm2 > 0.0f) grad_norm2 = double(T(wg_sum<T>(g2, red)));
+        solver_failed = bad > 0;
+      }
+      if (tid == 0) {
+        const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
+        int rc;  // 0 step, 1 solver failed for good, 2 early stop, -1 retry (same iteration, next trip)
+        if (built) n_solves++;
+        if (!solver_failed) {
+          rc = 0;
+        } else {  // optimizer.h:370-390
+          S.num_consec = (S.num_consec + 1) & 0xff;
+          S.num_failures = (S.num_failures + 1) & 0xff;
+          if (S.cost_nres == 0) { S.stop = TOA_STOP_SKIPPED; rc = 2; }
+          else if (isnan(S.cost_val) || isinf(S.cost_val)) { S.stop = TOA_STOP_NAN_OR_INF; rc = 2; }
+          else if (opt.max_consec_failures > 0 && S.num_consec >= unsigned(opt.max_consec_failures)) {
+            if (S.final_cost < double(NumLimits<T>::max())) S.stop = TOA_STOP_MAX_CONSEC_NO_DECR;
+            rc = 1;
+          } else {
+            lm_bad_step(S, opt);  // FailedStep == BadStep  lm.h:148
+            rc = (S.num_consec <= max_tries) ? -1 : 1;
+          }
+        }
+        int action = 0;  // 1: x += dx, last_dx = dx ; 2: x -= last_dx
+        int cont = 1;
+        if (rc >= 0) {
+          int status = 0;
+          if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399
+          if (rc == 0) status = lm_judge_core<T>(S, opt, res, p, dx_norm2, grad_norm2, true);
+          bool eval_only = false;  // optimizer.h:269-309
+          if (status & 1) {
+            action = 1;
+            S.has_last_dx = 1;
+            S.last_was_success = 1;
+            if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
+          } else {
+            if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
+            else if (status & 2) { action = 1; S.has_last_dx = 1; }
+            eval_only = (S.last_was_success == 0);
+            S.last_was_success = 0;
+          }
+          if (is_lm) S.rebuild = eval_only ? 0 : 1;
+          S.num_iters = S.num_iters + 1;
+          S.iter = S.iter + 1;
+          cont = (S.stop == TOA_STOP_NONE && S.iter < S.max_iters) ? 1 : 0;
+        }
+        sh_action = action;
+        sh_cont = cont;
+      }
+      __syncthreads();
+      const int action = sh_action;
+      if (action == 1) for (int i = tid; i < n; i += 256) { const T d = dx[i]; xs[i] += d; ldx[i] = d; }  // traits.h:184-190
+      if (action == 2) for (int i = tid; i < n; i += 256) xs[i] -= ldx[i];
+      __syncthreads();
+      LF_TICK(5)
+      if (!sh_cont) break;
+    }
+    // ---------------- optimizer.h:313-327: the problem is done ----------------
+    for (int i = tid; i < n; i += 256) a.x[p * n + i] = xs[i];
+    if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
+      double* Hout = res.final_hessian + size_t(p) * n * n;
+      for (size_t e = tid; e < size_t(n) * n; e += 256) {
+        const int i = int(e / n), j = int(e % n);
+        T v = Hs[e];
+        if (i == j) { v = hd[i]; if (is_lm && S.prev_lambda > T(0)) v = v / (T(1.0f) + S.prev_lambda); }
+        Hout[e] = double(v);
+      }
+    }
+    if (tid == 0) {
+      if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
+      res.stop_reason[p] = S.stop;
+      res.num_iters[p] = S.num_iters;
+      res.final_cost[p] = S.final_cost;
+      if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+      if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+      if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+      if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+      n_problems++;
+    }
+    __syncthreads();  // Hs / LDS of this problem are free again
+  }
+#ifdef TOA_LF_TIMING
+  if (tid == 0 && blockIdx.x == 0)
+    printf("large_fused wg0: passes %llu+%llu  shader clock %.0f MHz during the data pass; data pass %.1f us  fold+build %.1f us  image %.1f us  factor %.1f us  substitutions %.1f us  step %.1f us\n",
+           n_acc, n_eval, double(ck_pass) / (tk[0] * 0.01), tk[0] * 0.01, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01, tk[4] * 0.01, tk[5] * 0.01);
+#endif
+  if (tid == 0) {
+    if (a.counters) {
+      atomicAdd(&a.counters[0], n_acc);
+      atomicAdd(&a.counters[1], n_eval);
+      atomicAdd(&a.counters[2], n_solves);
+      atomicAdd(&a.counters[3], n_problems);
+    }
+    const int gone = atomicAdd(&a.queue[16], 1);  // the last workgroup to leave resets the queue for the next launch
+    if (gone == int(gridDim.x) - 1) {
+      __hip_atomic_store(&a.queue[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.queue[16], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <typename T, int NB>
+int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
+                       uint64_t* counters) {
+  using Acc = typename Mfma<T>::Acc;
+  constexpr int NT = NB * (NB + 1) / 2;
+  auto kern = large_fused_kernel<T, NB>;
+  const size_t lds = ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15);  // + the slack WgLdlt's unconditional reads may touch
+  int wg_per_cu = 0;
+  for (int i = 0; i < h->ncfg; ++i)
+    if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == lds && h->cfg[i].wg_per_cu > 0) wg_per_cu = h->cfg[i].wg_per_cu;
+  if (wg_per_cu == 0) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, 256, lds));
+    if (wg_per_cu < 1) return toa_fail(TOA_E_UNSUPPORTED, "large-n fused kernel does not fit this device");
+    if (h->ncfg < 256) h->cfg[h->ncfg++] = {(const void*)kern, lds, wg_per_cu};
+  }
+  long long grid = (long long)h->num_cus * wg_per_cu;
+  if (grid > P) grid = P;
+  if (grid < 1) return TOA_OK;
+  const size_t per_wg = ((size_t(4) * NT * 64 * sizeof(Acc) + size_t(n) * n * sizeof(T)) + 255) & ~size_t(255);
+  const size_t need = per_wg * size_t(grid);
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->scratch, need));
+    h->scratch_bytes = need;
+  }
+  if (h->queue_dirty) {
+    HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));
+    h->queue_dirty = false;
+  }
+  LfArgs<T> a;
+  a.data = data; a.x = x; a.n = n; a.m = m; a.P = P; a.opt = opt; a.res = res;
+  a.queue = h->queue;
+  a.scratch = static_cast<char*>(h->scratch);
+  a.scratch_per_wg = per_wg;
+  a.counters = reinterpret_cast<unsigned long long*>(counters);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, h->stream, a);
+  if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess) {
+    h->queue_dirty = true;
+    return toa_fail(TOA_E_HIP, std::string("large_fused_kernel launch: ") + hipGetErrorString(e_));
+  }
+  return TOA_OK;
+}
+
+template <typename T>
+int large_fused_dispatch(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
+                         const toa_results& res, uint64_t* counters) {
+  switch ((n + 15) / 16) {
+    case 4: return launch_large_fused<T, 4>(h, n, m, P, data, x, opt, res, counters);
+    case 5: return launch_large_fused<T, 5>(h, n, m, P, data, x, opt, res, counters);
+    case 6: return launch_large_fused<T, 6>(h, n, m, P, data, x, opt, res, counters);
+    case 7:  // fp64: 28 tiles = 224 accumulator registers; the loop spills them (tools/isa_lint.py rejects the result)
+      if constexpr (sizeof(T) == 4) return launch_large_fused<T, 7>(h, n, m, P, data, x, opt, res, counters);
+      [[fallthrough]];
+    case 8:
+      if constexpr (sizeof(T) == 4) return launch_large_fused<T, 8>(h, n, m, P, data, x, opt, res, counters);
+      [[fallthrough]];
+    default: return toa_fail(TOA_E_UNSUPPORTED, "large-n fused kernel: n out of range");
+  }
+}
+
+}  // namespace
+}  // namespace toa
+
+// 64 <= n <= 128 in fp32, 64 <= n <= 96 in fp64 (28 / 36 fp64 tiles = 224 / 288 accumulator registers: the loop spills), and the Cholesky
+// image n (n + 1) sizeof(T) must fit the LDS.
+bool toa_large_fused_eligible(toa_handle h, int dtype, int n, int m) {
+  static const bool off = [] { const char* e = std::getenv("TOA_LARGE_PIPELINE"); return e && e[0] == '1'; }();
+  if (off) return false;
+  const size_t esz = dtype == TOA_F32 ? 4 : 8;
+  if (n < 64 || n > (dtype == TOA_F32 ? 128 : 96)) return false;
+  if (size_t(n) * (n + 1) * esz + 16384 > size_t(h->max_lds)) return false;
+  if ((unsigned long long)m * (unsigned long long)(n + 1) * esz >= (1ull << 32)) return false;  // 32-bit buffer offsets
+  return true;
+}
+
+int toa_large_fused_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                           const toa_results* results, uint64_t* counters) {
+  if (dtype == TOA_F32)
+    return toa::large_fused_dispatch<float>(h, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options, *results, counters);
+  return toa::large_fused_dispatch<double>(h, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results, counters);
+}

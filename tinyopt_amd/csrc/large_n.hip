@@ -895,6 +895,8 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 
 int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                      const toa_results* results, uint64_t* counters) {
+  // 64 <= n <= 128: the whole loop in one persistent kernel, Gram on the matrix cores (large_fused.hip)
+  if (toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   toa::RocApi& api = toa::roc_api();
   if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
   if (dtype == TOA_F32)
