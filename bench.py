@@ -31,7 +31,7 @@ WORKLOADS = {
     "c4": (12500, 50, 2000, torch.float32, "f32", "C4 shard: 12500 problems/GPU x n=50 x m=2000 DenseRow fp32 (8 GPUs = 100k-problem C4)"),
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
     # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
-    "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, library-backed path (n > 63)"),
+    "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, workgroup-per-problem kernel (64 <= n <= 128)"),
 }
 # single-problem configs of BASELINE.json (latency-bound: SURVEY §8d "report us/iter and GB/s"); replicas only at N > 1
 SINGLE = {
@@ -411,8 +411,13 @@ def main():
         stream_read = None
     # secondary ceiling ("MFMA ceiling reported additionally"): matrix-core flops ISSUED by the accumulate
     # passes (NBM(NBM+1)/2 tiles of v_mfma_*_16x16x4 = 2048 flop per 4 rows) against the dense fp32 / fp64 MFMA peak
-    if large:  # the library GEMM computes the full n x n square: 2 m n^2 flop per accumulate pass
-        mfma_flop_per_pass = 2 * m * n * n
+    if large:
+        # ALGORITHMIC flops of one accumulate pass: the symmetric Gram of [J | r], (n + 1)(n + 2) / 2 multiply-adds per row.
+        # (Round 1 priced this path at 2 m n^2, the FULL square its rocBLAS GEMM computed; large_fused_kernel only computes
+        # the lower block triangle, so that accounting would now credit flops nobody performs.)
+        mfma_flop_per_pass = m * (n + 1) * (n + 2)
+        nbl = (n + 15) // 16
+        mfma_issued_per_pass = 4 * ((((m + 3) // 4 + 3) // 4)) * (nbl * (nbl + 1) // 2) * 2048   # 4 waves x steps x tiles x 16*16*4*2
     else:
         lay = ta.api.dense_row_layout(tdt, n, m)
         mfma_flop_per_pass = (lay["rows_padded"] // 4) * (lay["nb"] * (lay["nb"] + 1) // 2) * 2048
@@ -429,7 +434,7 @@ def main():
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
-        "metric": "LM iterations/s (batched dense n<=50)" if not large else f"LM iterations/s (batched dense n={n}, library-backed path)",
+        "metric": "LM iterations/s (batched dense n<=50)" if not large else f"LM iterations/s (batched dense n={n}, 64 <= n <= 128 path)",
         "value": iters_all / elapsed,
         "unit": "LM iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,7 +449,7 @@ def main():
                    "iters_per_problem": iters_all / args.steps / (P * world),
                    "lm_iterations_per_step_per_gpu_min_max": rank_iters,
                    "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else "large_rows_vec_kernel + rocBLAS gemm_batched + large_chol_solve_kernel (whole pass)",
+        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else "large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of the same workload and binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,
@@ -456,11 +461,16 @@ def main():
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
                                         "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
-    if large:  # AI = 2 m n^2 / (m (n + 1) sizeof) = 64 flop/B at n = 128 fp32, beyond the 19.7 flop/B ridge: the MFMA roof bounds this path
+    if large:  # AI = (n + 2) / sizeof = 32.5 flop/B at n = 128 fp32, beyond the 19.7 flop/B ridge: the MFMA roof bounds this path
         r = result["roofline"]
         sec = r.pop("mfma_secondary")
         result["roofline"] = {"bound": "mfma", "kernel": r["kernel"], "achieved": sec["achieved"], "peak": sec["peak"], "unit": "TFLOP/s",
                               "frac": sec["frac"], "traffic": None, "flop_per_accumulate_pass": sec["issued_flop_per_accumulate_pass"],
+                              "flop_accounting": "algorithmic: m (n+1)(n+2) per accumulate pass (symmetric Gram of [J | r]); evaluate passes, "
+                                                 "the LDL^T and the step are in the time but not in the flops",
+                              "issued_mfma_flop_per_accumulate_pass": mfma_issued_per_pass,
+                              "frac_issued": mfma_issued_per_pass * sec["accumulate_passes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12 / sec["peak"],
+                              "achieved_full_square_accounting_r01": 2 * m * n * n * sec["accumulate_passes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12,
                               "accumulate_passes_per_launch": sec["accumulate_passes_per_launch"],
                               "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_all": r["kernel_ms_all"],
                               "hbm_secondary": {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"],

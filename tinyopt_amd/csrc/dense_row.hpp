@@ -67,14 +67,24 @@ struct GramStep {
   static __device__ __forceinline__ void from(Acc* acc, const T* w) {
     if constexpr (I < NB) {
       if constexpr (sizeof(T) == 4)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
       else
-        asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
       if constexpr (J + 1 < NB) from<I, J + 1>(acc, w);
       else from<I + 1, I + 1>(acc, w);
     }
   }
-  static __device__ __forceinline__ void run(Acc* acc, const T* w) { from<0, 0>(acc, w); }
+  // ONE s_nop in front of the step, in a statement that names every operand of the step as an input: whatever VALU
+  // instruction produces w[j] is then ordered before it, and no VALU write can sit directly in front of a later MFMA that
+  // reads it.  (A nop in front of every MFMA costs an issue slot each: 36 x 8 cycles per step at NB = 8, measured as
+  // 175 us instead of ~147 us per accumulate pass of the n = 128 benchmark.)
+  static __device__ __forceinline__ void run(Acc* acc, const T* w) {
+    static_assert(NB <= 8, "operand list below");
+    constexpr int L = NB - 1;  // blocks beyond NB repeat the last one
+    asm volatile("s_nop 1" : : "v"(w[0]), "v"(w[1 < L ? 1 : L]), "v"(w[2 < L ? 2 : L]), "v"(w[3 < L ? 3 : L]), "v"(w[4 < L ? 4 : L]),
+                 "v"(w[5 < L ? 5 : L]), "v"(w[6 < L ? 6 : L]), "v"(w[L]));
+    from<0, 0>(acc, w);
+  }
   static __device__ __forceinline__ void run_tail(Acc* acc, const T* w, int last_in) {
     run(acc, w);
     const int last = __builtin_amdgcn_readfirstlane(last_in);

@@ -56,7 +56,7 @@ __device__ __forceinline__ double wg_sum(const double v, double* red) {  // fixe
 
 // -DTOA_LF_TIMING: workgroup 0 prints where its time went (100 MHz ticks -> us), phase by phase
 #ifndef TOA_LF_DEPTH
-#define TOA_LF_DEPTH 3
+#define TOA_LF_DEPTH 2   // ring depth of the data pass: 3 measured no faster (4.27 vs 4.25 ms, one MFMA-bound wave per SIMD) and costs 36 registers
 #endif
 #ifdef TOA_LF_TIMING
 #define LF_TICK_START unsigned long long tk_prev = wall_clock64(); const long long ck0 = clock64();
@@ -71,11 +71,15 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
 #ifdef TOA_LF_TIMING
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
   long long ck_pass = 0;
+  unsigned long long tk_eval = 0;
 #endif
   using Gram = DenseRowGram<T, NB, 1>;
   using Acc = typename Mfma<T>::Acc;
   constexpr int NT = Gram::NT;
   constexpr int NV = 16 * NB;  // padded vector length (>= n)
+  // ring depth of the cost-only pass (see there).  fp64 with NB >= 5: the deeper ring's registers do not fit beside the rest
+  // of the kernel, and hipcc then parks in-flight load destinations in AGPRs (tools/isa_lint.py rejects that code)
+  constexpr int kEvalDepth = sizeof(T) == 4 ? 4 : (NB <= 4 ? 3 : 2);
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   T* Aimg = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image of the damped matrix, factored in place
   __shared__ T xs[NV], g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
@@ -140,11 +144,16 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
           for (int t = 0; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
           gram.extract_g_diag_cost(gfold[wave], hdw[wave], lay, n, lane, &costw[wave]);
         } else {
-          const T c = gram.template pass_natural<false, TOA_LF_DEPTH>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+          // cost only: no matrix-core work to hide the HBM latency behind, and one wave per SIMD — three batches (24 KB
+          // per wave) in flight instead of one: 245 -> 9x us per evaluate pass at n = 128, m = 4096
+          const T c = gram.template pass_natural<false, kEvalDepth>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
           if (lane == 0) costw[wave] = c;
         }
       }
       __syncthreads();
+#ifdef TOA_LF_TIMING
+      if (!do_acc) tk_eval += wall_clock64() - tk_prev;
+#endif
       LF_TICK(0)
 #ifdef TOA_LF_TIMING
       ck_pass += clock64() - ck0;
@@ -316,8 +325,8 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   }
 #ifdef TOA_LF_TIMING
   if (tid == 0 && blockIdx.x == 0)
-    printf("large_fused wg0: passes %llu+%llu  shader clock %.0f MHz during the data pass; data pass %.1f us  fold+build %.1f us  image %.1f us  factor %.1f us  substitutions %.1f us  step %.1f us\n",
-           n_acc, n_eval, double(ck_pass) / (tk[0] * 0.01), tk[0] * 0.01, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01, tk[4] * 0.01, tk[5] * 0.01);
+    printf("large_fused wg0: passes %llu+%llu  shader clock %.0f MHz during the data pass; data pass %.1f us (of which the cost-only passes %.1f us)  fold+build %.1f us  image %.1f us  factor %.1f us  substitutions %.1f us  step %.1f us\n",
+           n_acc, n_eval, double(ck_pass) / (tk[0] * 0.01), tk[0] * 0.01, tk_eval * 0.01, tk[1] * 0.01, tk[2] * 0.01, tk[3] * 0.01, tk[4] * 0.01, tk[5] * 0.01);
 #endif
   if (tid == 0) {
     if (a.counters) {
