@@ -15,6 +15,7 @@
 #include <string>
 
 #include "kernels.hpp"
+#include "ldlt_wg.hpp"
 
 namespace toa {
 namespace {
@@ -496,106 +497,55 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   }
 }
 
-// (H + lambda diag H) sol = g for n <= 128 (the measured crossover with rocSOLVER) without the library: one workgroup per problem, the matrix REGISTER-resident in
-// a 16 x 16 block-cyclic distribution (thread (ty, tx) owns rows 16a + ty, columns 16b + tx of the lower block triangle:
-// NB (NB + 1) / 2 values), right-looking Cholesky with ONE barrier per column: the owners of column k publish it
-// (unscaled) to a double-buffered LDS vector and into the LDS image the substitutions read, everybody updates its own
-// elements with A_ij -= A_ik A_jk / d_k.  L = A diag(1 / sqrt d) is applied inside the two triangular solves, which run in
-// wave 0 with the unknowns in registers (two per lane) and the pivot value broadcast by v_readlane.  Skips problems that
-// have stopped or whose Build failed, which the library calls cannot.
+// (H + lambda diag H) sol = g for 64 <= n <= 128 (the measured crossover with rocSOLVER) without the library: one workgroup
+// per problem, blocked LDL^T of the LDS image by its four waves with the trailing updates on the matrix cores, substitutions
+// in wave 0 (ldlt_wg.hpp; the column-by-column register Cholesky this replaces took ~100 us per n = 128 matrix against
+// ~45 us).  Skips problems that have stopped or whose Build failed, which the library calls cannot.
 template <typename T, int NB>
-__global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T> a) {
+__global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  T* A = reinterpret_cast<T*>(lds_raw);  // n x LD image of the unscaled columns of L
-  __shared__ T col[2][NB * 16];
-  __shared__ T diag[NB * 16];  // 1 / sqrt(d_k)
-  __shared__ int fail_at;
+  T* M = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image, factored in place
+  __shared__ T dinv[16 * NB], sol[16 * NB];
   const size_t p = blockIdx.x;
   if (!a.active[p] || !a.built[p]) return;
-  const int n = a.n, LD = n + 1, tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
+  const int n = a.n, LD = n | 1, tid = threadIdx.x;
   const T* Wp = a.work + p * size_t(n) * n;
-  T e[NB][NB];
-  static_for<NB>([&](auto ac) __attribute__((always_inline)) {
-    static_for<NB>([&](auto bc) __attribute__((always_inline)) {
-      constexpr int ab = decltype(ac)::value, bb = decltype(bc)::value;
-      if constexpr (bb <= ab) {
-        const int i = 16 * ab + ty, j = 16 * bb + tx;
-        e[ab][bb] = (i < n && j < n) ? Wp[size_t(i) * n + j] : T(0);
-      }
-    });
-  });
-  if (tid == 0) fail_at = 0;
-  __syncthreads();
-  bool failed = false;
-  for (int k = 0; k < n && !failed; ++k) {
-    const int kb = k >> 4, kx = k & 15, buf = k & 1;
-    // one specialisation of the column step per block column KB: every block loop below has compile-time bounds
-    static_for<NB>([&](auto kbc) __attribute__((always_inline)) {
-      constexpr int KB = decltype(kbc)::value;
-      if (KB != kb) return;  // workgroup-uniform
-      if (tx == kx) {  // the owners of column k publish it
-        static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
-          constexpr int ab = KB + decltype(ac)::value;
-          const int i = 16 * ab + ty;
-          const T v = e[ab][KB];
-          col[buf][i] = v;
-          if (i >= k && i < n) A[i * LD + k] = v;
-        });
-      }
-      __syncthreads();
-      const T d = col[buf][k];  // the same value in every thread: the branch below is workgroup-uniform
-      if (!(d > NumLimits<T>::min_normal()) || !(d < NumLimits<T>::max())) {
-        if (tid == 0) fail_at = k + 1;
-        failed = true;
-        return;
-      }
-      const T dinv = T(1) / d;
-      if (tid == 0) diag[k] = T(1) / sqrt(d);
-      T li[NB], lj[NB];
-      static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
-        constexpr int ab = KB + decltype(ac)::value;
-        const int i = 16 * ab + ty, j = 16 * ab + tx;
-        li[ab] = i > k ? col[buf][i] * dinv : T(0);  // zero factors mask the rows / columns <= k of block column KB
-        lj[ab] = j > k ? col[buf][j] : T(0);
-      });
-      static_for<NB - KB>([&](auto ac) __attribute__((always_inline)) {
-        static_for<NB - KB>([&](auto bc) __attribute__((always_inline)) {
-          constexpr int ab = KB + decltype(ac)::value, bb = KB + decltype(bc)::value;
-          if constexpr (bb <= ab) e[ab][bb] = fma(-li[ab], lj[bb], e[ab][bb]);
-        });
-      });
-    });
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    M[i * LD + j] = Wp[e];
   }
+  for (int i = tid; i < 16 * NB; i += 256) sol[i] = i < n ? a.rhs[p * n + i] : T(0);
   __syncthreads();
-  if (fail_at != 0) {
-    if (tid == 0) a.info[p] = fail_at;
+  const bool ok = WgLdlt<T, NB>::factor(M, LD, n, dinv, tid);
+  if (!ok) {
+    if (tid == 0) a.info[p] = 1;
     return;
   }
-  if (tid < 64) {
-    const int lane = tid;
-    T* rp = a.rhs + p * n;
-    T y0 = lane < n ? rp[lane] : T(0), y1 = lane + 64 < n ? rp[lane + 64] : T(0);
-    const T rs0 = lane < n ? diag[lane] : T(0), rs1 = lane + 64 < n ? diag[lane + 64] : T(0);
-    for (int k = 0; k < n; ++k) {  // L y = b, column sweep;  L[i][k] = A[i][k] rs[k],  L[k][k] = 1 / rs[k]
-      const int ku = __builtin_amdgcn_readfirstlane(k);
-      const T rk = diag[ku];
-      const T yk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) * rk;
-      if (lane == (ku & 63)) { if (ku < 64) y0 = yk; else y1 = yk; }
-      const T s = yk * rk;
-      if (lane > ku && lane < n) y0 = fma(-A[lane * LD + ku], s, y0);
-      if (lane + 64 > ku && lane + 64 < n) y1 = fma(-A[(lane + 64) * LD + ku], s, y1);
-    }
-    for (int k = n - 1; k >= 0; --k) {  // L^T x = y: row k of L is column k of L^T;  L[k][i] = A[k][i] rs[i]
-      const int ku = __builtin_amdgcn_readfirstlane(k);
-      const T xk = (ku < 64 ? wave_bcast(y0, ku) : wave_bcast(y1, ku - 64)) * diag[ku];
-      if (lane == (ku & 63)) { if (ku < 64) y0 = xk; else y1 = xk; }
-      if (lane < ku) y0 = fma(-A[ku * LD + lane] * rs0, xk, y0);
-      if (lane + 64 < ku) y1 = fma(-A[ku * LD + lane + 64] * rs1, xk, y1);
-    }
-    if (lane < n) rp[lane] = y0;
-    if (lane + 64 < n) rp[lane + 64] = y1;
-    if (lane == 0) a.info[p] = 0;
+  if (tid < 64) WgLdlt<T, NB>::solve(M, LD, n, dinv, sol, tid);
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = sol[i];
+  if (tid == 0) a.info[p] = 0;
+}
+template <typename T>
+inline size_t ldlt_image_bytes(int n) { return ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15); }
+template <typename T>
+const void* ldlt_solve_fn(int n) {
+  switch ((n + 15) / 16) {
+    case 1: case 2: case 3: case 4: return (const void*)large_ldlt_solve_kernel<T, 4>;
+    case 5: return (const void*)large_ldlt_solve_kernel<T, 5>;
+    case 6: return (const void*)large_ldlt_solve_kernel<T, 6>;
+    case 7: return (const void*)large_ldlt_solve_kernel<T, 7>;
+    default: return (const void*)large_ldlt_solve_kernel<T, 8>;
+  }
+}
+template <typename T>
+void launch_ldlt_solve(int n, unsigned P, size_t lds, hipStream_t st, const LargeArgs<T>& a) {
+  switch ((n + 15) / 16) {
+    case 1: case 2: case 3: case 4: hipLaunchKernelGGL((large_ldlt_solve_kernel<T, 4>), dim3(P), dim3(256), lds, st, a); break;
+    case 5: hipLaunchKernelGGL((large_ldlt_solve_kernel<T, 5>), dim3(P), dim3(256), lds, st, a); break;
+    case 6: hipLaunchKernelGGL((large_ldlt_solve_kernel<T, 6>), dim3(P), dim3(256), lds, st, a); break;
+    case 7: hipLaunchKernelGGL((large_ldlt_solve_kernel<T, 7>), dim3(P), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((large_ldlt_solve_kernel<T, 8>), dim3(P), dim3(256), lds, st, a); break;
   }
 }
 
@@ -765,13 +715,12 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.hptr = reinterpret_cast<T**>(take(b_ptr));
   if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
-  // 64 <= n <= 128: the LDS-resident Cholesky above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
+  // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
-  const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
+  const size_t chol_lds = ldlt_image_bytes<T>(n);
   const bool own_chol = !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
   if (own_chol) {
-    const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
-    if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
+    if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
   }
   HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
@@ -812,8 +761,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
     int rc = 0;
     if (own_chol) {
-      if (n <= 64) hipLaunchKernelGGL((large_chol_solve_kernel<T, 4>), dim3(unsigned(P)), dim3(256), chol_lds, st, a);
-      else hipLaunchKernelGGL((large_chol_solve_kernel<T, 8>), dim3(unsigned(P)), dim3(256), chol_lds, st, a);
+      launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);
     } else if constexpr (sizeof(T) == 4) {
       rc = api.spotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
       if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
@@ -836,7 +784,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
 }
 
 
-// The K3 seam (toa_solve_damped) for 64 <= n <= 128 on the workgroup Cholesky above instead of the library.
+// The K3 seam (toa_solve_damped) for 64 <= n <= 128 on the workgroup LDL^T above instead of the library.
 template <typename T>
 __global__ void __launch_bounds__(256) large_fill_ones_kernel(int* __restrict__ v, const long long count) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -859,14 +807,12 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
   a.info = reinterpret_cast<int*>(base + b_work + b_rhs);
   a.active = reinterpret_cast<int*>(base + b_work + b_rhs + b_i);  // every matrix is solved
   a.built = a.active;
-  const size_t chol_lds = size_t(n) * (n + 1) * sizeof(T);
-  const void* fn = n <= 64 ? (const void*)large_chol_solve_kernel<T, 4> : (const void*)large_chol_solve_kernel<T, 8>;
-  if (int rc = ensure_lds_attr(h, fn, chol_lds)) return rc;
+  const size_t chol_lds = ldlt_image_bytes<T>(n);
+  if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
   hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P);
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
-  if (n <= 64) hipLaunchKernelGGL((large_chol_solve_kernel<T, 4>), dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
-  else hipLaunchKernelGGL((large_chol_solve_kernel<T, 8>), dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
+  launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
   hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
@@ -878,8 +824,8 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
                     int32_t* ok) {
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
-  const size_t chol_lds = size_t(n) * (n + 1) * (dtype == TOA_F32 ? 4 : 8);
-  if (!force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup Cholesky, up to its measured crossover with the library
+  const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
+  if (!force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup LDL^T (ldlt_wg.hpp), up to its measured crossover with the library
     if (dtype == TOA_F32)
       return toa::large_solve_own_t<float>(h, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
     return toa::large_solve_own_t<double>(h, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);

@@ -31,14 +31,28 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for wl in ("c3", "c2", "c5"):
+    for wl in ("c3", "c2", "c5", "large128"):
         hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
         if hits:
             shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
-    if os.path.exists(os.path.join(SRC, "ad_ratio.txt")):
-        shutil.copy(os.path.join(SRC, "ad_ratio.txt"), os.path.join(DST, f"{tag}_ad_ratio.txt"))
+    for txt in ("ad_ratio", "large_n_bench", "k3_crossover"):
+        if os.path.exists(os.path.join(SRC, txt + ".txt")):
+            shutil.copy(os.path.join(SRC, txt + ".txt"), os.path.join(DST, f"{tag}_{txt}.txt"))
+    if os.path.isdir(os.path.join(SRC, "pmc_large128")):   # counters of the n = 128 workgroup-per-problem kernel
+        lf = {}
+        for d in sorted(glob.glob(os.path.join(SRC, "pmc_large128", "*"))):
+            try:
+                c, durs = counters(d, "large_fused_kernel")
+            except IndexError:
+                continue
+            lf.update(c)
+            lf.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
+        with open(os.path.join(DST, f"{tag}_pmc_large128.json"), "w") as f:
+            json.dump({"round": tag, "workload": "large128", "kernel": "large_fused_kernel<float, 8>",
+                       "counters_per_launch": {k: v for k, v in lf.items() if not k.startswith("_")},
+                       "kernel_ms_under_pmc": lf.get("_kernel_ms", {})}, f, indent=1)
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
-                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_large128"):
+                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput of the n > 63 path (TOA_MODEL_DENSE_ROW_NATURAL: rows kernel + rocBLAS GEMM + rocSOLVER Cholesky + LM
-state machine kernels) on synthetic DenseRow problems, next to the one-wavefront fused kernel at n = 63 and the CPU
+"""Throughput of the n > 63 path (TOA_MODEL_DENSE_ROW_NATURAL: the workgroup-per-problem persistent kernel of
+large_fused.hip up to n = 128 (fp64: 96), rows kernel + rocBLAS GEMM + workgroup LDL^T / rocSOLVER Cholesky + LM state
+machine kernels beyond) on synthetic DenseRow problems, next to the one-wavefront fused kernel at n = 63 and the CPU
 restatement (1 thread) on a bounded sample.   usage: python tools/large_n_bench.py [--no-cpu]"""
 import os
 import sys
@@ -26,10 +27,12 @@ def synth(P, n, m, dt, seed=1):
 def main():
     no_cpu = "--no-cpu" in sys.argv
     opts = ta.Options.benchmark()
-    print("| dtype | n | m | problems | ms / solve of the batch | LM it/s | algorithmic GB/s (m (n+1) per pass) | GEMM TFLOP/s equivalent | CPU oracle it/s (1 thread) |")
+    print("| dtype | n | m | problems | ms / solve of the batch | LM it/s | algorithmic GB/s (m (n+1) per pass) | TFLOP/s, full-square 2 m n^2 accounting (symmetric: half) | CPU oracle it/s (1 thread) |")
     print("|---|---|---|---|---|---|---|---|---|")
-    for dt, n, m, P in ((torch.float32, 63, 2000, 2048), (torch.float32, 64, 2000, 2048), (torch.float32, 128, 4096, 512),
-                        (torch.float32, 256, 8192, 128), (torch.float32, 512, 8192, 64), (torch.float64, 128, 4096, 256)):
+    for dt, n, m, P in ((torch.float32, 63, 2000, 2048), (torch.float32, 64, 2000, 2048), (torch.float32, 96, 3000, 1024),
+                        (torch.float32, 128, 4096, 512), (torch.float32, 128, 4096, 2048),
+                        (torch.float32, 256, 8192, 128), (torch.float32, 512, 8192, 64), (torch.float64, 64, 2000, 1024),
+                        (torch.float64, 96, 3000, 512), (torch.float64, 128, 4096, 256)):
         A, b, x0, xs = synth(P, n, m, dt)
         model = ta.DenseRowNatural(A, b) if n > 63 else ta.DenseRow.from_arrays(A, b)
         x = x0.clone()
