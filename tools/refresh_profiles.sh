@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O   # NOTE: also delete the LOCAL gpurun_out/refresh before calling gpurun (results are merged, not mirrored)
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
 for wl in c4 c3 c2 c5 c1; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
