@@ -239,9 +239,24 @@ def test_argument_errors(ta):
     o = ta.Options(); o.solver_type = 2         # GradientDescent is not on this path (optimize.h:75 throws)
     with pytest.raises(ta.ToaError):
         ta.Optimize(x0, model, o)
-    o = ta.Options(); o.hessian.use_ldlt = False
-    with pytest.raises(ta.ToaError):
-        ta.Optimize(x0, model, o)
+
+
+def test_use_ldlt_false_unchecked_inverse(ta, oracle):
+    """gn.h:157-162: with use_ldlt = false the step is -H.inverse() * g, unchecked.  Same trajectories as the oracle's LU
+    inverse (n = 12 fp64, n = 50 fp32), through the fused, the row-split and the stepping form."""
+    for dtype, n, m, P in ((np.float64, 12, 200, 10), (np.float32, 50, 600, 6)):
+        A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=5)
+        model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        for o in (ta.Options(), ta.Options.benchmark()):
+            o.hessian.use_ldlt = False
+            ref = oracle.dense_row_lm(A, b, x0, o.to_pod(), history=True)
+            for splits in (0, 4):
+                x = torch.from_numpy(x0.copy()).cuda()
+                out = ta.Optimize(x, model, o, history=True, splits=splits)
+                torch.cuda.synchronize()
+                st = check_trajectories(gpu_dict(out, x), _ref_dict(ref), dtype, o.to_pod(), label=f"use_ldlt=false n={n} splits={splits}")
+                assert st["full"] + st["ties"] == P, st
+                assert np.abs(x.cpu().numpy() - xs).max() < 2e-2
 
 
 def test_failure_paths_match_reference_semantics(ta, oracle):

@@ -570,8 +570,8 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
     cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
-    asynchronous on torch's current stream — except ``DenseRowNatural`` (n > 63), whose host loop reads two integers
-    back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
+    asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128 (fp64: 96), whose host loop reads
+    two integers back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
     library (every path accumulates).
     """
     options = options or Options()

@@ -615,8 +615,8 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");
   if (options->solver_type != 0 && options->solver_type != 1)
     return fail(TOA_E_ARG, "toa_lm_run: solver_type must be 0 (LM) or 1 (GN) on this path");  // optimize.h:75
-  if (!options->use_ldlt && n > 1)
-    return fail(TOA_E_UNSUPPORTED, "toa_lm_run: use_ldlt=false is only implemented for n == 1 (gn.h:157-162)");
+  if (!options->use_ldlt && n > 63)
+    return fail(TOA_E_UNSUPPORTED, "toa_lm_run: use_ldlt=false (gn.h:157-162) is implemented for n <= 63");
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return fail(TOA_E_ARG, "toa_lm_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");

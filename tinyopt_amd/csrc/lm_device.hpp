@@ -213,10 +213,20 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
           ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
           if (ok) L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, rhs);
         }
-      } else {  // gn.h:157-162, Dims == 1 branch only (host rejects n > 1 without LDLT)
+      } else if (n == 1) {  // gn.h:157-162, Dims == 1 branch
         const T h = L.hd[0];
         const T d = (h > float_epsilon<T>()) ? -(T(1) / h) * L.g[0] : T(0);
         L.dx[lane] = in_n ? d : T(0);
+        ok = true;
+      } else {  // gn.h:162: dx = -H.inverse() * g, UNCHECKED (no success flag, no positivity test).  Here: the pivoted
+                // factorisation with its verdict ignored — the same solution to rounding for every non-singular H, definite
+                // or not; a singular H gets the pseudo-inverse where Eigen's inverse() returns inf / nan
+        model.write_sym(L.M, L.LD, n, lane);
+        wave_sync();
+        if (in_n) L.M[lane * L.LD + lane] = L.hd[lane];
+        wave_sync();
+        (void)ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
+        L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, in_n ? -L.g[lane] : T(0));
         ok = true;
       }
       wave_sync();
