@@ -451,9 +451,9 @@ def synth_ba(P, ncam, npts, dtype, seed=0x71940917, noise_px=0.5, pose_pert=0.02
     return data.astype(dtype), x0.astype(dtype), xs.astype(dtype)
 
 
-def ba_lm(data, x0, ncam, npts, pod: ToaOptions, history=True):
+def ba_lm(data, x0, ncam, npts, pod: ToaOptions, history=True, lib=None):
     """Bundle adjustment solved the reference's way: dense (6C + 3N)^2 Hessian + dense LDL^T (oracle/ba.hpp)."""
-    lib = load()
+    lib = lib or load()
     x = np.array(x0, copy=True)
     P = x.shape[0]
     stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); fails = np.zeros(P, np.int32)

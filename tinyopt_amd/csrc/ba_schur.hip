@@ -118,8 +118,15 @@ __device__ __forceinline__ void ba_obs(const T* P, const T* q, const T f, const 
   }
 }
 
+// Two workgroups per CU (256 registers per lane; the fp64 instances spill ~25 of them): uncapped, hipcc takes 340 registers
+// for fp64 and ONE workgroup — four waves — is all a CU runs, with nothing to cover the latency of the phase-to-phase L2
+// round trips.  Measured (bench.py --workload ba, 1024 scenes x 8 cameras x 256 points fp64): 3.76 ms uncapped, 2.46 ms
+// with 2, 3.8 ms with 3 (118 spills).
+#ifndef TOA_BA_WGS
+#define TOA_BA_WGS 2
+#endif
 template <typename T, int NBM, int THIN>
-__global__ void __launch_bounds__(256) ba_schur_kernel(const BaParams* __restrict__ prm) {
+__global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParams* __restrict__ prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C = prm->C, N = prm->N, n = 6 * C;

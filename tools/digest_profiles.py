@@ -31,7 +31,7 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for wl in ("c3", "c2", "c5", "large128"):
+    for wl in ("c3", "c2", "c5", "large128", "ba"):
         hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
         if hits:
             shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
@@ -52,7 +52,7 @@ def main():
                        "counters_per_launch": {k: v for k, v in lf.items() if not k.startswith("_")},
                        "kernel_ms_under_pmc": lf.get("_kernel_ms", {})}, f, indent=1)
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
-                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128"):
+                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
