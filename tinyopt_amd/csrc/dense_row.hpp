@@ -555,14 +555,9 @@ struct DenseRowGram {
     if (THIN) wait_batch<kLeave, kDwT>(t[0], t[1], t[2], t[3]);
   }
 
-  // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
-  // of `m` / `tv` (no staging copies: the other slot set is the one being refilled meanwhile).
-  template <bool WANT_H, bool TAIL = false, bool ROBUST = false>
-  __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, PassCtx& pc, T& csum,
-                                                const int last = 0, const int row0 = 0) {
-    T wa[U][NBM];
-    T va[U][THIN ? THIN : 1];
-    T part[U];
+  // Unpack the load registers of one batch and form each lane's partial a_i.x of its U steps.
+  __device__ __forceinline__ void batch_dots(const Slots& m, const SlotsT& tv, const PassCtx& pc, T (&wa)[U][NBM],
+                                             T (&va)[U][THIN ? THIN : 1], T (&part)[U]) const {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       unsigned raw[kDw];
@@ -580,6 +575,156 @@ struct DenseRowGram {
       for (int j = 0; j + 1 < THIN; ++j) pu += va[u][j] * pc.xt[j];
       part[u] = pu;
     }
+  }
+
+  // One step of the batch once the scale sc = 1 + 0.1 cos(a_i.x) and rbase = a_i.x + 0.1 sin(a_i.x) of its four rows are
+  // known: J = sc a in registers, r = rbase - b, the step's MFMAs and thin products (or, cost only, r^2).  w / v: the
+  // step's main / thin operands; row_u: index of the step's first row (ROBUST bookkeeping).
+  template <bool WANT_H, bool TAIL_STEP, bool ROBUST>
+  __device__ __forceinline__ void apply_step(T (&w)[NBM], T (&v)[THIN ? THIN : 1], T sc, const T rbase, PassCtx& pc, T& csum,
+                                             const int last, const int row_u) {
+    T rsq = T(0);  // ROBUST: sqrt(s) * r of this row
+    if constexpr (ROBUST) {
+      // the residual of this row on every lane of its row group: the thin tail is broadcast-loaded (all 16 lanes hold
+      // b); with b in the main block only its owner has it, and a 16-lane reduction hands r to the others
+      T r;
+      if constexpr (THIN == 0) r = row16_allreduce_sum(pc.isB_lane ? rbase - w[NBM - 1] : T(0));
+      else r = rbase - v[THIN - 1];
+      const T n2 = r * r;
+      T l, sw;
+      robust_norm(pc.loss, n2, pc.th2, l, sw);
+      const bool valid = row_u + pc.k < pc.rows_real;
+      const bool book = pc.owner && valid;
+      csum += book ? l : T(0);                       // Cost += l
+      pc.inl += (book && n2 <= pc.th2) ? T(1) : T(0);   // cost.h:84-95: inliers are the residuals inside the threshold
+      const T sq = r_sqrt(sw);
+      sc *= sq;
+      rsq = r * sq;
+    }
+    if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
+      using f2 = float __attribute__((ext_vector_type(2)));
+      constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
+#pragma unroll
+      for (int cb = 0; cb + 1 < kScaled; cb += 2) {
+        const f2 wp = f2{w[cb], w[cb + 1]} * f2{sc, sc};
+        w[cb] = wp[0];
+        w[cb + 1] = wp[1];
+      }
+      if constexpr (kScaled & 1) w[kScaled - 1] *= sc;
+#pragma unroll
+      for (int j = 0; j + 2 < THIN; j += 2) {
+        const f2 vp = f2{v[j], v[j + 1]} * f2{sc, sc};
+        v[j] = vp[0];
+        v[j + 1] = vp[1];
+      }
+      if constexpr (THIN > 1 && ((THIN - 1) & 1)) v[THIN - 2] *= sc;
+    } else {
+#pragma unroll
+      for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
+      if (THIN != 0) w[NBM - 1] *= sc;
+#pragma unroll
+      for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
+    }
+    // THIN == 0: the lane holding b turns it into r = rbase - b, every other lane scales its column by sc; written as
+    // one FMA with per-lane constants (mA, mB) = (1, 0) / (0, 1) instead of a select (fp64: no exec-mask branch)
+    if constexpr (ROBUST) {
+      if constexpr (THIN == 0) w[NBM - 1] = pc.isB_lane ? rsq : w[NBM - 1] * sc;
+      else v[THIN - 1] = rsq;
+    } else {
+      if constexpr (THIN == 0) w[NBM - 1] = fma(w[NBM - 1], fma(sc, pc.mA, -pc.mB), rbase * pc.mB);
+      else v[THIN - 1] = rbase - v[THIN - 1];
+    }
+    if (WANT_H) {
+#if defined(TOA_SPLIT_MFMA)
+#pragma unroll
+      for (int i = 0; i < NBM; ++i)
+#pragma unroll
+        for (int j = i; j < NBM; ++j) {
+          if constexpr (sizeof(T) == 4)
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+          else
+            asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+        }
+#elif !defined(TOA_ABL_NOMFMA)
+      if (TAIL_STEP) GramStep<T, NBM>::run_tail(acc, w, last);
+      else GramStep<T, NBM>::run(acc, w);
+#else
+#pragma unroll
+      for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
+#endif
+#ifndef TOA_ABL_NOTHIN
+      if constexpr (sizeof(T) == 4 && THIN > 0) {
+        // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
+        // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
+        using f2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int pb = 0; pb < NBM / 2; ++pb) {
+          const f2 wp = {w[2 * pb], w[2 * pb + 1]};
+#pragma unroll
+          for (int j = 0; j < THIN; ++j) {
+            f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
+            a += wp * f2{v[j], v[j]};
+            accT[ti(2 * pb, j)] = a[0];
+            accT[ti(2 * pb + 1, j)] = a[1];
+          }
+        }
+        if constexpr (NBM & 1) {
+#ifndef TOA_NO_THIN_PAIR_LAST
+          // the odd block against the thin columns two at a time: (v[j], v[j+1]) is an aligned pair of the load tuple
+#pragma unroll
+          for (int j = 0; j + 1 < THIN; j += 2) {
+            f2 a = {accT[ti(NBM - 1, j)], accT[ti(NBM - 1, j + 1)]};
+            a += f2{w[NBM - 1], w[NBM - 1]} * f2{v[j], v[j + 1]};
+            accT[ti(NBM - 1, j)] = a[0];
+            accT[ti(NBM - 1, j + 1)] = a[1];
+          }
+          if constexpr (THIN & 1) accT[ti(NBM - 1, THIN - 1)] += w[NBM - 1] * v[THIN - 1];
+#else
+#pragma unroll
+          for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
+#endif
+        }
+        // thin x thin corner, column j2 at a time: (j, j+1) pairs against a splat of v[j2] in one packed FMA
+#pragma unroll
+        for (int j2 = 0; j2 < THIN; ++j2) {
+#pragma unroll
+          for (int j = 0; j + 1 <= j2; j += 2) {
+            f2 a = {accTT[tt(j, j2)], accTT[tt(j + 1, j2)]};
+            a += f2{v[j], v[j + 1]} * f2{v[j2], v[j2]};
+            accTT[tt(j, j2)] = a[0];
+            accTT[tt(j + 1, j2)] = a[1];
+          }
+          if ((j2 & 1) == 0) accTT[tt(j2, j2)] += v[j2] * v[j2];
+        }
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < NBM; ++cb)
+#pragma unroll
+          for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
+#pragma unroll
+        for (int j = 0; j < THIN; ++j)
+#pragma unroll
+          for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
+      }
+#else
+#pragma unroll
+      for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
+#endif
+    } else if constexpr (!ROBUST) {
+      if constexpr (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
+      else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
+    }
+  }
+
+  // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
+  // of `m` / `tv` (no staging copies: the other slot set is the one being refilled meanwhile).
+  template <bool WANT_H, bool TAIL = false, bool ROBUST = false>
+  __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, PassCtx& pc, T& csum,
+                                                const int last = 0, const int row0 = 0) {
+    T wa[U][NBM];
+    T va[U][THIN ? THIN : 1];
+    T part[U];
+    batch_dots(m, tv, pc, wa, va, part);
     // a_i.x of the four steps in one transposed reduction; quad lane q then owns step q: ONE sin/cos per batch
     const T tsel = quad_transpose_reduce(part, pc.q0, pc.q1);
     T sn, cs;
@@ -592,143 +737,11 @@ struct DenseRowGram {
     const T rb_sel = tsel + T(0.1) * sn;
     static_for<U>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
-      T(&w)[NBM] = wa[u];
-      T(&v)[THIN ? THIN : 1] = va[u];
-      T sc = quad_bcast<u>(sc_sel);
-      const T rbase = quad_bcast<u>(rb_sel);
-      T rsq = T(0);  // ROBUST: sqrt(s) * r of this row
-      if constexpr (ROBUST) {
-        // the residual of this row on every lane of its row group: the thin tail is broadcast-loaded (all 16 lanes hold
-        // b); with b in the main block only its owner has it, and a 16-lane reduction hands r to the others
-        T r;
-        if constexpr (THIN == 0) r = row16_allreduce_sum(pc.isB_lane ? rbase - w[NBM - 1] : T(0));
-        else r = rbase - v[THIN - 1];
-        const T n2 = r * r;
-        T l, sw;
-        robust_norm(pc.loss, n2, pc.th2, l, sw);
-        const bool valid = row0 + 4 * u + pc.k < pc.rows_real;
-        const bool book = pc.owner && valid;
-        csum += book ? l : T(0);                       // Cost += l
-        pc.inl += (book && n2 <= pc.th2) ? T(1) : T(0);   // cost.h:84-95: inliers are the residuals inside the threshold
-        const T sq = r_sqrt(sw);
-        sc *= sq;
-        rsq = r * sq;
-      }
-      if constexpr (sizeof(T) == 4) {  // J = sc * a, two columns per v_pk_mul_f32
-        using f2 = float __attribute__((ext_vector_type(2)));
-        constexpr int kScaled = THIN == 0 ? NBM - 1 : NBM;  // THIN == 0: the last main element may be b
-#pragma unroll
-        for (int cb = 0; cb + 1 < kScaled; cb += 2) {
-          const f2 wp = f2{w[cb], w[cb + 1]} * f2{sc, sc};
-          w[cb] = wp[0];
-          w[cb + 1] = wp[1];
-        }
-        if constexpr (kScaled & 1) w[kScaled - 1] *= sc;
-#pragma unroll
-        for (int j = 0; j + 2 < THIN; j += 2) {
-          const f2 vp = f2{v[j], v[j + 1]} * f2{sc, sc};
-          v[j] = vp[0];
-          v[j + 1] = vp[1];
-        }
-        if constexpr (THIN > 1 && ((THIN - 1) & 1)) v[THIN - 2] *= sc;
-      } else {
-#pragma unroll
-        for (int cb = 0; cb + 1 < NBM; ++cb) w[cb] *= sc;
-        if (THIN != 0) w[NBM - 1] *= sc;
-#pragma unroll
-        for (int j = 0; j + 1 < THIN; ++j) v[j] *= sc;
-      }
-      // THIN == 0: the lane holding b turns it into r = rbase - b, every other lane scales its column by sc; written as
-      // one FMA with per-lane constants (mA, mB) = (1, 0) / (0, 1) instead of a select (fp64: no exec-mask branch)
-      if constexpr (ROBUST) {
-        if constexpr (THIN == 0) w[NBM - 1] = pc.isB_lane ? rsq : w[NBM - 1] * sc;
-        else v[THIN - 1] = rsq;
-      } else {
-        if constexpr (THIN == 0) w[NBM - 1] = fma(w[NBM - 1], fma(sc, pc.mA, -pc.mB), rbase * pc.mB);
-        else v[THIN - 1] = rbase - v[THIN - 1];
-      }
-      if (WANT_H) {
-#if defined(TOA_SPLIT_MFMA)
-#pragma unroll
-        for (int i = 0; i < NBM; ++i)
-#pragma unroll
-          for (int j = i; j < NBM; ++j) {
-            if constexpr (sizeof(T) == 4)
-              asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
-            else
-              asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
-          }
-#elif !defined(TOA_ABL_NOMFMA)
-        if (TAIL && u == U - 1) GramStep<T, NBM>::run_tail(acc, w, last);
-        else GramStep<T, NBM>::run(acc, w);
-#else
-#pragma unroll
-        for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
-#endif
-#ifndef TOA_ABL_NOTHIN
-        if constexpr (sizeof(T) == 4 && THIN > 0) {
-          // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
-          // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
-          using f2 = float __attribute__((ext_vector_type(2)));
-#pragma unroll
-          for (int pb = 0; pb < NBM / 2; ++pb) {
-            const f2 wp = {w[2 * pb], w[2 * pb + 1]};
-#pragma unroll
-            for (int j = 0; j < THIN; ++j) {
-              f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
-              a += wp * f2{v[j], v[j]};
-              accT[ti(2 * pb, j)] = a[0];
-              accT[ti(2 * pb + 1, j)] = a[1];
-            }
-          }
-          if constexpr (NBM & 1) {
-#ifndef TOA_NO_THIN_PAIR_LAST
-            // the odd block against the thin columns two at a time: (v[j], v[j+1]) is an aligned pair of the load tuple
-#pragma unroll
-            for (int j = 0; j + 1 < THIN; j += 2) {
-              f2 a = {accT[ti(NBM - 1, j)], accT[ti(NBM - 1, j + 1)]};
-              a += f2{w[NBM - 1], w[NBM - 1]} * f2{v[j], v[j + 1]};
-              accT[ti(NBM - 1, j)] = a[0];
-              accT[ti(NBM - 1, j + 1)] = a[1];
-            }
-            if constexpr (THIN & 1) accT[ti(NBM - 1, THIN - 1)] += w[NBM - 1] * v[THIN - 1];
-#else
-#pragma unroll
-            for (int j = 0; j < THIN; ++j) accT[ti(NBM - 1, j)] += w[NBM - 1] * v[j];
-#endif
-          }
-          // thin x thin corner, column j2 at a time: (j, j+1) pairs against a splat of v[j2] in one packed FMA
-#pragma unroll
-          for (int j2 = 0; j2 < THIN; ++j2) {
-#pragma unroll
-            for (int j = 0; j + 1 <= j2; j += 2) {
-              f2 a = {accTT[tt(j, j2)], accTT[tt(j + 1, j2)]};
-              a += f2{v[j], v[j + 1]} * f2{v[j2], v[j2]};
-              accTT[tt(j, j2)] = a[0];
-              accTT[tt(j + 1, j2)] = a[1];
-            }
-            if ((j2 & 1) == 0) accTT[tt(j2, j2)] += v[j2] * v[j2];
-          }
-        } else {
-#pragma unroll
-          for (int cb = 0; cb < NBM; ++cb)
-#pragma unroll
-            for (int j = 0; j < THIN; ++j) accT[ti(cb, j)] += w[cb] * v[j];
-#pragma unroll
-          for (int j = 0; j < THIN; ++j)
-#pragma unroll
-            for (int j2 = j; j2 < THIN; ++j2) accTT[tt(j, j2)] += v[j] * v[j2];
-        }
-#else
-#pragma unroll
-        for (int j = 0; j < THIN; ++j) asm volatile("" ::"v"(v[j]));
-#endif
-      } else if constexpr (!ROBUST) {
-        if constexpr (THIN == 0) csum += pc.isB_lane ? w[NBM - 1] * w[NBM - 1] : T(0);
-        else csum += (pc.c == 0) ? v[THIN - 1] * v[THIN - 1] : T(0);
-      }
+      apply_step<WANT_H, (TAIL && u == U - 1), ROBUST>(wa[u], va[u], quad_bcast<u>(sc_sel), quad_bcast<u>(rb_sel), pc, csum, last,
+                                                        row0 + 4 * u);
     });
   }
+
 
   // One step (4 residual rows, one per row group) handed in as operands instead of being loaded: w = this lane's NBM main
   // columns of W = [J | r], v = the thin columns (every lane of the row group holds the same values).  For the models
@@ -780,6 +793,7 @@ struct DenseRowGram {
                                     const int rows_real = 0, int* ninl = nullptr) {
     if constexpr (!ROBUST) {
       if (ninl) *ninl = -1;
+      if constexpr (kSuper16) return pass16<WANT_H>(prob, lay, n, xs, lane);
     }
     const int k = lane >> 4, c = lane & 15;
     const int RS = lay.rs, rsm = lay.rsm;
@@ -871,6 +885,156 @@ struct DenseRowGram {
         for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
       }
       if constexpr (ROBUST) return wave_allreduce_sum(csum);   // sum of l; the Gram's (r, r) entry holds sum of s r^2
+      return T(0);
+    }
+    return wave_allreduce_sum(csum);
+  }
+
+  // ---- fp64, n <= 15: SIXTEEN steps (64 rows) per sin / cos ---------------------------------------------------------------
+  // The quad-transposed reduction above leaves each a_i.x on FOUR lanes (16 row totals per batch on 64 lanes), so the
+  // polynomial sin / cos — 20 half-rate fp64 operations + ~20 selects / integer operations, a third of the fp64 pass's issue
+  // cycles — is evaluated four times per row.  Here four batches are reduced together: a 16-way transposed reduction
+  // (butterfly over the lane bits 0..3 of a row group: quad swaps, then row rotations by 4 / 12 and by 8) leaves the total
+  // of step s on lane c == s of its row group — 64 distinct rows on 64 lanes, ONE sin / cos per 64 rows — and each step
+  // fetches its (scale, residual base) back with a row broadcast (DPP row_newbcast).  Costs 32 load registers instead of 16
+  // (NBM = 1); the loads of the next super-batch are issued batch by batch into the registers the MFMAs have just freed.
+#ifndef TOA_NO_SUPER16
+  // NBM == 1, THIN == 0 only (n <= 15: the shapes of BASELINE's fp64 configs C2 / C3).  Measured on one MI355X, same-box
+  // interleaved: C3 (n = 12, m = 500, 10 000 problems) 0.653 -> 0.586 ms per launch although the kernel goes from 120 to
+  // 156 registers (4 -> 3 waves / SIMD); NBM == 2 (n = 24, 31): 200 registers, 2 waves / SIMD, 1-2 % SLOWER — off there;
+  // with a thin tail the four batches' thin registers and products take the kernel past 300 registers.
+  static constexpr bool kSuper16 = sizeof(T) == 8 && NBM == 1 && THIN == 0;
+#else
+  static constexpr bool kSuper16 = false;
+#endif
+  template <int CTRL, int BANK_MASK, bool BOUND>
+  static __device__ __forceinline__ T dpp_move(const T old, const T v) {
+    static_assert(sizeof(T) == 8, "fp64 helper");
+    const long long b = __double_as_longlong(v), o = __double_as_longlong(old);
+    const int lo = __builtin_amdgcn_update_dpp(int(o & 0xffffffffll), int(b & 0xffffffffll), CTRL, 0xf, BANK_MASK, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(int(o >> 32), int(b >> 32), CTRL, 0xf, BANK_MASK, BOUND);
+    return __longlong_as_double((long long)(unsigned)lo | ((long long)hi << 32));
+  }
+  // value of lane c ^ 4 of the same 16-lane row: rotation by 12 (source c - 4) everywhere, then rotation by 4 (source c + 4)
+  // written over the banks whose lanes have bit 2 clear (banks 0 and 2 = lanes 0-3, 8-11)
+  static __device__ __forceinline__ T row_xor4(const T v) {
+    const T a = dpp_move<0x120 + 12, 0xf, true>(T(0), v);
+    return dpp_move<0x120 + 4, 0x5, false>(a, v);
+  }
+  template <int S>
+  static __device__ __forceinline__ T row_bcast16(const T v) { return dpp_move<0x150 + S, 0xf, true>(T(0), v); }  // row_newbcast:S
+  static __device__ __forceinline__ T reduce16(const T (&p)[16], const int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+    T r1[8], r2[4], r3[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const T keep = b0 ? p[2 * i + 1] : p[2 * i], send = b0 ? p[2 * i] : p[2 * i + 1];
+      r1[i] = keep + dpp_quad<kQuadSwap1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T keep = b1 ? r1[2 * i + 1] : r1[2 * i], send = b1 ? r1[2 * i] : r1[2 * i + 1];
+      r2[i] = keep + dpp_quad<kQuadSwap2>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T keep = b2 ? r2[2 * i + 1] : r2[2 * i], send = b2 ? r2[2 * i] : r2[2 * i + 1];
+      r3[i] = keep + row_xor4(send);
+    }
+    const T keep = b3 ? r3[1] : r3[0], send = b3 ? r3[0] : r3[1];
+    return keep + dpp_row_ror<8>(send);
+  }
+
+  template <bool WANT_H>
+  __device__ __forceinline__ T pass16(const T* __restrict__ prob, const DenseRowLayout& lay, const int n, const T* __restrict__ xs,
+                                      const int lane) {
+    const int k = lane >> 4, c = lane & 15;
+    const int RS = lay.rs, rsm = lay.rsm;
+    const bool active = c * NBM < rsm;
+    PassCtx pc;
+    pc.c = c;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      const int q = NBM * c + cb;
+      pc.xr[cb] = (q < lay.nmr) ? xs[q] : T(0);
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < THIN; ++j) pc.xt[j] = (c == 0) ? xs[lay.nmr + j] : T(0);
+    pc.q0 = (lane & 1) != 0;
+    pc.q1 = (lane & 2) != 0;
+    pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);
+    pc.mA = pc.isB_lane ? T(0) : T(1);
+    pc.mB = pc.isB_lane ? T(1) : T(0);
+    pc.loss = 0;
+    pc.th2 = T(0);
+    pc.k = k;
+    pc.rows_real = 0;
+    pc.owner = THIN == 0 ? pc.isB_lane : c == 0;
+    pc.inl = T(0);
+    if (WANT_H) clear();
+    T csum = 0;
+    const int steps = lay.m4 >> 2;
+    const unsigned prob_bytes = unsigned(lay.m4) * unsigned(RS) * unsigned(sizeof(T));
+    const i32x4 rsrc = make_rsrc(prob, prob_bytes);
+    const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
+    const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));
+    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(4 * RS) * unsigned(sizeof(T)))));
+    constexpr int NBATCH = 4;   // batches of U steps per super-batch
+    Slots S[NBATCH];
+    SlotsT St[NBATCH];
+    T wa[NBATCH][U][NBM];
+    T va[NBATCH][U][THIN ? THIN : 1];
+    T part[NBATCH * U];
+    // wait for batch j (the younger batches of the super-batch may stay outstanding) and form its partial dot products
+    auto land = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int leave = (NBATCH - 1 - j) * kLoadsPerBatch;
+      wait_batch<leave, kDw>(S[j][0], S[j][1], S[j][2], S[j][3]);
+      if (THIN) wait_batch<leave, kDwT>(St[j][0], St[j][1], St[j][2], St[j][3]);
+      T pj[U];
+      batch_dots(S[j], St[j], pc, wa[j], va[j], pj);
+#pragma unroll
+      for (int u = 0; u < U; ++u) part[j * U + u] = pj[u];
+    };
+    static_for<NBATCH>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      issue_batch(S[j], St[j], rsrc, voff, vofft, unsigned(j * U) * step_bytes_u, step_bytes_u);
+    });
+    static_for<NBATCH>(land);
+    // Loop invariant at the back-edge: NO load is in flight (every batch of the next super-batch has landed and been folded
+    // into part[] at the bottom of the body), so the register copies hipcc places on the back-edge only ever touch data that
+    // has arrived (tools/isa_lint.py checks exactly that).
+    for (int s0 = 0; s0 < steps; s0 += NBATCH * U) {
+      const T t16 = reduce16(part, lane);
+      T sn, cs;
+      sincos_t(t16, &sn, &cs);
+      const T sc16 = T(1) + T(0.1) * cs;
+      const T rb16 = t16 + T(0.1) * sn;
+      const int last = __builtin_amdgcn_readfirstlane(int(s0 + NBATCH * U >= steps));
+      static_for<NBATCH>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        static_for<U>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value;
+          apply_step<WANT_H, (j == NBATCH - 1 && u == U - 1), false>(wa[j][u], va[j][u], row_bcast16<j * U + u>(sc16),
+                                                                       row_bcast16<j * U + u>(rb16), pc, csum, last, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // refill the registers this batch's MFMAs have just consumed with the same batch of the NEXT super-batch
+        const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + NBATCH * U + j * U) * step_bytes_u)));
+        issue_batch(S[j], St[j], rsrc, voff, vofft, soff, step_bytes_u);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      static_for<NBATCH>(land);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (WANT_H) {
+      mfma_retire();
+      if (THIN) {
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+      }
       return T(0);
     }
     return wave_allreduce_sum(csum);
