@@ -563,7 +563,8 @@ def main():
         r = result["roofline"]
         sec = r.pop("mfma_secondary")
         result["roofline"] = {"bound": "mfma", "kernel": r["kernel"], "achieved": sec["achieved"], "peak": sec["peak"], "unit": "TFLOP/s",
-                              "frac": sec["frac"], "traffic": None, "flop_per_accumulate_pass": sec["issued_flop_per_accumulate_pass"],
+                              "frac": sec["frac"], "traffic": r["traffic"], "traffic_source": r["traffic_source"],
+                              "flop_per_accumulate_pass": sec["issued_flop_per_accumulate_pass"],
                               "flop_accounting": "algorithmic: m (n+1)(n+2) per accumulate pass (symmetric Gram of [J | r]); evaluate passes, "
                                                  "the LDL^T and the step are in the time but not in the flops",
                               "issued_mfma_flop_per_accumulate_pass": mfma_issued_per_pass,

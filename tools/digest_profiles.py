@@ -47,10 +47,7 @@ def main():
                 continue
             lf.update(c)
             lf.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
-        with open(os.path.join(DST, f"{tag}_pmc_large128.json"), "w") as f:
-            json.dump({"round": tag, "workload": "large128", "kernel": "large_fused_kernel<float, 8>",
-                       "counters_per_launch": {k: v for k, v in lf.items() if not k.startswith("_")},
-                       "kernel_ms_under_pmc": lf.get("_kernel_ms", {})}, f, indent=1)
+        globals()["_large128"] = lf   # finished below, once the FETCH_SIZE calibration is known
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
                  "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
@@ -88,6 +85,24 @@ def main():
     for name in (f"{tag}_pmc.json", "pmc_latest.json"):
         with open(os.path.join(DST, name), "w") as f:
             json.dump(out, f, indent=1)
+    lf = globals().get("_large128")
+    if lf and os.path.exists(os.path.join(DST, f"{tag}_bench_large128.json")):
+        bl = json.loads(open(os.path.join(DST, f"{tag}_bench_large128.json")).read())
+        hs = bl["roofline"]["hbm_secondary"]
+        alg_l = hs["passes_per_launch"] * hs["algorithmic_bytes_per_pass"]
+        hbm_l = lf["FETCH_SIZE"] * 1024.0 * cal if "FETCH_SIZE" in lf else None
+        outl = {"round": tag, "workload": "large128", "problems": bl["config"]["problems_per_gpu"], "kernel": "large_fused_kernel<float, 8>",
+                "counters_per_launch": {k: v for k, v in lf.items() if not k.startswith("_")},
+                "fetch_calibration_bytes_per_reported_byte": cal,
+                "fetch_calibration_note": "the C4 calibration (wide coalesced streams report 1/2 on gfx950); reads only — the kernel's writes "
+                                          "(partial Grams, H) stay in L2 and are not in this figure",
+                "hbm_bytes_per_launch": hbm_l, "algorithmic_bytes_per_launch": alg_l,
+                "traffic_over_algorithmic": (hbm_l / alg_l) if hbm_l else None,
+                "kernel_ms_under_pmc": lf.get("_kernel_ms", {})}
+        for name in (f"{tag}_pmc_large128.json", "pmc_latest_large128.json"):
+            with open(os.path.join(DST, name), "w") as f:
+                json.dump(outl, f, indent=1)
+        print("large128", {k: outl[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
     # ---- the same HBM-traffic measurement for the C3 launch (fp64, n = 12)
     if os.path.isdir(os.path.join(SRC, "pmc_fused_c3")):
         b3 = json.loads(open(os.path.join(DST, f"{tag}_bench_c3.json")).read())
