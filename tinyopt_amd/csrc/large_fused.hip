@@ -166,7 +166,9 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
         // H = sum of the four partial Grams, to the L2-resident copy Hs (kept undamped for eval-only iterations and the
         // final export) AND straight into the LDS image the factorisation works on
 #pragma unroll 3
-        for (int idx = tid; idx < NT * 64; idx += 256) {
+        for (int it = 0; it < (NT * 64 + 255) / 256; ++it) {  // three tiles' partial loads in flight at once (all nine: 512 registers, spills)
+          const int idx = tid + 256 * it;
+          if (idx >= NT * 64) break;
           const int t = idx >> 6, l = idx & 63;
           const Acc v = (part[(0 * NT + t) * 64 + l] + part[(1 * NT + t) * 64 + l]) +
                         (part[(2 * NT + t) * 64 + l] + part[(3 * NT + t) * 64 + l]);
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
           hd[i] = d;
           if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
         }
-        if (wg_sum<T>(low, red) > 0) built = false;
+        if (opt.check_min_H_diag > 0 && wg_sum<T>(low, red) > 0) built = false;   // (uniform: nine barriers saved when the check is off)
       }
       __syncthreads();
       if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double

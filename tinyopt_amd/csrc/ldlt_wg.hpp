@@ -59,34 +59,38 @@ struct WgLdlt {
           P[q] = (in_rows && 16 * J + q < n) ? v : T(0);
         });
         __syncthreads();  // every wave has read the diagonal block before wave 0 overwrites it with L / D
+        // The 16 pivots of the panel without a branch per pivot: a pivot outside the safe range only raises `bad` (the
+        // arithmetic carries on with inf / nan, harmlessly: the factorisation is abandoned at the end of the panel), and the
+        // reciprocals stay in a register until the panel is done.
+        bool bad = false;
+        T dinv_lane = T(0);  // lane k (< 16): 1 / d of pivot 16 J + k
         static_for<16>([&](auto kc) __attribute__((always_inline)) {
           constexpr int k = decltype(kc)::value;
           constexpr int kg = 16 * J + k;
-          if (kg < n && ok) {  // uniform
+          if (kg < n) {  // uniform
             const T cv = P[k];
             const T d = wave_bcast(cv, k);  // lane k holds row kg
-            if (!LdltRegs<T, 16>::pivot_in_range(d)) {
-              ok = false;
-            } else {
-              const T inv = LdltRegs<T, 16>::recip(d);
-              const bool below = lane > k;  // lanes >= 16 are rows beyond the diagonal block
-              const T l = below ? cv * inv : T(0);
-              P[k] = below ? l : cv;
-              if (wave == 0 && lane == k) dinv[kg] = inv;
-              T cj[15];
-              static_for<15 - k>([&](auto jj) __attribute__((always_inline)) {
-                constexpr int j = k + 1 + decltype(jj)::value;
-                cj[j - 1] = wave_bcast(cv, j);  // S[16 J + j][kg]
-              });
-              __builtin_amdgcn_sched_barrier(0);
-              static_for<15 - k>([&](auto jj) __attribute__((always_inline)) {
-                constexpr int j = k + 1 + decltype(jj)::value;
-                P[j] = fma(-l, cj[j - 1], P[j]);
-              });
-              __builtin_amdgcn_sched_barrier(0);
-            }
+            bad = bad || !LdltRegs<T, 16>::pivot_in_range(d);
+            const T inv = LdltRegs<T, 16>::recip(d);
+            const bool below = lane > k;  // lanes >= 16 are rows beyond the diagonal block
+            const T l = below ? cv * inv : T(0);
+            P[k] = below ? l : cv;
+            dinv_lane = (lane == k) ? inv : dinv_lane;
+            T cj[15];
+            static_for<15 - k>([&](auto jj) __attribute__((always_inline)) {
+              constexpr int j = k + 1 + decltype(jj)::value;
+              cj[j - 1] = wave_bcast(cv, j);  // S[16 J + j][kg]
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<15 - k>([&](auto jj) __attribute__((always_inline)) {
+              constexpr int j = k + 1 + decltype(jj)::value;
+              P[j] = fma(-l, cj[j - 1], P[j]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
           }
         });
+        ok = !bad;
+        if (wave == 0 && lane < 16 && 16 * J + lane < n) dinv[16 * J + lane] = dinv_lane;
         if (ok && in_rows && (lane >= 16 || wave == 0)) {
           static_for<16>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
