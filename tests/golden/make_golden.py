@@ -82,12 +82,42 @@ def robust_cases():
     np.savez_compressed(os.path.join(OUT, "robust_f64.npz"), **out)
 
 
+def round2_cases():
+    """Round-2 paths: bundle adjustment solved the reference's dense way (oracle/ba.hpp), a DenseRow batch with a Huber loss
+    on every residual, and a natural-layout n = 72 batch (the workgroup-per-problem kernel's range).  Inputs are stored
+    (small) or regenerated from their seed with a checksum."""
+    out = {}
+    C, N, P = 3, 20, 2
+    data, x0, xs = pyoracle.synth_ba(P, C, N, np.float64, seed=77, invisible=0.2)
+    r = pyoracle.ba_lm(data, x0, C, N, Options().to_pod(), history=True)
+    out.update(ba_C=C, ba_N=N, ba_data=data, ba_x0=x0, ba_x=r["x"], ba_stop=r["stop"], ba_iters=r["iters"], ba_cost=r["cost"],
+               ba_errs=r["errs"], ba_succ=r["succ"], ba_deltas2=r["deltas2"])
+    A, b, x0d, xsd = pyoracle.synth_dense_row(3, 6, 120, np.float64, seed=21)
+    b[:, ::10] += 3.0                                    # planted outliers
+    th2 = 0.25
+    g, H, c, nres, inl = pyoracle.dense_row_accumulate(A, b, x0d, loss="huber", th2=th2)
+    rl = pyoracle.dense_row_lm(A, b, x0d, Options().to_pod(), history=True, loss="huber", th2=th2)
+    out.update(hub_A=A, hub_b=b, hub_x0=x0d, hub_th2=np.float64(th2), hub_g=g, hub_H=H, hub_cost=c, hub_inl=inl, hub_x=rl["x"], hub_stop=rl["stop"],
+               hub_iters=rl["iters"], hub_final_cost=rl["cost"], hub_errs=rl["errs"], hub_succ=rl["succ"], hub_deltas2=rl["deltas2"])
+    n, m, Pn = 72, 150, 2
+    An, bn, x0n, xsn = pyoracle.synth_dense_row(Pn, n, m, np.float64, seed=5)
+    rn = pyoracle.dense_row_lm(An, bn, x0n, Options.benchmark().to_pod(), history=True)
+    out.update(nat_n=n, nat_m=m, nat_P=Pn, nat_seed=5, nat_A_sum=np.float64(An.sum()), nat_x0=x0n, nat_xstar=xsn, nat_x=rn["x"],
+               nat_stop=rn["stop"], nat_iters=rn["iters"], nat_cost=rn["cost"], nat_errs=rn["errs"], nat_succ=rn["succ"],
+               nat_deltas2=rn["deltas2"])
+    np.savez_compressed(os.path.join(OUT, "round2_f64.npz"), **out)
+
+
 if __name__ == "__main__":
     if "--only-robust" in sys.argv:
         robust_cases()
+        sys.exit(0)
+    if "--only-round2" in sys.argv:
+        round2_cases()
         sys.exit(0)
     sqrt2_traces()
     dense_row_cases()
     ldlt_cases()
     robust_cases()
+    round2_cases()
     print("golden fixtures written to", OUT)

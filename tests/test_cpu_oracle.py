@@ -133,3 +133,29 @@ def test_robust_golden(oracle):
     assert np.allclose(r["x"], g["se3_x"], atol=1e-10) and np.allclose(r["cost"], g["se3_cost"], rtol=1e-10)
     assert np.allclose(r["inlier_ratio"], g["se3_inlier_ratio"])
     assert np.abs(r["x"] - g["se3_pstar"]).max() < 1e-2     # 200 points, 0.5 px noise: outliers do not drag the pose away
+
+
+def test_round2_golden(oracle):
+    """tests/golden/round2_f64.npz: the oracle's bundle adjustment (dense Hessian, oracle/ba.hpp), DenseRow with a Huber loss on
+    every residual, and an n = 72 natural-layout batch reproduce their frozen trajectories."""
+    from tinyopt_amd.api import Options
+    g = np.load(os.path.join(GOLD, "round2_f64.npz"))
+    r = oracle.ba_lm(g["ba_data"], g["ba_x0"], int(g["ba_C"]), int(g["ba_N"]), Options().to_pod(), history=True)
+    assert np.array_equal(r["stop"], g["ba_stop"]) and np.array_equal(r["iters"], g["ba_iters"])
+    assert np.allclose(r["x"], g["ba_x"], rtol=1e-9, atol=1e-11) and np.allclose(r["cost"], g["ba_cost"], rtol=1e-9)
+    assert np.array_equal(r["succ"], g["ba_succ"])
+    dof = 2 * g["ba_data"][:, 8 + 2 * int(g["ba_C"]) * int(g["ba_N"]):].sum(1) - (6 * int(g["ba_C"]) + 3 * int(g["ba_N"])) + 7
+    assert (r["cost"] < 0.25 / 3 * dof * 2.0).all()                 # independent of the fixture: ends at the planted pixel-noise level
+    th2 = float(g["hub_th2"])
+    gg, H, c, _, inl = oracle.dense_row_accumulate(g["hub_A"], g["hub_b"], g["hub_x0"], loss="huber", th2=th2)
+    assert np.allclose(gg, g["hub_g"], rtol=1e-12, atol=1e-12) and np.allclose(H, g["hub_H"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(c, g["hub_cost"], rtol=1e-12) and np.allclose(inl, g["hub_inl"])
+    rl = oracle.dense_row_lm(g["hub_A"], g["hub_b"], g["hub_x0"], Options().to_pod(), history=True, loss="huber", th2=th2)
+    assert np.array_equal(rl["stop"], g["hub_stop"]) and np.array_equal(rl["iters"], g["hub_iters"])
+    assert np.allclose(rl["x"], g["hub_x"], rtol=1e-10, atol=1e-12)
+    n, m, P = int(g["nat_n"]), int(g["nat_m"]), int(g["nat_P"])
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float64, seed=int(g["nat_seed"]))
+    assert np.isclose(A.sum(), g["nat_A_sum"], rtol=1e-12) and np.array_equal(x0, g["nat_x0"])
+    rn = oracle.dense_row_lm(A, b, x0, Options.benchmark().to_pod(), history=True)
+    assert np.array_equal(rn["stop"], g["nat_stop"]) and np.array_equal(rn["iters"], g["nat_iters"])
+    assert np.allclose(rn["x"], g["nat_x"], rtol=1e-10, atol=1e-12) and np.abs(rn["x"] - xs).max() < 2e-2
