@@ -454,9 +454,12 @@ class BundleAdjustment:
 
 
 class DenseRowNatural:
-    """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout,
-    J^T J through a batched rocBLAS GEMM, the damped solve through rocSOLVER's batched Cholesky, the LM state machine of
-    optimizer.h:242-539 in small kernels between them.  A: [P, m, n], b: [P, m]; stored per problem as A then b."""
+    """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout.
+    64 <= n <= 128 (fp64: 96): the whole loop in one persistent kernel, a workgroup per problem, J^T J on the matrix cores
+    without materialising J, blocked LDL^T by the four waves (csrc/large_fused.hip).  Beyond: J^T J through a batched rocBLAS
+    GEMM, the damped solve through the workgroup LDL^T / rocSOLVER's batched Cholesky, the LM state machine of
+    optimizer.h:242-539 in small kernels between them (csrc/large_n.hip).  A: [P, m, n], b: [P, m]; stored per problem as A
+    then b."""
     model_id = MODEL_DENSE_ROW_NATURAL
 
     def __init__(self, A: torch.Tensor, b: torch.Tensor):
