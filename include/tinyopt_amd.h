@@ -262,7 +262,7 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      problems to their StopReason.  counters_dev (optional, [4] uint64): {accumulate passes,
  *      evaluate-only passes, linear solves, problems} ADDED to by every path (the caller zeroes them) — the units the
  *      roofline accounting in bench.py multiplies by the algorithmic bytes per pass.
- *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128 (fp64: beyond 96): that
+ *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128: that
  *      regime reads two integers back per pass (it blocks the host and cannot be captured in a hipGraph); 64 <= n <= 128
  *      is one persistent kernel like the rest. */
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,

@@ -75,7 +75,7 @@ def _run_natural(ta, A, b, x0, opts, history=False):
     return x.cpu().numpy(), out
 
 
-# 64 <= n <= 128 (fp32) / 96 (fp64): the workgroup-per-problem persistent kernel (large_fused.hip), one case per block
+# 64 <= n <= 128: the workgroup-per-problem persistent kernel (large_fused.hip; fp64 beyond 96 in two half-tile passes), one case per block
 # count NB = ceil(n / 16) = 4..8 and ragged row counts; the others: the library-backed pipeline (large_n.hip)
 @pytest.mark.parametrize("dtype,n,m,xtol", [(np.float64, 64, 300, 1e-8), (np.float64, 100, 400, 1e-8),
                                              (np.float32, 96, 400, 2e-3), (np.float64, 12, 100, 1e-8),

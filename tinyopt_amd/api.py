@@ -455,7 +455,7 @@ class BundleAdjustment:
 
 class DenseRowNatural:
     """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout.
-    64 <= n <= 128 (fp64: 96): the whole loop in one persistent kernel, a workgroup per problem, J^T J on the matrix cores
+    64 <= n <= 128: the whole loop in one persistent kernel, a workgroup per problem, J^T J on the matrix cores
     without materialising J, blocked LDL^T by the four waves (csrc/large_fused.hip).  Beyond: J^T J through a batched rocBLAS
     GEMM, the damped solve through the workgroup LDL^T / rocSOLVER's batched Cholesky, the LM state machine of
     optimizer.h:242-539 in small kernels between them (csrc/large_n.hip).  A: [P, m, n], b: [P, m]; stored per problem as A
@@ -573,7 +573,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
     cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
-    asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128 (fp64: 96), whose host loop reads
+    asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128, whose host loop reads
     two integers back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
     library (every path accumulates).
     """

@@ -90,6 +90,31 @@ struct GramStep {
     const int last = __builtin_amdgcn_readfirstlane(last_in);
     asm volatile("s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 2\n\ts_nop 15\n\ts_nop 15" : : [last] "s"(last) : "scc", "memory");
   }
+  // Only the tiles T0 <= tile(I, J) < T1 (row-major order over the upper block triangle): for accumulator sets that do not fit
+  // the register file in one go (fp64, NB >= 7: large_fused.hip makes two passes over the rows, half of the tiles each).
+  template <int T0, int T1, int I, int J>
+  static __device__ __forceinline__ void from_range(Acc* acc, const T* w) {
+    if constexpr (I < NB) {
+      if constexpr (tile(I, J) >= T0 && tile(I, J) < T1) {
+        if constexpr (sizeof(T) == 4)
+          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+        else
+          asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+      }
+      if constexpr (J + 1 < NB) from_range<T0, T1, I, J + 1>(acc, w);
+      else from_range<T0, T1, I + 1, I + 1>(acc, w);
+    }
+  }
+  template <int T0, int T1>
+  static __device__ __forceinline__ void run_range(Acc* acc, const T* w, int last_in) {
+    static_assert(NB <= 8, "operand list below");
+    constexpr int L = NB - 1;
+    asm volatile("s_nop 1" : : "v"(w[0]), "v"(w[1 < L ? 1 : L]), "v"(w[2 < L ? 2 : L]), "v"(w[3 < L ? 3 : L]), "v"(w[4 < L ? 4 : L]),
+                 "v"(w[5 < L ? 5 : L]), "v"(w[6 < L ? 6 : L]), "v"(w[L]));
+    from_range<T0, T1, 0, 0>(acc, w);
+    const int last = __builtin_amdgcn_readfirstlane(last_in);
+    asm volatile("s_cmp_eq_u32 %[last], 0\n\ts_cbranch_scc1 2\n\ts_nop 15\n\ts_nop 15" : : [last] "s"(last) : "scc", "memory");
+  }
 };
 #define TOA_GRAM_STEP(T, TAG, NBV, BODY, ACCS, WS)                                                      \
   template <>                                                                                           \
@@ -389,6 +414,17 @@ struct RawVec<14> {
     o[12] = d[0]; o[13] = d[1];
   }
 };
+template <>
+struct RawVec<16> {
+  u32x4 a, b, c, d;
+  TOA_RAWVEC_ISSUE("buffer_load_dwordx4 %0, %4, %5, %6 offen offset:%7\n\tbuffer_load_dwordx4 %1, %4, %5, %6 offen offset:%8\n\t"
+                   "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:%9\n\tbuffer_load_dwordx4 %3, %4, %5, %6 offen offset:%10",
+                   "=&v"(a) TOA_C "=&v"(b) TOA_C "=&v"(c) TOA_C "=&v"(d),
+                   "v"(voff) TOA_C "s"(r) TOA_C "s"(soff) TOA_C "n"(IMM) TOA_C "n"(IMM + 16) TOA_C "n"(IMM + 32) TOA_C "n"(IMM + 48))
+  __device__ __forceinline__ void get(unsigned* o) const {
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; o[8 + i] = c[i]; o[12 + i] = d[i]; }
+  }
+};
 #undef TOA_RAWVEC_ISSUE
 // Wait for every outstanding VMEM load of this wave; the operands make the four batch slots
 // data-dependent on the wait so that no consumer is hoisted above it.
@@ -580,7 +616,8 @@ struct DenseRowGram {
   // One step of the batch once the scale sc = 1 + 0.1 cos(a_i.x) and rbase = a_i.x + 0.1 sin(a_i.x) of its four rows are
   // known: J = sc a in registers, r = rbase - b, the step's MFMAs and thin products (or, cost only, r^2).  w / v: the
   // step's main / thin operands; row_u: index of the step's first row (ROBUST bookkeeping).
-  template <bool WANT_H, bool TAIL_STEP, bool ROBUST>
+  // T0, T1: tile range of this pass (all of them by default); THINP: form the thin products too.
+  template <bool WANT_H, bool TAIL_STEP, bool ROBUST, int T0 = 0, int T1 = NT, bool THINP = true>
   __device__ __forceinline__ void apply_step(T (&w)[NBM], T (&v)[THIN ? THIN : 1], T sc, const T rbase, PassCtx& pc, T& csum,
                                              const int last, const int row_u) {
     T rsq = T(0);  // ROBUST: sqrt(s) * r of this row
@@ -646,14 +683,16 @@ struct DenseRowGram {
             asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
         }
 #elif !defined(TOA_ABL_NOMFMA)
-      if (TAIL_STEP) GramStep<T, NBM>::run_tail(acc, w, last);
+      if constexpr (T0 != 0 || T1 != NT) GramStep<T, NBM>::template run_range<T0, T1>(acc, w, TAIL_STEP ? last : 0);
+      else if (TAIL_STEP) GramStep<T, NBM>::run_tail(acc, w, last);
       else GramStep<T, NBM>::run(acc, w);
 #else
 #pragma unroll
       for (int cb = 0; cb < NBM; ++cb) asm volatile("" ::"v"(w[cb]));
 #endif
 #ifndef TOA_ABL_NOTHIN
-      if constexpr (sizeof(T) == 4 && THIN > 0) {
+      if constexpr (!THINP) {
+      } else if constexpr (sizeof(T) == 4 && THIN > 0) {
         // v_pk_fma_f32: two column blocks per instruction; accT is laid out so that the pair (cb, cb+1) of a
         // given j sits in adjacent elements (see ti()), w[cb], w[cb+1] are adjacent lanes of the load tuple
         using f2 = float __attribute__((ext_vector_type(2)));
@@ -718,7 +757,7 @@ struct DenseRowGram {
 
   // The arithmetic of one batch (U steps of 4 rows), reading the operands straight out of the load registers
   // of `m` / `tv` (no staging copies: the other slot set is the one being refilled meanwhile).
-  template <bool WANT_H, bool TAIL = false, bool ROBUST = false>
+  template <bool WANT_H, bool TAIL = false, bool ROBUST = false, int T0 = 0, int T1 = NT, bool THINP = true>
   __device__ __forceinline__ void compute_batch(const Slots& m, const SlotsT& tv, PassCtx& pc, T& csum,
                                                 const int last = 0, const int row0 = 0) {
     T wa[U][NBM];
@@ -737,8 +776,8 @@ struct DenseRowGram {
     const T rb_sel = tsel + T(0.1) * sn;
     static_for<U>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
-      apply_step<WANT_H, (TAIL && u == U - 1), ROBUST>(wa[u], va[u], quad_bcast<u>(sc_sel), quad_bcast<u>(rb_sel), pc, csum, last,
-                                                        row0 + 4 * u);
+      apply_step<WANT_H, (TAIL && u == U - 1), ROBUST, T0, T1, THINP>(wa[u], va[u], quad_bcast<u>(sc_sel), quad_bcast<u>(rb_sel), pc,
+                                                                       csum, last, row0 + 4 * u);
     });
   }
 
@@ -1044,7 +1083,8 @@ struct DenseRowGram {
   // `bv` = their nrows right-hand sides (THIN == 1: the thin tail is b alone, fetched through its own descriptor).  A lane
   // whose NBM columns straddle the end of a row reads the head of the next one: those columns q >= n meet x = 0 in a_i.x,
   // and the Gram rows / columns they pollute are never read back (extract_g_diag_cost / the caller's fold stop at n).
-  template <bool WANT_H, int D = 3>   // D: slot sets in the ring (D - 1 batches in flight while one computes)
+  // T0, T1, THINP: this pass forms the tiles T0 <= t < T1 only, and the thin products (g, cost) only if THINP.
+  template <bool WANT_H, int D = 3, int T0 = 0, int T1 = NT, bool THINP = true>   // D: slot sets in the ring
   __device__ __forceinline__ T pass_natural(const T* __restrict__ A, const T* __restrict__ bv, const int n, const int nrows,
                                             const T* __restrict__ xs, const int lane) {
     static_assert(THIN == 1 && D >= 2 && D <= 4, "natural layout: b is the whole thin tail");
@@ -1068,7 +1108,16 @@ struct DenseRowGram {
     pc.rows_real = nrows;
     pc.owner = c == 0;
     pc.inl = T(0);
-    if (WANT_H) clear();
+    if (WANT_H) {
+#pragma unroll
+      for (int t = T0; t < T1; ++t) acc[t] = Acc{0, 0, 0, 0};
+      if (THINP) {
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) accT[t] = T(0);
+#pragma unroll
+        for (int t = 0; t < (NTT ? NTT : 1); ++t) accTT[t] = T(0);
+      }
+    }
     T csum = 0;
     const int steps = (nrows + 3) >> 2;
     const i32x4 rsA = make_rsrc(A, unsigned(nrows) * unsigned(n) * unsigned(sizeof(T)));
@@ -1106,9 +1155,9 @@ struct DenseRowGram {
         issue_nat(S[refill], St[refill], s0 + (i + D - 1) * U);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i == D - 1)
-          compute_batch<WANT_H, true>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + D * U >= steps)), 4 * (s0 + i * U));
+          compute_batch<WANT_H, true, false, T0, T1, THINP>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + D * U >= steps)), 4 * (s0 + i * U));
         else
-          compute_batch<WANT_H, false>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
+          compute_batch<WANT_H, false, false, T0, T1, THINP>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
         __builtin_amdgcn_sched_barrier(0);
         wait_nat(S[(i + 1) % D], St[(i + 1) % D]);
       });
@@ -1121,11 +1170,15 @@ struct DenseRowGram {
       });
     }
     if (WANT_H) {
-      mfma_retire();
+      asm volatile("s_nop 7" ::: "memory");   // mfma_retire() over the tiles of this pass
 #pragma unroll
-      for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+      for (int t = T0; t < T1; ++t) asm volatile("" : "+a"(acc[t]));
+      if (THINP) {
 #pragma unroll
-      for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+        for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+      }
       return T(0);
     }
     return wave_allreduce_sum(csum);

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   T* Aimg = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image of the damped matrix, factored in place
   __shared__ T xs[NV], g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
-  __shared__ T gfold[4][NV], hdw[4][NV];
+  __shared__ T gfold[4][NV];
   __shared__ T costw[4];
   __shared__ double red[256];
   __shared__ LmState<T> S;
@@ -100,8 +100,6 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   const int rows_per_wave = (((m + 3) / 4 + 3) / 4) * 4;
   const int row0 = wave * rows_per_wave;
   const int nrows = row0 >= m ? 0 : (m - row0 < rows_per_wave ? m - row0 : rows_per_wave);
-  DenseRowLayout lay;
-  lay.nbm = NB; lay.thin = 1; lay.nmr = n; lay.rsm = NV; lay.rs = n; lay.m4 = m;
   unsigned long long n_acc = 0, n_eval = 0, n_solves = 0, n_problems = 0;  // thread 0 only
 
   bool first = true;
@@ -138,11 +136,24 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       {
         Gram gram;
         if (do_acc) {
-          gram.template pass_natural<true, TOA_LF_DEPTH>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+          // fp64 with NB >= 7: 28 / 36 tiles of 8 registers do not fit the register file — two passes over the rows, half of
+          // the tiles each (the pass is matrix-core bound: 32 flop / byte against a ridge of 10, reading the rows twice is free)
+          constexpr bool kTwoPass = sizeof(T) == 8 && NB >= 7;
+          constexpr int NTH = kTwoPass ? (NT + 1) / 2 : NT;
           Acc* mine = part + size_t(wave) * NT * 64;
+          gram.template pass_natural<true, TOA_LF_DEPTH, 0, NTH, true>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
-          gram.extract_g_diag_cost(gfold[wave], hdw[wave], lay, n, lane, &costw[wave]);
+          for (int t = 0; t < NTH; ++t) mine[t * 64 + lane] = gram.acc[t];
+          if (lane < 16) {   // J^T r of this lane's NB columns and ||r||^2 (folded over the four row groups by the pass)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) gfold[wave][NB * lane + cb] = gram.accT[Gram::ti(cb, 0)];
+          }
+          if (lane == 0) costw[wave] = gram.accTT[0];
+          if constexpr (kTwoPass) {
+            gram.template pass_natural<true, TOA_LF_DEPTH, NTH, NT, false>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+#pragma unroll
+            for (int t = NTH; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
+          }
         } else {
           // cost only: no matrix-core work to hide the HBM latency behind, and one wave per SIMD — three batches (24 KB
           // per wave) in flight instead of one: 245 -> 9x us per evaluate pass at n = 128, m = 4096
@@ -183,19 +194,21 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
               Hs[qi * n + qj] = v[r];
               Aimg[qi * LD + qj] = v[r];
               if (bi != bj) { Hs[qj * n + qi] = v[r]; Aimg[qj * LD + qi] = v[r]; }
+              else if (qi == qj) hd[qi] = v[r];   // the undamped diagonal (lm.h:108-117 acts on this copy)
             }
           }
         }
-        double low = 0;
         for (int i = tid; i < n; i += 256) {
           T gi = (gfold[0][i] + gfold[1][i]) + (gfold[2][i] + gfold[3][i]);
           if (opt.grad_clipping != 0) { const T mm = opt.grad_clipping; gi = fmin(fmax(gi, -mm), mm); }  // base.h:29-38
           g[i] = gi;
-          const T d = (hdw[0][i] + hdw[1][i]) + (hdw[2][i] + hdw[3][i]);  // == the folded H_ii (same order of additions)
-          hd[i] = d;
-          if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
         }
-        if (opt.check_min_H_diag > 0 && wg_sum<T>(low, red) > 0) built = false;   // (uniform: nine barriers saved when the check is off)
+      }
+      __syncthreads();
+      if (built && do_acc && opt.check_min_H_diag > 0) {  // lm.h:82-86 (workgroup-uniform condition)
+        double low = 0;
+        for (int i = tid; i < n; i += 256) low += fabs(hd[i]) < T(opt.check_min_H_diag) ? 1.0 : 0.0;
+        if (wg_sum<T>(low, red) > 0) built = false;
       }
       __syncthreads();
       if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double
@@ -399,12 +412,8 @@ int large_fused_dispatch(toa_handle h, int n, int m, int64_t P, const T* data, T
     case 4: return launch_large_fused<T, 4>(h, n, m, P, data, x, opt, res, counters);
     case 5: return launch_large_fused<T, 5>(h, n, m, P, data, x, opt, res, counters);
     case 6: return launch_large_fused<T, 6>(h, n, m, P, data, x, opt, res, counters);
-    case 7:  // fp64: 28 tiles = 224 accumulator registers; the loop spills them (tools/isa_lint.py rejects the result)
-      if constexpr (sizeof(T) == 4) return launch_large_fused<T, 7>(h, n, m, P, data, x, opt, res, counters);
-      [[fallthrough]];
-    case 8:
-      if constexpr (sizeof(T) == 4) return launch_large_fused<T, 8>(h, n, m, P, data, x, opt, res, counters);
-      [[fallthrough]];
+    case 7: return launch_large_fused<T, 7>(h, n, m, P, data, x, opt, res, counters);   // (fp64, NB >= 7: two half-tile passes)
+    case 8: return launch_large_fused<T, 8>(h, n, m, P, data, x, opt, res, counters);
     default: return toa_fail(TOA_E_UNSUPPORTED, "large-n fused kernel: n out of range");
   }
 }
@@ -412,13 +421,13 @@ int large_fused_dispatch(toa_handle h, int n, int m, int64_t P, const T* data, T
 }  // namespace
 }  // namespace toa
 
-// 64 <= n <= 128 in fp32, 64 <= n <= 96 in fp64 (28 / 36 fp64 tiles = 224 / 288 accumulator registers: the loop spills), and the Cholesky
+// 64 <= n <= 128 (fp64 beyond 96: two half-tile passes, see the kernel), and the LDL^T
 // image n (n + 1) sizeof(T) must fit the LDS.
 bool toa_large_fused_eligible(toa_handle h, int dtype, int n, int m) {
   static const bool off = [] { const char* e = std::getenv("TOA_LARGE_PIPELINE"); return e && e[0] == '1'; }();
   if (off) return false;
   const size_t esz = dtype == TOA_F32 ? 4 : 8;
-  if (n < 64 || n > (dtype == TOA_F32 ? 128 : 96)) return false;
+  if (n < 64 || n > 128) return false;
   if (size_t(n) * (n + 1) * esz + 16384 > size_t(h->max_lds)) return false;
   if ((unsigned long long)m * (unsigned long long)(n + 1) * esz >= (1ull << 32)) return false;  // 32-bit buffer offsets
   return true;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the n > 63 path (TOA_MODEL_DENSE_ROW_NATURAL: the workgroup-per-problem persistent kernel of
-large_fused.hip up to n = 128 (fp64: 96), rows kernel + rocBLAS GEMM + workgroup LDL^T / rocSOLVER Cholesky + LM state
+large_fused.hip up to n = 128, rows kernel + rocBLAS GEMM + workgroup LDL^T / rocSOLVER Cholesky + LM state
 machine kernels beyond) on synthetic DenseRow problems, next to the one-wavefront fused kernel at n = 63 and the CPU
 restatement (1 thread) on a bounded sample.   usage: python tools/large_n_bench.py [--no-cpu]"""
 import os
