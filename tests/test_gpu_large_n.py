@@ -206,3 +206,17 @@ def test_large_n_fused_kernel_work_queue(ta, oracle):
     assert np.abs(xg - ref["x"]).max() < 2e-3
     assert np.abs(xg - xs).max() < 5e-2
     assert abs(out.num_iters.cpu().numpy().mean() - ref["iters"].mean()) <= 0.5
+
+
+def test_large_n_rejects_a_loss(ta, oracle):
+    """toa_set_loss is wired into the n <= 63 families only: the natural-layout path must refuse, not ignore it."""
+    A, b, x0, _ = oracle.synth_dense_row(2, 64, 128, np.float64)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0).cuda()
+    model.loss, model.th = "huber", 1.0              # what a _LossMixin model carries; pushed to the handle by Optimize
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(x, model)
+    model.loss = None
+    out = ta.Optimize(x, model)                      # and the handle is clean again
+    torch.cuda.synchronize()
+    assert (out.stop_reason.cpu().numpy() >= 0).all()

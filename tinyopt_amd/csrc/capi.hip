@@ -622,7 +622,11 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
-  if (natural) return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
+  if (natural) {
+    if (h->loss != TOA_LOSS_L2)   // never silently: the handle's M-estimator is not wired into the n > 63 kernels
+      return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is not available for TOA_MODEL_DENSE_ROW_NATURAL");
+    return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
+  }
   FusedParams prm;
   std::memset(&prm, 0, sizeof(prm));
   prm.data = data;
