@@ -125,11 +125,21 @@ __device__ __forceinline__ void ba_obs(const T* P, const T* q, const T f, const 
 #ifndef TOA_BA_WGS
 #define TOA_BA_WGS 2
 #endif
+#ifdef TOA_BA_TIMING   // workgroup 0 prints where its time went (constant 100 MHz ticks -> us)
+#define BA_TICK_START unsigned long long tkp_ = wall_clock64();
+#define BA_TICK(i) { const unsigned long long now_ = wall_clock64(); tk_[i] += now_ - tkp_; tkp_ = now_; }
+#else
+#define BA_TICK_START
+#define BA_TICK(i)
+#endif
 template <typename T, int NBM, int THIN>
 __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParams* __restrict__ prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C = prm->C, N = prm->N, n = 6 * C;
+#ifdef TOA_BA_TIMING
+  unsigned long long tk_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   const long long p = blockIdx.x;
   const BaWork<T> wk(C, N);
   // ---- LDS carve: [ WaveLds of wave 0 | part: n*n | pvec, phd: 64 + 64 | poses: 12 C | U: 36 C | gc, rhs: 64 + 64 | red | flags ]
@@ -142,15 +152,21 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   T* gc = U + 36 * C;
   T* red = gc + 64;             // [8]
   int* flags = reinterpret_cast<int*>(red + 8);   // [0] continue, [1] do_acc, [2] action, [3] build ok, [4] solve ok
-  const T* data = static_cast<const T*>(prm->data) + size_t(p) * (8 + size_t(3) * C * N);
+  // Every HBM array is addressed through address_space(1) pointers.  The parameter block is read from memory, so hipcc
+  // cannot prove that the pointers in it are global and emits flat_load / flat_store for plain `T*` (528 + 474 of them in
+  // this kernel): a flat access counts on BOTH memory counters, so every LDS wait also drains the outstanding HBM accesses
+  // and the other way round — the phases of an iteration were serialised on memory latency.
+  using GT = __attribute__((address_space(1))) T;
+  using GCT = const __attribute__((address_space(1))) T;
+  GCT* data = (GCT*)(static_cast<const T*>(prm->data) + size_t(p) * (8 + size_t(3) * C * N));
   const T f = data[0], cx = data[1], cy = data[2];
-  const T* uv = data + 8;
-  const T* vis = uv + size_t(2) * C * N;
-  T* X = static_cast<T*>(prm->x) + size_t(p) * (size_t(12) * C + size_t(3) * N);
-  T* pts = X + 12 * C;
-  T* work = static_cast<T*>(prm->work) + size_t(p) * wk.total;
-  T* Wb = work + wk.W; T* Voff = work + wk.Voff; T* hdp = work + wk.hdp; T* gp = work + wk.gp;
-  T* Rinv = work + wk.Rinv; T* qv = work + wk.q; T* dp = work + wk.dp; T* ldp = work + wk.ldp;
+  GCT* uv = data + 8;
+  GCT* vis = uv + size_t(2) * C * N;
+  GT* X = (GT*)(static_cast<T*>(prm->x) + size_t(p) * (size_t(12) * C + size_t(3) * N));
+  GT* pts = X + 12 * C;
+  GT* work = (GT*)(static_cast<T*>(prm->work) + size_t(p) * wk.total);
+  GT* Wb = work + wk.W; GT* Voff = work + wk.Voff; GT* hdp = work + wk.hdp; GT* gp = work + wk.gp;
+  GT* Rinv = work + wk.Rinv; GT* qv = work + wk.q; GT* dp = work + wk.dp; GT* ldp = work + wk.ldp;
   const DenseRowLayout lay = DenseRowLayout::make(n, 4);
 
   if (wave == 0) {
@@ -172,6 +188,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
 
   for (;;) {  // one pass = Build (+ Solve) of the loop at optimizer.h:358; a failed solve retries without advancing the iteration
     const bool do_acc = !is_lm || S.rebuild;
+    BA_TICK_START
     // ================= Accumulate / Evaluate (gn.h:97-113) =================
     T csum = 0, nvis = 0;
     for (int c = 0; c < C; ++c) {
@@ -226,7 +243,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           }
 #pragma unroll
           for (int k = 0; k < 3; ++k) { hdp[3 * j + k] = v6[k]; Voff[3 * j + k] = v6[3 + k]; gp[3 * j + k] = g3[k]; }
-          T* Wd = Wb + (size_t(c) * N + j) * 18;
+          GT* Wd = Wb + (size_t(c) * N + j) * 18;
 #pragma unroll
           for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -258,6 +275,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         __syncthreads();
       }
     }
+    BA_TICK(0)
     const T cost_raw = ba_block_sum<T>(csum, red);
     const int nres = int(ba_block_sum<T>(nvis, red));
     __syncthreads();
@@ -293,6 +311,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       for (int i = tid; i < 3 * N; i += 256) hdp[i] = T(double(hdp[i]) * s);
     }
     __syncthreads();
+    BA_TICK(1)
     // ================= Solve (gn.h:150-171) through the Schur complement =================
     T bad = 0;
     if (built) {
@@ -318,7 +337,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           r21 = -l21 * r11 * r22;
           r20 = -(l20 * r00 + l21 * r10) * r22;
         }
-        T* Rj = Rinv + 6 * j;
+        GT* Rj = Rinv + 6 * j;
         Rj[0] = r00; Rj[1] = r10; Rj[2] = r11; Rj[3] = r20; Rj[4] = r21; Rj[5] = r22;
         const T g0 = gp[3 * j], g1 = gp[3 * j + 1], g2 = gp[3 * j + 2];
         qv[3 * j] = r00 * g0;
@@ -327,6 +346,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       }
       bad = ba_block_sum<T>(bad, red);
       __syncthreads();
+      BA_TICK(2)
       // M = U (block diagonal, damped diagonal), rhs = -g_c
       for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
@@ -343,37 +363,57 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         const int k = lane >> 4, c16 = lane & 15;
         const bool isB = (THIN == 0) && ((c16 + 1) * NBM == lay.rsm);
         const int npts_w = N > wave ? (N - wave + 3) / 4 : 0;
-        for (int s = 0; s < npts_w; ++s) {
-          const int j = wave + 4 * s;
-          T rk[3] = {T(0), T(0), T(0)};   // row k of R_j^-1 (k == 3: the unused fourth row of the step stays zero)
-          T qk = T(0);
-          if (k < 3) {
-            const T* Rj = Rinv + 6 * j;
-            if (k == 0) rk[0] = Rj[0];
-            else if (k == 1) { rk[0] = Rj[1]; rk[1] = Rj[2]; }
-            else { rk[0] = Rj[3]; rk[1] = Rj[4]; rk[2] = Rj[5]; }
-            qk = qv[3 * j + k];
+        // The values a lane needs of one point — the W entries of its NBM (+ thin) columns, row k of R^-1, q[k] — are fetched
+        // one point AHEAD of the Gram step that consumes them: a point is ~13 independent loads (L2 hits, ~0.7 us) followed
+        // by 0.2 us of arithmetic, and without the prefetch every point paid the full round trip (Schur phase of an 8 x 256
+        // scene: 105 -> 73 us per iteration; two points ahead needs 26 more registers, spills under the 256 cap and is slower).
+        constexpr int NCOL = NBM + (THIN > 0 ? THIN - 1 : 0);
+        struct PtVals { T wv[NCOL][3]; T rk[3]; T qk; };
+        // column of Z handled by slot i of this lane: its NBM main columns, then the thin ones
+        auto slot_col = [&](const int i) -> int { return i < NBM ? NBM * c16 + i : lay.nmr + (i - NBM); };
+        auto load_pt = [&](const int sidx) __attribute__((always_inline)) {
+          PtVals pv;
+          const int j = wave + 4 * sidx;
+          const bool live = sidx < npts_w && k < 3;
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) pv.rk[b2] = T(0);
+          pv.qk = T(0);
+          if (live) {
+            GCT* Rj = Rinv + 6 * j;
+            if (k == 0) pv.rk[0] = Rj[0];
+            else if (k == 1) { pv.rk[0] = Rj[1]; pv.rk[1] = Rj[2]; }
+            else { pv.rk[0] = Rj[3]; pv.rk[1] = Rj[4]; pv.rk[2] = Rj[5]; }
+            pv.qk = qv[3 * j + k];
           }
-          auto zcol = [&](int col) -> T {  // Z_j[col][k] = sum_b W_{cam,j}[dof][b] R^-1[k][b]
-            if (col >= n || k >= 3) return T(0);
-            const T* Wd = Wb + (size_t(col / 6) * N + j) * 18 + 3 * (col % 6);
-            return Wd[0] * rk[0] + Wd[1] * rk[1] + Wd[2] * rk[2];
-          };
+#pragma unroll
+          for (int i = 0; i < NCOL; ++i) {
+            const int col = slot_col(i);
+            const bool use = live && col < n && (i >= NBM || col < lay.nmr);
+            GCT* Wd = Wb + (size_t(use ? col / 6 : 0) * N + (use ? j : 0)) * 18 + 3 * (use ? col % 6 : 0);
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2]; pv.wv[i][b2] = use ? v0 : T(0); }   // unconditional load, masked
+          }
+          return pv;
+        };
+        PtVals cur = load_pt(0);
+        for (int s = 0; s < npts_w; ++s) {
+          const PtVals nxt = load_pt(s + 1);   // in flight during this point's arithmetic
+          // Z_j[col][k] = sum_b W_{cam,j}[dof][b] R^-1[k][b]
+          auto zslot = [&](const int i) -> T { return cur.wv[i][0] * cur.rk[0] + cur.wv[i][1] * cur.rk[1] + cur.wv[i][2] * cur.rk[2]; };
           T w[NBM], v[THIN ? THIN : 1];
 #pragma unroll
-          for (int cb = 0; cb < NBM; ++cb) {
-            const int qcol = NBM * c16 + cb;
-            w[cb] = qcol < lay.nmr ? zcol(qcol) : T(0);
-          }
+          for (int cb = 0; cb < NBM; ++cb) w[cb] = zslot(cb);
           if constexpr (THIN == 0) {
-            if (isB) w[NBM - 1] = qk;
+            if (isB) w[NBM - 1] = cur.qk;
           } else {
 #pragma unroll
-            for (int jt = 0; jt + 1 < THIN; ++jt) v[jt] = zcol(lay.nmr + jt);
-            v[THIN - 1] = qk;
+            for (int jt = 0; jt + 1 < THIN; ++jt) v[jt] = zslot(NBM + jt);
+            v[THIN - 1] = cur.qk;
           }
           gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == npts_w)));
+          cur = nxt;
         }
+        BA_TICK(7)
         gram.finish_steps();
         for (int wv = 0; wv < 4; ++wv) {   // fold the four partial Grams in wave order
           if (wave == wv) {
@@ -389,6 +429,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           __syncthreads();
         }
       }
+      BA_TICK(3)
       // reduced camera system: the one-wavefront LDL^T with the reference's acceptance rule
       if (wave == 0) {
         bool ok;
@@ -408,6 +449,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       }
       __syncthreads();
     }
+    BA_TICK(4)
     const bool solved = built && flags[4] != 0;
     // back-substitution, |dx|^2, |g|^2 (optimizer.h:412-415)
     T d2 = 0, g2 = 0;
@@ -416,14 +458,14 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         T u3[3] = {gp[3 * j], gp[3 * j + 1], gp[3 * j + 2]};
         g2 += u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];
         for (int c = 0; c < C; ++c) {
-          const T* Wd = Wb + (size_t(c) * N + j) * 18;
+          GCT* Wd = Wb + (size_t(c) * N + j) * 18;
 #pragma unroll
           for (int kk = 0; kk < 6; ++kk) {
             const T dck = L.dx[6 * c + kk];
             u3[0] += Wd[3 * kk] * dck; u3[1] += Wd[3 * kk + 1] * dck; u3[2] += Wd[3 * kk + 2] * dck;
           }
         }
-        const T* Rj = Rinv + 6 * j;
+        GCT* Rj = Rinv + 6 * j;
         const T y0 = Rj[0] * u3[0], y1 = Rj[1] * u3[0] + Rj[2] * u3[1], y2 = Rj[3] * u3[0] + Rj[4] * u3[1] + Rj[5] * u3[2];
         const T e0 = -(Rj[0] * y0 + Rj[1] * y1 + Rj[3] * y2), e1 = -(Rj[2] * y1 + Rj[4] * y2), e2 = -(Rj[5] * y2);
         dp[3 * j] = e0; dp[3 * j + 1] = e1; dp[3 * j + 2] = e2;
@@ -431,6 +473,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       }
       for (int i = tid; i < n; i += 256) { d2 += L.dx[i] * L.dx[i]; g2 += gc[i] * gc[i]; }
     }
+    BA_TICK(5)
     const T d2s = ba_block_sum<T>(d2, red);
     const T g2s = ba_block_sum<T>(g2, red);
     __syncthreads();
@@ -487,8 +530,14 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       for (int i = tid; i < 3 * N; i += 256) pts[i] -= ldp[i];
     }
     __syncthreads();
+    BA_TICK(6)
     if (!flags[0]) break;
   }
+#ifdef TOA_BA_TIMING
+  if (tid == 0 && blockIdx.x == 0)
+    printf("ba wg0: accumulate %.1f us  build %.1f us  point Cholesky %.1f us  Schur Gram %.1f + fold %.1f us  camera solve %.1f us  back-substitution %.1f us  step %.1f us\n",
+           tk_[0] * 0.01, tk_[1] * 0.01, tk_[2] * 0.01, tk_[7] * 0.01, tk_[3] * 0.01, tk_[4] * 0.01, tk_[5] * 0.01, tk_[6] * 0.01);
+#endif
   // ---- optimizer.h:313-327
   for (int i = tid; i < 12 * C; i += 256) X[i] = poses[i];
   if (tid == 0) {
