@@ -568,13 +568,16 @@ struct Se3ReprojModel {
   __device__ __forceinline__ void set_loss(int, double) {}  // this family carries its loss in the data header
   static constexpr int kNpad = 16;
   static constexpr int kXdim = 12;
-  const T* data;
-  const T* d;
+  // address_space(1): the data pointer reaches the kernels through a parameter block in memory, so hipcc cannot prove it
+  // global and would emit flat loads, which count on the LDS counter too and serialise against the LDS-resident state machine
+  using GP = const __attribute__((address_space(1))) T*;
+  GP data;
+  GP d;
   int npts, pt0, pt1;
   int ninl;  // inlier residuals of the last pass (cost.h:84 NumInliers)
   T G[28];
   static __device__ __forceinline__ constexpr int tt(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
-  __device__ __forceinline__ void init(int, int m, const void* dp) { npts = m / 2; data = static_cast<const T*>(dp); }
+  __device__ __forceinline__ void init(int, int m, const void* dp) { npts = m / 2; data = (GP)static_cast<const T*>(dp); }
   __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (8 + 5 * size_t(npts)); pt0 = 0; pt1 = npts; }
   __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int) {
     d = data + size_t(p) * (8 + 5 * size_t(npts));
@@ -598,7 +601,7 @@ struct Se3ReprojModel {
     }
     T csum = 0;
     T inl = 0;  // exact in T: <= 2 * points per lane
-    const T* pts = d + 8;
+    GP pts = d + 8;
     // one point ahead: the next point's five scalars are in flight while this one is folded (a single resident wave
     // per chunk on the row-split path would otherwise pay one HBM round trip per point)
     T nq[5];
