@@ -31,6 +31,7 @@ struct BaParams {
   toa_results res;
   unsigned long long* counters;
   int lds_wave;               // bytes of the WaveLds carve (wave 0's LDL^T workspace + vectors + LmState)
+  int lds_gpart;              // byte offset of the per-wave camera sums
 };
 
 template <typename T>
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   T* gc = U + 36 * C;
   T* red = gc + 64;             // [8]
   int* flags = reinterpret_cast<int*>(red + 8);   // [0] continue, [1] do_acc, [2] action, [3] build ok, [4] solve ok
+  T* gpart = reinterpret_cast<T*>(smem + prm->lds_gpart);   // [4 waves][C][32]: per-wave totals of the cameras' 28 sums
   // Every HBM array is addressed through address_space(1) pointers.  The parameter block is read from memory, so hipcc
   // cannot prove that the pointers in it are global and emits flat_load / flat_store for plain `T*` (528 + 474 of them in
   // this kernel): a flat access counts on BOTH memory counters, so every LDS wait also drains the outstanding HBM accesses
@@ -254,26 +256,26 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         csum += r[0] * r[0] + r[1] * r[1];
         nvis += seen ? T(2) : T(0);
       }
-      if (do_acc) {  // fold the camera's 28 sums over the workgroup, fixed order
+      if (do_acc) {  // this wave's totals of the camera's 28 sums: one transposed reduction, parked in LDS until every camera is done
+        T G32[32];
 #pragma unroll
-        for (int i = 0; i < 28; ++i) G[i] = wave_allreduce_sum(G[i]);
-        __syncthreads();
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < 28; ++i) part[wave * 28 + i] = G[i];
-        }
-        __syncthreads();
-        if (tid < 28) {
-          const T tot = (part[tid] + part[28 + tid]) + (part[56 + tid] + part[84 + tid]);
-          // tt(a, b) = a * 7 - a (a - 1) / 2 + (b - a): scatter into the 6 x 6 block, g_c
-          int a = 0, rem = tid;
-          while (rem >= 7 - a) { rem -= 7 - a; ++a; }
-          const int b = a + rem;
-          if (b < 6) { U[36 * c + 6 * a + b] = tot; U[36 * c + 6 * b + a] = tot; }
-          else if (a < 6) gc[6 * c + a] = tot;
-        }
-        __syncthreads();
+        for (int i = 0; i < 32; ++i) G32[i] = i < 28 ? G[i] : T(0);
+        const T tot = wave_transposed_reduce32(G32, lane);
+        if (lane < 28) gpart[(wave * C + c) * 32 + lane] = tot;
       }
+    }
+    if (do_acc) {  // fold the four waves' totals in fixed order and scatter: 6 x 6 block of camera c, g_c
+      __syncthreads();
+      for (int idx = tid; idx < 28 * C; idx += 256) {
+        const int c = idx / 28, t = idx - 28 * c;
+        const T tot = (gpart[(0 * C + c) * 32 + t] + gpart[(1 * C + c) * 32 + t]) + (gpart[(2 * C + c) * 32 + t] + gpart[(3 * C + c) * 32 + t]);
+        int a = 0, rem = t;  // tt(a, b) = a * 7 - a (a - 1) / 2 + (b - a)
+        while (rem >= 7 - a) { rem -= 7 - a; ++a; }
+        const int b = a + rem;
+        if (b < 6) { U[36 * c + 6 * a + b] = tot; U[36 * c + 6 * b + a] = tot; }
+        else if (a < 6) gc[6 * c + a] = tot;
+      }
+      __syncthreads();
     }
     BA_TICK(0)
     const T cost_raw = ba_block_sum<T>(csum, red);
@@ -566,7 +568,10 @@ int launch_ba(toa_handle h, BaParams& prm) {
   size_t pw = WaveLds<T>::bytes(n);
   pw = (pw + 15) & ~size_t(15);
   prm.lds_wave = int(pw);
-  const size_t lds = pw + (size_t(n) * n + 64 + 64 + size_t(12) * prm.C + size_t(36) * prm.C + 64 + 8) * sizeof(T) + 64;
+  size_t lds = pw + (size_t(n) * n + 64 + 64 + size_t(12) * prm.C + size_t(36) * prm.C + 64 + 8) * sizeof(T) + 64;
+  lds = (lds + 15) & ~size_t(15);
+  prm.lds_gpart = int(lds);
+  lds += size_t(4) * prm.C * 32 * sizeof(T);
   if (lds > size_t(160 * 1024)) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: LDS footprint exceeds 160 KiB");
   const BaWork<T> wk(prm.C, prm.N);
   const size_t need = size_t(prm.P) * wk.total * sizeof(T);
