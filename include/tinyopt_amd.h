@@ -207,13 +207,14 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6].
- * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024, P <= 65535; data_dev: per problem A row-major [m][n] then b [m]
+ * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024 (P <= 65535 outside 64 <= n <= 128); data_dev: per problem A row-major [m][n] then b [m]
  *                           (problem stride m (n + 1) elements); x: [P][n]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).
  * want_grad = 0  <=>  grad == nullptr (cost only).  g_dev: [P][n] T; H_dev: [P][n*n] T full symmetric
- * (assigned, not accumulated); cost_dev: [P] double (= ||r||^2, un-normalised); nres_dev: [P] int32. */
+ * (assigned, not accumulated); cost_dev: [P] double (= ||r||^2, un-normalised); nres_dev: [P] int32.
+ * TOA_MODEL_DENSE_ROW_NATURAL: available for 64 <= n <= 128 (the data pass + fold of the workgroup-per-problem kernel). */
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                    const void* data_dev, const void* x_dev, int want_grad,
                    void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);
@@ -222,8 +223,8 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
  *      -> SolveLDLT math.h:232-240).  H_ii <- H_ii * scale (double, Marquardt multiplicative), then
  *      dx = -H^-1 g by pivoted LDL^T with Eigen's acceptance rule (info()==Success && isPositive()).
  *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure).
- *      n <= 63: one wavefront per matrix.  64 <= n <= 128: one workgroup per matrix (register-resident
- *      Cholesky).  Beyond, up to 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs) — the measured crossover. */
+ *      n <= 63: one wavefront per matrix.  64 <= n <= 128: one workgroup per matrix (blocked LDL^T, trailing updates
+ *      on the matrix cores).  Beyond, up to 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs) — the measured crossover. */
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);
 

@@ -220,3 +220,28 @@ def test_large_n_rejects_a_loss(ta, oracle):
     out = ta.Optimize(x, model)                      # and the handle is clean again
     torch.cuda.synchronize()
     assert (out.stop_reason.cpu().numpy() >= 0).all()
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 64, 130), (np.float64, 72, 257), (np.float64, 100, 300), (np.float64, 128, 515),
+                                       (np.float32, 64, 259), (np.float32, 80, 300), (np.float32, 96, 333), (np.float32, 112, 400),
+                                       (np.float32, 128, 1024)])
+def test_large_n_accumulate_seam_matches_oracle(ta, oracle, dtype, n, m):
+    """toa_accumulate for the natural layout at 64 <= n <= 128 (the data pass + fold of the workgroup-per-problem kernel on
+    their own): g, H, cost against the oracle's accumulate, with and without the gradient — every block count, both dtypes
+    (fp64 beyond 96: the two half-tile passes)."""
+    P = 3
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, dtype, seed=13)
+    gr, Hr, cr, nr = oracle.dense_row_accumulate(A, b, x0)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(x0).cuda())
+    torch.cuda.synchronize()
+    tol = 1e-11 if dtype == np.float64 else 3e-5
+    scale_H = np.abs(Hr).max()
+    assert np.abs(H.cpu().numpy() - Hr).max() <= tol * scale_H
+    assert np.abs(g.cpu().numpy() - gr).max() <= tol * max(np.abs(gr).max(), scale_H)
+    assert np.allclose(c.cpu().numpy(), cr, rtol=tol * 10)
+    assert np.array_equal(nres.cpu().numpy(), nr)
+    Hh = H.cpu().numpy()
+    assert np.array_equal(Hh, np.swapaxes(Hh, 1, 2))          # exactly symmetric: mirrored, not recomputed
+    _, _, c2, _ = ta.accumulate(model, torch.from_numpy(x0).cuda(), want_grad=False)
+    assert np.allclose(c2.cpu().numpy(), cr, rtol=tol * 10)

@@ -540,6 +540,17 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, const void* x,
                    int want_grad, void* g, void* H, double* cost, int32_t* nres) {
   if (!h) return fail(TOA_E_ARG, "null handle");
+  if (model == TOA_MODEL_DENSE_ROW_NATURAL) {  // the seam beyond one wavefront: 64 <= n <= 128 (large_fused.hip)
+    if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+    if (m < 1 || P < 0 || !data) return fail(TOA_E_ARG, "toa_accumulate: bad shape or null data pointer");
+    if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
+    if (!toa_large_fused_eligible(h, dtype, n, m))
+      return fail(TOA_E_UNSUPPORTED, "toa_accumulate: TOA_MODEL_DENSE_ROW_NATURAL is available for 64 <= n <= 128");
+    if (h->loss != TOA_LOSS_L2) return fail(TOA_E_UNSUPPORTED, "toa_accumulate: toa_set_loss is not available for TOA_MODEL_DENSE_ROW_NATURAL");
+    if (P == 0) return TOA_OK;
+    TOA_ON_DEVICE(h->device);
+    return toa_large_accumulate(h, dtype, n, m, P, data, x, want_grad, g, H, cost, nres);
+  }
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (int rc = check_model(model, n, m, data)) return rc;
   if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
@@ -603,7 +614,9 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
     if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");
     if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
-    if (P < 0 || P > 65535) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: P must be in [0, 65535]");
+    // the launch-per-stage pipeline indexes problems through grid.y (65 535); the persistent 64 <= n <= 128 kernel does not
+    if (P < 0 || (P > 65535 && !toa_large_fused_eligible(h, dtype, n, m)))
+      return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: P must be in [0, 65535] for this n");
     if (!data) return fail(TOA_E_ARG, "null data pointer");
     if (mode != 0 || splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: toa_lm_run only");
   } else {

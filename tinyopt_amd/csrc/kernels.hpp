@@ -1915,6 +1915,9 @@ bool toa_large_fused_eligible(toa_context* h, int dtype, int n, int m);
 int toa_large_fused_lm_run(toa_context* h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                            const toa_results* results, uint64_t* counters);
 
+int toa_large_accumulate(toa_context* h, int dtype, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
+                         void* H, double* cost, int32_t* nres);
+
 // error reporting lives in capi.hip (one thread_local message for the whole library)
 int toa_fail(int code, const std::string& msg);
 #define HIP_TRY(expr)                                                                           \

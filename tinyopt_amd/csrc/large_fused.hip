@@ -358,6 +358,124 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   }
 }
 
+// K1 / K2 seam for 64 <= n <= 128 (toa_accumulate with TOA_MODEL_DENSE_ROW_NATURAL): the data pass + fold of the kernel above
+// on their own — g [P][n], H [P][n][n] full symmetric, cost, nres — a workgroup per problem, grid-stride.
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) large_accumulate_kernel(const T* __restrict__ data, const T* __restrict__ x, const int n,
+                                                               const int m, const long long P, const int want_grad,
+                                                               T* __restrict__ g_out, T* __restrict__ H_out,
+                                                               double* __restrict__ cost, int* __restrict__ nres,
+                                                               char* __restrict__ scratch, const size_t scratch_per_wg) {
+  using Gram = DenseRowGram<T, NB, 1>;
+  using Acc = typename Mfma<T>::Acc;
+  constexpr int NT = Gram::NT;
+  constexpr int NV = 16 * NB;
+  constexpr int kEvalDepth = sizeof(T) == 4 ? 4 : (NB <= 4 ? 3 : 2);
+  __shared__ T xs[NV];
+  __shared__ T gfold[4][NV];
+  __shared__ T costw[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Acc* part = reinterpret_cast<Acc*>(scratch + size_t(blockIdx.x) * scratch_per_wg);   // [4][NT][64]
+  const int rows_per_wave = (((m + 3) / 4 + 3) / 4) * 4;
+  const int row0 = wave * rows_per_wave;
+  const int nrows = row0 >= m ? 0 : (m - row0 < rows_per_wave ? m - row0 : rows_per_wave);
+  for (long long p = blockIdx.x; p < P; p += gridDim.x) {
+    const T* A = data + size_t(p) * m * (size_t(n) + 1);
+    const T* bv = A + size_t(m) * n;
+    for (int i = tid; i < NV; i += 256) xs[i] = i < n ? x[p * n + i] : T(0);
+    __syncthreads();
+    {
+      Gram gram;
+      if (want_grad) {
+        constexpr bool kTwoPass = sizeof(T) == 8 && NB >= 7;
+        constexpr int NTH = kTwoPass ? (NT + 1) / 2 : NT;
+        Acc* mine = part + size_t(wave) * NT * 64;
+        gram.template pass_natural<true, TOA_LF_DEPTH, 0, NTH, true>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) mine[t * 64 + lane] = gram.acc[t];
+        if (lane < 16) {
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) gfold[wave][NB * lane + cb] = gram.accT[Gram::ti(cb, 0)];
+        }
+        if (lane == 0) costw[wave] = gram.accTT[0];
+        if constexpr (kTwoPass) {
+          gram.template pass_natural<true, TOA_LF_DEPTH, NTH, NT, false>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+#pragma unroll
+          for (int t = NTH; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
+        }
+      } else {
+        const T c = gram.template pass_natural<false, kEvalDepth>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+        if (lane == 0) costw[wave] = c;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      cost[p] = double(T((costw[0] + costw[1]) + (costw[2] + costw[3])));
+      if (nres) nres[p] = m;
+    }
+    if (want_grad) {
+      T* Hp = H_out + size_t(p) * n * n;
+#pragma unroll 3
+      for (int it = 0; it < (NT * 64 + 255) / 256; ++it) {
+        const int idx = tid + 256 * it;
+        if (idx >= NT * 64) break;
+        const int t = idx >> 6, l = idx & 63;
+        const Acc v = (part[(0 * NT + t) * 64 + l] + part[(1 * NT + t) * 64 + l]) +
+                      (part[(2 * NT + t) * 64 + l] + part[(3 * NT + t) * 64 + l]);
+        int bi = 0, rem = t;
+        while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+        const int bj = bi + rem;
+        const int qj = NB * (l & 15) + bj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = NB * Mfma<T>::out_row(l, r) + bi;
+          if (qi < n && qj < n) {
+            Hp[qi * n + qj] = v[r];
+            if (bi != bj) Hp[qj * n + qi] = v[r];
+          }
+        }
+      }
+      for (int i = tid; i < n; i += 256) g_out[p * n + i] = (gfold[0][i] + gfold[1][i]) + (gfold[2][i] + gfold[3][i]);
+    }
+    __syncthreads();   // xs / gfold / the scratch block are free for the next problem
+  }
+}
+
+template <typename T, int NB>
+int launch_large_accumulate(toa_handle h, int n, int m, int64_t P, const T* data, const T* x, int want_grad, T* g, T* H,
+                            double* cost, int32_t* nres) {
+  using Acc = typename Mfma<T>::Acc;
+  constexpr int NT = NB * (NB + 1) / 2;
+  long long grid = std::min<long long>(P, (long long)h->num_cus * 2);
+  const size_t per_wg = (size_t(4) * NT * 64 * sizeof(Acc) + 255) & ~size_t(255);
+  const size_t need = per_wg * size_t(grid);
+  if (need > h->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&h->scratch, need));
+    h->scratch_bytes = need;
+  }
+  hipLaunchKernelGGL((large_accumulate_kernel<T, NB>), dim3((unsigned)grid), dim3(256), 0, h->stream, data, x, n, m, (long long)P,
+                     want_grad, g, H, cost, nres, static_cast<char*>(h->scratch), per_wg);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+template <typename T>
+int large_accumulate_dispatch(toa_handle h, int n, int m, int64_t P, const T* data, const T* x, int want_grad, T* g, T* H,
+                              double* cost, int32_t* nres) {
+  switch ((n + 15) / 16) {
+    case 4: return launch_large_accumulate<T, 4>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 5: return launch_large_accumulate<T, 5>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 6: return launch_large_accumulate<T, 6>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 7: return launch_large_accumulate<T, 7>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    case 8: return launch_large_accumulate<T, 8>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+    default: return toa_fail(TOA_E_UNSUPPORTED, "large-n accumulate: n out of range");
+  }
+}
+
 template <typename T, int NB>
 int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
                        uint64_t* counters) {
@@ -438,4 +556,13 @@ int toa_large_fused_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, con
   if (dtype == TOA_F32)
     return toa::large_fused_dispatch<float>(h, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options, *results, counters);
   return toa::large_fused_dispatch<double>(h, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results, counters);
+}
+
+int toa_large_accumulate(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
+                         void* H, double* cost, int32_t* nres) {
+  if (dtype == TOA_F32)
+    return toa::large_accumulate_dispatch<float>(h, n, m, P, static_cast<const float*>(data), static_cast<const float*>(x), want_grad,
+                                                 static_cast<float*>(g), static_cast<float*>(H), cost, nres);
+  return toa::large_accumulate_dispatch<double>(h, n, m, P, static_cast<const double*>(data), static_cast<const double*>(x), want_grad,
+                                                static_cast<double*>(g), static_cast<double*>(H), cost, nres);
 }
