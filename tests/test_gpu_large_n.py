@@ -208,18 +208,45 @@ def test_large_n_fused_kernel_work_queue(ta, oracle):
     assert abs(out.num_iters.cpu().numpy().mean() - ref["iters"].mean()) <= 0.5
 
 
-def test_large_n_rejects_a_loss(ta, oracle):
-    """toa_set_loss is wired into the n <= 63 families only: the natural-layout path must refuse, not ignore it."""
-    A, b, x0, _ = oracle.synth_dense_row(2, 64, 128, np.float64)
-    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
-    x = torch.from_numpy(x0).cuda()
-    model.loss, model.th = "huber", 1.0              # what a _LossMixin model carries; pushed to the handle by Optimize
-    with pytest.raises(ta.ToaError):
-        ta.Optimize(x, model)
-    model.loss = None
-    out = ta.Optimize(x, model)                      # and the handle is clean again
+@pytest.mark.parametrize("dtype,n,m,kind,th", [(np.float64, 72, 300, "huber", 0.5), (np.float64, 96, 400, "cauchy", 0.5),
+                                                (np.float32, 100, 400, "huber", 0.5), (np.float32, 128, 600, "arctan", 0.5),
+                                                (np.float32, 64, 259, "geman_mcclure", 0.7)])
+def test_large_n_with_a_loss_matches_oracle(ta, oracle, dtype, n, m, kind, th):
+    """An M-estimator on every residual (robust_norms.h:20-26) through the workgroup-per-problem kernel: planted outliers,
+    whole trajectories and the inlier ratio against the oracle."""
+    P = 4
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=17)
+    rng = np.random.default_rng(5)
+    out_rows = rng.choice(m, size=m // 20, replace=False)
+    b[:, out_rows] += rng.choice([-1.0, 1.0], size=(P, len(out_rows))) * rng.uniform(1.0, 3.0, size=(P, len(out_rows)))
+    opts = ta.Options()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True, loss=kind, th2=th * th)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()).with_loss(kind, th)
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
     torch.cuda.synchronize()
-    assert (out.stop_reason.cpu().numpy() >= 0).all()
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    st = check_trajectories(gpu_dict(out, x), refd, dtype, opts.to_pod(), label=f"natural + {kind} n={n}")
+    assert st["full"] + st["ties"] == P, st
+    ir = out.final_inlier_ratio.cpu().numpy()
+    assert np.abs(ir - ref["inlier_ratio"]).max() <= (0.5 / m if dtype == np.float64 else 2.5 / m)
+    assert (ir < 1.0).all() and (ir > 0.8).all()
+    assert np.abs(x.cpu().numpy() - xs).max() < 0.15          # the outliers do not drag the solution away (m / n is only ~4)
+
+
+def test_large_n_loss_limits(ta, oracle):
+    """toa_set_loss on the natural-layout path: refused, not ignored, where it is not built (n > 128: the pipeline; fp64
+    beyond n = 96: the two half-tile passes), and the handle is clean afterwards."""
+    for dtype, n in ((np.float32, 160), (np.float64, 112)):
+        A, b, x0, _ = oracle.synth_dense_row(2, n, n + 40, dtype)
+        model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        x = torch.from_numpy(x0).cuda()
+        with pytest.raises(ta.ToaError):
+            ta.Optimize(x, model.with_loss("huber", 1.0))
+        out = ta.Optimize(x, model)
+        torch.cuda.synchronize()
+        assert (out.stop_reason.cpu().numpy() >= 0).all()
 
 
 @pytest.mark.parametrize("dtype,n,m", [(np.float64, 64, 130), (np.float64, 72, 257), (np.float64, 100, 300), (np.float64, 128, 515),

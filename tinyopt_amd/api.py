@@ -453,7 +453,7 @@ class BundleAdjustment:
         return (3 * self.ncam * self.npts + 3 * self.npts) * self.packed.element_size()
 
 
-class DenseRowNatural:
+class DenseRowNatural(_LossMixin):
     """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout.
     64 <= n <= 128: the whole loop in one persistent kernel, a workgroup per problem, J^T J on the matrix cores
     without materialising J, blocked LDL^T by the four waves (csrc/large_fused.hip).  Beyond: J^T J through a batched rocBLAS

@@ -636,8 +636,8 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   if (natural) {
-    if (h->loss != TOA_LOSS_L2)   // never silently: the handle's M-estimator is not wired into the n > 63 kernels
-      return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is not available for TOA_MODEL_DENSE_ROW_NATURAL");
+    if (h->loss != TOA_LOSS_L2 && !toa_large_fused_eligible(h, dtype, n, m))   // never silently: not wired into the n > 128 pipeline
+      return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is available for TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 only");
     return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   }
   FusedParams prm;

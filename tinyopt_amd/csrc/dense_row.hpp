@@ -632,8 +632,10 @@ struct DenseRowGram {
       robust_norm(pc.loss, n2, pc.th2, l, sw);
       const bool valid = row_u + pc.k < pc.rows_real;
       const bool book = pc.owner && valid;
-      csum += book ? l : T(0);                       // Cost += l
-      pc.inl += (book && n2 <= pc.th2) ? T(1) : T(0);   // cost.h:84-95: inliers are the residuals inside the threshold
+      if constexpr (THINP) {                           // (a second half-tile pass over the same rows books nothing)
+        csum += book ? l : T(0);                       // Cost += l
+        pc.inl += (book && n2 <= pc.th2) ? T(1) : T(0);   // cost.h:84-95: inliers are the residuals inside the threshold
+      }
       const T sq = r_sqrt(sw);
       sc *= sq;
       rsq = r * sq;
@@ -1084,9 +1086,12 @@ struct DenseRowGram {
   // whose NBM columns straddle the end of a row reads the head of the next one: those columns q >= n meet x = 0 in a_i.x,
   // and the Gram rows / columns they pollute are never read back (extract_g_diag_cost / the caller's fold stop at n).
   // T0, T1, THINP: this pass forms the tiles T0 <= t < T1 only, and the thin products (g, cost) only if THINP.
-  template <bool WANT_H, int D = 3, int T0 = 0, int T1 = NT, bool THINP = true>   // D: slot sets in the ring
+  // ROBUST: every residual goes through the M-estimator (loss, th2); returns the sum of the losses (also for WANT_H) and
+  // the number of inlier rows through *ninl.
+  template <bool WANT_H, int D = 3, int T0 = 0, int T1 = NT, bool THINP = true, bool ROBUST = false>   // D: slot sets in the ring
   __device__ __forceinline__ T pass_natural(const T* __restrict__ A, const T* __restrict__ bv, const int n, const int nrows,
-                                            const T* __restrict__ xs, const int lane) {
+                                            const T* __restrict__ xs, const int lane, const int loss = 0, const T th2 = T(0),
+                                            int* ninl = nullptr) {
     static_assert(THIN == 1 && D >= 2 && D <= 4, "natural layout: b is the whole thin tail");
     const int k = lane >> 4, c = lane & 15;
     PassCtx pc;
@@ -1102,8 +1107,8 @@ struct DenseRowGram {
     pc.isB_lane = false;
     pc.mA = T(1);
     pc.mB = T(0);
-    pc.loss = 0;
-    pc.th2 = T(0);
+    pc.loss = loss;
+    pc.th2 = th2;
     pc.k = k;
     pc.rows_real = nrows;
     pc.owner = c == 0;
@@ -1155,9 +1160,9 @@ struct DenseRowGram {
         issue_nat(S[refill], St[refill], s0 + (i + D - 1) * U);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i == D - 1)
-          compute_batch<WANT_H, true, false, T0, T1, THINP>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + D * U >= steps)), 4 * (s0 + i * U));
+          compute_batch<WANT_H, true, ROBUST, T0, T1, THINP>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + D * U >= steps)), 4 * (s0 + i * U));
         else
-          compute_batch<WANT_H, false, false, T0, T1, THINP>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
+          compute_batch<WANT_H, false, ROBUST, T0, T1, THINP>(S[i], St[i], pc, csum, 0, 4 * (s0 + i * U));
         __builtin_amdgcn_sched_barrier(0);
         wait_nat(S[(i + 1) % D], St[(i + 1) % D]);
       });
@@ -1169,6 +1174,9 @@ struct DenseRowGram {
         wait_batch<0, kDwT>(St[i][0], St[i][1], St[i][2], St[i][3]);
       });
     }
+    if constexpr (ROBUST) {
+      if (ninl) *ninl = int(wave_allreduce_sum(pc.inl));   // exact in T: one count per row
+    }
     if (WANT_H) {
       asm volatile("s_nop 7" ::: "memory");   // mfma_retire() over the tiles of this pass
 #pragma unroll
@@ -1179,6 +1187,7 @@ struct DenseRowGram {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
       }
+      if constexpr (ROBUST) return wave_allreduce_sum(csum);   // sum of l; the Gram's (r, r) entry holds sum of s r^2
       return T(0);
     }
     return wave_allreduce_sum(csum);

@@ -39,6 +39,8 @@ struct LfArgs {
   char* scratch;                 // per resident workgroup: 4 partial Grams + the folded H
   size_t scratch_per_wg;
   unsigned long long* counters;  // [4] or null
+  int loss;                      // TOA_LOSS_* of the handle (toa_set_loss): the ROBUST instantiation applies it to every residual
+  double loss_th2;
 };
 
 template <typename T>
@@ -66,7 +68,9 @@ __device__ __forceinline__ double wg_sum(const double v, double* red) {  // fixe
 #define LF_TICK(i)
 #endif
 
-template <typename T, int NB>
+// ROBUST: every residual through the handle's M-estimator (robust_norms.h:20-26: cost += l, the row's J^T J and J^T r scaled by
+// s) — a separate instantiation, so the plain kernel's instruction stream and registers are untouched.
+template <typename T, int NB, bool ROBUST = false>
 __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
 #ifdef TOA_LF_TIMING
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
@@ -85,6 +89,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   __shared__ T xs[NV], g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
   __shared__ T gfold[4][NV];
   __shared__ T costw[4];
+  __shared__ int ninlw[4];
   __shared__ double red[256];
   __shared__ LmState<T> S;
   __shared__ int sh_p, sh_action, sh_cont;
@@ -141,24 +146,29 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
           constexpr bool kTwoPass = sizeof(T) == 8 && NB >= 7;
           constexpr int NTH = kTwoPass ? (NT + 1) / 2 : NT;
           Acc* mine = part + size_t(wave) * NT * 64;
-          gram.template pass_natural<true, TOA_LF_DEPTH, 0, NTH, true>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+          int ni = nrows;
+          const T cl = gram.template pass_natural<true, TOA_LF_DEPTH, 0, NTH, true, ROBUST>(A + size_t(row0) * n, bv + row0, n, nrows, xs,
+                                                                                           lane, a.loss, T(a.loss_th2), &ni);
 #pragma unroll
           for (int t = 0; t < NTH; ++t) mine[t * 64 + lane] = gram.acc[t];
           if (lane < 16) {   // J^T r of this lane's NB columns and ||r||^2 (folded over the four row groups by the pass)
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) gfold[wave][NB * lane + cb] = gram.accT[Gram::ti(cb, 0)];
           }
-          if (lane == 0) costw[wave] = gram.accTT[0];
+          if (lane == 0) { costw[wave] = ROBUST ? cl : gram.accTT[0]; ninlw[wave] = ni; }   // ROBUST: sum of the losses, not r^T r
           if constexpr (kTwoPass) {
-            gram.template pass_natural<true, TOA_LF_DEPTH, NTH, NT, false>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
+            gram.template pass_natural<true, TOA_LF_DEPTH, NTH, NT, false, ROBUST>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane,
+                                                                                    a.loss, T(a.loss_th2));
 #pragma unroll
             for (int t = NTH; t < NT; ++t) mine[t * 64 + lane] = gram.acc[t];
           }
         } else {
           // cost only: no matrix-core work to hide the HBM latency behind, and one wave per SIMD — three batches (24 KB
           // per wave) in flight instead of one: 245 -> 9x us per evaluate pass at n = 128, m = 4096
-          const T c = gram.template pass_natural<false, kEvalDepth>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane);
-          if (lane == 0) costw[wave] = c;
+          int ni = nrows;
+          const T c = gram.template pass_natural<false, kEvalDepth, 0, NT, true, ROBUST>(A + size_t(row0) * n, bv + row0, n, nrows, xs, lane,
+                                                                                          a.loss, T(a.loss_th2), &ni);
+          if (lane == 0) { costw[wave] = c; ninlw[wave] = ni; }
         }
       }
       __syncthreads();
@@ -219,7 +229,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
         if (do_acc) n_acc++; else n_eval++;
         S.cost_val = cost_val;
         S.cost_nres = m;
-        S.cost_ninl = m;
+        S.cost_ninl = ROBUST ? (ninlw[0] + ninlw[1]) + (ninlw[2] + ninlw[3]) : m;
       }
       for (int i = tid; i < NV; i += 256) rhs[i] = i < n ? g[i] : T(0);
       __syncthreads();
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
       if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
       if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
-      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
       n_problems++;
     }
     __syncthreads();  // Hs / LDS of this problem are free again
@@ -476,12 +486,12 @@ int large_accumulate_dispatch(toa_handle h, int n, int m, int64_t P, const T* da
   }
 }
 
-template <typename T, int NB>
-int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
-                       uint64_t* counters) {
+template <typename T, int NB, bool ROBUST>
+int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
+                         uint64_t* counters) {
   using Acc = typename Mfma<T>::Acc;
   constexpr int NT = NB * (NB + 1) / 2;
-  auto kern = large_fused_kernel<T, NB>;
+  auto kern = large_fused_kernel<T, NB, ROBUST>;
   const size_t lds = ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15);  // + the slack WgLdlt's unconditional reads may touch
   int wg_per_cu = 0;
   for (int i = 0; i < h->ncfg; ++i)
@@ -515,12 +525,26 @@ int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* 
   a.scratch = static_cast<char*>(h->scratch);
   a.scratch_per_wg = per_wg;
   a.counters = reinterpret_cast<unsigned long long*>(counters);
+  a.loss = h->loss;
+  a.loss_th2 = h->loss_th2;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, h->stream, a);
   if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess) {
     h->queue_dirty = true;
     return toa_fail(TOA_E_HIP, std::string("large_fused_kernel launch: ") + hipGetErrorString(e_));
   }
   return TOA_OK;
+}
+
+template <typename T, int NB>
+int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
+                       uint64_t* counters) {
+  if (h->loss != TOA_LOSS_L2) {
+    // fp64 beyond n = 96 (the two half-tile passes): with the M-estimator's registers on top hipcc copies in-flight load
+    // destinations (tools/isa_lint.py rejects that code) — refused rather than built
+    if constexpr (sizeof(T) == 8 && NB >= 7) return toa_fail(TOA_E_UNSUPPORTED, "toa_set_loss with fp64 natural-layout rows: n <= 96");
+    else return launch_large_fused_r<T, NB, true>(h, n, m, P, data, x, opt, res, counters);
+  }
+  return launch_large_fused_r<T, NB, false>(h, n, m, P, data, x, opt, res, counters);
 }
 
 template <typename T>
