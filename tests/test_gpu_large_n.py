@@ -161,7 +161,7 @@ def test_large_n_covariance(ta, oracle):
 
 def test_large_n_option_variants(ta, oracle):
     """Every option branch of the state machine (same list as test_gpu_dense_row.py::test_option_variants) through the
-    library-backed path at n = 72, against the oracle."""
+    workgroup-per-problem kernel at n = 72, against the oracle."""
     pyoracle = oracle
     A, b, x0, xs = pyoracle.synth_dense_row(8, 72, 300, np.float64, seed=3)
     model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())

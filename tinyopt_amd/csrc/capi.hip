@@ -609,7 +609,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
                        const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
                        int mode = 0, void* state = nullptr, int32_t* active = nullptr, const int32_t* stop_request = nullptr) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  const bool natural = model == TOA_MODEL_DENSE_ROW_NATURAL;  // the library-backed path for n beyond one wavefront
+  const bool natural = model == TOA_MODEL_DENSE_ROW_NATURAL;  // n beyond one wavefront (large_fused.hip / large_n.hip)
   if (natural) {
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
     if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       __syncthreads();
       LF_TICK(1)
       // ---------------- Solve (gn.h:150-171): blocked LDL^T of H with the damped diagonal (ldlt_wg.hpp) ----------------
-      bool chol_ok = false;
+      bool ldlt_ok = false;
       if (built) {
         if (do_acc) {  // the fold has filled the image; only the damped diagonal is missing
           for (int i = tid; i < n; i += 256) Aimg[i * LD + i] = hd[i];
@@ -247,9 +247,9 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
         }
         __syncthreads();
         LF_TICK(2)
-        chol_ok = WgLdlt<T, NB>::factor(Aimg, LD, n, diag, tid);
+        ldlt_ok = WgLdlt<T, NB>::factor(Aimg, LD, n, diag, tid);
         LF_TICK(3)
-        if (chol_ok && tid < 64) WgLdlt<T, NB>::solve(Aimg, LD, n, diag, rhs, lane);
+        if (ldlt_ok && tid < 64) WgLdlt<T, NB>::solve(Aimg, LD, n, diag, rhs, lane);
         __syncthreads();
         LF_TICK(4)
       }
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       bool solver_failed = true;
       double dx_norm2 = 0, grad_norm2 = 0;
       if (built) {
-        double bad = chol_ok ? 0.0 : 1.0, d2 = 0, g2 = 0;
+        double bad = ldlt_ok ? 0.0 : 1.0, d2 = 0, g2 = 0;
         for (int i = tid; i < n; i += 256) {
           const T v = -rhs[i];
           if (!(fabs(v) <= NumLimits<T>::max())) bad = 1.0;
