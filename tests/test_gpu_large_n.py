@@ -272,3 +272,17 @@ def test_large_n_accumulate_seam_matches_oracle(ta, oracle, dtype, n, m):
     assert np.array_equal(Hh, np.swapaxes(Hh, 1, 2))          # exactly symmetric: mirrored, not recomputed
     _, _, c2, _ = ta.accumulate(model, torch.from_numpy(x0).cuda(), want_grad=False)
     assert np.allclose(c2.cpu().numpy(), cr, rtol=tol * 10)
+
+
+def test_large_n_batch_independence_and_determinism(ta, oracle):
+    """The workgroup-per-problem kernel folds its four partial Grams in a fixed order and takes problems from a queue: the
+    result of a problem must not depend on which workgroup solved it, on the batch it was in, or on the run."""
+    P, n, m = 600, 96, 200
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, np.float32, seed=23)
+    opts = ta.Options.benchmark()
+    xa, oa = _run_natural(ta, A, b, x0, opts)
+    xb, ob = _run_natural(ta, A, b, x0, opts)
+    assert np.array_equal(xa, xb) and np.array_equal(oa.final_cost.cpu().numpy(), ob.final_cost.cpu().numpy())
+    sub = slice(293, 300)
+    xs_, os_ = _run_natural(ta, A[sub].copy(), b[sub].copy(), x0[sub].copy(), opts)
+    assert np.array_equal(xs_, xa[sub]) and np.array_equal(os_.num_iters.cpu().numpy(), oa.num_iters.cpu().numpy()[sub])
