@@ -178,6 +178,28 @@ __device__ __forceinline__ T wave_transposed_reduce32(const T (&p)[32], const in
   return r5 + __shfl_xor(r5, 32, 64);
 }
 
+// All-reduce N independent per-lane partial sums: on return every lane holds every total.  N >= 12: transposed reductions of
+// 32 values at a time, then one broadcast per value (~290 instructions per 32 fp64 values instead of ~800); below that the
+// plain all-reduces are cheaper.
+template <int N, typename T>
+__device__ __forceinline__ void wave_allreduce_many(T (&G)[N], const int lane) {
+  if constexpr (N < 12) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) G[i] = wave_allreduce_sum(G[i]);
+  } else {
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += 32) {
+      T p[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) p[i] = (c0 + i < N) ? G[(c0 + i < N) ? c0 + i : 0] : T(0);
+      const T r = wave_transposed_reduce32(p, lane);
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        if (c0 + i < N) G[c0 + i] = wave_bcast(r, i);
+    }
+  }
+}
+
 // Wave-uniform value helpers
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
