@@ -1457,6 +1457,8 @@ struct PartialSumModel {
   T* hsum;
   int S, n_, m;
   int ninl;
+  bool direct = false;  // the partials live in LDS (team form, S <= 8): lane e sums element e over the chunks itself — S LDS reads
+                        // and S - 1 additions instead of the transposed wave reductions that hide HBM latency in fold_small
   __device__ __forceinline__ T fold(int off) const {
     T s = 0;
     const int stride = n_ * n_ + n_ + 2;
@@ -1513,7 +1515,7 @@ struct PartialSumModel {
   __device__ __forceinline__ bool small() const { return n_ * n_ + n_ + 2 <= 64; }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     if (small()) {
-      const T tot = fold_small(lane, true);
+      const T tot = direct ? (lane < n * n + n + 2 ? fold(lane) : T(0)) : fold_small(lane, true);
       const int nn = n * n;
       if (lane < nn) {
         hsum[lane] = tot;
@@ -1535,7 +1537,7 @@ struct PartialSumModel {
   }
   __device__ __forceinline__ void evaluate(WaveLds<T>&, int n, int lane, T& cost, int& nres) {
     if (small()) {
-      const T tot = fold_small(lane, false);
+      const T tot = direct ? (lane >= n * n + n && lane < n * n + n + 2 ? fold(lane) : T(0)) : fold_small(lane, false);
       cost = wave_bcast(tot, n * n + n);
       ninl = int(wave_bcast(tot, n * n + n + 1));
     } else {
@@ -1718,6 +1720,7 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
 
   PartialSumModel<T, NPAD, Manifold> fold;
   fold.S = S; fold.n_ = n; fold.m = prm->m;
+  fold.direct = true;
   fold.part = parts;
   fold.hsum = (n * n <= 64) ? L.aux : static_cast<T*>(prm->hsum) + size_t(p) * n * n;
 
@@ -1734,6 +1737,12 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
     if (lane == 0) { flags[0] = 0; flags[1] = L.st->rebuild; }
   }
   __syncthreads();
+#ifdef TOA_TEAM_TIMING
+  unsigned long long tt_[4] = {0, 0, 0, 0}, ttp_ = wall_clock64();
+#define TEAM_TICK(i) { const unsigned long long n_ = wall_clock64(); tt_[i] += n_ - ttp_; ttp_ = n_; }
+#else
+#define TEAM_TICK(i)
+#endif
   for (;;) {
     if (flags[0] != 0) break;  // workgroup-uniform: written before the barrier every wave has just passed
     if (!leader) { L.xs[lane] = xshare[lane]; wave_sync(); }
@@ -1752,9 +1761,12 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
       model.evaluate(L, n, lane, c, nr);
     }
     if (lane == 0) { part[n * n + n] = c; part[n * n + n + 1] = T(model_inliers(model, -1, 0)); }
+    TEAM_TICK(0)
     __syncthreads();
+    TEAM_TICK(1)
     if (leader) {
       const bool more = lm_iteration<T>(fold, L, n, lane, p);
+      TEAM_TICK(2)
       if (!more) {
         lm_finalize<T>(fold, L, n, lane, p);
         T* X = static_cast<T*>(prm->x);
@@ -1770,7 +1782,13 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
       if (lane == 0) { flags[0] = more ? 0 : 1; flags[1] = L.st->rebuild; }
     }
     __syncthreads();
+    TEAM_TICK(3)
   }
+#ifdef TOA_TEAM_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("team p=0 S=%d: data pass %.1f us  barrier %.1f us  iteration %.1f us  publish + barrier %.1f us\n", S, tt_[0] * 0.01, tt_[1] * 0.01,
+           tt_[2] * 0.01, tt_[3] * 0.01);
+#endif
 }
 
 template <typename Model, int NPAD, typename Manifold>
