@@ -568,14 +568,16 @@ def _results_pod(out: Output) -> ToaResults:
 
 
 def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, history: bool = False,
-             ctx: Optional[Context] = None, out: Optional[Output] = None, splits: Optional[int] = None) -> Output:
+             ctx: Optional[Context] = None, out: Optional[Output] = None, splits: Optional[int] = None,
+             zero_counters: bool = True) -> Output:
     """``tinyopt::Optimize(x, cost, options)`` (optimize.h:16-77) for a batch of independent problems.
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
     cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
     asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128, whose host loop reads
     two integers back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
-    library (every path accumulates).
+    library (every path accumulates); ``zero_counters=False`` skips that fill launch for a caller whose ``out`` is fresh or who
+    wants running totals (it is ~8 us of a 50 us single-problem solve; the C-ABI takes the counters as they are).
     """
     options = options or Options()
     _check_call(x, cost)
@@ -591,7 +593,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
             o2 = copy.deepcopy(options)
             o2.hessian.save_last = False
             out = _alloc_output(P, 1, o2, history, x.device)
-        else:
+        elif zero_counters:
             out.counters.zero_()
         res = _results_pod(out)
         check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
@@ -604,7 +606,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
     pod = options.to_pod()
     if out is None:
         out = _alloc_output(P, n, options, history, x.device)
-    else:
+    elif zero_counters:
         out.counters.zero_()
     res = _results_pod(out)
     _apply_loss(ctx, cost)

@@ -18,6 +18,7 @@
 // has a fixed order (per-lane partial sums, wave butterflies, waves folded 0..3), so results are bit-reproducible.
 //   data: [f cx cy 0 0 0 0 0 | uv: C x N x 2 | vis: C x N]     x: [12 C poses (R row-major, t) | 3 N points], in place
 #include "kernels.hpp"
+#include "ldlt_wg.hpp"
 
 namespace toa {
 
@@ -39,7 +40,9 @@ struct BaWork {  // element offsets into a scene's scratch block
   size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, total;
   __host__ __device__ BaWork(int C, int N) {
     size_t o = 0;
-    W = o; o += size_t(C) * N * 18;   // W_cj = J_c^T J_p, 6 x 3 row-major
+    W = o; o += size_t(C) * N * 18;   // W_cj = J_c^T J_p, 6 x 3 row-major, block (c, j) at (c N + j) 18.  (A point-minor layout — element
+                                      // e of every block contiguous over j — makes the accumulate phase's stores coalesced, 237 -> 178 us
+                                      // per solve, but the Schur and back-substitution reads 3x slower: 1.41 -> 1.61 ms per 1024 scenes.)
     Voff = o; o += size_t(N) * 3;     // V_j off-diagonals (0,1) (0,2) (1,2)
     hdp = o; o += size_t(N) * 3;      // CURRENT (damped) diagonal of V_j
     gp = o; o += size_t(N) * 3;
@@ -358,61 +361,67 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       }
       for (int i = tid; i < 64; i += 256) L.vec[i] = i < n ? -gc[i] : T(0);
       __syncthreads();
-      // the Schur Gram on the matrix cores: wave w takes points w, w + 4, ...; rows a = 0..2 of a point sit in row groups 0..2
+      // the Schur Gram on the matrix cores.  Points go in groups of four consecutive ones, wave w takes groups w, w + 4, ...;
+      // a 4-row MFMA step carries row a of [Z_j | q_j] for the four points of a group (one point per row group), so the three
+      // steps of a group share ONE fetch of the group's W / R^-1 / q values.
       {
         DenseRowGram<T, NBM, THIN> gram;
         gram.clear();
         const int k = lane >> 4, c16 = lane & 15;
         const bool isB = (THIN == 0) && ((c16 + 1) * NBM == lay.rsm);
-        const int npts_w = N > wave ? (N - wave + 3) / 4 : 0;
-        // The values a lane needs of one point — the W entries of its NBM (+ thin) columns, row k of R^-1, q[k] — are fetched
-        // one point AHEAD of the Gram step that consumes them: a point is ~13 independent loads (L2 hits, ~0.7 us) followed
-        // by 0.2 us of arithmetic, and without the prefetch every point paid the full round trip (Schur phase of an 8 x 256
-        // scene: 105 -> 73 us per iteration; two points ahead needs 26 more registers, spills under the 256 cap and is slower).
+        const int ngroups = (N + 3) >> 2;
+        const int ngr_w = ngroups > wave ? (ngroups - wave + 3) / 4 : 0;
+        // The values a lane needs of its point — the W entries of its NBM (+ thin) columns, R^-1, q — are fetched one group
+        // AHEAD of the Gram steps that consume them: they are L2 hits (~0.7 us) in front of 0.2 us of arithmetic.  (First form
+        // of this loop: one point per step in row groups 0..2 — the fourth idle, every W value fetched by three row groups:
+        // 13 loads per lane and step instead of 6, 64 steps per wave of an 8 x 256 scene instead of 48.)
         constexpr int NCOL = NBM + (THIN > 0 ? THIN - 1 : 0);
-        struct PtVals { T wv[NCOL][3]; T rk[3]; T qk; };
+        struct PtVals { T wv[NCOL][3]; T r[6]; T q[3]; };
         // column of Z handled by slot i of this lane: its NBM main columns, then the thin ones
         auto slot_col = [&](const int i) -> int { return i < NBM ? NBM * c16 + i : lay.nmr + (i - NBM); };
-        auto load_pt = [&](const int sidx) __attribute__((always_inline)) {
+        auto load_grp = [&](const int sidx) __attribute__((always_inline)) {
           PtVals pv;
-          const int j = wave + 4 * sidx;
-          const bool live = sidx < npts_w && k < 3;
+          const int j = 4 * (wave + 4 * sidx) + k;
+          const bool live = sidx < ngr_w && j < N;
+          const int jj = live ? j : 0;          // every load is unconditional (a valid address), its value masked
+          GCT* Rj = Rinv + 6 * jj;
 #pragma unroll
-          for (int b2 = 0; b2 < 3; ++b2) pv.rk[b2] = T(0);
-          pv.qk = T(0);
-          if (live) {
-            GCT* Rj = Rinv + 6 * j;
-            if (k == 0) pv.rk[0] = Rj[0];
-            else if (k == 1) { pv.rk[0] = Rj[1]; pv.rk[1] = Rj[2]; }
-            else { pv.rk[0] = Rj[3]; pv.rk[1] = Rj[4]; pv.rk[2] = Rj[5]; }
-            pv.qk = qv[3 * j + k];
-          }
+          for (int b2 = 0; b2 < 6; ++b2) { const T v0 = Rj[b2]; pv.r[b2] = live ? v0 : T(0); }
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) { const T v0 = qv[3 * jj + b2]; pv.q[b2] = live ? v0 : T(0); }
 #pragma unroll
           for (int i = 0; i < NCOL; ++i) {
             const int col = slot_col(i);
             const bool use = live && col < n && (i >= NBM || col < lay.nmr);
             GCT* Wd = Wb + (size_t(use ? col / 6 : 0) * N + (use ? j : 0)) * 18 + 3 * (use ? col % 6 : 0);
 #pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2]; pv.wv[i][b2] = use ? v0 : T(0); }   // unconditional load, masked
+            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2]; pv.wv[i][b2] = use ? v0 : T(0); }
           }
           return pv;
         };
-        PtVals cur = load_pt(0);
-        for (int s = 0; s < npts_w; ++s) {
-          const PtVals nxt = load_pt(s + 1);   // in flight during this point's arithmetic
-          // Z_j[col][k] = sum_b W_{cam,j}[dof][b] R^-1[k][b]
-          auto zslot = [&](const int i) -> T { return cur.wv[i][0] * cur.rk[0] + cur.wv[i][1] * cur.rk[1] + cur.wv[i][2] * cur.rk[2]; };
-          T w[NBM], v[THIN ? THIN : 1];
+        PtVals cur = load_grp(0);
+        for (int s = 0; s < ngr_w; ++s) {
+          const PtVals nxt = load_grp(s + 1);   // in flight during this group's arithmetic
 #pragma unroll
-          for (int cb = 0; cb < NBM; ++cb) w[cb] = zslot(cb);
-          if constexpr (THIN == 0) {
-            if (isB) w[NBM - 1] = cur.qk;
-          } else {
+          for (int a = 0; a < 3; ++a) {
+            // Z_j[col][a] = sum_b W_{cam,j}[dof][b] R^-1[a][b]   (R^-1 lower triangular: r = {00, 10, 11, 20, 21, 22})
+            auto zslot = [&](const int i) -> T {
+              if (a == 0) return cur.wv[i][0] * cur.r[0];
+              if (a == 1) return cur.wv[i][0] * cur.r[1] + cur.wv[i][1] * cur.r[2];
+              return cur.wv[i][0] * cur.r[3] + cur.wv[i][1] * cur.r[4] + cur.wv[i][2] * cur.r[5];
+            };
+            T w[NBM], v[THIN ? THIN : 1];
 #pragma unroll
-            for (int jt = 0; jt + 1 < THIN; ++jt) v[jt] = zslot(NBM + jt);
-            v[THIN - 1] = cur.qk;
+            for (int cb = 0; cb < NBM; ++cb) w[cb] = zslot(cb);
+            if constexpr (THIN == 0) {
+              if (isB) w[NBM - 1] = cur.q[a];
+            } else {
+#pragma unroll
+              for (int jt = 0; jt + 1 < THIN; ++jt) v[jt] = zslot(NBM + jt);
+              v[THIN - 1] = cur.q[a];
+            }
+            gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == ngr_w && a == 2)));
           }
-          gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == npts_w)));
           cur = nxt;
         }
         BA_TICK(7)
@@ -432,17 +441,24 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         }
       }
       BA_TICK(3)
-      // reduced camera system: the one-wavefront LDL^T with the reference's acceptance rule
+      // reduced camera system (6C unknowns): blocked LDL^T of the LDS image by the four waves, trailing updates on the matrix
+      // cores (ldlt_wg.hpp; the one-wavefront register factorisation used here before took 33 us of a 145 us iteration at
+      // C = 8 in fp64).  It factors in place, so the image is parked in `part` (free since the fold) first: a pivot that is
+      // not safely positive falls back to the pivoted factorisation with the reference's acceptance rule on the restored image.
+      for (int e = tid; e < n * n; e += 256) part[e] = L.M[(e / n) * L.LD + (e % n)];
+      __syncthreads();
+      constexpr int NBS = NBM + (THIN > 1 ? 1 : 0);   // 16-column panels covering n = 16 NBM + max(THIN - 1, 0) (- 1 without a thin tail)
+      const bool wg_ok = WgLdlt<T, NBS>::factor(L.M, L.LD, n, L.tmp, tid);
       if (wave == 0) {
-        bool ok;
-        const T rhs = lane < n ? L.vec[lane] : T(0);
-        {
-          LdltRegs<T, ((16 * NBM + (THIN ? THIN - 1 : -1)) + 7) & ~7> F;
-          F.load(L.M, L.LD, n, lane);
-          ok = F.factor(n, lane);
-          if (ok) L.dx[lane] = F.solve(n, lane, rhs);
-        }
-        if (!ok) {
+        bool ok = wg_ok;
+        if (ok) {
+          L.dx[lane] = lane < n ? L.vec[lane] : T(0);
+          wave_sync();
+          WgLdlt<T, NBS>::solve(L.M, L.LD, n, L.tmp, L.dx, lane);
+        } else {
+          const T rhs = lane < n ? L.vec[lane] : T(0);
+          for (int e = lane; e < n * n; e += 64) L.M[(e / n) * L.LD + (e % n)] = part[e];
+          wave_sync();
           ok = ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
           if (ok) L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, rhs);
         }
