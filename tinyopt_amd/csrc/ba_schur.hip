@@ -38,11 +38,16 @@ struct BaParams {
 template <typename T>
 struct BaWork {  // element offsets into a scene's scratch block
   size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, total;
+  int nb64;
   __host__ __device__ BaWork(int C, int N) {
     size_t o = 0;
-    W = o; o += size_t(C) * N * 18;   // W_cj = J_c^T J_p, 6 x 3 row-major, block (c, j) at (c N + j) 18.  (A point-minor layout — element
-                                      // e of every block contiguous over j — makes the accumulate phase's stores coalesced, 237 -> 178 us
-                                      // per solve, but the Schur and back-substitution reads 3x slower: 1.41 -> 1.61 ms per 1024 scenes.)
+    // W_cj = J_c^T J_p (6 x 3, element e = 3 dof + b): points in tiles of 64 (one wave's worth), element-major inside a tile —
+    // block (c, j) element e at ((c nb64 + j / 64) 18 + e) 64 + j % 64.  The lanes of a wave (consecutive points) then touch
+    // consecutive addresses and the 18 elements are compile-time offsets.  (Block-major [c][j][18] made every store of a wave
+    // 64 separate cache lines: 18 such stores per observation kept the accumulate phase on the address unit.  The per-point
+    // arrays below stay point-major: component-major costs more registers than the kernel has — 52 spills, slower.)
+    nb64 = (N + 63) / 64;
+    W = o; o += size_t(C) * nb64 * 18 * 64;
     Voff = o; o += size_t(N) * 3;     // V_j off-diagonals (0,1) (0,2) (1,2)
     hdp = o; o += size_t(N) * 3;      // CURRENT (damped) diagonal of V_j
     gp = o; o += size_t(N) * 3;
@@ -146,6 +151,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
 #endif
   const long long p = blockIdx.x;
   const BaWork<T> wk(C, N);
+  const int nb64 = wk.nb64;
   // ---- LDS carve: [ WaveLds of wave 0 | part: n*n | pvec, phd: 64 + 64 | poses: 12 C | U: 36 C | gc, rhs: 64 + 64 | red | flags ]
   WaveLds<T> L = WaveLds<T>::carve(smem, n);
   T* part = reinterpret_cast<T*>(smem + prm->lds_wave);
@@ -248,11 +254,11 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           }
 #pragma unroll
           for (int k = 0; k < 3; ++k) { hdp[3 * j + k] = v6[k]; Voff[3 * j + k] = v6[3 + k]; gp[3 * j + k] = g3[k]; }
-          GT* Wd = Wb + (size_t(c) * N + j) * 18;
+          GT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
 #pragma unroll
           for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) Wd[3 * k + b] = Jc[0][k] * Jp[0][b] + Jc[1][k] * Jp[1][b];
+            for (int b = 0; b < 3; ++b) Wd[(3 * k + b) * 64] = Jc[0][k] * Jp[0][b] + Jc[1][k] * Jp[1][b];
         } else if (seen) {
           ba_obs<T, false>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, nullptr, nullptr);
         }
@@ -393,9 +399,10 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           for (int i = 0; i < NCOL; ++i) {
             const int col = slot_col(i);
             const bool use = live && col < n && (i >= NBM || col < lay.nmr);
-            GCT* Wd = Wb + (size_t(use ? col / 6 : 0) * N + (use ? j : 0)) * 18 + 3 * (use ? col % 6 : 0);
+            const int ju = use ? j : 0;
+            GCT* Wd = Wb + ((size_t(use ? col / 6 : 0) * nb64 + (ju >> 6)) * 18 + 3 * (use ? col % 6 : 0)) * 64 + (ju & 63);
 #pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2]; pv.wv[i][b2] = use ? v0 : T(0); }
+            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2 * 64]; pv.wv[i][b2] = use ? v0 : T(0); }
           }
           return pv;
         };
@@ -476,11 +483,15 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         T u3[3] = {gp[3 * j], gp[3 * j + 1], gp[3 * j + 2]};
         g2 += u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];
         for (int c = 0; c < C; ++c) {
-          GCT* Wd = Wb + (size_t(c) * N + j) * 18;
+          GCT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
+          T wl[18];   // the block's 18 loads go out together (left to itself hipcc reuses ONE register pair: 18 round trips)
+#pragma unroll
+          for (int e = 0; e < 18; ++e) wl[e] = Wd[e * 64];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int kk = 0; kk < 6; ++kk) {
             const T dck = L.dx[6 * c + kk];
-            u3[0] += Wd[3 * kk] * dck; u3[1] += Wd[3 * kk + 1] * dck; u3[2] += Wd[3 * kk + 2] * dck;
+            u3[0] += wl[3 * kk] * dck; u3[1] += wl[3 * kk + 1] * dck; u3[2] += wl[3 * kk + 2] * dck;
           }
         }
         GCT* Rj = Rinv + 6 * j;
