@@ -37,7 +37,7 @@ struct BaParams {
 
 template <typename T>
 struct BaWork {  // element offsets into a scene's scratch block
-  size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, total;
+  size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, ptsb, total;
   int nb64;
   __host__ __device__ BaWork(int C, int N) {
     size_t o = 0;
@@ -55,6 +55,7 @@ struct BaWork {  // element offsets into a scene's scratch block
     q = o; o += size_t(N) * 3;
     dp = o; o += size_t(N) * 3;
     ldp = o; o += size_t(N) * 3;
+    ptsb = o; o += size_t(N) * 3;     // the points of the last BUILD (eval-only iterations solve with that system while x sits at a trial point)
     total = (o + 63) & ~size_t(63);
   }
 };
@@ -121,9 +122,59 @@ __device__ __forceinline__ void ba_obs(const T* P, const T* q, const T f, const 
       D[a][5] = -(P[3 * a] * q[1] - P[3 * a + 1] * q[0]);
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { Jc[0][k] = du0 * D[0][k] + du2 * D[2][k]; Jc[1][k] = dv1 * D[1][k] + dv2 * D[2][k]; }
+    for (int k = 0; k < 6; ++k) { Jc[0][k] = fma(du0, D[0][k], du2 * D[2][k]); Jc[1][k] = fma(dv1, D[1][k], dv2 * D[2][k]); }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { Jp[0][k] = du0 * P[k] + du2 * P[6 + k]; Jp[1][k] = dv1 * P[3 + k] + dv2 * P[6 + k]; }
+    for (int k = 0; k < 3; ++k) { Jp[0][k] = fma(du0, P[k], du2 * P[6 + k]); Jp[1][k] = fma(dv1, P[3 + k], dv2 * P[6 + k]); }
+  }
+}
+
+// W_cj[dof][b] = (J_c^T J_p)[dof][b]: ONE spelling for every site that forms it (the contraction into fma must not differ
+// between the accumulate phase, the Schur loop and the back-substitution)
+template <typename T>
+__device__ __forceinline__ T ba_w(const T jc0, const T jc1, const T jp0, const T jp1) { return fma(jc0, jp0, jc1 * jp1); }
+// element d of a 6-vector held in registers, d known only at run time (a dynamic index would go through scratch)
+template <typename T>
+__device__ __forceinline__ T ba_pick6(const T (&a)[6], const int d) {
+  T v = a[0];
+#pragma unroll
+  for (int k = 1; k < 6; ++k) {
+    v = d == k ? a[k] : v;
+    asm volatile("" : "+v"(v));   // keeps it a chain of selects: hipcc otherwise turns it back into an indexed load from scratch
+  }
+  return v;
+}
+
+// Rows dof0 .. dof0 + NR - 1 of W_cj = J_c^T J_p for observation (camera P, point q): the same expressions as ba_obs + ba_w, but
+// only the NR camera columns a lane of the Schur loop owns (dof0 is a multiple of NR, known at run time only).
+template <typename T, int NR>
+__device__ __forceinline__ void ba_obs_wrows(const T* P, const T* q, const T f, const int dof0, T (&w)[NR][3]) {
+  const T X = P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + P[9];
+  const T Y = P[3] * q[0] + P[4] * q[1] + P[5] * q[2] + P[10];
+  const T Z = P[6] * q[0] + P[7] * q[1] + P[8] * q[2] + P[11];
+  const T iz = T(1) / Z;
+  const T du0 = f * iz, du2 = -f * X * iz * iz, dv1 = f * iz, dv2 = -f * Y * iz * iz;
+  T Jp[2][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Jp[0][k] = fma(du0, P[k], du2 * P[6 + k]); Jp[1][k] = fma(dv1, P[3 + k], dv2 * P[6 + k]); }
+  T D[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    D[a][0] = P[3 * a]; D[a][1] = P[3 * a + 1]; D[a][2] = P[3 * a + 2];
+    D[a][3] = -(P[3 * a + 1] * q[2] - P[3 * a + 2] * q[1]);
+    D[a][4] = -(-P[3 * a] * q[2] + P[3 * a + 2] * q[0]);
+    D[a][5] = -(P[3 * a] * q[1] - P[3 * a + 1] * q[0]);
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    T d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if constexpr (NR == 3) d[a] = dof0 != 0 ? D[a][3 + i] : D[a][i];   // translation or rotation half
+      else d[a] = ba_pick6<T>(D[a], dof0 + i);
+    }
+    const T jc0 = fma(du0, d[0], du2 * d[2]), jc1 = fma(dv1, d[1], dv2 * d[2]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) w[i][b] = ba_w<T>(jc0, jc1, Jp[0][b], Jp[1][b]);
   }
 }
 
@@ -152,13 +203,20 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   const long long p = blockIdx.x;
   const BaWork<T> wk(C, N);
   const int nb64 = wk.nb64;
-  // ---- LDS carve: [ WaveLds of wave 0 | part: n*n | pvec, phd: 64 + 64 | poses: 12 C | U: 36 C | gc, rhs: 64 + 64 | red | flags ]
+  // W is 18 values per observation: written once and read twice per iteration it was 3/4 of the kernel's HBM traffic (the 151 MB
+  // of the resident scenes' W do not fit the L2s; PMC: 6.0 GB per launch against 0.28 GB of algorithmic bytes).  Where all the
+  // Schur columns of a lane belong to ONE camera (NBM divides 6, no thin Z columns) W is never stored: the Schur loop and the
+  // back-substitution re-form it from the observation — pose and point of the last build (poses_b, ptsb), u, v, visibility:
+  // 24 bytes per observation instead of 144, ~110 flops.
+  constexpr bool kRecomputeW = (6 % NBM == 0) && THIN <= 1;
+  // ---- LDS carve: [ WaveLds of wave 0 | part: n*n | pvec, phd: 64 + 64 | poses, poses_b: 12 C + 12 C | U: 36 C | gc, rhs: 64 + 64 | red | flags ]
   WaveLds<T> L = WaveLds<T>::carve(smem, n);
   T* part = reinterpret_cast<T*>(smem + prm->lds_wave);
   T* pvec = part + size_t(n) * n;
   T* phd = pvec + 64;
   T* poses = phd + 64;
-  T* U = poses + 12 * C;        // undamped 6 x 6 blocks (row-major); the damped diagonal lives in L.hd
+  T* poses_b = poses + 12 * C;  // the poses of the last build (see kRecomputeW)
+  T* U = poses_b + 12 * C;        // undamped 6 x 6 blocks (row-major); the damped diagonal lives in L.hd
   T* gc = U + 36 * C;
   T* red = gc + 64;             // [8]
   int* flags = reinterpret_cast<int*>(red + 8);   // [0] continue, [1] do_acc, [2] action, [3] build ok, [4] solve ok
@@ -177,7 +235,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   GT* pts = X + 12 * C;
   GT* work = (GT*)(static_cast<T*>(prm->work) + size_t(p) * wk.total);
   GT* Wb = work + wk.W; GT* Voff = work + wk.Voff; GT* hdp = work + wk.hdp; GT* gp = work + wk.gp;
-  GT* Rinv = work + wk.Rinv; GT* qv = work + wk.q; GT* dp = work + wk.dp; GT* ldp = work + wk.ldp;
+  GT* Rinv = work + wk.Rinv; GT* qv = work + wk.q; GT* dp = work + wk.dp; GT* ldp = work + wk.ldp; GT* ptsb = work + wk.ptsb;
   const DenseRowLayout lay = DenseRowLayout::make(n, 4);
 
   if (wave == 0) {
@@ -202,6 +260,8 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
     BA_TICK_START
     // ================= Accumulate / Evaluate (gn.h:97-113) =================
     T csum = 0, nvis = 0;
+    if (do_acc)
+      for (int i = tid; i < 12 * C; i += 256) poses_b[i] = poses[i];   // read again only behind later barriers
     for (int c = 0; c < C; ++c) {
       T Pm[12];
 #pragma unroll
@@ -254,11 +314,15 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           }
 #pragma unroll
           for (int k = 0; k < 3; ++k) { hdp[3 * j + k] = v6[k]; Voff[3 * j + k] = v6[3 + k]; gp[3 * j + k] = g3[k]; }
-          GT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
+          if constexpr (kRecomputeW) {
+            if (c == 0) { ptsb[3 * j] = q[0]; ptsb[3 * j + 1] = q[1]; ptsb[3 * j + 2] = q[2]; }
+          } else {
+            GT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
 #pragma unroll
-          for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) Wd[(3 * k + b) * 64] = Jc[0][k] * Jp[0][b] + Jc[1][k] * Jp[1][b];
+              for (int b = 0; b < 3; ++b) Wd[(3 * k + b) * 64] = ba_w(Jc[0][k], Jc[1][k], Jp[0][b], Jp[1][b]);
+          }
         } else if (seen) {
           ba_obs<T, false>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, nullptr, nullptr);
         }
@@ -382,9 +446,14 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         // of this loop: one point per step in row groups 0..2 — the fourth idle, every W value fetched by three row groups:
         // 13 loads per lane and step instead of 6, 64 steps per wave of an 8 x 256 scene instead of 48.)
         constexpr int NCOL = NBM + (THIN > 0 ? THIN - 1 : 0);
-        struct PtVals { T wv[NCOL][3]; T r[6]; T q[3]; };
+        // stored-W form: the lane's W entries; recomputed form: what W is made of (point of the last build, u, v, visibility)
+        struct PtVals { T wv[kRecomputeW ? 1 : NCOL][3]; T pt[3]; T vs; T r[6]; T q[3]; };
         // column of Z handled by slot i of this lane: its NBM main columns, then the thin ones
         auto slot_col = [&](const int i) -> int { return i < NBM ? NBM * c16 + i : lay.nmr + (i - NBM); };
+        const int col0 = NBM * c16;                       // kRecomputeW: the lane's columns col0 .. col0 + NBM - 1 are
+        const int cam_l = col0 / 6, dof0 = col0 % 6;      // degrees of freedom dof0 .. of camera cam_l
+        const bool cam_ok = cam_l < C;
+        const T* Pb = poses_b + 12 * (cam_ok ? cam_l : 0);
         auto load_grp = [&](const int sidx) __attribute__((always_inline)) {
           PtVals pv;
           const int j = 4 * (wave + 4 * sidx) + k;
@@ -395,27 +464,55 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           for (int b2 = 0; b2 < 6; ++b2) { const T v0 = Rj[b2]; pv.r[b2] = live ? v0 : T(0); }
 #pragma unroll
           for (int b2 = 0; b2 < 3; ++b2) { const T v0 = qv[3 * jj + b2]; pv.q[b2] = live ? v0 : T(0); }
+          if constexpr (kRecomputeW) {
+            const size_t ob = size_t(cam_ok ? cam_l : 0) * N + jj;
 #pragma unroll
-          for (int i = 0; i < NCOL; ++i) {
-            const int col = slot_col(i);
-            const bool use = live && col < n && (i >= NBM || col < lay.nmr);
-            const int ju = use ? j : 0;
-            GCT* Wd = Wb + ((size_t(use ? col / 6 : 0) * nb64 + (ju >> 6)) * 18 + 3 * (use ? col % 6 : 0)) * 64 + (ju & 63);
+            for (int b2 = 0; b2 < 3; ++b2) pv.pt[b2] = ptsb[3 * jj + b2];
+            const T vs = vis[ob];
+            pv.vs = (live && cam_ok) ? vs : T(0);
+          } else {
 #pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2 * 64]; pv.wv[i][b2] = use ? v0 : T(0); }
+            for (int i = 0; i < NCOL; ++i) {
+              const int col = slot_col(i);
+              const bool use = live && col < n && (i >= NBM || col < lay.nmr);
+              const int ju = use ? j : 0;
+              GCT* Wd = Wb + ((size_t(use ? col / 6 : 0) * nb64 + (ju >> 6)) * 18 + 3 * (use ? col % 6 : 0)) * 64 + (ju & 63);
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) { const T v0 = Wd[b2 * 64]; pv.wv[i][b2] = use ? v0 : T(0); }
+            }
           }
           return pv;
         };
         PtVals cur = load_grp(0);
         for (int s = 0; s < ngr_w; ++s) {
           const PtVals nxt = load_grp(s + 1);   // in flight during this group's arithmetic
+          T wrec[NBM][3];   // kRecomputeW: the lane's W rows, re-formed from the observation (cam_l, point of row group k)
+          if constexpr (kRecomputeW) {
+            T Pm[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Pm[i] = Pb[i];
+            ba_obs_wrows<T, NBM>(Pm, cur.pt, f, dof0, wrec);
+            const bool seen = cur.vs != T(0);
+#pragma unroll
+            for (int i = 0; i < NBM; ++i) {
+              const bool use = seen && col0 + i < n && col0 + i < lay.nmr;
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) wrec[i][b2] = use ? wrec[i][b2] : T(0);
+            }
+          }
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             // Z_j[col][a] = sum_b W_{cam,j}[dof][b] R^-1[a][b]   (R^-1 lower triangular: r = {00, 10, 11, 20, 21, 22})
             auto zslot = [&](const int i) -> T {
-              if (a == 0) return cur.wv[i][0] * cur.r[0];
-              if (a == 1) return cur.wv[i][0] * cur.r[1] + cur.wv[i][1] * cur.r[2];
-              return cur.wv[i][0] * cur.r[3] + cur.wv[i][1] * cur.r[4] + cur.wv[i][2] * cur.r[5];
+              T w3[3];
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) {
+                if constexpr (kRecomputeW) w3[b2] = wrec[i < NBM ? i : 0][b2];
+                else w3[b2] = cur.wv[i][b2];
+              }
+              if (a == 0) return w3[0] * cur.r[0];
+              if (a == 1) return w3[0] * cur.r[1] + w3[1] * cur.r[2];
+              return w3[0] * cur.r[3] + w3[1] * cur.r[4] + w3[2] * cur.r[5];
             };
             T w[NBM], v[THIN ? THIN : 1];
 #pragma unroll
@@ -482,12 +579,27 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       for (int j = tid; j < N; j += 256) {
         T u3[3] = {gp[3 * j], gp[3 * j + 1], gp[3 * j + 2]};
         g2 += u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];
+        T qb[3] = {T(0), T(0), T(0)};
+        if constexpr (kRecomputeW) { qb[0] = ptsb[3 * j]; qb[1] = ptsb[3 * j + 1]; qb[2] = ptsb[3 * j + 2]; }
         for (int c = 0; c < C; ++c) {
-          GCT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
-          T wl[18];   // the block's 18 loads go out together (left to itself hipcc reuses ONE register pair: 18 round trips)
+          T wl[18];
+          if constexpr (kRecomputeW) {   // W_cj re-formed from the observation at the point of the last build
+            T Pm[12], Jc[2][6], Jp[2][3], rr[2];
 #pragma unroll
-          for (int e = 0; e < 18; ++e) wl[e] = Wd[e * 64];
-          __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 12; ++i) Pm[i] = poses_b[12 * c + i];
+            const bool seen = vis[size_t(c) * N + j] != T(0);
+            ba_obs<T, true>(Pm, qb, f, T(0), T(0), T(0), T(0), rr, Jc, Jp);   // the Jacobians do not depend on cx, cy, u, v
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+              for (int b = 0; b < 3; ++b) { const T w0 = ba_w<T>(Jc[0][kk], Jc[1][kk], Jp[0][b], Jp[1][b]); wl[3 * kk + b] = seen ? w0 : T(0); }
+          } else {
+            GCT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
+            // the block's 18 loads go out together (left to itself hipcc reuses ONE register pair: 18 round trips)
+#pragma unroll
+            for (int e = 0; e < 18; ++e) wl[e] = Wd[e * 64];
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int kk = 0; kk < 6; ++kk) {
             const T dck = L.dx[6 * c + kk];
@@ -595,7 +707,7 @@ int launch_ba(toa_handle h, BaParams& prm) {
   size_t pw = WaveLds<T>::bytes(n);
   pw = (pw + 15) & ~size_t(15);
   prm.lds_wave = int(pw);
-  size_t lds = pw + (size_t(n) * n + 64 + 64 + size_t(12) * prm.C + size_t(36) * prm.C + 64 + 8) * sizeof(T) + 64;
+  size_t lds = pw + (size_t(n) * n + 64 + 64 + size_t(24) * prm.C + size_t(36) * prm.C + 64 + 8) * sizeof(T) + 64;
   lds = (lds + 15) & ~size_t(15);
   prm.lds_gpart = int(lds);
   lds += size_t(4) * prm.C * 32 * sizeof(T);

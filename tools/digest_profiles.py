@@ -103,6 +103,31 @@ def main():
             with open(os.path.join(DST, name), "w") as f:
                 json.dump(outl, f, indent=1)
         print("large128", {k: outl[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
+    # ---- HBM traffic of the bundle-adjustment kernel (work arrays included: they do not fit the L2s)
+    if os.path.isdir(os.path.join(SRC, "pmc_ba")) and os.path.exists(os.path.join(DST, f"{tag}_bench_ba.json")):
+        bb = json.loads(open(os.path.join(DST, f"{tag}_bench_ba.json")).read())
+        ba = {}
+        for d in sorted(glob.glob(os.path.join(SRC, "pmc_ba", "*"))):
+            c, durs = counters(d, "ba_schur_kernel")
+            ba.update(c)
+            ba.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
+        rb = bb["roofline"]
+        alg_b = rb["passes_per_launch"] * rb["algorithmic_bytes_per_pass"]
+        raw = ba["FETCH_SIZE"] * 1024.0 + ba["WRITE_SIZE"] * 1024.0
+        hbm_b = ba["FETCH_SIZE"] * 1024.0 * cal + ba["WRITE_SIZE"] * 1024.0
+        ms = sum(ba["_kernel_ms"]["FETCH_SIZE"][1:]) / max(1, len(ba["_kernel_ms"]["FETCH_SIZE"]) - 1)
+        outb = {"round": tag, "workload": "ba", "scenes": bb["config"]["problems_per_gpu"], "kernel": "ba_schur_kernel<double, 3, 1>",
+                "FETCH_SIZE_KB_per_launch": ba["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": ba["WRITE_SIZE"],
+                "fetch_calibration_bytes_per_reported_byte": cal,
+                "fetch_calibration_note": "the C4 calibration (a wide coalesced stream reports 1/2 on gfx950); this kernel's reads are a mix "
+                                          "of coalesced rows and gathers, so the true figure lies between the raw and the calibrated one",
+                "hbm_bytes_per_launch_raw": raw, "hbm_bytes_per_launch": hbm_b, "algorithmic_bytes_per_launch": alg_b,
+                "traffic_over_algorithmic": hbm_b / alg_b, "kernel_ms_under_pmc": ba["_kernel_ms"],
+                "hbm_GBps_raw": raw / (ms * 1e-3) / 1e9, "hbm_GBps": hbm_b / (ms * 1e-3) / 1e9}
+        for name in (f"{tag}_pmc_ba.json", "pmc_latest_ba.json"):
+            with open(os.path.join(DST, name), "w") as f:
+                json.dump(outb, f, indent=1)
+        print("ba", {k: outb[k] for k in ("hbm_bytes_per_launch_raw", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "hbm_GBps_raw", "hbm_GBps")})
     # ---- the same HBM-traffic measurement for the C3 launch (fp64, n = 12)
     if os.path.isdir(os.path.join(SRC, "pmc_fused_c3")):
         b3 = json.loads(open(os.path.join(DST, f"{tag}_bench_c3.json")).read())

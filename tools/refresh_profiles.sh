@@ -33,5 +33,9 @@ for C in "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIV
   tag=$(echo $C | tr " " "_" | cut -c1-48)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_large128/$tag -- python $R/bench.py --workload large128 --steps 5 --warmup 1 --no-cpu > /dev/null 2>&1
 done
+# HBM traffic of the bundle-adjustment kernel (its per-scene work arrays do not fit the L2s)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_ba/$C -- python $R/bench.py --workload ba --steps 5 --warmup 1 --no-cpu > /dev/null 2>&1
+done
 find $O -name "*.csv" | wc -l
 du -sh $O
