@@ -313,10 +313,11 @@ def run_ba(args, ta, rank, world, local_rank):
                      "traffic_source": ("profiles/pmc_latest_ba.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload and "
                                         "binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,
                      "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
-                     "note": "algorithmic bytes = observations (u, v, visibility) + points per pass.  The kernel's REAL traffic is 15-20x "
-                             "that: the W blocks (18 values per observation, written once and read twice per iteration; 151 MB over the "
-                             "512 resident scenes) do not fit the L2s — `traffic` — so the launch runs at 3-4.5 TB/s of actual HBM "
-                             "traffic; DESIGN.md 4c",
+                     "note": "algorithmic bytes = observations (u, v, visibility) + points per pass; `traffic` = FETCH_SIZE x the C4 stream "
+                             "calibration + WRITE_SIZE of the whole launch, per-scene work arrays included (`traffic_raw_counters`: "
+                             "uncalibrated).  With the W blocks materialised (18 values per observation, written once and read twice "
+                             "per iteration, 151 MB over the 512 resident scenes) it was 6.0 GB = 21x algorithmic "
+                             "(profiles/r02_pmc_ba_before.json); the kernel is latency / issue-bound now, DESIGN.md 4c",
                      "kernel_ms_avg": kern_s * 1e3, "kernel_ms_all": kern_ms},
     }
     if not args.no_cpu and world == 1:
