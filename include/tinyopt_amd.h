@@ -322,7 +322,7 @@ int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P
  *      LDL^T, math.h:232-240, or Eigen's SimplicialLDLT on the sparse matrix, math.h:266-277, README.md:30,165-167).
  *      Same Levenberg-Marquardt state machine, StopReasons and Output fields; the linear step uses the block structure:
  *      per-point 3x3 blocks eliminated, the reduced camera system (6C <= 60 unknowns) accumulated on the matrix cores and
- *      solved by the one-wavefront LDL^T, points recovered by back-substitution; Marquardt damping on every diagonal
+ *      solved by the workgroup's blocked LDL^T (pivoted one-wavefront fallback), points recovered by back-substitution; Marquardt damping on every diagonal
  *      entry.  One workgroup per scene, one launch per solve, P independent scenes per call (P <= 65535).
  *        x_dev:    [P][12 C + 3 N] of T = C poses (rotation matrix row-major, translation), then N points; updated in
  *                  place: pose <- pose * exp(delta) (3rdparty/traits/sophus.h:24-26), point += delta (traits.h:184-190)

@@ -5,7 +5,7 @@
 // 266-277; README.md:30,165-167 "sparse is slow") — which is what the oracle does (oracle/ba.hpp).  Here the block
 // structure of H = [[U, W], [W^T, V]] (U: 6x6 per camera, V: 3x3 per point, W: 6x3 per observation) is used:
 //
-//   (U - W V^-1 W^T) dc = -g_c + W V^-1 g_p            reduced camera system, 6C <= 60 unknowns: the one-wavefront LDL^T
+//   (U - W V^-1 W^T) dc = -g_c + W V^-1 g_p            reduced camera system, 6C <= 60 unknowns: blocked LDL^T by the four waves
 //   dp_j = -V_j^-1 (g_pj + W_j^T dc)                   back-substitution, a 3x3 solve per point
 //
 // with Marquardt's multiplicative damping on EVERY diagonal entry of H (lm.h:108-117), cameras and points alike.
@@ -25,7 +25,7 @@ namespace toa {
 struct BaParams {
   const void* data;
   void* x;
-  void* work;                 // per scene: W blocks, V, g_p, R^-1, q, dp, last dp (see BaWork)
+  void* work;                 // per scene: (W blocks,) V, g_p, R^-1, q, dp, last dp, points of the last build (see BaWork)
   long long P;
   int C, N;
   toa_options opt;
@@ -33,6 +33,7 @@ struct BaParams {
   unsigned long long* counters;
   int lds_wave;               // bytes of the WaveLds carve (wave 0's LDL^T workspace + vectors + LmState)
   int lds_gpart;              // byte offset of the per-wave camera sums
+  int lds_part2;              // byte offset of a second partial-Gram buffer (n*n + 128 elements), 0 = none (LDS budget)
 };
 
 template <typename T>
@@ -530,18 +531,45 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
         }
         BA_TICK(7)
         gram.finish_steps();
-        for (int wv = 0; wv < 4; ++wv) {   // fold the four partial Grams in wave order
-          if (wave == wv) {
-            gram.write_sym(part, n, lay, n, lane);
-            (void)gram.extract_g_diag_cost(pvec, phd, lay, n, lane, &red[4]);
+        // fold the four partial Grams in wave order: M - G0 - G1 - G2 - G3, rhs + p0 + p1 + p2 + p3.  With a second LDS buffer
+        // (where two workgroups per CU still fit) two waves publish at a time: half the barriers, the same arithmetic.
+        if (prm->lds_part2 != 0) {
+          T* part2 = reinterpret_cast<T*>(smem + prm->lds_part2);
+          T* pvec2 = part2 + size_t(n) * n;
+          T* phd2 = pvec2 + 64;
+          for (int h2 = 0; h2 < 2; ++h2) {
+            if (wave == 2 * h2) {
+              gram.write_sym(part, n, lay, n, lane);
+              (void)gram.extract_g_diag_cost(pvec, phd, lay, n, lane, &red[4]);
+            } else if (wave == 2 * h2 + 1) {
+              gram.write_sym(part2, n, lay, n, lane);
+              (void)gram.extract_g_diag_cost(pvec2, phd2, lay, n, lane, &red[5]);
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += 256) {
+              const int i = e / n, j = e % n;
+              T m = L.M[i * L.LD + j];
+              m -= (i == j) ? phd[i] : part[e];
+              m -= (i == j) ? phd2[i] : part2[e];
+              L.M[i * L.LD + j] = m;
+            }
+            for (int i = tid; i < n; i += 256) L.vec[i] = (L.vec[i] + pvec[i]) + pvec2[i];
+            __syncthreads();
           }
-          __syncthreads();
-          for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, j = e % n;
-            L.M[i * L.LD + j] -= (i == j) ? phd[i] : part[e];
+        } else {
+          for (int wv = 0; wv < 4; ++wv) {
+            if (wave == wv) {
+              gram.write_sym(part, n, lay, n, lane);
+              (void)gram.extract_g_diag_cost(pvec, phd, lay, n, lane, &red[4]);
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += 256) {
+              const int i = e / n, j = e % n;
+              L.M[i * L.LD + j] -= (i == j) ? phd[i] : part[e];
+            }
+            for (int i = tid; i < n; i += 256) L.vec[i] += pvec[i];
+            __syncthreads();
           }
-          for (int i = tid; i < n; i += 256) L.vec[i] += pvec[i];
-          __syncthreads();
         }
       }
       BA_TICK(3)
@@ -711,6 +739,14 @@ int launch_ba(toa_handle h, BaParams& prm) {
   lds = (lds + 15) & ~size_t(15);
   prm.lds_gpart = int(lds);
   lds += size_t(4) * prm.C * 32 * sizeof(T);
+  lds = (lds + 15) & ~size_t(15);
+  prm.lds_part2 = 0;
+  {  // second partial-Gram buffer for the fold, if two workgroups per CU still fit with it
+    const size_t with2 = lds + (size_t(n) * n + 128) * sizeof(T);
+#ifndef TOA_BA_ONE_PART   // A/B switch: the four-round fold
+    if (with2 <= size_t(h->max_lds) / TOA_BA_WGS) { prm.lds_part2 = int(lds); lds = with2; }
+#endif
+  }
   if (lds > size_t(160 * 1024)) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: LDS footprint exceeds 160 KiB");
   const BaWork<T> wk(prm.C, prm.N);
   const size_t need = size_t(prm.P) * wk.total * sizeof(T);
