@@ -258,12 +258,21 @@ int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a_d
  *      n > 63 (up to 4096, P <= 65535): Cholesky against the identity through rocSOLVER. */
 int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, void* C_dev, int32_t* ok_dev);
 
+#define TOA_NUM_COUNTERS 8
+
 /* ---- fused batched solve (replaces Optimizer_::OptimizeAcc optimizer.h:242-327 + Step :331-539 +
  *      SolverLM lm.h:46-171 for P independent problems).  x_dev: [P][n] T, updated in place
  *      (reference: `x` by non-const ref).  One launch; no host round trips; each wavefront runs whole
- *      problems to their StopReason.  counters_dev (optional, [4] uint64): {accumulate passes,
- *      evaluate-only passes, linear solves, problems} ADDED to by every path (the caller zeroes them) — the units the
- *      roofline accounting in bench.py multiplies by the algorithmic bytes per pass.
+ *      problems to their StopReason.  counters_dev (optional, [TOA_NUM_COUNTERS = 8] uint64): {accumulate passes
+ *      that streamed the rows, evaluate-only passes, linear solves, problems, Builds served WITHOUT streaming the rows
+ *      (see below), 3 reserved} ADDED to by every path (the caller zeroes them) — [0] + [1] are the units the roofline
+ *      accounting in bench.py multiplies by the algorithmic bytes per pass.
+ *      Builds without a data pass ([4]): the Accumulate callback is a pure function of x, and the loop asks for the same
+ *      linearisation twice in two places — a failed solve re-enters Build at the same x (optimizer.h:358-393), and the
+ *      iteration after a rejected step accumulates again at the rolled-back point (optimizer.h:283-287, :266).  The fused
+ *      kernel of the DenseRow families parks the Gram registers of every accepted point (one slot per resident wave) and,
+ *      when the roll-back restored x BIT FOR BIT, reads them back instead of streaming the rows again; g, H and the cost
+ *      are the bits a second pass would have produced (tests/test_gpu_memo.py; TOA_MEMO=0 switches the memo off).
  *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128: that
  *      regime reads two integers back per pass (it blocks the host and cannot be captured in a hipGraph); 64 <= n <= 128
  *      is one persistent kernel like the rest. */
@@ -342,7 +351,9 @@ int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t
  *        toa_comm_init_rank  collective over the ranks of that id (ncclCommInitRank on the handle's GPU);
  *        toa_gather          stream-ordered on the handle's stream.  local: the rank's result arrays — stop_reason,
  *                            num_iters and final_cost are required; all / x_all_dev: destination arrays of P_total entries on
- *                            the root (ignored elsewhere; NULL members are skipped).
+ *                            the root (ignored elsewhere; NULL members are skipped).  xdim: stored scalars of x per
+ *                            problem, any width (n = 50 at C4; up to 1024 for TOA_MODEL_DENSE_ROW_NATURAL; 12 C + 3 N for
+ *                            toa_ba_run) — only P_total x record bytes is bounded (1 TiB over all ranks).
  *      RCCL is opened with dlopen on first use (TOA_E_UNSUPPORTED if absent); single-problem configs (C2, C5) do not shard. */
 #define TOA_COMM_ID_BYTES 128
 typedef struct toa_comm_s* toa_comm;

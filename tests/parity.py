@@ -132,3 +132,71 @@ def gpu_dict(out, x):
              stop=out.stop_reason.cpu().numpy(), x=x.cpu().numpy(), cost=out.final_cost.cpu().numpy(),
              fails=out.num_failures.cpu().numpy(), deltas2=out.deltas2.cpu().numpy())
     return d
+
+
+# ---- the second reading of the LM state machine (tests/golden/make_reference_traces.py) -------------------------------------
+def load_reference_traces():
+    """[(case dict, ToaOptions)] of tests/golden/reference_traces.json — per-iteration traces of an independent Python
+    restatement of optimizer.h / lm.h / gn.h (written from the reference, not from oracle/)."""
+    import json
+    import os
+    from tinyopt_amd._capi import ToaOptions
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_traces.json")) as f:
+        cases = json.load(f)["cases"]
+    out = []
+    for c in cases:
+        o = c["options"]
+        p = ToaOptions()
+        p.solver_type = 0 if o["solver"] == "lm" else 1
+        p.max_iters = o["max_iters"]
+        p.min_error, p.min_rerr_dec = o["min_error"], o["min_rerr_dec"]
+        p.min_step_norm2, p.min_grad_norm2 = o["min_step_norm2"], o["min_grad_norm2"]
+        p.max_total_failures, p.max_consec_failures = o["max_total_failures"], o["max_consec_failures"]
+        p.damping_init, p.damping_min, p.damping_max = o["damping_init"], o["damping_range"][0], o["damping_range"][1]
+        p.good_factor, p.bad_factor = o["good_factor"], o["bad_factor"]
+        p.grad_clipping, p.check_min_H_diag = o["grad_clipping"], o["check_min_H_diag"]
+        p.check_final_cost, p.use_step_quality_approx = int(o["check_final_cost"]), int(o["use_step_quality_approx"])
+        p.use_ldlt, p.H_is_full, p.save_last = int(o["use_ldlt"]), 1, 1
+        p.use_squared_norm, p.downscale_by_2, p.normalize = int(o["use_squared_norm"]), int(o["downscale_by_2"]), int(o["normalize"])
+        out.append((c, p))
+    return out
+
+
+def check_against_trace(c, got, label=""):
+    """`got` (dict: errs, deltas2, succ, stop, iters, fails, x, cost — one problem) against one fixture case: identical
+    StopReason / iteration / failure counts and accept-reject flags, costs and steps to 1e-8 relative (the traces amplify
+    the last-bit differences of two LDL^T operation orders over up to 66 iterations; measured <= 1e-10).
+    Returns "full", or "tie" when the two part at a PROVEN tie: after a rejected step the loop rolls x back and accumulates
+    again at that point (optimizer.h:283-287, :266), so `err < final_cost` (:428-429) compares two numbers that are equal in
+    exact arithmetic — 0 exactly when (x + dx) - dx restored x bit for bit, a last-bit coin toss otherwise.  Then: same
+    point evaluated on both sides, its cost equal to the last accepted cost to 1e-12, everything before identical."""
+    k = len(c["errs"])
+    e, d2 = np.asarray(c["errs"]), np.asarray(c["deltas2"])
+    kg = int(got["iters"])
+    ge, gs = np.asarray(got["errs"]), np.asarray(got["succ"], dtype=np.int64)
+    fs = np.asarray(c["successes"], dtype=np.int64)
+    scale = np.abs(e).max() if k else 1.0
+    kk = min(k, kg, len(ge))
+    div = None
+    for i in range(kk):
+        if gs[i] != fs[i]:
+            div = i
+            break
+    upto = kk if div is None else div + 1
+    assert np.allclose(ge[:upto], e[:upto], rtol=1e-8, atol=1e-12 * scale), (label, "cost history", div)
+    if div is not None:
+        assert div >= 2, (label, "parted before any step was rejected", div)
+        acc_f = [i for i in range(div) if fs[i] or i == 0][-1]
+        assert abs(e[div] - e[acc_f]) <= 1e-12 * abs(e[acc_f]) and abs(ge[div] - ge[acc_f]) <= 1e-12 * abs(ge[acc_f]), \
+            (label, "accept / reject flags differ away from a tie", div, e[div], ge[div], e[acc_f])
+        return "tie"
+    assert int(got["stop"]) == c["stop_reason"], (label, "stop", int(got["stop"]), c["stop_reason"])
+    assert kg == c["num_iters"], (label, "iters", kg, c["num_iters"])
+    assert int(got["fails"]) == c["num_failures"], (label, "fails", int(got["fails"]), c["num_failures"])
+    if k:
+        assert np.allclose(np.asarray(got["deltas2"])[:k], d2, rtol=1e-6, atol=1e-12 * max(d2.max(), 1e-300)), (label, "|dx|^2 history")
+    xs = np.asarray(c["x"])
+    assert np.abs(np.asarray(got["x"]) - xs).max() <= 1e-8 * max(1.0, np.abs(xs).max()), (label, "x")
+    if c["final_cost"] < 1e300:
+        assert abs(float(got["cost"]) - c["final_cost"]) <= 1e-8 * abs(c["final_cost"]) + 1e-12 * scale, (label, "final cost")
+    return "full"

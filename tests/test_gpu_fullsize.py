@@ -43,7 +43,7 @@ def test_full_size_properties(ta, oracle, tag, P, n, m, dtype, tdt, tol_star, to
         assert ok.all(), (k, np.flatnonzero(~ok)[:5])
     # counters: one linear solve per iteration, at least one data pass per iteration
     cnt = out.counters.cpu().numpy()
-    assert cnt[3] == P and cnt[2] == iters.sum() and cnt[0] + cnt[1] >= iters.sum()
+    assert cnt[3] == P and cnt[2] == iters.sum() and cnt[0] + cnt[1] + cnt[4] >= iters.sum()   # [4]: Builds served from the memo
 
     # idempotence: restart from the solution
     x2 = x.clone()
@@ -106,7 +106,9 @@ def test_full_size_properties(ta, oracle, tag, P, n, m, dtype, tdt, tol_star, to
     else:
         # fp32: the device's blocked sums resolve slightly smaller cost decreases than the oracle's sequential float
         # sum, so it takes a few more last-bit steps; bound the mean (measured round 1: 7.44 vs 7.25 it/problem)
-        assert abs(it_gpu.mean() - it_ref.mean()) <= 0.5, (it_gpu.mean(), it_ref.mean())
+        # (measured: +0.19; the bound is on the DIRECTION too — the metric counts iterations, so the device must not buy
+        # throughput with iterations the reference algorithm would not make — bench.py prints `value_at_oracle_iters`)
+        assert -0.25 <= it_gpu.mean() - it_ref.mean() <= 0.25, (it_gpu.mean(), it_ref.mean())
         assert np.abs(it_gpu.astype(int) - it_ref.astype(int)).max() <= opts.max_iters + 1
     print(f"[{tag}] sampled parity: {full} identical to the end, {ties} proven ties; iterations/problem "
           f"GPU {it_gpu.mean():.3f} oracle {it_ref.mean():.3f}")

@@ -43,3 +43,23 @@ def test_gather_se3_xdim_and_errors(ta, oracle):
     assert res["x"].shape == (3, 12) and torch.equal(res["x"], x)
     with pytest.raises(ta.ToaError):
         ta.gather_native(comm, x, out, P_total=3, root=1)                 # root out of range
+
+
+@pytest.mark.parametrize("xdim,tdt", [(200, torch.float32), (1024, torch.float64), (12 * 8 + 3 * 256, torch.float64), (65, torch.float32)])
+def test_gather_wide_parameter_blocks(ta, xdim, tdt):
+    """DenseRowNatural (n up to 1024) and bundle adjustment (12 C + 3 N stored scalars) have x far wider than one wavefront:
+    the record layout is generic in xdim (the round-2 limit of 64 is gone)."""
+    from types import SimpleNamespace
+    P = 23
+    g = torch.Generator(device="cpu").manual_seed(xdim)
+    x = torch.randn(P, xdim, generator=g, dtype=tdt).cuda()
+    out = SimpleNamespace(stop_reason=torch.randint(-4, 9, (P,), generator=g, dtype=torch.int32).cuda(),
+                          num_iters=torch.randint(0, 50, (P,), generator=g, dtype=torch.int32).cuda(),
+                          final_cost=torch.rand(P, generator=g, dtype=torch.float64).cuda())
+    comm = ta.Communicator.from_torch(ta.api.default_context())
+    res = ta.gather_native(comm, x, out, P_total=P)
+    torch.cuda.synchronize()
+    assert torch.equal(res["x"], x)
+    assert torch.equal(res["stop_reason"], out.stop_reason) and torch.equal(res["num_iters"], out.num_iters)
+    assert torch.equal(res["final_cost"], out.final_cost)
+    comm.close()

@@ -135,3 +135,37 @@ def test_loss_argument_errors(ta):
         ta.Optimize(x0.clone(), model.with_loss("huber", 0.0))          # a loss needs a positive threshold
     out = ta.Optimize(x0.clone(), model)                                 # and the handle is back to plain L2 afterwards
     assert float(out.final_inlier_ratio.min()) == 1.0
+
+
+def test_sticky_handle_loss_is_refused_not_ignored(ta):
+    """toa_set_loss is handle state.  A C-ABI caller who sets a loss and then launches a family WITHOUT an M-estimator must
+    get TOA_E_UNSUPPORTED — not a plain L2 solve reported as TOA_OK with inlier_ratio = 1 (round-2 advisor finding)."""
+    import ctypes as C
+    from tinyopt_amd._capi import check
+    ctx = ta.api.default_context()
+    P, n = 4, 6
+    y = torch.zeros(P, n, dtype=torch.float64, device="cuda")
+    sig = torch.ones(P, n, dtype=torch.float64, device="cuda")
+    prior = ta.GaussianPrior(y, sig)
+    x = torch.ones(P, n, dtype=torch.float64, device="cuda")
+    opts = ta.Options()
+    out = ta.api._alloc_output(P, n, opts, False, x.device)
+    res = ta.api._results_pod(out)
+    pod = opts.to_pod()
+    check(ctx.lib.toa_set_loss(ctx.h, ta.api.LOSS_KINDS["huber"], 0.25))
+    try:
+        with pytest.raises(ta.ToaError):
+            check(ctx.lib.toa_lm_run(ctx.h, prior.model_id, 1, n, n, P, prior.packed.data_ptr(), x.data_ptr(), C.byref(pod),
+                                     C.byref(res), out.counters.data_ptr()))
+        g = torch.zeros(P, n, dtype=torch.float64, device="cuda")
+        H = torch.zeros(P, n, n, dtype=torch.float64, device="cuda")
+        c = torch.zeros(P, dtype=torch.float64, device="cuda")
+        nres = torch.zeros(P, dtype=torch.int32, device="cuda")
+        with pytest.raises(ta.ToaError):
+            check(ctx.lib.toa_accumulate(ctx.h, prior.model_id, 1, n, n, P, prior.packed.data_ptr(), x.data_ptr(), 1, g.data_ptr(),
+                                         H.data_ptr(), c.data_ptr(), nres.data_ptr()))
+    finally:
+        check(ctx.lib.toa_set_loss(ctx.h, 0, 0.0))
+    # the Python mirror sets the handle's loss from the model before every launch, so the same model solves fine through it
+    out2 = ta.Optimize(x, prior, opts)
+    assert bool((out2.stop_reason >= 0).all())

@@ -1,0 +1,65 @@
+"""The second reading on the device: every case of tests/golden/reference_traces.json (per-iteration traces of an independent
+Python restatement of optimizer.h:242-539 / lm.h / gn.h — tests/golden/make_reference_traces.py) replayed on the device
+TestFn models through the C-ABI.  StopReason, iteration and failure counts and the whole accept / reject sequence must be
+the fixture's; costs, steps and x agree to 1e-8 (rejected steps, roll-backs, eval-only iterations, failed solves
+re-entering Build, max_consec / max_total failure limits, check_final_cost, GaussNewton)."""
+import numpy as np
+import pytest
+import torch
+
+from parity import check_against_trace, load_reference_traces
+
+pytestmark = pytest.mark.gpu
+
+
+def _options(ta, c):
+    o = ta.Options()
+    f = c["options"]
+    o.solver_type = 0 if f["solver"] == "lm" else 1
+    o.max_iters = f["max_iters"]
+    for k in ("min_error", "min_rerr_dec", "min_step_norm2", "min_grad_norm2", "max_total_failures", "max_consec_failures",
+              "check_final_cost", "use_step_quality_approx", "grad_clipping"):
+        setattr(o, k, f[k])
+    o.lm.damping_init = f["damping_init"]
+    o.lm.damping_range = tuple(f["damping_range"])
+    o.lm.good_factor, o.lm.bad_factor = f["good_factor"], f["bad_factor"]
+    return o
+
+
+def test_device_follows_the_second_reading(ta):
+    cases = load_reference_traces()
+    assert len(cases) >= 24
+    ties = 0
+    for c, pod in cases:
+        o = _options(ta, c)
+        got_pod = o.to_pod()
+        for name, _ in pod._fields_:       # the Options mirror produces exactly the fixture's POD
+            if name not in ("save_last", "H_is_full"):
+                assert getattr(got_pod, name) == getattr(pod, name), (name, getattr(got_pod, name), getattr(pod, name))
+        x = torch.tensor([c["x0"]], dtype=torch.float64, device="cuda")
+        out = ta.Optimize(x, ta.TestFn(c["function"], 1), o, history=True)
+        torch.cuda.synchronize()
+        got = dict(errs=out.errs.cpu().numpy()[0], deltas2=out.deltas2.cpu().numpy()[0], succ=out.successes.cpu().numpy()[0],
+                   stop=int(out.stop_reason[0]), iters=int(out.num_iters[0]), fails=int(out.num_failures[0]),
+                   x=x.cpu().numpy()[0], cost=float(out.final_cost[0]))
+        if check_against_trace(c, got, label=f"{c['function']} {c['x0']} ({c['comment']})") == "tie":
+            ties += 1
+            continue
+        if c["options"]["solver"] == "lm" and out.final_hessian is not None and c["stop_reason"] >= 0:
+            H = np.asarray(c["final_hessian"])
+            assert np.allclose(out.final_hessian.cpu().numpy()[0], H, rtol=1e-7, atol=1e-9 * np.abs(H).max())
+    assert ties <= len(cases) // 8, f"{ties} of {len(cases)} cases parted at a round-off tie"
+
+
+def test_device_follows_the_second_reading_stepping_form(ta):
+    """The same traces through the stepping form (`optimizer.Step`, optimizer.h:331-539): one loop pass per call."""
+    for c, _ in load_reference_traces()[:12]:
+        o = _options(ta, c)
+        x = torch.tensor([c["x0"]], dtype=torch.float64, device="cuda")
+        opt = ta.Optimizer(x, ta.TestFn(c["function"], 1), o, history=True)
+        out = opt()
+        torch.cuda.synchronize()
+        got = dict(errs=out.errs.cpu().numpy()[0], deltas2=out.deltas2.cpu().numpy()[0], succ=out.successes.cpu().numpy()[0],
+                   stop=int(out.stop_reason[0]), iters=int(out.num_iters[0]), fails=int(out.num_failures[0]),
+                   x=x.cpu().numpy()[0], cost=float(out.final_cost[0]))
+        check_against_trace(c, got, label=f"stepping {c['function']} {c['x0']}")

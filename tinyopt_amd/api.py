@@ -495,7 +495,7 @@ class Output:
     errs: Optional[torch.Tensor] = None
     deltas2: Optional[torch.Tensor] = None
     successes: Optional[torch.Tensor] = None
-    counters: Optional[torch.Tensor] = None  # [acc passes, eval passes, solves, problems]
+    counters: Optional[torch.Tensor] = None  # [acc passes streamed, eval passes, solves, problems, Builds served from the memo, 3 reserved]
     final_inlier_ratio: Optional[torch.Tensor] = None
 
     def Covariance(self, rescaled: bool = False):
@@ -537,7 +537,7 @@ def _alloc_output(P: int, n: int, options: Options, history: bool, dev) -> Outpu
         stop_reason=torch.zeros(P, **i32), num_iters=torch.zeros(P, **i32), num_failures=torch.zeros(P, **i32),
         num_consec_failures=torch.zeros(P, **i32), final_cost=torch.zeros(P, **f64),
         final_num_residuals=torch.zeros(P, **i32), final_rerr_dec=torch.zeros(P, **f64),
-        counters=torch.zeros(4, dtype=torch.int64, device=dev),
+        counters=torch.zeros(8, dtype=torch.int64, device=dev),
         final_inlier_ratio=torch.ones(P, dtype=torch.float32, device=dev))
     if options.hessian.save_last:
         out.final_hessian = torch.zeros(P, n, n, **f64)
@@ -596,6 +596,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
         elif zero_counters:
             out.counters.zero_()
         res = _results_pod(out)
+        _apply_loss(ctx, cost)   # no M-estimator here: clears whatever an earlier launch left on the handle
         check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
                                  C.byref(pod), C.byref(res), out.counters.data_ptr()))
         return out

@@ -801,6 +801,8 @@ extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_poin
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return toa_fail(TOA_E_ARG, "toa_ba_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
+  if (h->loss != TOA_LOSS_L2)   // sticky handle state must not be ignored silently (include/tinyopt_amd.h, toa_set_loss)
+    return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: bundle adjustment has no M-estimator and a loss is set on the handle (toa_set_loss); clear it first");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   BaParams prm;

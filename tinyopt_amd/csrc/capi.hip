@@ -312,6 +312,7 @@ int toa_destroy(toa_handle h) {
   if (h->queue) (void)hipFree(h->queue);
   if (h->params_dev) (void)hipFree(h->params_dev);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->memo) (void)hipFree(h->memo);
   if (h->blas && h->blas_destroy) (void)h->blas_destroy(h->blas);
   for (int i = 0; i < h->nwgraphs; ++i) (void)hipGraphExecDestroy(h->wgraphs[i].exec);
   delete h;
@@ -537,6 +538,7 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
   return TOA_OK;
 }
 
+static int check_loss_supported(toa_handle h, int model, const char* who);
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, const void* x,
                    int want_grad, void* g, void* H, double* cost, int32_t* nres) {
   if (!h) return fail(TOA_E_ARG, "null handle");
@@ -553,6 +555,7 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
   }
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (int rc = check_model(model, n, m, data)) return rc;
+  if (int rc = check_loss_supported(h, model, "toa_accumulate")) return rc;
   if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
@@ -605,6 +608,20 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* 
   return toa_inst_inv_cov(dtype == TOA_F32 ? 0 : 1, 16 * ((n + 15) / 16), h, n, P, H, C, ok);
 }
 
+// toa_set_loss is sticky handle state: a launch of a family that has no M-estimator while a loss is set would silently be a
+// plain L2 solve with inlier_ratio = 1.  Refused instead (the header promises "refused, never ignored").
+static int check_loss_supported(toa_handle h, int model, const char* who) {
+  if (h->loss == TOA_LOSS_L2) return TOA_OK;
+  switch (model) {
+    case TOA_MODEL_DENSE_ROW: case TOA_MODEL_CIRCLE_FIT: case TOA_MODEL_DENSE_ROW_AD6: case TOA_MODEL_DENSE_ROW_NATURAL:
+      return TOA_OK;   // (NATURAL: its own range check follows in the callers)
+    case TOA_MODEL_SE3_REPROJ:
+      return fail(TOA_E_UNSUPPORTED, std::string(who) + ": TOA_MODEL_SE3_REPROJ takes its loss from its data header; clear the handle's (toa_set_loss(h, TOA_LOSS_L2, 0))");
+    default:
+      return fail(TOA_E_UNSUPPORTED, std::string(who) + ": this model family has no M-estimator and a loss is set on the handle (toa_set_loss); clear it first");
+  }
+}
+
 static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                        const toa_options* options, const toa_results* results, uint64_t* counters, int splits,
                        int mode = 0, void* state = nullptr, int32_t* active = nullptr, const int32_t* stop_request = nullptr) {
@@ -623,6 +640,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (int rc = check_shape(dtype, n, m, P)) return rc;
     if (int rc = check_model(model, n, m, data)) return rc;
   }
+  if (int rc = check_loss_supported(h, model, "toa_lm_run")) return rc;
   if (!x || !options || !results) return fail(TOA_E_ARG, "toa_lm_run: null pointer");
   if (!results->stop_reason || !results->num_iters || !results->final_cost)
     return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");

@@ -1193,6 +1193,40 @@ struct DenseRowGram {
     return wave_allreduce_sum(csum);
   }
 
+  // ---- memo of a finished Gram (lm_device.hpp: lm_memo): the accumulators exactly as the pass left them (after the thin
+  // products' row-group fold), element r of lane l at slot[r * 64 + l] — every store / load is one contiguous 256-byte
+  // (1 KB for the tiles) line per wave.  save -> load returns the same bits, so everything derived from the registers
+  // afterwards (g, diagonal, cost, the LDL^T image) equals what a second pass over the rows would have produced.
+  static constexpr int kMemoElems = (NT * 4 + NTM + NTT) * 64;
+  __device__ __forceinline__ void memo_save(T* __restrict__ slot, const int lane_in) const {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));   // keep the per-lane addresses out of LICM's reach (see extract_g_diag_cost)
+    Acc* __restrict__ st = reinterpret_cast<Acc*>(slot);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st[t * 64 + lane] = acc[t];
+    T* __restrict__ s2 = slot + NT * 4 * 64;
+    if (THIN) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) s2[t * 64 + lane] = accT[t];
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) s2[(NTM + t) * 64 + lane] = accTT[t];
+    }
+  }
+  __device__ __forceinline__ void memo_load(const T* __restrict__ slot, const int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const Acc* __restrict__ st = reinterpret_cast<const Acc*>(slot);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = st[t * 64 + lane];
+    const T* __restrict__ s2 = slot + NT * 4 * 64;
+    if (THIN) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) accT[t] = s2[t * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) accTT[t] = s2[(NTM + t) * 64 + lane];
+    }
+  }
+
   // Scatter: g[q] (q<n), undamped diagonal hd[q], and the cost.  Returns the cost (wave-uniform).
   __device__ __forceinline__ T extract_g_diag_cost(T* __restrict__ g, T* __restrict__ hd, const DenseRowLayout& lay,
                                                    const int n, const int lane_in, T* __restrict__ cost_slot) const {

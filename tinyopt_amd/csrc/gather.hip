@@ -11,7 +11,19 @@
 // RCCL is opened with dlopen on first use, like rocBLAS / rocSOLVER in large_n.hip: it is not a load-time dependency of
 // the single-GPU product path; inside a torch process the name resolves to the copy torch has already loaded.
 #include <dlfcn.h>
+// RCCL is a RUN-time option of this library (dlopen below), so its development headers must not be a BUILD-time requirement
+// of the single-GPU product either: without them the handful of types / enumerators used here are declared locally, with
+// the values of nccl.h 2.x (rccl.h carries the same ABI).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+}
+#endif
 
 #include <mutex>
 
@@ -81,18 +93,27 @@ __host__ __device__ inline long long shard_lo(long long P, int r, int G) {
 // record layout: [ x : xd * sizeof(T) | stop_reason i32 | num_iters i32 | final_cost f64 ], 8-byte aligned
 __host__ __device__ inline size_t rec_bytes(int xd, int tsize) { return ((size_t(xd) * tsize + 7) & ~size_t(7)) + 16; }
 
+// One thread per record ELEMENT (xd values of x, then one slot for the three trailer fields): consecutive threads read
+// consecutive elements of x and write consecutive bytes of a record, so both sides coalesce for any xd (a thread per record
+// walked its record with stride rec: 64 separate cache lines per wave access).
 template <typename T>
 __global__ void gather_pack_kernel(const T* __restrict__ x, const int* __restrict__ stop, const int* __restrict__ iters,
                                    const double* __restrict__ cost, long long P_local, int xd, char* __restrict__ out) {
   const size_t rec = rec_bytes(xd, sizeof(T));
   const size_t xb = (size_t(xd) * sizeof(T) + 7) & ~size_t(7);
-  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P_local; p += (long long)gridDim.x * blockDim.x) {
+  const long long per = (long long)xd + 1;
+  const long long total = P_local * per;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long p = e / per;
+    const int j = int(e - p * per);
     char* r = out + size_t(p) * rec;
-    T* rx = reinterpret_cast<T*>(r);
-    for (int j = 0; j < xd; ++j) rx[j] = x[size_t(p) * xd + j];
-    reinterpret_cast<int*>(r + xb)[0] = stop[p];
-    reinterpret_cast<int*>(r + xb)[1] = iters[p];
-    *reinterpret_cast<double*>(r + xb + 8) = cost[p];
+    if (j < xd) {
+      reinterpret_cast<T*>(r)[j] = x[size_t(p) * xd + j];
+    } else {
+      reinterpret_cast<int*>(r + xb)[0] = stop[p];
+      reinterpret_cast<int*>(r + xb)[1] = iters[p];
+      *reinterpret_cast<double*>(r + xb + 8) = cost[p];
+    }
   }
 }
 
@@ -101,17 +122,23 @@ __global__ void gather_unpack_kernel(const char* __restrict__ in, long long P_to
                                      T* __restrict__ x, int* __restrict__ stop, int* __restrict__ iters, double* __restrict__ cost) {
   const size_t rec = rec_bytes(xd, sizeof(T));
   const size_t xb = (size_t(xd) * sizeof(T) + 7) & ~size_t(7);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < P_total; q += (long long)gridDim.x * blockDim.x) {
+  const long long per = (long long)xd + 1;
+  const long long total = P_total * per;
+  const long long base = P_total / G, rem = P_total % G;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long q = e / per;
+    const int j = int(e - q * per);
     // owner of problem id q under the block partition
-    const long long base = P_total / G, rem = P_total % G;
-    int r = (q < rem * (base + 1)) ? int(q / (base + 1)) : int(rem + (q - rem * (base + 1)) / (base > 0 ? base : 1));
+    const int r = (q < rem * (base + 1)) ? int(q / (base + 1)) : int(rem + (q - rem * (base + 1)) / (base > 0 ? base : 1));
     const long long local = q - shard_lo(P_total, r, G);
     const char* src = in + (size_t(r) * P_max + size_t(local)) * rec;
-    const T* rx = reinterpret_cast<const T*>(src);
-    if (x) for (int j = 0; j < xd; ++j) x[size_t(q) * xd + j] = rx[j];
-    if (stop) stop[q] = reinterpret_cast<const int*>(src + xb)[0];
-    if (iters) iters[q] = reinterpret_cast<const int*>(src + xb)[1];
-    if (cost) cost[q] = *reinterpret_cast<const double*>(src + xb + 8);
+    if (j < xd) {
+      if (x) x[size_t(q) * xd + j] = reinterpret_cast<const T*>(src)[j];
+    } else {
+      if (stop) stop[q] = reinterpret_cast<const int*>(src + xb)[0];
+      if (iters) iters[q] = reinterpret_cast<const int*>(src + xb)[1];
+      if (cost) cost[q] = *reinterpret_cast<const double*>(src + xb + 8);
+    }
   }
 }
 
@@ -184,7 +211,8 @@ int toa_gather(toa_handle h, toa_comm c, int dtype, int xdim, int64_t P_total, c
                int root, void* x_all_dev, const toa_results* all) {
   if (!h || !c) return toa_fail(TOA_E_ARG, "toa_gather: null handle / communicator");
   if (dtype != TOA_F32 && dtype != TOA_F64) return toa_fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
-  if (xdim < 1 || xdim > 64 || P_total < 0 || P_total > 0x7fffffff) return toa_fail(TOA_E_ARG, "toa_gather: bad shape");
+  // any parameter-block width (DenseRowNatural: n up to 1024; bundle adjustment: 12 C + 3 N); only the byte counts are bounded
+  if (xdim < 1 || xdim > (1 << 24) || P_total < 0 || P_total > 0x7fffffff) return toa_fail(TOA_E_ARG, "toa_gather: bad shape");
   if (root < 0 || root >= c->nranks) return toa_fail(TOA_E_ARG, "toa_gather: root out of range");
   if (c->device != h->device) return toa_fail(TOA_E_ARG, "toa_gather: communicator belongs to another device");
   const bool is_root = c->rank == root;
@@ -201,6 +229,8 @@ int toa_gather(toa_handle h, toa_comm c, int dtype, int xdim, int64_t P_total, c
   const size_t rec = rec_bytes(xdim, tsize);
   const long long P_max = (P_total + c->nranks - 1) / c->nranks;
   const size_t send_bytes = size_t(P_max) * rec;
+  if (send_bytes / rec != size_t(P_max) || send_bytes > (size_t(1) << 40) / size_t(c->nranks))
+    return toa_fail(TOA_E_ARG, "toa_gather: P_total * record size exceeds 1 TiB");
   if (int rc = ensure(&c->send, &c->send_bytes, send_bytes)) return rc;
   if (is_root)
     if (int rc = ensure(&c->recv, &c->recv_bytes, send_bytes * size_t(c->nranks))) return rc;

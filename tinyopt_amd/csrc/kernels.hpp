@@ -94,6 +94,18 @@ struct DenseRowModel {
   __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const {
     gram.write_sym(M, LD, lay, n, lane);
   }
+  // memo of the last accepted linearisation (lm_device.hpp): the Gram registers parked in / read back from the wave's HBM slot
+  static constexpr bool kMemo = !ROBUST;   // (with a loss the cost is the pass's own sum, not a Gram entry)
+  static constexpr size_t kMemoBytes = size_t(DenseRowGram<T, NBM, THIN>::kMemoElems) * sizeof(T);
+  __device__ __forceinline__ void memo_save(WaveLds<T>& L, int lane) const { gram.memo_save(reinterpret_cast<T*>(L.st->memo_slot), lane); }
+  __device__ __forceinline__ void memo_reextract(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+    nres = m;
+  }
+  __device__ __forceinline__ void memo_restore(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    gram.memo_load(reinterpret_cast<const T*>(L.st->memo_slot), lane);
+    memo_reextract(L, n, lane, cost, nres);
+  }
 };
 
 // The model whose data passes honour toa_set_loss, for the kernels that only run passes (Model itself where the family
@@ -962,6 +974,18 @@ struct JetRowModel {
   }
   template <typename O>
   __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const { gram.write_sym(M, LD, lay, n, lane); }
+  // memo of the last accepted linearisation (lm_device.hpp) — worth 25 x more here than on the analytic rows
+  static constexpr bool kMemo = true;
+  static constexpr size_t kMemoBytes = size_t(DenseRowGram<T, NBM, THIN>::kMemoElems) * sizeof(T);
+  __device__ __forceinline__ void memo_save(WaveLds<T>& L, int lane) const { gram.memo_save(reinterpret_cast<T*>(L.st->memo_slot), lane); }
+  __device__ __forceinline__ void memo_reextract(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+    nres = m;
+  }
+  __device__ __forceinline__ void memo_restore(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
+    gram.memo_load(reinterpret_cast<const T*>(L.st->memo_slot), lane);
+    memo_reextract(L, n, lane, cost, nres);
+  }
 };
 
 // Per-problem LM state parked in HBM between launches: the stepping form (`Optimizer_::Step`, optimizer.h:331-539, one
@@ -991,46 +1015,6 @@ __device__ __forceinline__ void wide_store_state(const WaveLds<T>& L, WideState<
   ws->dx[lane] = L.dx[lane]; ws->ldx[lane] = L.ldx[lane];
 }
 
-// Work-item hand-over inside the fused kernel: everything of the per-problem state except the per-WAVE work counters
-// that happen to live in the same LDS record.  Every word goes through an agent-scope RELAXED atomic (sc1: written
-// through to / fetched from memory), so the hand-over is coherent across XCDs without agent-scope fences — a
-// release/acquire pair per work item writes back and invalidates a whole L2 and made the launch slower, not faster.
-template <typename W>
-__device__ __forceinline__ void coh_store(W* dst, W v) {
-  if constexpr (sizeof(W) == 4) {
-    __hip_atomic_store(reinterpret_cast<int*>(dst), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    __hip_atomic_store(reinterpret_cast<long long*>(dst), __builtin_bit_cast(long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-template <typename W>
-__device__ __forceinline__ W coh_load(const W* src) {
-  if constexpr (sizeof(W) == 4) {
-    return __builtin_bit_cast(W, __hip_atomic_load(reinterpret_cast<const int*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else {
-    return __builtin_bit_cast(W, __hip_atomic_load(reinterpret_cast<const long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  }
-}
-template <typename T>
-__device__ __forceinline__ void park_store(const WaveLds<T>& L, WideState<T>* ws, int lane) {
-  wave_sync();
-  const int* src = reinterpret_cast<const int*>(L.st);
-  int* dst = reinterpret_cast<int*>(&ws->st);
-  for (int i = lane; i < int(offsetof(LmState<T>, acc_passes) / 4); i += 64) coh_store(dst + i, src[i]);
-  coh_store(&ws->xs[lane], L.xs[lane]); coh_store(&ws->g[lane], L.g[lane]); coh_store(&ws->hd[lane], L.hd[lane]);
-  coh_store(&ws->dx[lane], L.dx[lane]); coh_store(&ws->ldx[lane], L.ldx[lane]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the state has left this CU before the problem is re-queued
-}
-template <typename T>
-__device__ __forceinline__ void park_load(WaveLds<T>& L, const WideState<T>* ws, int lane) {
-  const int* src = reinterpret_cast<const int*>(&ws->st);
-  int* dst = reinterpret_cast<int*>(L.st);
-  for (int i = lane; i < int(offsetof(LmState<T>, acc_passes) / 4); i += 64) dst[i] = coh_load(src + i);
-  L.xs[lane] = coh_load(&ws->xs[lane]); L.g[lane] = coh_load(&ws->g[lane]); L.hd[lane] = coh_load(&ws->hd[lane]);
-  L.dx[lane] = coh_load(&ws->dx[lane]); L.ldx[lane] = coh_load(&ws->ldx[lane]);
-  wave_sync();
-}
-
 struct FusedParams {
   const void* data;
   void* x;
@@ -1039,10 +1023,7 @@ struct FusedParams {
   toa_options opt;
   toa_results res;
   unsigned long long* counters;  // [4] or null
-  int* queue;                    // [0] pop counter, [16] push counter, [32] problems finished (separate cache lines)
-  int* ring;                     // re-queued problems, in push order; -1 = not yet published
-  int ring_cap;
-  void* park;                    // WideState<T>[P]: the state of a problem between two of its work items
+  int* queue;                    // [0] pop counter, [16] waves that have left the kernel (separate cache lines)
   unsigned long long* timeline;  // debug (TOA_TIMELINE=file): [P][2] start / end of every problem in 100 MHz ticks
   int lds_per_wave;
   int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form);
@@ -1052,6 +1033,9 @@ struct FusedParams {
   const int* stop_request;       // mode 3: [P] StopReason to impose on a still-running problem (0 = leave it running)
   int loss;                      // TOA_LOSS_* of the handle (toa_set_loss): applied per residual by the DenseRow / Jet families
   double loss_th2;
+  void* memo;                    // mode 0, models with kMemo: one slot of memo_stride bytes per resident wave (null = off)
+  unsigned long long memo_stride;
+  int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
 };
 
 // (An occupancy request via __launch_bounds__'s second argument is NOT usable here: under the tighter register budget
@@ -1073,7 +1057,14 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     const int* src_r = reinterpret_cast<const int*>(&prm_g->res);
     int* dst_r = reinterpret_cast<int*>(L.res);
     for (int i = lane; i < int(sizeof(toa_results) / 4); i += 64) dst_r[i] = src_r[i];
-    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0;
+    L.st->acc_passes = 0; L.st->eval_passes = 0; L.st->solves = 0; L.st->problems = 0; L.st->reused_passes = 0;
+    L.st->memo_slot = 0;
+    if constexpr (ModelMemo<Model>::value) {
+      if (prm_g->memo_lds_off)   // (a generic pointer into LDS: the flat stores / loads of memo_save / memo_load reach it too)
+        L.st->memo_slot = reinterpret_cast<unsigned long long>(static_cast<void*>(smem + size_t(wave) * prm_g->lds_per_wave + prm_g->memo_lds_off));
+      else if (prm_g->memo)
+        L.st->memo_slot = reinterpret_cast<unsigned long long>(prm_g->memo) + (size_t(blockIdx.x) * 4 + wave) * prm_g->memo_stride;
+    }
   }
   wave_sync();
   const long long P = prm_g->P;
@@ -1083,7 +1074,6 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   T* X = static_cast<T*>(prm_g->x);
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
-#ifndef TOA_QUEUE_DRAIN
   int solved = 0;
   // The first problem of every wave is assigned statically (wave w of the launch takes problem w); the shared counter hands
   // out the rest.  4 096 waves popping the same address at launch time serialise in the L2 (~5 ns per atomic = 20-30 us
@@ -1100,29 +1090,21 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
       p = __builtin_amdgcn_readfirstlane(p);
     }
     if (p >= P) break;
-#ifndef TOA_PRIO_SCHEME
-#define TOA_PRIO_SCHEME 1
-#endif
-#if TOA_PRIO_SCHEME != 0
     // Fairness between the waves of a SIMD.  The issue arbiter serves the OLDEST wave first, and a wave keeps its age for
     // the whole (persistent) kernel: the launch timeline shows the oldest wave of each SIMD solving a problem in 0.8 ms
     // while the youngest needs up to 6.9 ms for its first one and is still far from done when the queue runs dry — the
     // drain is then as long as those starved problems.  Priority outranks age, so the waves that are behind are given
-    // the issue slots.  Scheme 1: a wave drops one level per problem it has finished.  Scheme 2: its level follows how
-    // far it is behind the average wave (p / #resident waves = rounds of problems handed out so far).
+    // the issue slots: a wave drops one level per problem it has finished.  (Measured and rejected, profiles/r02_ab_log.md:
+    // no priorities; a level that follows the lag behind the average wave; re-queueing unfinished problems iteration by
+    // iteration through HBM during the drain.)
     {
-#if TOA_PRIO_SCHEME == 1
       const int lag = 1 - solved;
-#else
-      const int lag = p / int(gridDim.x * 4) - solved;
-#endif
       if (lag >= 1) __builtin_amdgcn_s_setprio(3);
       else if (lag == 0) __builtin_amdgcn_s_setprio(2);
       else if (lag == -1) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
     ++solved;
-#endif
     model.bind(p);
     wave_sync();
     L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
@@ -1132,80 +1114,14 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
     if (prm_g->timeline && lane == 0) { prm_g->timeline[2 * size_t(p)] = tl0; prm_g->timeline[2 * size_t(p) + 1] = wall_clock64(); }
   }
-#else
-  // EXPERIMENT (-DTOA_QUEUE_DRAIN), off by default.  The timeline of a launch (TOA_TIMELINE=file, tools/timeline.py)
-  // shows ~2 500 problems in flight until the queue runs dry at 80 % of the launch and then a 1.9 ms drain during which
-  // SIMDs go idle one after the other (~10 % of a C4 launch, 30 % of a C3 launch).  This variant lets idle waves take
-  // over unfinished problems: a problem that is not finished parks its state in HBM (1.3 KB against the 408 KB its next
-  // data pass streams) and is re-queued — after every iteration once the queue is dry (whole problems before that).
-  // Results stay bit-identical.  Measured: C4 shard 9.07 -> 8.94 ms (8.82 when every iteration is an item from the
-  // start), but C3 0.73 -> 1.13 ms (1.50): for 50 us items the hand-over (same-address queue atomics, sc1 round trips)
-  // costs more than the drain it removes.  With agent-scope release/acquire fences per item instead of the sc1 accesses
-  // every hand-over wrote back / invalidated a whole L2: C4 10.5 ms.  A problem is only parked when its next iteration
-  // rebuilds H (rebuild == 1): on eval-only iterations H lives in this wave's registers (lm.h:96-117).
-  //   queue[0] pop counter: items 0..P-1 are the problems themselves (first iteration), item P + s is ring[s]
-  //   queue[1] push counter, queue[2] problems finished (exit condition for waves waiting on an empty queue)
-  int* ring = prm_g->ring;
-  WideState<T>* park = static_cast<WideState<T>*>(prm_g->park);
-  for (;;) {
-    int idx = 0;
-    if (lane == 0) idx = atomicAdd(&queue[0], 1);
-    idx = __builtin_amdgcn_readfirstlane(idx);
-    int p;
-    const bool fresh = idx < P;
-    if (fresh) {
-      p = idx;
-    } else {
-      const int slot = idx - int(P);
-      if (slot >= prm_g->ring_cap) break;
-      int v;
-      for (;;) {
-        v = __hip_atomic_load(&ring[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >= 0) break;
-        if (__hip_atomic_load(&queue[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= int(P)) break;
-        __builtin_amdgcn_s_sleep(4);
-      }
-      if (v < 0) break;  // every problem has finished
-      p = __builtin_amdgcn_readfirstlane(v);
-    }
-    model.bind(p);
-    wave_sync();
-    if (fresh) {
-      L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
-      wave_sync();
-      lm_init<T>(L, lane);
-    } else {
-      park_load(L, park + p, lane);
-    }
-    // Whole problems while the queue still has fresh ones (no hand-over cost in steady state); once it has run dry —
-    // the drain, when SIMDs go idle one after the other — a problem that is not finished is parked after each iteration
-    // so that the idle waves waiting on the ring can take it over.
-    bool more;
-    do {
-      more = lm_iteration<T>(model, L, n, lane, (long long)p);
-    } while (more && !(L.st->rebuild == 1 &&
-                       __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= int(P)));
-    if (more) {
-      park_store(L, park + p, lane);
-      if (lane == 0) {
-        const int s = atomicAdd(&queue[16], 1);
-        __hip_atomic_store(&ring[s], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else {
-      lm_finalize<T>(model, L, n, lane, (long long)p);
-      if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
-      if (lane == 0) atomicAdd(&queue[32], 1);
-    }
-  }
-#endif
   unsigned long long* counters = prm_g->counters;
   if (counters && lane == 0) {
     atomicAdd(&counters[0], L.st->acc_passes);
     atomicAdd(&counters[1], L.st->eval_passes);
     atomicAdd(&counters[2], L.st->solves);
     atomicAdd(&counters[3], L.st->problems);
+    if (L.st->reused_passes) atomicAdd(&counters[4], L.st->reused_passes);
   }
-#ifndef TOA_QUEUE_DRAIN
   // The work queue cleans itself: the last wave to leave puts the pop counter (and this exit counter) back to zero, so the
   // next launch on the stream needs no memset in front of it (one stream operation, ~5 us, per solve: 1 % of a C3 launch).
   if (lane == 0) {
@@ -1215,7 +1131,6 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
       __hip_atomic_store(&queue[16], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-#endif
 }
 
 // K1/K2 seam: one wave per problem (grid-stride), writes g [P][n], H [P][n*n], cost, nres.
@@ -1928,6 +1843,8 @@ struct toa_context {
   size_t params_shadow_bytes = 0;
   void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
   size_t scratch_bytes = 0;
+  void* memo = nullptr;        // fused kernel: one parked linearisation per resident wave (lm_device.hpp; grown on demand)
+  size_t memo_bytes = 0;
   // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (TOA_USE_GRAPH=1)
   struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
   WideGraph wgraphs[16];
@@ -1985,9 +1902,15 @@ struct DeviceGuard {
 
 // Raise a kernel's dynamic-LDS limit once per (kernel, size): hipFuncSetAttribute costs ~1 ms per call.
 inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
+  size_t max_set = 0;
   for (int i = 0; i < h->ncfg; ++i)
-    if (h->cfg[i].fn == fn && h->cfg[i].lds == bytes) return TOA_OK;
-  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (h->cfg[i].fn == fn) {
+      if (h->cfg[i].lds == bytes) return TOA_OK;
+      if (h->cfg[i].lds > max_set) max_set = h->cfg[i].lds;
+    }
+  // the limit only ever grows: a smaller request (another n on the same instantiation) must not lower it under a larger
+  // size whose cache entry would make later launches skip this call
+  if (bytes > max_set) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   if (h->ncfg < 256) h->cfg[h->ncfg++] = {fn, bytes, -1};
   return TOA_OK;
 }
@@ -1996,6 +1919,15 @@ inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
 // buffers (an outer loop re-solving, the stepping form, the benchmark) present byte-identical blocks: the upload — a
 // staged ~10 us stream operation in front of every launch — is skipped when the block already there is the same.
 inline int upload_params(toa_handle h, const void* blk, size_t bytes) {
+  // Under stream capture the copy below is only RECORDED: the device block changes when the graph is launched, not now, so
+  // the shadow would claim contents the device does not hold yet.  While capturing: always record the upload and forget
+  // the shadow (the next eager call uploads again).
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
+    h->params_shadow_bytes = 0;
+    return TOA_OK;
+  }
   if (bytes == h->params_shadow_bytes && std::memcmp(h->params_shadow, blk, bytes) == 0) return TOA_OK;
   HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
   std::memcpy(h->params_shadow, blk, bytes);
@@ -2046,47 +1978,59 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
-#ifdef TOA_QUEUE_DRAIN
-  HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));  // [0] pops, [16] pushes, [32] finished: one cache line each
-#else
   // [0] pop counter, [16] waves that have left: zeroed when the handle is created and by the last wave of every launch
   // (lm_fused_kernel); a launch that failed may have left them dirty, so the next one starts from a memset again
   if (h->queue_dirty) {
     HIP_TRY(hipMemsetAsync(h->queue, 0, 48 * sizeof(int), h->stream));
     h->queue_dirty = false;
   }
-#endif
-#ifdef TOA_QUEUE_DRAIN
-  {  // iteration-granular work queue: park states + ring of re-queued problems in the context's scratch block
-    const long long iters_max = (long long)prm.opt.max_iters + 3;
-    const size_t b_park = (size_t(prm.P) * sizeof(WideState<T>) + 255) & ~size_t(255);
-    const size_t ring_cap = size_t(prm.P) * size_t(iters_max);
-    const size_t b_ring = (ring_cap * sizeof(int) + 255) & ~size_t(255);
-    if (ring_cap > 0x7fffffffull) return toa_fail(TOA_E_UNSUPPORTED, "P * (max_iters + 3) exceeds the work-queue index range");
-    const size_t need = b_park + b_ring;
-    if (need > h->scratch_bytes) {
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      if (h->scratch) (void)hipFree(h->scratch);
-      h->scratch = nullptr;
-      h->scratch_bytes = 0;
-      HIP_TRY(hipMalloc(&h->scratch, need));
-      h->scratch_bytes = need;
-    }
-    prm.park = h->scratch;
-    prm.ring = reinterpret_cast<int*>(static_cast<char*>(h->scratch) + b_park);
-    prm.ring_cap = int(ring_cap);
-    HIP_TRY(hipMemsetAsync(prm.ring, 0xFF, ring_cap * sizeof(int), h->stream));
-  }
-#endif
   auto kern = lm_fused_kernel<Model>;
+  // resident workgroups per CU for a dynamic-LDS size (cached: the two HIP calls cost milliseconds)
+  auto occupancy = [&](size_t lds_bytes, int* out) -> int {
+    int w = 0;
+    size_t max_set = 0;
+    for (int i = 0; i < h->ncfg; ++i)
+      if (h->cfg[i].fn == (const void*)kern) {
+        if (h->cfg[i].lds == lds_bytes && h->cfg[i].wg_per_cu > 0) w = h->cfg[i].wg_per_cu;
+        if (h->cfg[i].lds > max_set) max_set = h->cfg[i].lds;
+      }
+    if (w == 0) {
+      if (lds_bytes > max_set)   // the limit only ever grows: a smaller request must not lower it under a cached larger one
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, kern, 256, lds_bytes));
+      if (w < 1) w = 1;
+      if (h->ncfg < 256) h->cfg[h->ncfg++] = {(const void*)kern, lds_bytes, w};
+    }
+    *out = w;
+    return TOA_OK;
+  };
   int wg_per_cu = 0;
-  for (int i = 0; i < h->ncfg; ++i)
-    if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == pwg && h->cfg[i].wg_per_cu > 0) wg_per_cu = h->cfg[i].wg_per_cu;
-  if (wg_per_cu == 0) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pwg));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, 256, pwg));
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    if (h->ncfg < 256) h->cfg[h->ncfg++] = {(const void*)kern, pwg, wg_per_cu};
+  if (int rc = occupancy(pwg, &wg_per_cu)) return rc;
+  prm.memo = nullptr;
+  prm.memo_stride = 0;
+  prm.memo_lds_off = 0;
+  bool memo_on = false;
+  if constexpr (ModelMemo<Model>::value) {
+    // One parked linearisation per resident wave (the Gram registers of the last accepted point: ~10 KB at n = 50, 2 KB at
+    // n = 12 fp64): the re-accumulation that follows a rejected step reads it back instead of streaming the problem's rows
+    // again.  TOA_MEMO=0 switches it off (A/B, and the test that the results do not depend on it).
+    const char* env = std::getenv("TOA_MEMO");
+    memo_on = !(env && env[0] == '0');
+    if (memo_on) {
+      // a small Gram is parked in LDS when that costs no resident workgroup (C3: parking in HBM after every accepted step
+      // measured 1.5 % of the launch for a workload that never rejects a step)
+      const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
+      if (mb <= 4096 && (pw + mb) * 4 <= 160 * 1024) {
+        int w2 = 0;
+        if (int rc = occupancy((pw + mb) * 4, &w2)) return rc;
+        if (w2 == wg_per_cu) {
+          prm.memo_lds_off = (int)pw;
+          pw += mb;
+          pwg = pw * 4;
+          prm.lds_per_wave = (int)pw;
+        }
+      }
+    }
   }
   long long grid = (long long)h->num_cus * wg_per_cu;
   const long long need = (prm.P + 3) / 4;
@@ -2097,6 +2041,22 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   {
     static const char* cap_env = std::getenv("TOA_MAX_WGS");  // experiments only
     if (cap_env && std::atoll(cap_env) > 0 && grid > std::atoll(cap_env)) grid = std::atoll(cap_env);
+  }
+  if constexpr (ModelMemo<Model>::value) {
+    if (memo_on && prm.memo_lds_off == 0) {
+      const size_t stride = (Model::kMemoBytes + 255) & ~size_t(255);
+      const size_t need_b = stride * size_t(grid) * 4;
+      if (need_b > h->memo_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->memo) (void)hipFree(h->memo);
+        h->memo = nullptr;
+        h->memo_bytes = 0;
+        HIP_TRY(hipMalloc(&h->memo, need_b));
+        h->memo_bytes = need_b;
+      }
+      prm.memo = h->memo;
+      prm.memo_stride = stride;
+    }
   }
   static_assert(sizeof(FusedParams) <= 1024, "parameter block too large");
   // stream-ordered upload of the parameter block (kept out of the kernarg segment so that its ~60

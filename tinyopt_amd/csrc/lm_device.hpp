@@ -17,6 +17,8 @@
 //   evaluate(L, n, lane, cost, nres)    cost only (grad == nullptr)
 //   write_sym(M, LD, n, lane)           emit the symmetric undamped H into an LD-strided image
 #pragma once
+#include <type_traits>
+
 #include "../../include/tinyopt_amd.h"
 #include "ldlt_blocked.hpp"
 #include "ldlt_lds.hpp"
@@ -41,6 +43,9 @@ __device__ __forceinline__ auto model_inliers(const M& m, int nres, int) -> decl
 template <typename M>
 __device__ __forceinline__ int model_inliers(const M&, int nres, long) { return nres; }
 
+__device__ __forceinline__ bool bits_equal(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool bits_equal(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
 // Compiler-only barrier: nothing held in registers may be assumed equal to memory across it.
 __device__ __forceinline__ void reg_fence() { asm volatile("" ::: "memory"); }
 
@@ -62,9 +67,24 @@ struct LmState {
   // OptimizeAcc locals  optimizer.h:262-263
   int has_last_dx, last_was_success;
   int iter, max_iters;
+  // Memo of linearisations (fused kernel, models with kMemo; see lm_memo_* below).  acc_at_x: the model's Gram registers hold
+  // the linearisation AT the current x; memo_valid: the wave's HBM slot holds the Gram of the point tagged in L.xsv;
+  // memo_hit: the roll-back of the last iteration restored exactly that point, the next Build may read the slot back.
+  int acc_at_x, memo_valid, memo_hit;
   // per-wave work counters (summed into the batch counters at kernel exit)
   unsigned long long acc_passes, eval_passes, solves, problems;
+  unsigned long long reused_passes;   // Builds served without streaming the rows (memo read-back or Gram still in registers)
+  // this WAVE's memo slot in HBM (0 = memo off: every path but the fused kernel).  Kept here, in LDS, rather than in the
+  // WaveLds carve: the carve lives in registers across the hot pass and the wave index is not provably uniform (2 VGPRs).
+  unsigned long long memo_slot;
 };
+
+// Models whose Accumulate result can be parked and read back bit for bit declare `static constexpr bool kMemo = true` and
+// supply memo_save / memo_restore / memo_reextract.
+template <typename M, typename = void>
+struct ModelMemo { static constexpr bool value = false; };
+template <typename M>
+struct ModelMemo<M, std::enable_if_t<M::kMemo>> { static constexpr bool value = true; };
 
 // Per-wave LDS carve.  All vectors are 64 elements so lane-indexed access needs no bounds.
 template <typename T>
@@ -78,6 +98,7 @@ struct WaveLds {
   T* dx;      // step of the current iteration
   T* ldx;     // last accepted / tried step (optimizer.h:262 last_dx)
   T* aux;     // model scratch that survives the factorisation (row-split path: folded H for n <= 8)
+  T* xsv;     // the x the memo slot's linearisation was taken at (lm_memo_*)
   int* perm;  // pivot permutation
   LmState<T>* st;
   toa_options* opt;
@@ -87,7 +108,7 @@ struct WaveLds {
   // workspace elements, rounded so that the 64-element vectors behind it stay 16-byte aligned (ds_read_b128)
   static __host__ __device__ size_t m_elems(int n) { return (size_t(n) * ld_for(n) + 3) & ~size_t(3); }
   static __host__ __device__ size_t bytes(int n) {
-    size_t b = (m_elems(n) + 8 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t b = (m_elems(n) + 9 * 64) * sizeof(T) + 64 * sizeof(int);
     b = (b + 15) & ~size_t(15);
     b += (sizeof(LmState<T>) + 15) & ~size_t(15);
     b += (sizeof(toa_options) + 15) & ~size_t(15);
@@ -107,8 +128,9 @@ struct WaveLds {
     w.dx = p; p += 64;
     w.ldx = p; p += 64;
     w.aux = p; p += 64;
+    w.xsv = p; p += 64;
     w.perm = reinterpret_cast<int*>(p);
-    size_t off = (m_elems(n) + 8 * 64) * sizeof(T) + 64 * sizeof(int);
+    size_t off = (m_elems(n) + 9 * 64) * sizeof(T) + 64 * sizeof(int);
     off = (off + 15) & ~size_t(15);
     w.st = reinterpret_cast<LmState<T>*>(base + off);
     off += (sizeof(LmState<T>) + 15) & ~size_t(15);
@@ -165,10 +187,27 @@ __device__ __forceinline__ int lm_build_and_solve(Model& model, WaveLds<T>& L, c
     T c;
     int nres;
     reg_fence();
-    if (do_acc) model.accumulate(L, n, lane, c, nres);  // clear + acc(x, grad, H)  gn.h:77-81,109-113
-    else model.evaluate(L, n, lane, c, nres);           // lm.h:96-105 -> gn.h:97-105 (grad == nullptr)
+    bool streamed = true;
+    if (do_acc) {  // clear + acc(x, grad, H)  gn.h:77-81,109-113
+      if constexpr (ModelMemo<Model>::value) {
+        // The callback is a pure function of x: when the linearisation at THIS x (bit for bit) is still in the Gram
+        // registers (a failed solve re-entering Build, optimizer.h:358-393) or in the wave's memo slot (the re-accumulation
+        // after a roll-back, optimizer.h:283-287 + :266), it is taken from there instead of streaming the rows again.
+        if (S.memo_slot && S.acc_at_x) { model.memo_reextract(L, n, lane, c, nres); streamed = false; }
+        else if (S.memo_slot && S.memo_hit) { model.memo_restore(L, n, lane, c, nres); streamed = false; }
+        else model.accumulate(L, n, lane, c, nres);
+        S.acc_at_x = 1;
+        S.memo_hit = 0;
+      } else {
+        model.accumulate(L, n, lane, c, nres);
+      }
+    } else {
+      model.evaluate(L, n, lane, c, nres);           // lm.h:96-105 -> gn.h:97-105 (grad == nullptr)
+    }
     reg_fence();
-    if (do_acc) S.acc_passes++; else S.eval_passes++;
+    if (!streamed) S.reused_passes++;
+    else if (do_acc) S.acc_passes++;
+    else S.eval_passes++;
     S.cost_val = normalize_cost(double(c), nres, opt);
     S.cost_nres = nres;
     S.cost_ninl = model_inliers(model, nres, 0);
@@ -330,6 +369,7 @@ __device__ __forceinline__ void lm_init(WaveLds<T>& L, const int lane) {
   S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
   S.has_last_dx = 0; S.last_was_success = 1;
   S.iter = 0;
+  S.acc_at_x = 0; S.memo_valid = 0; S.memo_hit = 0;
   L.ldx[lane] = T(0);
   L.dx[lane] = T(0);
   wave_sync();
@@ -348,8 +388,24 @@ __device__ __forceinline__ bool lm_iteration(Model& model, WaveLds<T>& L, const 
   // ================= back in OptimizeAcc  optimizer.h:269-309 =================
   const toa_options& opt = *L.opt;
   bool eval_only = false;
+  S.memo_hit = 0;                   // (only the roll-back below may arm it, for the Build that follows directly)
   if (status & 1) {                 // :271-279
+    if constexpr (ModelMemo<Model>::value) {
+      // x is about to leave an ACCEPTED point.  If the step that follows is rejected, the loop comes back here
+      // (x (+)= -last_dx, :283-287) and accumulates again (:266 with rebuild == 1): park the linearisation of this point.
+      // (An eval-only iteration that succeeds leaves from a point whose linearisation was never formed: nothing to park.)
+      if (S.memo_slot) {
+        if (S.acc_at_x) {
+          model.memo_save(L, lane);
+          L.xsv[lane] = L.xs[lane];
+          S.memo_valid = 1;
+        } else {
+          S.memo_valid = 0;
+        }
+      }
+    }
     model.plus_eq(L, L.dx, T(1), n, lane);   // ptrait::PlusEq(x, dx): traits.h:184-190 / sophus.h:24-26
+    S.acc_at_x = 0;
     L.ldx[lane] = L.dx[lane];
     S.has_last_dx = 1;
     S.last_was_success = 1;
@@ -358,8 +414,18 @@ __device__ __forceinline__ bool lm_iteration(Model& model, WaveLds<T>& L, const 
     if (S.has_last_dx) {
       model.plus_eq(L, L.ldx, T(-1), n, lane);  // roll back: PlusEq(x, -last_dx)
       S.has_last_dx = 0;
+      S.acc_at_x = 0;
+      if constexpr (ModelMemo<Model>::value) {
+        // (x + dx) - dx is x again only when both roundings cancel: compare the BIT PATTERNS with the parked point's, and
+        // let the next Build read the memo back only on a match in every component (never an approximation).
+        if (S.memo_slot) {
+          wave_sync();
+          S.memo_hit = (S.memo_valid && __all(bits_equal(L.xs[lane], L.xsv[lane]))) ? 1 : 0;
+        }
+      }
     } else if (status & 2) {
       model.plus_eq(L, L.dx, T(1), n, lane);
+      S.acc_at_x = 0;
       L.ldx[lane] = L.dx[lane];
       S.has_last_dx = 1;
     }
