@@ -86,7 +86,7 @@ def test_results_do_not_depend_on_the_memo(ta, oracle, dtype, n, m, P, over):
     assert c_on[1] == c_off[1] and c_on[2] == c_off[2] and c_on[3] == c_off[3] == P
     # the oracle always re-accumulates: the trajectories must still be its own
     ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
-    check_trajectories(gpu_dict(o_on, x_on), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"],
+    check_trajectories(gpu_dict(o_on, torch.from_numpy(x_on)), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"],
                                                   x=ref["x"], cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]),
                        dtype, opts.to_pod())
 

@@ -21,6 +21,7 @@
 // DPP rows); s = 1 + 0.1 cos t scales the lane's a-values into J in registers; the lane holding
 // b_i replaces it by r_i = t + 0.1 sin t - b_i.
 #pragma once
+#include <type_traits>
 #include "robust.hpp"
 #include "wave_utils.hpp"
 
@@ -931,6 +932,98 @@ struct DenseRowGram {
     return wave_allreduce_sum(csum);
   }
 
+  // ---- one CHUNK of a pass (cooperative tail, kernels.hpp DenseRowModel::coop_*): the steps [step0, step1) of the problem,
+  // accumulated FROM ZERO.  A pass that is the fixed-order fold of such chunk partials gives the same bits whether one wave
+  // computes every chunk or the four waves of a workgroup share them — which is what lets an idle wave take rows of a
+  // sibling's problem once the work queue is dry without giving up run-to-run and batch-independent results.
+  // step0 is a multiple of kDepth * U (so the ring never straddles a chunk boundary); the buffer descriptor ends at the
+  // chunk's last row: the prefetches past it return 0 without touching memory.  No thin-product fold here (fold_thin(),
+  // once, after the chunk partials have been summed).  !WANT_H: returns the chunk's wave-reduced sum of squares.
+  template <bool WANT_H>
+  __device__ __forceinline__ T pass_chunk(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
+                                          const T* __restrict__ xs, const int lane_in, const int step0, const int step1) {
+    static_assert(!kSuper16, "the 64-row super-batches are not chunked");
+    // Opaque copy of the lane id: everything below that depends only on the lane and the layout is invariant across chunks,
+    // passes and problems, and LICM would hoist it out of all three loops and pin it across the LDL^T and the state machine.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int k = lane >> 4, c = lane & 15;
+    const int RS = lay.rs, rsm = lay.rsm;
+    const bool active = c * NBM < rsm;
+    PassCtx pc;
+    pc.c = c;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      const int q = NBM * c + cb;
+      pc.xr[cb] = (q < lay.nmr) ? xs[q] : T(0);
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < THIN; ++j) pc.xt[j] = (c == 0) ? xs[lay.nmr + j] : T(0);
+    pc.q0 = (lane & 1) != 0;
+    pc.q1 = (lane & 2) != 0;
+    pc.isB_lane = (THIN == 0) && ((c + 1) * NBM == rsm);
+    pc.mA = pc.isB_lane ? T(0) : T(1);
+    pc.mB = pc.isB_lane ? T(1) : T(0);
+    pc.loss = 0;
+    pc.th2 = T(0);
+    pc.k = k;
+    pc.rows_real = 0;
+    pc.owner = THIN == 0 ? pc.isB_lane : c == 0;
+    pc.inl = T(0);
+    if (WANT_H) clear();
+    T csum = 0;
+    const int steps = step1 - step0;
+    const unsigned step_bytes = unsigned(4 * RS) * unsigned(sizeof(T));
+    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(step_bytes)));
+    const i32x4 rsrc = make_rsrc(prob, unsigned(step1) * step_bytes);   // ends with the chunk
+    const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
+    const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));
+    const unsigned base = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(step0) * step_bytes)));
+    Slots S[kDepth];
+    SlotsT St[kDepth];
+    static_for<kDepth - 1>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      issue_batch(S[i], St[i], rsrc, voff, vofft, base + unsigned(i * U) * step_bytes_u, step_bytes_u);
+    });
+    wait_slots(S[0], St[0]);
+    for (int s0 = 0; s0 < steps; s0 += kDepth * U) {
+      static_for<kDepth>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int refill = (i + kDepth - 1) % kDepth;
+        const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(base + unsigned(s0 + (i + kDepth - 1) * U) * step_bytes_u)));
+        issue_batch(S[refill], St[refill], rsrc, voff, vofft, soff, step_bytes_u);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i == kDepth - 1)
+          compute_batch<WANT_H, true, false>(S[i], St[i], pc, csum, __builtin_amdgcn_readfirstlane(int(s0 + kDepth * U >= steps)), 0);
+        else
+          compute_batch<WANT_H, false, false>(S[i], St[i], pc, csum, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_slots(S[(i + 1) % kDepth], St[(i + 1) % kDepth]);
+      });
+    }
+    if constexpr (kDepth > 2) {
+      static_for<kDepth>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        wait_batch<0, kDw>(S[i][0], S[i][1], S[i][2], S[i][3]);
+        if (THIN) wait_batch<0, kDwT>(St[i][0], St[i][1], St[i][2], St[i][3]);
+      });
+    }
+    if (WANT_H) {
+      mfma_retire();
+      return T(0);
+    }
+    return wave_allreduce_sum(csum);
+  }
+  // the thin products' fold over the 4 row groups (what pass() does at its end), after the chunk partials were summed
+  __device__ __forceinline__ void fold_thin() {
+    if (THIN) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) accTT[t] = kgroup_allreduce_sum(accTT[t]);
+    }
+  }
+
   // ---- fp64, n <= 15: SIXTEEN steps (64 rows) per sin / cos ---------------------------------------------------------------
   // The quad-transposed reduction above leaves each a_i.x on FOUR lanes (16 row totals per batch on 64 lanes), so the
   // polynomial sin / cos — 20 half-rate fp64 operations + ~20 selects / integer operations, a third of the fp64 pass's issue
@@ -1198,12 +1291,18 @@ struct DenseRowGram {
   // (1 KB for the tiles) line per wave.  save -> load returns the same bits, so everything derived from the registers
   // afterwards (g, diagonal, cost, the LDL^T image) equals what a second pass over the rows would have produced.
   static constexpr int kMemoElems = (NT * 4 + NTM + NTT) * 64;
+  // (One tile at a time, with scheduling barriers in between: left alone hipcc issues every load of a fold first — 24 tile +
+  //  15 thin registers for the loads, as many for the accumulator copies, as many for the sums — and those ~120 transient
+  //  registers on top of the kernel's long-lived ones became the register count of the WHOLE fused kernel.)
   __device__ __forceinline__ void memo_save(T* __restrict__ slot, const int lane_in) const {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));   // keep the per-lane addresses out of LICM's reach (see extract_g_diag_cost)
     Acc* __restrict__ st = reinterpret_cast<Acc*>(slot);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) st[t * 64 + lane] = acc[t];
+    static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      st[t * 64 + lane] = acc[t];
+      __builtin_amdgcn_sched_barrier(0);
+    });
     T* __restrict__ s2 = slot + NT * 4 * 64;
     if (THIN) {
 #pragma unroll
@@ -1212,12 +1311,86 @@ struct DenseRowGram {
       for (int t = 0; t < NTT; ++t) s2[(NTM + t) * 64 + lane] = accTT[t];
     }
   }
+  // slot += the registers, element by element (the fold of one chunk partial into the running total of a pass)
+  __device__ __forceinline__ void memo_add(T* __restrict__ slot, const int lane_in) const {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    Acc* __restrict__ st = reinterpret_cast<Acc*>(slot);
+    static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      const Acc o = st[t * 64 + lane];
+      st[t * 64 + lane] = Acc{o[0] + acc[t][0], o[1] + acc[t][1], o[2] + acc[t][2], o[3] + acc[t][3]};
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    T* __restrict__ s2 = slot + NT * 4 * 64;
+    if (THIN) {
+      static_for<NTM>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        s2[t * 64 + lane] = s2[t * 64 + lane] + accT[t];
+        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NTT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        s2[(NTM + t) * 64 + lane] = s2[(NTM + t) * 64 + lane] + accTT[t];
+        if constexpr ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // memo_load for the END of a chunked pass: the same values, but every register is written as a function of its OLD content
+  // (old & 0 | loaded, with a zero the compiler cannot see through).  A plain load starts new live ranges for the 24 + 15
+  // accumulators next to the ones the chunk loop just used, and hipcc then kept both sets: 156 -> 180 registers for the
+  // whole fused kernel (3 -> 2 waves / SIMD at n = 50).
+  template <int t>
+  __device__ __forceinline__ void lds_read_tile(unsigned a0) {
+    if constexpr (sizeof(T) == 4) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(acc[t]) : "v"(a0), "n"(t * 64 * 16));
+    } else {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[0]) : "v"(a0), "n"(t * 64 * 32));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[1]) : "v"(a0), "n"(t * 64 * 32 + 16));
+    }
+    if constexpr (t + 1 < NT) lds_read_tile<t + 1>(a0);
+  }
+  template <int t, int N, int BASE>
+  static __device__ __forceinline__ void lds_read_thin(T* dst, unsigned a1) {
+    if constexpr (t < N) {
+      if constexpr (sizeof(T) == 4) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 4));
+      else asm volatile("ds_read_b64 %0, %1 offset:%2" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 8));
+      lds_read_thin<t + 1, N, BASE>(dst, a1);
+    }
+  }
+  __device__ __forceinline__ void memo_load_inplace(const T* __restrict__ slot, const int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    // LDS byte address of this lane's first element; the ds_read destinations are IN-OUT operands (tied to the registers the
+    // chunk loop used), and nothing reads them before the wait at the end names them all again
+    const unsigned a0 = unsigned(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)(slot))) + unsigned(lane) * unsigned(sizeof(Acc));
+    lds_read_tile<0>(a0);
+    if (THIN) {
+      const unsigned a1 = unsigned(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)(slot + NT * 4 * 64))) + unsigned(lane) * unsigned(sizeof(T));
+      lds_read_thin<0, NTM, 0>(accT, a1);
+      lds_read_thin<0, NTT, NTM>(accTT, a1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+    if (THIN) {
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) asm volatile("" : "+v"(accT[t]));
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) asm volatile("" : "+v"(accTT[t]));
+    }
+  }
   __device__ __forceinline__ void memo_load(const T* __restrict__ slot, const int lane_in) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const Acc* __restrict__ st = reinterpret_cast<const Acc*>(slot);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = st[t * 64 + lane];
+    static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      acc[t] = st[t * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+    });
     const T* __restrict__ s2 = slot + NT * 4 * 64;
     if (THIN) {
 #pragma unroll

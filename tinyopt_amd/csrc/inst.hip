@@ -121,13 +121,22 @@ int TOA_CAT(toa_inst_inv_cov_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, in
 }
 #else
 int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm) {
+  // the fused kernel runs the COOP variant of the model (ticketed row chunks: kernels.hpp CoopCtl) wherever one exists —
+  // everywhere but the fp64 n <= 15 shapes, whose pass works in 64-row super-batches
+  // ... and the three layouts where the variant costs a resident wave per SIMD (tools/kernel_regs.py against the plain
+  // variant: f32 (1,1) 80 -> 84 registers, f32 (1,2) 92 -> 100, f64 (2,4) 256 -> 260)
+  constexpr bool kF32 = sizeof(InstT) == 4;
+  constexpr bool kCoop0 = !DenseRowGram<InstT, TOA_INST_NBM, 0>::kSuper16;
+  constexpr bool kCoop1 = !(kF32 && TOA_INST_NBM == 1);
+  constexpr bool kCoop2 = !(kF32 && TOA_INST_NBM == 1);
+  constexpr bool kCoop4 = !(!kF32 && TOA_INST_NBM == 2);
   switch (thin) {
-    case 0: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 0>>(h, prm);
+    case 0: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 0, false, kCoop0>>(h, prm);
 #if TOA_INST_NBM <= 3
-    case 1: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 1>>(h, prm);
-    case 2: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 2>>(h, prm);
-    case 3: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 3>>(h, prm);
-    case 4: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 4>>(h, prm);
+    case 1: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 1, false, kCoop1>>(h, prm);
+    case 2: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 2, false, kCoop2>>(h, prm);
+    case 3: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 3, false, true>>(h, prm);
+    case 4: return launch_fused<DenseRowModel<InstT, TOA_INST_NBM, 4, false, kCoop4>>(h, prm);
 #endif
     default: return toa_fail(TOA_E_ARG, "bad thin-tail width");
   }

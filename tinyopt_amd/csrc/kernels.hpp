@@ -40,10 +40,33 @@ __device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign
   L.xs[lane] += sign * d[lane];
 }
 
+// ---- cooperative passes (the tail of a fused launch) ------------------------------------------------------------------------
+// Once the work queue is dry, the waves of a workgroup that have nothing left help the ones that do: a data pass is K CHUNKS
+// of rows, handed out by ticket to whoever asks (the owner of the problem included), each accumulated from zero and folded
+// into the owner's LDS total in TICKET ORDER.  The fold is therefore the same fixed-order sum whether the owner computed all
+// K chunks itself (steady state: nobody is idle) or its three siblings took some: results do not depend on timing, on the
+// batch size or on the position of a problem in the batch.  All of it lives in LDS at workgroup scope; no barrier (the
+// four waves run different problems at their own pace), no HBM traffic.
+struct CoopSlot {          // one per wave, written by the OWNER except ticket (everybody) and turn (whoever folds)
+  int p;                   // problem of the open pass
+  int kind;                // 1: accumulate (Gram), 0: evaluate-only (sum of squares)
+  int ticket;              // next chunk to hand out; >= K: no open pass
+  int turn;                // next chunk whose partial may be folded; == K: the pass is complete
+  double cost;             // evaluate-only: the running sum (holds a T)
+  int pad_[2];
+};
+struct CoopCtl {
+  CoopSlot slot[4];
+  int active[4];           // wave w still has (or may still get) problems of its own
+};
+
 // ROBUST = true: the variant whose passes apply the handle's M-estimator (toa_set_loss) to every residual.  It exists only in
 // the small kernels of the launch-per-iteration forms (accumulate_kernel, wide_partial_kernel): compiled into the fused
 // kernel, the estimators' exp / log / atan2 raise its register count from 168 to 232 (3 -> 2 waves per SIMD for everybody).
-template <typename T, int NBM, int THIN, bool ROBUST = false>
+// COOP = true: the variant whose passes are ALWAYS the ticketed chunk form (coop_K >= 1; one chunk = the classic pass, bit
+// for bit) — instantiated by the fused kernel only.  A compile-time property, not a run-time branch: two MFMA loops over
+// the same accumulators in one kernel made hipcc keep two AGPR sets (156 -> 196 registers at n = 50: 3 -> 2 waves / SIMD).
+template <typename T, int NBM, int THIN, bool ROBUST = false, bool COOP = false>
 struct DenseRowModel {
   using Scalar = T;
   static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
@@ -60,17 +83,24 @@ struct DenseRowModel {
   T th2;
   int rows_real;   // rows of the bound problem / chunk that exist (the packed layout pads to a multiple of 4)
   int ninl;        // inlier residuals of the last pass; -1 = all of them (no loss)
+  // cooperative passes (fused kernel only; see CoopCtl above): chunks per pass (0 = off), steps per chunk, and where the
+  // workgroup's control block / the per-wave carves sit in LDS
+  static constexpr bool kCoop = COOP;
+  static_assert(!(COOP && (ROBUST || DenseRowGram<T, NBM, THIN>::kSuper16)), "no cooperative form of the robust / 64-row super-batch passes");
+  int coop_K, coop_cs, coop_lds_per_wave, cur_p, helping, help_o, help_c;
   __device__ __forceinline__ void init(int n, int m_, const void* d) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
     loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
+    coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
   }
+  __device__ __forceinline__ void coop_init(int K, int chunk_steps, int lds_per_wave) { coop_K = K; coop_cs = chunk_steps; coop_lds_per_wave = lds_per_wave; }
   __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
 #ifdef TOA_ABL_REUSE  // ablation: every wave streams one of 64 problems (cache-resident data, same instruction stream)
   __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); rows_real = m; }
 #else
-  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); rows_real = m; }
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); rows_real = m; cur_p = int(p); }
 #endif
   // row-split execution: restrict the model to rows [row0, row0 + rows) of problem p (rows % 4 == 0)
   __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int n) {
@@ -80,14 +110,150 @@ struct DenseRowModel {
     lay.m4 = rows;
     rows_real = max(0, min(rows, m - row0));
   }
+  // One pass in the ticketed chunk form — the owner's side AND the helper's side, in ONE loop: hipcc keeps a separate AGPR
+  // set alive for every MFMA loop over the accumulators it finds in a kernel (two inlined copies of the chunk loop took
+  // the n = 50 kernel from 156 to 196 registers, 3 -> 2 waves / SIMD), so the kernel may contain exactly one.
+  //   owner   (helping == 0): opens a pass on its own slot, takes its tickets like everybody else, waits for the last fold,
+  //           reads the total back into the Gram registers;
+  //   helper  (helping == 1, only ever through the WANT_H instantiation — see lm_fused_kernel's "ghost problem"): this wave
+  //           has no problem left; it serves the siblings' open ACCUMULATE passes until none of them is active.  (Evaluate-
+  //           only passes — one in seven at C4 — are chunked and folded the same way but never shared: a second kind of
+  //           chunk in this loop costs the kernel its third wave per SIMD.)
+  // The shape of the loop is what hipcc's register allocation tolerated (A/B log, profiles/r03_ab_log.md): do-while, the
+  // scalars that cross the pass re-derived behind optimisation barriers, the total read back through in-out asm operands.
+  // Returns the cost of an evaluate-only pass.
+  template <bool WANT_H>
+  __device__ __forceinline__ T coop_pass(WaveLds<T>& L, const int n, const int lane) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const bool help = WANT_H && helping != 0;
+    const int st = lay.m4 >> 2;
+    int c, o;
+    if (!help) {
+      o = w;
+      CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[w];
+      if (lane == 0) {
+        S.p = cur_p;
+        S.kind = WANT_H ? 1 : 0;
+        S.turn = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // x (L.xs) and the fields above, before the counter opens
+      // the counter opens at 1: chunk 0 is the owner's (it always has a valid ticket when it enters the loop below)
+      if (lane == 0) __hip_atomic_store(&S.ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      c = 0;
+    } else {   // the ticket lm_fused_kernel's search found for this ghost
+      o = __builtin_amdgcn_readfirstlane(help_o);
+      c = __builtin_amdgcn_readfirstlane(help_c);
+    }
+    do {   // (both sides arrive with a valid ticket: no guard — a guard costs the kernel its third wave per SIMD)
+      const T* xs_o = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n).xs;
+      const T* pr = help ? data + size_t(__builtin_amdgcn_readfirstlane(reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[o].p)) * lay.elems_per_problem()
+                         : prob;
+      reg_fence();
+      const T part = gram.template pass_chunk<WANT_H>(pr, lay, n, xs_o, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
+      reg_fence();
+      // Everything the fold needs is re-derived from the two scalars that crossed the pass, behind an optimisation barrier.
+      c = __builtin_amdgcn_readfirstlane(c);
+      o = __builtin_amdgcn_readfirstlane(o);
+      asm volatile("" : "+s"(c), "+s"(o));
+      CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[o];
+      T* totp = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n).M;
+      // fold in ticket order
+      // (bounded: a protocol bug must end in a trapped launch, not in a GPU that never comes back — ~1 s of polling)
+      for (int spin = 0; __hip_atomic_load(&S.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != c; ++spin) {
+        __builtin_amdgcn_s_sleep(2);
+        if (spin > (1 << 24)) asm volatile("s_trap 2");
+      }
+      if (WANT_H) {
+        if (coop_K > 1) {   // (one chunk per pass: the registers ARE the total)
+          if (c == 0) gram.memo_save(totp, lane);
+          else gram.memo_add(totp, lane);
+        }
+      } else if (lane == 0) {
+        T* cs = reinterpret_cast<T*>(&S.cost);
+        *cs = c == 0 ? part : *cs + part;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&S.turn, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // next ticket of the same pass
+      if (lane == 0) c = __hip_atomic_fetch_add(&S.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      c = __builtin_amdgcn_readfirstlane(c);
+    } while (c < coop_K);
+    // (A helper falls through the owner's epilogue as well — its own slot's turn has been K since its last pass, and what
+    //  the read-back puts into its dead Gram registers does not matter: an early return for it here, i.e. a path on which
+    //  the accumulators die, made hipcc allocate 16 more registers for the whole kernel.)
+    CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[w];
+    for (int spin = 0; __hip_atomic_load(&S.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K; ++spin) {
+      __builtin_amdgcn_s_sleep(2);
+      if (spin > (1 << 24)) asm volatile("s_trap 2");
+    }
+    if constexpr (WANT_H) {
+      if (coop_K > 1) gram.memo_load_inplace(L.M, lane);
+      gram.fold_thin();
+      return T(0);
+    } else {
+      return *reinterpret_cast<const T*>(&S.cost);
+    }
+  }
+  // A wave whose queue is dry looks for a sibling's open ACCUMULATE pass and takes a ticket of it (kind is written before
+  // the counter opens and cannot change while tickets of that pass are outstanding).  false: no sibling is active any more.
+  __device__ __forceinline__ bool coop_find(const int lane) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave);
+    if (!helping) {
+      helping = 1;
+      help_o = w;
+      if (lane == 0) __hip_atomic_store(&ctl->active[w], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (int spins = 0;;) {
+      bool any = false;
+      for (int t = 1; t < 4; ++t) {
+        const int q = (help_o + t) & 3;
+        if (q == w) continue;
+        if (__hip_atomic_load(&ctl->active[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
+        any = true;
+        if (__hip_atomic_load(&ctl->slot[q].ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= coop_K) continue;
+        if (__hip_atomic_load(&ctl->slot[q].kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
+        int cc = 0;
+        if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cc = __builtin_amdgcn_readfirstlane(cc);
+        if (cc < coop_K) {
+          help_o = __builtin_amdgcn_readfirstlane(q);
+          help_c = cc;
+          return true;
+        }
+      }
+      if (!any) return false;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 24)) asm volatile("s_trap 2");   // (a sibling that never finishes: trap rather than hang)
+    }
+  }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    const T cl = gram.template pass<true, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
-    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
-    if constexpr (ROBUST) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
-    nres = m;
+    if constexpr (kCoop) {
+      ninl = -1;
+      (void)coop_pass<true>(L, n, lane);
+      if (helping) {   // the ghost problem of a wave whose queue is dry (lm_fused_kernel): "no residuals" ends it at once
+        cost = T(0);
+        nres = 0;
+        return;
+      }
+      cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+      nres = m;
+    } else {
+      const T cl = gram.template pass<true, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
+      cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
+      if constexpr (ROBUST) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
+      nres = m;
+    }
   }
   __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    cost = gram.template pass<false, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
+    if constexpr (kCoop) {
+      ninl = -1;
+      cost = coop_pass<false>(L, n, lane);
+    } else {
+      cost = gram.template pass<false, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
+    }
     nres = m;
   }
   template <typename O>
@@ -111,7 +277,7 @@ struct DenseRowModel {
 // The model whose data passes honour toa_set_loss, for the kernels that only run passes (Model itself where the family
 // has no separate variant: the Jet models branch at run time, the others have no M-estimator).
 template <typename M> struct RobustOf { using type = M; };
-template <typename T, int NBM, int THIN> struct RobustOf<DenseRowModel<T, NBM, THIN, false>> { using type = DenseRowModel<T, NBM, THIN, true>; };
+template <typename T, int NBM, int THIN, bool COOP> struct RobustOf<DenseRowModel<T, NBM, THIN, false, COOP>> { using type = DenseRowModel<T, NBM, THIN, true, false>; };
 
 // Gaussian prior  r = (x - y) / sigma,  m = n — the residual of the reference's published dense
 // benchmark, with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66, 90-99;
@@ -1036,7 +1202,14 @@ struct FusedParams {
   void* memo;                    // mode 0, models with kMemo: one slot of memo_stride bytes per resident wave (null = off)
   unsigned long long memo_stride;
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
+  int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
+  int coop_cs;                   // steps (of 4 rows) per chunk, a multiple of the load ring's period
 };
+
+template <typename M, typename = void>
+struct ModelCoop { static constexpr bool value = false; };
+template <typename M>
+struct ModelCoop<M, std::enable_if_t<M::kCoop>> { static constexpr bool value = true; };
 
 // (An occupancy request via __launch_bounds__'s second argument is NOT usable here: under the tighter register budget
 // hipcc parks the destination registers of the in-flight asm loads in AGPRs right after issuing them — tools/isa_lint.py
@@ -1074,22 +1247,47 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   T* X = static_cast<T*>(prm_g->x);
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
+  if constexpr (ModelCoop<Model>::value) {   // the workgroup's control block: every wave marks itself as an owner, no pass open
+    model.coop_init(prm_g->coop_K, prm_g->coop_cs, prm_g->lds_per_wave);
+    CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(4) * prm_g->lds_per_wave);
+    if (lane == 0) {
+      ctl->slot[wave].ticket = prm_g->coop_K;
+      ctl->slot[wave].turn = prm_g->coop_K;
+      ctl->active[wave] = 1;
+    }
+    __syncthreads();   // the only workgroup barrier of the kernel: nobody scans the slots before they exist
+  }
   int solved = 0;
   // The first problem of every wave is assigned statically (wave w of the launch takes problem w); the shared counter hands
   // out the rest.  4 096 waves popping the same address at launch time serialise in the L2 (~5 ns per atomic = 20-30 us
   // before the last wave has its first problem: 4 % of a C3 launch, visible in the launch timeline).
   const int nwaves = int(gridDim.x) * 4;
-  bool first = true;
+  bool first = true, dry = false;
   for (;;) {  // one work item = one whole problem
     int p = 0;
     if (first) {
       p = int(blockIdx.x) * 4 + wave;
       first = false;
+    } else if (dry) {
+      p = int(P);
     } else {
       if (lane == 0) p = atomicAdd(queue, 1) + nwaves;
       p = __builtin_amdgcn_readfirstlane(p);
     }
-    if (p >= P) break;
+    bool ghost = false;
+    if (p >= P) {
+      // The queue is dry.  A wave of a cooperative model does not leave yet: it looks for a sibling's open Accumulate pass,
+      // takes a chunk ticket of it (DenseRowModel::coop_find) and runs a GHOST problem through the very same state-machine
+      // code — whose single Accumulate call is where the chunk loop lives (DenseRowModel::coop_pass: hipcc tolerates
+      // exactly one MFMA loop per kernel).  That call works the ticket (and the pass's remaining ones) off, then reports
+      // "no residuals", which ends the ghost at once (kSkipped, optimizer.h:372-375) with nothing written anywhere (p < 0);
+      // the wave comes back here for the next ticket until no sibling is active any more.
+      dry = true;
+      if constexpr (ModelCoop<Model>::value) {
+        if (model.coop_K > 1) ghost = model.coop_find(lane);
+      }
+      if (!ghost) break;
+    }
     // Fairness between the waves of a SIMD.  The issue arbiter serves the OLDEST wave first, and a wave keeps its age for
     // the whole (persistent) kernel: the launch timeline shows the oldest wave of each SIMD solving a problem in 0.8 ms
     // while the youngest needs up to 6.9 ms for its first one and is still far from done when the queue runs dry — the
@@ -1105,12 +1303,17 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
       else __builtin_amdgcn_s_setprio(0);
     }
     ++solved;
+    if (ghost) p = 0;
     model.bind(p);
     wave_sync();
-    L.xs[lane] = lane < xd ? X[size_t(p) * xd + lane] : T(0);
+    L.xs[lane] = (lane < xd && !ghost) ? X[size_t(p) * xd + lane] : T(0);
     wave_sync();
     const unsigned long long tl0 = prm_g->timeline ? wall_clock64() : 0ull;
-    lm_solve_problem<T>(model, L, n, lane, (long long)p);
+    lm_solve_problem<T>(model, L, n, lane, ghost ? -1ll : (long long)p);
+    if (ghost) {
+      if (lane == 0) L.st->acc_passes -= 1;   // the ghost's Build streamed nothing of its own
+      continue;
+    }
     if (lane < xd) X[size_t(p) * xd + lane] = L.xs[lane];
     if (prm_g->timeline && lane == 0) { prm_g->timeline[2 * size_t(p)] = tl0; prm_g->timeline[2 * size_t(p) + 1] = wall_clock64(); }
   }
@@ -2030,6 +2233,27 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
           prm.lds_per_wave = (int)pw;
         }
       }
+    }
+  }
+  prm.coop_K = 0;
+  prm.coop_cs = 0;
+  if constexpr (ModelCoop<Model>::value) {
+    prm.coop_K = 1;                       // one chunk = the classic pass, bit for bit
+    prm.coop_cs = (prm.m + 3) / 4;
+    pwg += 256;                           // the control block (the waves' carves are far below the LDS limit of a smaller grid)
+    // Cooperative passes (CoopCtl): on for a SHAPE (never for a batch size or a position in the batch, so that a problem's
+    // bits do not depend on them), when a pass has enough rows to be worth sharing and the chunk total fits the LDL^T
+    // workspace it borrows during a pass.  TOA_COOP=0 switches it off (A/B).
+    const char* env = std::getenv("TOA_COOP");
+    const int steps_total = ((prm.m + 3) / 4);
+    if (!(env && env[0] == '0') && prm.m >= 1024 && Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T)) {
+      int K = 4;                     // chunks per pass (TOA_COOP_K: experiments)
+      if (const char* ek = std::getenv("TOA_COOP_K")) { const int v = std::atoi(ek); if (v >= 2 && v <= 64) K = v; }
+      const int period = 8;          // 8 = DenseRowGram::kDepth * U steps
+      int cs = (steps_total + K - 1) / K;
+      cs = (cs + period - 1) / period * period;
+      prm.coop_cs = cs;
+      prm.coop_K = (steps_total + cs - 1) / cs;
     }
   }
   long long grid = (long long)h->num_cus * wg_per_cu;

@@ -447,7 +447,7 @@ __device__ __forceinline__ void lm_finalize(Model& model, WaveLds<T>& L, const i
   const toa_options& opt = *L.opt;
   const toa_results& res = *L.res;
   // ---- final Hessian, undamped  optimizer.h:313-316, lm.h:157-171
-  if (opt.save_last && res.final_hessian) {
+  if (opt.save_last && res.final_hessian && p >= 0) {
     double* Hout = res.final_hessian + size_t(p) * n * n;
     wave_sync();
     model.write_sym(Hout, n, n, lane);
@@ -457,7 +457,7 @@ __device__ __forceinline__ void lm_finalize(Model& model, WaveLds<T>& L, const i
       Hout[lane * n + lane] = double(d);
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && p >= 0) {   // (p < 0: the ghost problem of a helper wave, lm_fused_kernel)
     res.stop_reason[p] = S.stop;
     res.num_iters[p] = S.num_iters;
     res.final_cost[p] = S.final_cost;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void lm_finalize(Model& model, WaveLds<T>& L, const i
     if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
     if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
   }
-  S.problems++;
+  if (p >= 0) S.problems++;
   wave_sync();
 }
 
