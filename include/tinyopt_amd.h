@@ -340,6 +340,30 @@ int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P
 int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t P, const void* data_dev, void* x_dev,
                const toa_options* options, const toa_results* results, uint64_t* counters_dev);
 
+/* ---- run-time user functors (replaces "pass any callable": `Optimize(x, [](const auto& x) { return r(x); })`,
+ *      include/tinyopt/optimize.h:16-33, optimizers/optimizer.h:145-160, docs/API.md:21-35 — the residual is a C++ template
+ *      the reference differentiates with ceres::Jet when the USER's program is compiled).  A device path cannot take a host
+ *      callable; instead the user hands over the BODY of the residual as C++ source text, written like the reference's
+ *      lambda, generic in its scalar type:
+ *          const S dx = p[0] - x[0];  const S dy = p[1] - x[1];  r[0] = dx * dx + dy * dy - x[2] * x[2];     (tests/circle.cpp:32-68)
+ *      with  S  the scalar type (toa::Jet<T, N> for Accumulate, plain T for the cost-only form: the same text serves both,
+ *      optimize_autodiff.h:91-166),  x[j]  parameter j as an S,  p[k]  the item's data scalars and  h[k]  the problem's header
+ *      scalars as T,  r[q]  the item's residuals; every function of ceres::Jet (jet.h:557-1400: sin, exp, pow, atan2, ...)
+ *      is in scope.  toa_model_compile builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> with hiprtc
+ *      (opened with dlopen on first use; ~2-3 s, once) and loads the code object: no rebuild of the library.
+ *        num_params <= 12 (the register Gram); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
+ *        m = num_items * residuals_per_item residuals per problem.  log_out (optional): the compiler's diagnostics.
+ *        toa_jit_lm_run / toa_jit_accumulate: the contracts of toa_lm_run / toa_accumulate.  The handle's M-estimator
+ *        (toa_set_loss) applies to each item's squared residual norm, as for TOA_MODEL_CIRCLE_FIT. */
+typedef struct toa_jit_model_s* toa_jit_model;
+int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per_item, int scalars_per_item, int header_scalars,
+                      const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
+int toa_model_destroy(toa_jit_model m);
+int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
+                   const toa_options* options, const toa_results* results, uint64_t* counters_dev);
+int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, const void* x_dev,
+                       int want_grad, void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);
+
 /* ---- C1: the result gather of a sharded batch (SURVEY §8(b) export list `gather(handle_group...)`, §8(e)).
  *      Problems are independent (the reference optimises exactly one x per call, docs/API.md:12), so a batch of P_total
  *      problems shards across the GPUs of a node with no data-path communication: one process per GPU, rank g solves the

@@ -286,6 +286,71 @@ struct SE3Reproj : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ> {
       : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ>(ctx, P, 6, 2 * npts, 12, data, size_t(P) * (8 + 5 * size_t(npts))) {}
 };
 
+// A residual supplied as C++ source text at RUN time (toa_model_compile: hiprtc + hipModuleLoad, no rebuild of the library) —
+// the device-side form of `tinyopt::Optimize(x, [](const auto& x) { return r(x); })` (optimize.h:16-33, optimizer.h:145-160).
+// body: generic in its scalar type S; x[j] parameter j, p[k] the item's scalars, h[k] the header scalars, r[q] the residuals:
+//   JitResidual<double> fit(ctx, "const S dx = p[0] - x[0]; const S dy = p[1] - x[1]; r[0] = dx*dx + dy*dy - x[2]*x[2];", 3, 2);
+//   auto out = Optimize(x, fit.bind(P, npts, obs));                                            // tests/circle.cpp:32-68
+template <typename Scalar>
+class JitModel;
+template <typename Scalar>
+class JitResidual {
+ public:
+  JitResidual(const Context& ctx, const std::string& body, int n, int item_scalars, int residuals_per_item = 1, int header_scalars = 0)
+      : ctx_(&ctx), n_(n), kR_(residuals_per_item), kD_(item_scalars), kH_(header_scalars) {
+    std::vector<char> log(1 << 16);
+    const int rc = toa_model_compile(ctx.get(), dtype_of<Scalar>(), n, residuals_per_item, item_scalars, header_scalars, body.c_str(), &h_,
+                                     log.data(), log.size());
+    log_ = log.data();
+    check(rc);
+  }
+  ~JitResidual() { if (h_) (void)toa_model_destroy(h_); }
+  JitResidual(const JitResidual&) = delete;
+  JitResidual& operator=(const JitResidual&) = delete;
+  // data: [P][header_scalars + items * item_scalars] host scalars
+  JitModel<Scalar> bind(int64_t P, int items, const Scalar* data) const { return JitModel<Scalar>(*this, P, items, data); }
+  const std::string& compile_log() const { return log_; }
+  toa_jit_model handle() const { return h_; }
+  const Context& ctx() const { return *ctx_; }
+  int n() const { return n_; }
+  int residuals_per_item() const { return kR_; }
+  int item_scalars() const { return kD_; }
+  int header_scalars() const { return kH_; }
+
+ private:
+  const Context* ctx_;
+  toa_jit_model h_ = nullptr;
+  int n_, kR_, kD_, kH_;
+  std::string log_;
+};
+template <typename Scalar>
+class JitModel : public LossTag {
+ public:
+  JitModel(const JitResidual<Scalar>& res, int64_t P, int items, const Scalar* host)
+      : res_(&res), P_(P), items_(items), data_(res.ctx(), size_t(P) * (res.header_scalars() + size_t(items) * res.item_scalars())) {
+    data_.upload(host);
+  }
+  static constexpr int model_id = -1;
+  int64_t P() const { return P_; }
+  int n() const { return res_->n(); }
+  int m() const { return items_ * res_->residuals_per_item(); }
+  int xdim() const { return res_->n(); }
+  int items() const { return items_; }
+  const Scalar* data() const { return data_.data(); }
+  const Context& ctx() const { return res_->ctx(); }
+  toa_jit_model jit_handle() const { return res_->handle(); }
+
+ private:
+  const JitResidual<Scalar>* res_;
+  int64_t P_;
+  int items_;
+  DeviceBuffer<Scalar> data_;
+};
+namespace detail {
+template <typename C, typename = void> struct is_jit : std::false_type {};
+template <typename C> struct is_jit<C, std::void_t<decltype(std::declval<const C&>().jit_handle())>> : std::true_type {};
+}  // namespace detail
+
 // include/tinyopt/output.h:26-145, one entry per problem.
 struct BatchOutput {
   std::vector<int32_t> stop_reason, num_iters, num_failures, num_consec_failures, final_num_residuals;
@@ -323,7 +388,10 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   const int n = cost.n();
   if (int64_t(x.size()) != P * cost.xdim())
     throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P * (parameters per problem) scalars");
-  if (options.has_host_controls()) return OptimizeWithHostControls(x, cost, options, history);
+  if (options.has_host_controls()) {
+    if constexpr (detail::is_jit<Cost>::value) throw std::invalid_argument("a run-time compiled model runs as one launch per solve: no stop callbacks / time limit");
+    else return OptimizeWithHostControls(x, cost, options, history);
+  }
   const Context& ctx = cost.ctx();
   DeviceBuffer<Scalar> dx(ctx, x.size());
   dx.upload(x.data());
@@ -348,7 +416,10 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   }
   const toa_options pod = options.to_pod();
   apply_loss(cost);
-  check(toa_lm_run(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), &pod, &r, nullptr));
+  if constexpr (detail::is_jit<Cost>::value)
+    check(toa_jit_lm_run(ctx.get(), cost.jit_handle(), cost.items(), P, cost.data(), dx.data(), &pod, &r, nullptr));
+  else
+    check(toa_lm_run(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n, cost.m(), P, cost.data(), dx.data(), &pod, &r, nullptr));
   check(toa_synchronize(ctx.get()));
   dx.download(x.data());
   auto get = [&](auto& vec, const auto& buf) { vec.resize(buf.size()); buf.download(vec.data()); };

@@ -117,6 +117,39 @@ static void circle() {
   REQUIRE(std::abs(std::abs(x[2]) - 2) < 1e-5);
 }
 
+// The same circle fit with the residual handed over as SOURCE TEXT at run time (toa_model_compile: hiprtc, no library
+// rebuild) — the device-side form of tinyopt's "pass any callable" (optimize.h:16-33): same answer, same iteration count
+static void circle_jit() {
+  const int n = 10;
+  std::vector<double> obs(2 * n);
+  double angle = 0;
+  for (int i = 0; i < n; ++i) {
+    obs[2 * i] = 2 + 2 * std::cos(angle);
+    obs[2 * i + 1] = 7 + 2 * std::sin(angle);
+    angle += 2 * 3.14159265358979323846 / (n - 1);
+  }
+  Context ctx(0);
+  JitResidual<double> fit(ctx, "const S dx = p[0] - x[0]; const S dy = p[1] - x[1]; r[0] = dx * dx + dy * dy - x[2] * x[2];", 3, 2);
+  std::vector<double> x{0, 0, 1}, xb{0, 0, 1};
+  Options options;
+  options.lm.damping_init = 1e1;
+  const auto out = Optimize(x, fit.bind(1, n, obs.data()), options);
+  REQUIRE(out.Succeeded(0));
+  REQUIRE(std::abs(x[0] - 2) < 1e-5);
+  REQUIRE(std::abs(x[1] - 7) < 1e-5);
+  REQUIRE(std::abs(std::abs(x[2]) - 2) < 1e-5);
+  CircleFit<double> builtin(ctx, 1, n, obs.data());
+  const auto outb = Optimize(xb, builtin, options);
+  REQUIRE(out.num_iters[0] == outb.num_iters[0] && x[0] == xb[0] && x[1] == xb[1] && x[2] == xb[2]);
+  bool threw = false;
+  try {
+    JitResidual<double> bad(ctx, "r[0] = no_such_function(x[0]);", 1, 1);
+  } catch (const std::exception& e) {
+    threw = std::string(e.what()).find("no_such_function") != std::string::npos;
+  }
+  REQUIRE(threw);
+}
+
 // tests/cov.cpp:20-47 — Gaussian prior with sigma = 4.2: covariance from the final Hessian recovers sigma
 static void prior_cov() {
   Context ctx(0);
@@ -299,6 +332,7 @@ int main() {
   sqrt2<double>();
   sqrt2<float>();
   circle();
+  circle_jit();
   prior_cov();
   run<double>(5, 12, 200, 1e-7);
   run<float>(3, 50, 600, 2e-3);

@@ -1,0 +1,132 @@
+"""Run-time user functors (csrc/jit.hip, `toa_model_compile`): the device-side form of tinyopt's "pass any callable"
+(optimize.h:16-33, optimizer.h:145-160, docs/API.md:21-35).  The residual arrives as C++ source text at RUN time, hiprtc builds
+the fused LM kernel for it and the code object is loaded — libtinyopt_amd.so is not rebuilt.
+
+Done-criterion of the round-2 verdict: the circle fit of tests/circle.cpp:32-68, supplied as source, reproduces
+test_circle_fit_reference_known_answer and the oracle's trajectory."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CIRCLE = "const S dx = p[0] - x[0];\nconst S dy = p[1] - x[1];\nr[0] = dx * dx + dy * dy - x[2] * x[2];"
+
+
+def _circle_obs(P, n, dtype, seed=0):
+    """tests/circle.cpp:20-30: n points on a circle of radius 2 centred at (2, 7) + 1e-5 noise."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0, 2 * np.pi, n)[None, :] + rng.uniform(0, 1, (P, 1))
+    obs = np.stack([2 + 2 * np.cos(ang), 7 + 2 * np.sin(ang)], -1) + 1e-5 * rng.uniform(-1, 1, (P, n, 2))
+    return obs.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_circle_fit_supplied_as_source_at_run_time(ta, oracle, dtype, tdt):
+    """tests/circle.cpp:32-68: x0 = (0, 0, 1), lm.damping_init = 10 -> (2, 7, 2) +- 1e-5, Succeeded — with the residual
+    handed over as text; StopReason / iterations / cost / x equal to the oracle's and BIT-equal to the built-in CircleFit."""
+    P, npts = 7, 10
+    obs = _circle_obs(P, npts, dtype)
+    x0 = np.tile(np.array([0, 0, 1], dtype), (P, 1))
+    o = ta.Options()
+    o.lm.damping_init = 1e1
+    ref = oracle.circle_fit_lm(obs, x0, o.to_pod())
+    fit = ta.JitResidual(CIRCLE, n=3, item_scalars=2, dtype=tdt)
+    assert fit.compile_log == "" or "error" not in fit.compile_log
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, fit.bind(torch.from_numpy(obs).cuda()), o, history=True)
+    torch.cuda.synchronize()
+    xg, stop = x.cpu().numpy(), out.stop_reason.cpu().numpy()
+    assert (stop >= 0).all()
+    tol = 1e-5 if dtype == np.float64 else 2e-4
+    assert np.abs(xg[:, 0] - 2).max() < tol and np.abs(xg[:, 1] - 7).max() < tol and np.abs(np.abs(xg[:, 2]) - 2).max() < tol
+    if dtype == np.float64:
+        assert np.abs(xg - ref["x"]).max() < 1e-8
+        assert np.array_equal(stop, ref["stop"]) and np.array_equal(out.num_iters.cpu().numpy(), ref["iters"])
+        assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-6, atol=1e-18)
+    xb = torch.from_numpy(x0.copy()).cuda()
+    outb = ta.Optimize(xb, ta.CircleFit(torch.from_numpy(obs).cuda()), o, history=True)
+    torch.cuda.synchronize()
+    assert torch.equal(x, xb) and torch.equal(out.errs, outb.errs) and torch.equal(out.num_iters, outb.num_iters)
+
+
+def test_functor_with_header_two_residuals_and_transcendentals(ta):
+    """A residual the library has no built-in for: per problem a header (w, phi), per item (t, y0, y1); two residuals per
+    item through exp / sin / cos / atan2 / pow of the parameters.  (g, H, cost) of the device AD against torch.autograd of
+    the same formula in float64, then a solve that recovers the planted parameters."""
+    body = """
+    const S a = x[0], k = x[1], f = x[2], c = x[3];
+    const S e = exp(-k * p[0]);
+    r[0] = a * e * sin(f * p[0] + h[1]) + c - p[1];
+    r[1] = h[0] * (atan2(a * e * cos(f * p[0] + h[1]), S(1.0) + pow(c, 2)) - p[2]);
+    """
+    P, items = 11, 160
+    rng = np.random.default_rng(5)
+    xs = np.stack([rng.uniform(1.5, 2.5, P), rng.uniform(0.2, 0.6, P), rng.uniform(2.0, 3.0, P), rng.uniform(-0.5, 0.5, P)], axis=1)
+    hdr = np.stack([rng.uniform(0.5, 1.5, P), rng.uniform(-1, 1, P)], axis=1)
+    t = np.tile(np.linspace(0.0, 3.0, items), (P, 1))
+
+    def model_np(xv):
+        a, k, f, c = (xv[:, i:i + 1] for i in range(4))
+        e = np.exp(-k * t)
+        y0 = a * e * np.sin(f * t + hdr[:, 1:2]) + c
+        y1 = np.arctan2(a * e * np.cos(f * t + hdr[:, 1:2]), 1.0 + c ** 2)
+        return y0, y1
+    y0, y1 = model_np(xs)
+    y0 = y0 + 1e-3 * rng.uniform(-1, 1, y0.shape)
+    y1 = y1 + 1e-3 * rng.uniform(-1, 1, y1.shape)
+    data = np.stack([t, y0, y1], axis=2)
+    res = ta.JitResidual(body, n=4, item_scalars=3, residuals_per_item=2, header_scalars=2, dtype=torch.float64)
+    model = res.bind(torch.from_numpy(data).cuda(), torch.from_numpy(hdr).cuda())
+    x0 = xs + 0.05 * rng.uniform(-1, 1, xs.shape)
+    # ---- Accumulate against autograd
+    xt = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    tt, h0, h1 = torch.from_numpy(t), torch.from_numpy(hdr[:, 0:1]), torch.from_numpy(hdr[:, 1:2])
+
+    def residuals(xv):
+        a, k, f, c = (xv[:, i:i + 1] for i in range(4))
+        e = torch.exp(-k * tt)
+        r0 = a * e * torch.sin(f * tt + h1) + c - torch.from_numpy(y0)
+        r1 = h0 * (torch.atan2(a * e * torch.cos(f * tt + h1), 1.0 + c ** 2) - torch.from_numpy(y1))
+        return torch.stack([r0, r1], dim=2).reshape(P, -1)
+    rr = residuals(xt)
+    J = torch.stack([torch.autograd.grad(rr[:, i].sum(), xt, retain_graph=True)[0] for i in range(rr.shape[1])], dim=1)  # [P, m, n]
+    g_ref = torch.einsum("pmn,pm->pn", J, rr.detach()).numpy()
+    H_ref = torch.einsum("pmn,pmk->pnk", J, J).numpy()
+    c_ref = (rr.detach() ** 2).sum(dim=1).numpy()
+    g, H, c, nres = ta.accumulate(model, torch.from_numpy(x0).cuda())
+    torch.cuda.synchronize()
+    assert (nres.cpu().numpy() == 2 * items).all()
+    assert np.allclose(g.cpu().numpy(), g_ref, rtol=1e-10, atol=1e-10 * np.abs(g_ref).max())
+    assert np.allclose(H.cpu().numpy(), H_ref, rtol=1e-10, atol=1e-10 * np.abs(H_ref).max())
+    assert np.allclose(c.cpu().numpy(), c_ref, rtol=1e-12)
+    c0 = ta.accumulate(model, torch.from_numpy(x0).cuda(), want_grad=False)[2]
+    assert np.allclose(c0.cpu().numpy(), c_ref, rtol=1e-12)
+    # ---- and the solve
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, ta.Options())
+    torch.cuda.synchronize()
+    assert bool((out.stop_reason >= 0).all())
+    assert np.abs(x.cpu().numpy() - xs).max() < 5e-3
+    # a Huber loss on each item's squared norm (toa_set_loss applies to run-time models like to the built-in Jet families)
+    xl = torch.from_numpy(x0.copy()).cuda()
+    outl = ta.Optimize(xl, model.with_loss("huber", 0.05), ta.Options())
+    torch.cuda.synchronize()
+    assert bool((outl.stop_reason >= 0).all()) and np.abs(xl.cpu().numpy() - xs).max() < 5e-3
+    assert float(outl.final_inlier_ratio.min()) > 0.9
+
+
+def test_compile_errors_and_limits(ta):
+    with pytest.raises(ta.ToaError) as e:
+        ta.JitResidual("r[0] = undefined_symbol(x[0]);", n=1, item_scalars=1)
+    assert "undefined_symbol" in str(e.value)                       # the compiler's diagnostic reaches the caller
+    with pytest.raises(ta.ToaError):
+        ta.JitResidual("r[0] = x[0];", n=13, item_scalars=1)           # the register Gram stops at 12 parameters
+    res = ta.JitResidual("r[0] = x[0] * x[0] - p[0];", n=1, item_scalars=1)     # sqrt: the smallest possible model
+    data = torch.full((3, 1, 1), 2.0, dtype=torch.float64, device="cuda")
+    x = torch.tensor([[1.0], [-0.3], [3.2]], dtype=torch.float64, device="cuda")
+    o = ta.Options()
+    o.max_iters, o.max_consec_failures = 20, 0                                  # tests/sqrt2.cpp:106-112
+    out = ta.Optimize(x, res.bind(data), o)
+    torch.cuda.synchronize()
+    assert bool((out.stop_reason >= 1).all()) and float((x.abs() - 2 ** 0.5).abs().max()) < 1e-5       # tests/sqrt2.cpp:55

@@ -343,6 +343,70 @@ class CircleFit(_LossMixin):
         return self.m * 2 * self.packed.element_size()
 
 
+class JitResidual:
+    """A residual the library has never seen, compiled at run time: the device-side form of tinyopt's "pass any callable"
+    (``Optimize(x, [](const auto& x) { return r(x); })``, optimize.h:16-33, optimizer.h:145-160, docs/API.md:21-35).
+
+    ``body`` is the BODY of the residual as C++ source text, written like the reference's lambda and generic in its scalar
+    type ``S`` (instantiated on Jet<T, n> for Accumulate — forward-mode AD, optimize_autodiff.h:91-166 — and on plain T for
+    the cost-only form): ``x[j]`` parameter j (an S), ``p[k]`` the item's data scalars, ``h[k]`` the problem's header
+    scalars, ``r[q]`` the item's residuals; every ceres::Jet function (sin, exp, pow, atan2, ...) is in scope.  Example, the
+    circle fit of tests/circle.cpp:32-68::
+
+        fit = ta.JitResidual("const S dx = p[0] - x[0]; const S dy = p[1] - x[1]; r[0] = dx*dx + dy*dy - x[2]*x[2];",
+                             n=3, item_scalars=2, dtype=torch.float64)
+        out = ta.Optimize(x, fit.bind(points), options)        # points: [P, items, 2] on the GPU
+
+    hiprtc builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> (2-3 s, once per JitResidual) and the
+    code object is loaded into the process: no rebuild of libtinyopt_amd.so.  n <= 12."""
+
+    def __init__(self, body: str, n: int, item_scalars: int, residuals_per_item: int = 1, header_scalars: int = 0,
+                 dtype: torch.dtype = torch.float64, ctx: Optional["Context"] = None):
+        self.ctx = ctx or default_context()
+        self.n, self.kR, self.kD, self.kH, self.dtype = int(n), int(residuals_per_item), int(item_scalars), int(header_scalars), dtype
+        self._h = C.c_void_p()
+        log = C.create_string_buffer(1 << 16)
+        rc = self.ctx.lib.toa_model_compile(self.ctx.h, _dtype_code(dtype), self.n, self.kR, self.kD, self.kH, body.encode(),
+                                            C.byref(self._h), log, len(log))
+        self.compile_log = log.value.decode(errors="replace")
+        check(rc)
+
+    def bind(self, data: torch.Tensor, header: Optional[torch.Tensor] = None) -> "JitModel":
+        """data: [P, items, item_scalars] (and header: [P, header_scalars]) on the GPU -> the ``cost`` of Optimize(x, cost)."""
+        return JitModel(self, data, header)
+
+    def close(self) -> None:
+        if self._h:
+            self.ctx.lib.toa_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class JitModel(_LossMixin):
+    """A JitResidual bound to its problem data ([P][header | items x item_scalars], the layout of the built-in Jet families)."""
+    model_id = None
+
+    def __init__(self, res: JitResidual, data: torch.Tensor, header: Optional[torch.Tensor] = None):
+        assert data.dim() == 3 and data.shape[2] == res.kD and data.is_cuda and data.dtype == res.dtype
+        self.res = res
+        self.P, self.items, self.n, self.dtype = data.shape[0], data.shape[1], res.n, res.dtype
+        self.m = self.items * res.kR
+        flat = data.reshape(self.P, -1)
+        if res.kH:
+            assert header is not None and header.shape == (self.P, res.kH) and header.dtype == res.dtype
+            flat = torch.cat([header, flat], dim=1)
+        self.packed = flat.contiguous()
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return self.packed.shape[1] * self.packed.element_size()
+
+
 class SE3Prior:
     """SE3 pose prior — the reference's own manifold test (tests/sophus.cpp:26-44): residual(x) = log(prior_inv * x),
     differentiated on the device by dual numbers over the right perturbation (optimize_autodiff.h:48-77, sophus.h:24-26).
@@ -477,7 +541,7 @@ class DenseRowNatural(_LossMixin):
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
-_MODELS = (TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural, BundleAdjustment)
+_MODELS = (JitModel, TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural, BundleAdjustment)
 
 
 @dataclass
@@ -599,6 +663,19 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
         _apply_loss(ctx, cost)   # no M-estimator here: clears whatever an earlier launch left on the handle
         check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
                                  C.byref(pod), C.byref(res), out.counters.data_ptr()))
+        return out
+    if isinstance(cost, JitModel):
+        if options.has_host_controls() or splits is not None:
+            raise ValueError("a run-time compiled model runs as one launch per solve: no stop callbacks / splits")
+        pod = options.to_pod()
+        if out is None:
+            out = _alloc_output(P, n, options, history, x.device)
+        elif zero_counters:
+            out.counters.zero_()
+        res = _results_pod(out)
+        _apply_loss(ctx, cost)
+        check(ctx.lib.toa_jit_lm_run(ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(), C.byref(pod),
+                                     C.byref(res), out.counters.data_ptr()))
         return out
     if options.has_host_controls():
         if splits is not None or out is not None:
@@ -746,6 +823,11 @@ def accumulate(cost, x: torch.Tensor, want_grad: bool = True, ctx: Optional[Cont
     c = torch.zeros(P, dtype=torch.float64, device=dev)
     nres = torch.zeros(P, dtype=torch.int32, device=dev)
     _apply_loss(ctx, cost)
+    if isinstance(cost, JitModel):
+        check(ctx.lib.toa_jit_accumulate(ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(), int(want_grad),
+                                         g.data_ptr() if want_grad else None, H.data_ptr() if want_grad else None,
+                                         c.data_ptr(), nres.data_ptr()))
+        return g, H, c, nres
     check(ctx.lib.toa_accumulate(ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
                                  x.data_ptr(), int(want_grad), g.data_ptr() if want_grad else None,
                                  H.data_ptr() if want_grad else None, c.data_ptr(), nres.data_ptr()))

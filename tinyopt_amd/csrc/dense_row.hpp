@@ -1345,18 +1345,19 @@ struct DenseRowGram {
   template <int t>
   __device__ __forceinline__ void lds_read_tile(unsigned a0) {
     if constexpr (sizeof(T) == 4) {
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(acc[t]) : "v"(a0), "n"(t * 64 * 16));
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(acc[t]) : "v"(a0), "n"(t * 64 * 16) : "memory");
     } else {
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[0]) : "v"(a0), "n"(t * 64 * 32));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[1]) : "v"(a0), "n"(t * 64 * 32 + 16));
+      // fp64: a tile is 8 dwords, read as two halves through a cast of the register variable
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[0]) : "v"(a0), "n"(t * 64 * 32) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[1]) : "v"(a0), "n"(t * 64 * 32 + 16) : "memory");
     }
     if constexpr (t + 1 < NT) lds_read_tile<t + 1>(a0);
   }
   template <int t, int N, int BASE>
   static __device__ __forceinline__ void lds_read_thin(T* dst, unsigned a1) {
     if constexpr (t < N) {
-      if constexpr (sizeof(T) == 4) asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 4));
-      else asm volatile("ds_read_b64 %0, %1 offset:%2" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 8));
+      if constexpr (sizeof(T) == 4) asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 4) : "memory");
+      else asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+v"(dst[t]) : "v"(a1), "n"((BASE + t) * 64 * 8) : "memory");
       lds_read_thin<t + 1, N, BASE>(dst, a1);
     }
   }
@@ -1364,7 +1365,10 @@ struct DenseRowGram {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     // LDS byte address of this lane's first element; the ds_read destinations are IN-OUT operands (tied to the registers the
-    // chunk loop used), and nothing reads them before the wait at the end names them all again
+    // chunk loop used).  Every statement waits for its own data: an LDS read completes asynchronously, hipcc does not know
+    // that an asm statement's output is still in flight, and any register copy it places between two statements would read
+    // stale data (seen in fp64, whose tiles are read as two halves through a cast: run-to-run differences).  The ~20 serial
+    // LDS round trips per pass are hidden by the other waves of the SIMD.
     const unsigned a0 = unsigned(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)(slot))) + unsigned(lane) * unsigned(sizeof(Acc));
     lds_read_tile<0>(a0);
     if (THIN) {

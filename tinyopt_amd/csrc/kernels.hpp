@@ -10,13 +10,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#ifndef __HIPCC_RTC__
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
-#include <type_traits>
 #include <vector>
+#endif
 
 #include "../../include/tinyopt_amd.h"
 #include "dense_row.hpp"
@@ -2027,6 +2029,9 @@ __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* _
 
 }  // namespace toa
 
+// Everything below is host code (launchers, the handle).  A run-time compiled model (toa_model_compile: hiprtc of a
+// JetModel<T, UserFunctor> instantiation, csrc/jit.hip) includes this header for the device code above only.
+#ifndef __HIPCC_RTC__
 // ================================================================================================
 // host side shared by the translation units
 // ================================================================================================
@@ -2569,3 +2574,4 @@ int toa_inst_wide(int dtag, int model, int nbm, int thin, toa_handle h, const to
 int toa_inst_inv_cov(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, void* C, int32_t* ok);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok);
+#endif  // !__HIPCC_RTC__
