@@ -248,7 +248,10 @@ int toa_set_loss(toa_handle h, int kind, double th2);
  *      Jet<T, 2> seeded on (a, b).  fn: 0 + 1 - 2 * 3 / 4 abs 5 log 6 exp 7 sqrt 8 cos 9 sin 10 tan 11 atan 12 tanh
  *      13 atan2(a,b) 14 pow(a,2.5) 15 acos 16 asin 17 sinh 18 cosh 19 cbrt 20 exp2 21 log2 22 log10 23 log1p 24 expm1
  *      25 hypot(a,b) 26 fmax 27 fmin 28 erf 29 erfc 30 pow(a,b) 31 pow(scalar a, b) 32 fma(a,b,a) 33 fdim 34 floor 35 ceil
- *      36 norm 37 copysign(a,b) 38 mixed scalar/Jet arithmetic 2/a + a/4 - 3b  39 hypot(a, b, a*b).  a, b: [count] of T;
+ *      36 norm 37 copysign(a,b) 38 mixed scalar/Jet arithmetic 2/a + a/4 - 3b  39 hypot(a, b, a*b)
+ *      40 BesselJ0 41 BesselJ1 42 BesselJn(3, a) 43 cyl_bessel_j(0, a) + cyl_bessel_j(2, b) 44 lerp(a, b, a*b) 45 midpoint(a, b)
+ *      46 the classification / comparison functions (isfinite isinf isnan isnormal signbit isless ... fpclassify) of (a, b) as
+ *      a bit mask in the value (jet.h:958-1218).  a, b: [count] of T;
  *      out: [count][3] of T. */
 int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a_dev, const void* b_dev, void* out_dev);
 
@@ -339,6 +342,23 @@ int toa_lm_run_split(toa_handle h, int model, int dtype, int n, int m, int64_t P
  *      results->final_hessian is not written (the block Hessian is not exported). */
 int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t P, const void* data_dev, void* x_dev,
                const toa_options* options, const toa_results* results, uint64_t* counters_dev);
+
+/* ---- bundle adjustment with VISIBILITY LISTS: tens to hundreds of cameras, each point observed by a few of them — the shape
+ *      Eigen's SimplicialLDLT path exists for (math.h:266-277; README.md:30,165-167 "sparse is slow").  Same unknowns, update
+ *      rules, state machine, StopReasons and Output fields as toa_ba_run; the observations arrive as a LIST instead of a dense
+ *      C x N mask, and the reduced camera system (6 C unknowns, in HBM) is solved by the workgroup LDL^T up to 128 unknowns and
+ *      by rocSOLVER's batched Cholesky (potrf + potrs, opened with dlopen) beyond — up to 682 cameras.  A pipeline of small
+ *      kernels per Build + Solve attempt (csrc/ba_schur.hip, "bl_*"); every sum has a fixed order.  The host reads one integer
+ *      back per pass (it blocks until the solve is done; not graph-capturable), which is also where max_duration_ms is
+ *      honoured: > 0 ends every scene still running with kTimedOut once the launches' device time exceeds it
+ *      (Options::max_duration_ms, optimizer.h:302-305).
+ *        intr_dev:    [P][4] of T = f cx cy 0
+ *        obs_cam_dev, obs_pt_dev: [P][num_obs] int32, SORTED by (point, camera), each pair at most once (a scene whose list is
+ *                     malformed ends with kSkipped); obs_uv_dev: [P][num_obs][2] of T (pixels)
+ *        x_dev:       [P][12 C + 3 N] as for toa_ba_run, updated in place. */
+int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, int num_obs, int64_t P, const void* intr_dev,
+                     const int32_t* obs_cam_dev, const int32_t* obs_pt_dev, const void* obs_uv_dev, void* x_dev,
+                     const toa_options* options, const toa_results* results, uint64_t* counters_dev, double max_duration_ms);
 
 /* ---- run-time user functors (replaces "pass any callable": `Optimize(x, [](const auto& x) { return r(x); })`,
  *      include/tinyopt/optimize.h:16-33, optimizers/optimizer.h:145-160, docs/API.md:21-35 — the residual is a C++ template

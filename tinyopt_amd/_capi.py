@@ -96,6 +96,8 @@ PROTOTYPES = {
     "toa_inv_cov": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "toa_lm_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
                              C.POINTER(ToaResults), _P]),
+    "toa_ba_lists_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(ToaOptions),
+                                   C.POINTER(ToaResults), _P, C.c_double]),
     "toa_model_compile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "toa_model_destroy": (C.c_int, [_P]),
     "toa_jit_lm_run": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),

@@ -343,6 +343,47 @@ class CircleFit(_LossMixin):
         return self.m * 2 * self.packed.element_size()
 
 
+class BundleAdjustmentLists:
+    """Bundle adjustment with VISIBILITY LISTS (`toa_ba_lists_run`): tens to hundreds of SE3 cameras, each point observed by a
+    few of them — what the reference would hand to Eigen's SimplicialLDLT (math.h:266-277; README.md:30,165-167).  Same x as
+    ``BundleAdjustment`` ([P, 12 C + 3 N]); the observations are a list sorted by (point, camera):
+    intr [P, 4] = (f, cx, cy, 0), obs_cam / obs_pt [P, M] int32, obs_uv [P, M, 2].  ``Options.max_duration_ms`` is honoured."""
+    model_id = None
+
+    def __init__(self, intr: torch.Tensor, obs_cam: torch.Tensor, obs_pt: torch.Tensor, obs_uv: torch.Tensor, ncam: int, npts: int):
+        assert intr.dim() == 2 and intr.shape[1] == 4 and intr.is_cuda
+        P, M = obs_cam.shape
+        assert obs_pt.shape == (P, M) and obs_uv.shape == (P, M, 2) and intr.shape[0] == P
+        assert obs_cam.dtype == torch.int32 and obs_pt.dtype == torch.int32 and obs_uv.dtype == intr.dtype
+        self.P, self.ncam, self.npts, self.nobs, self.dtype = P, int(ncam), int(npts), M, intr.dtype
+        self.n, self.m, self.xdim = 6 * self.ncam + 3 * self.npts, 2 * M, 12 * self.ncam + 3 * self.npts
+        self.intr, self.obs_cam, self.obs_pt, self.obs_uv = intr.contiguous(), obs_cam.contiguous(), obs_pt.contiguous(), obs_uv.contiguous()
+
+    @staticmethod
+    def from_dense(data: torch.Tensor, ncam: int, npts: int) -> "BundleAdjustmentLists":
+        """From ``BundleAdjustment``'s dense layout [P, 8 + 3 C N] = [f cx cy 0.. | uv (C, N, 2) | vis (C, N)]; every scene must
+        have the same number of visible observations."""
+        P = data.shape[0]
+        uv = data[:, 8:8 + 2 * ncam * npts].reshape(P, ncam, npts, 2)
+        vis = data[:, 8 + 2 * ncam * npts:].reshape(P, ncam, npts) != 0
+        cams, pts, uvs = [], [], []
+        for p in range(P):
+            v = vis[p].t().contiguous()                    # [N, C]: point-major => sorted by (point, camera)
+            idx = v.nonzero(as_tuple=False)
+            pts.append(idx[:, 0].to(torch.int32))
+            cams.append(idx[:, 1].to(torch.int32))
+            uvs.append(uv[p].permute(1, 0, 2)[v])
+        if len({int(t.shape[0]) for t in pts}) != 1:
+            raise ValueError("every scene must have the same number of observations")
+        intr = torch.zeros(P, 4, dtype=data.dtype, device=data.device)
+        intr[:, :3] = data[:, :3]
+        return BundleAdjustmentLists(intr, torch.stack(cams), torch.stack(pts), torch.stack(uvs), ncam, npts)
+
+    @property
+    def algorithmic_bytes_per_pass(self) -> int:
+        return self.nobs * (2 * self.obs_uv.element_size() + 8) + self.xdim * self.obs_uv.element_size()
+
+
 class JitResidual:
     """A residual the library has never seen, compiled at run time: the device-side form of tinyopt's "pass any callable"
     (``Optimize(x, [](const auto& x) { return r(x); })``, optimize.h:16-33, optimizer.h:145-160, docs/API.md:21-35).
@@ -541,7 +582,7 @@ class DenseRowNatural(_LossMixin):
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
-_MODELS = (JitModel, TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural, BundleAdjustment)
+_MODELS = (BundleAdjustmentLists, JitModel, TestFn, MahaPrior, SE3Prior, DenseRow, GaussianPrior, Sqrt2, SE3Reproj, CircleFit, DenseRowAD6, DenseRowAD, DenseRowNatural, BundleAdjustment)
 
 
 @dataclass
@@ -663,6 +704,24 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
         _apply_loss(ctx, cost)   # no M-estimator here: clears whatever an earlier launch left on the handle
         check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
                                  C.byref(pod), C.byref(res), out.counters.data_ptr()))
+        return out
+    if isinstance(cost, BundleAdjustmentLists):
+        if options.stop_callback is not None or options.stop_callback2 is not None or splits is not None:
+            raise ValueError("BundleAdjustmentLists: no stop callbacks / splits (max_duration_ms is honoured)")
+        pod = options.to_pod()
+        pod.save_last = 0
+        if out is None:
+            import copy
+            o2 = copy.deepcopy(options)
+            o2.hessian.save_last = False
+            out = _alloc_output(P, 1, o2, history, x.device)
+        elif zero_counters:
+            out.counters.zero_()
+        res = _results_pod(out)
+        _apply_loss(ctx, cost)
+        check(ctx.lib.toa_ba_lists_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, cost.nobs, P, cost.intr.data_ptr(),
+                                       cost.obs_cam.data_ptr(), cost.obs_pt.data_ptr(), cost.obs_uv.data_ptr(), x.data_ptr(),
+                                       C.byref(pod), C.byref(res), out.counters.data_ptr(), float(options.max_duration_ms or 0.0)))
         return out
     if isinstance(cost, JitModel):
         if options.has_host_controls() or splits is not None:

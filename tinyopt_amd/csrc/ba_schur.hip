@@ -782,6 +782,735 @@ int launch_ba_any(toa_handle h, BaParams& prm) {
   return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: no kernel for this camera count");
 }
 
+
+// =====================================================================================================================
+// Bundle adjustment with VISIBILITY LISTS (round 3): tens to hundreds of cameras, each point seen by a few of them.
+//
+// The one-workgroup kernel above keeps the whole reduced camera system (6C <= 60 unknowns) of a scene in LDS and walks a
+// dense C x N visibility mask.  A real multi-pose problem is the opposite shape — C in the tens or hundreds, N in the
+// thousands, every point observed by a handful of cameras (the structure Eigen's SimplicialLDLT exists for, math.h:266-277;
+// README.md:30,165-167) — so this path takes the observations as a LIST and is a pipeline of small kernels per Build + Solve
+// attempt, with the reduced camera system S (6C x 6C) in HBM:
+//
+//   bl_obs      thread / observation   r, J_c (2 x 6), J_p (2 x 3) at the current x (build), r^2 (always)
+//   bl_point    thread / point         V_j = sum J_p^T J_p, g_pj = sum J_p^T r over the point's observations, in list order
+//   bl_cam      workgroup / camera     U_c = sum J_c^T J_c, g_c = sum J_c^T r over the camera's observations, fixed-order fold
+//   bl_build    workgroup / scene      cost, validity, clipping, diagonal check, Marquardt scale (lm.h:59-120)
+//   bl_psolve   thread / point         damp V_j, V_j^-1 (Cholesky), q_j = V_j^-1 g_pj
+//   bl_schur    workgroup / camera c   block row c of  S = U - sum_j W_cj V_j^-1 W_c'j^T  and of  g_c - W V^-1 g_p : thread c'
+//                                      owns block (c, c'), the camera's observations are walked in order (no atomics)
+//   solve       toa_large_solve        S dc = -(g_c - W V^-1 g_p): workgroup LDL^T up to 128 unknowns, rocSOLVER potrf beyond
+//   bl_back     thread / point         dp_j = -V_j^-1 (g_pj + sum W_ij^T dc), |dx|^2, |g|^2 partials
+//   bl_step     workgroup / scene      the rest of Step + the loop body of OptimizeAcc (optimizer.h:266-310, 370-539): the same
+//                                      scalar state machine as every other path (lm_judge_core, lm_good_step / lm_bad_step)
+//   bl_update   thread / pose, point   x (+)= dx or the roll-back (sophus.h:24-26, traits.h:184-190)
+//
+// W_ij = J_c^T J_p is never stored: every site contracts through the 2-vector J_c dc / the 2 x 3 J_p instead (18 values
+// per observation less HBM traffic).  Every sum has a fixed order: results are bit-reproducible and a scene solved alone
+// equals its row in a batch.  The host reads ONE integer back per pass (is any scene still running), which is also where
+// max_duration_ms is honoured (kTimedOut, optimizer.h:302-305).
+// Observations: sorted by (point, camera), each pair at most once.
+}  // namespace toa
+int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+namespace toa {
+struct BlParams {
+  const void* intr;           // [P][4]: f cx cy 0
+  const int* obs_cam;         // [P][M]
+  const int* obs_pt;          // [P][M]
+  const void* obs_uv;         // [P][M][2]
+  void* x;                    // [P][12 C + 3 N]
+  void* work;                 // per scene: see BlWork
+  int* iwork;                 // per scene: pt_start [N + 1], cam_start [C + 1], cam_order [M], flags [16]
+  long long P;
+  int C, N, M;
+  toa_options opt;
+  toa_results res;
+  unsigned long long* counters;
+  int* any_active;            // one int for the host
+  void* Sall;                 // [P][6C][6C] reduced camera systems, [P][6C] right-hand sides and solutions: contiguous over the
+  void* rhsall;               // batch so that ONE call of the batched solver serves every scene
+  void* dcall;
+};
+
+template <typename T>
+struct BlWork {  // element offsets into a scene's scratch block (T); obs arrays are component-major ([k][M]) for coalescing
+  size_t Jc, Jp, r, r2, ptcost, Vd, Voff, gp, Vinv, q, dp, ldp, U, gc, Ud, ldc, pd2, pg2, state, total;
+  __host__ __device__ BlWork(int C, int N, int M) {
+    size_t o = 0;
+    const size_t n = size_t(6) * C;
+    auto take = [&](size_t k) { const size_t at = o; o += (k + 7) & ~size_t(7); return at; };
+    Jc = take(size_t(12) * M); Jp = take(size_t(6) * M); r = take(size_t(2) * M); r2 = take(M);
+    ptcost = take(N); Vd = take(size_t(3) * N); Voff = take(size_t(3) * N); gp = take(size_t(3) * N); Vinv = take(size_t(6) * N);
+    q = take(size_t(3) * N); dp = take(size_t(3) * N); ldp = take(size_t(3) * N);
+    U = take(size_t(36) * C); gc = take(n); Ud = take(n); ldc = take(n);
+    pd2 = take(N); pg2 = take(N);
+    state = take((sizeof(LmState<T>) + sizeof(T) - 1) / sizeof(T) + 8);
+    total = o;
+  }
+};
+struct BlIdx {  // int offsets into a scene's index block
+  size_t pt_start, cam_start, cam_order, flags, total;
+  __host__ __device__ BlIdx(int C, int N, int M) {
+    size_t o = 0;
+    pt_start = o; o += size_t(N) + 1;
+    cam_start = o; o += size_t(C) + 1;
+    cam_order = o; o += size_t(M);
+    flags = o; o += 16;   // [0] continue, [1] do_acc of the NEXT pass, [2] action, [3] built, [4] bad points, [5] solve ok (int32 from the solver)
+    total = (o + 15) & ~size_t(15);
+  }
+};
+
+// index structures of a scene, by ONE thread (setup, once per solve: O(M + N + C))
+__global__ void bl_index_kernel(const BlParams* __restrict__ prm) {
+  if (threadIdx.x != 0) return;
+  const long long p = blockIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlIdx ix(C, N, M);
+  int* iw = prm->iwork + size_t(p) * ix.total;
+  const int* oc = prm->obs_cam + size_t(p) * M;
+  const int* op = prm->obs_pt + size_t(p) * M;
+  int* ps = iw + ix.pt_start;
+  int* cs = iw + ix.cam_start;
+  int* co = iw + ix.cam_order;
+  int j = 0, bad = 0;
+  for (int i = 0; i < M; ++i) {
+    const int pt = op[i], cm = oc[i];
+    if (pt < 0 || pt >= N || cm < 0 || cm >= C) { bad = 1; break; }
+    if (i > 0 && (op[i - 1] > pt || (op[i - 1] == pt && oc[i - 1] >= cm))) { bad = 1; break; }   // sorted by (point, camera), no duplicates
+    while (j <= pt) ps[j++] = i;
+  }
+  while (j <= N) ps[j++] = M;
+  for (int c = 0; c <= C; ++c) cs[c] = 0;
+  if (!bad) {
+    for (int i = 0; i < M; ++i) cs[oc[i] + 1]++;
+    for (int c = 0; c < C; ++c) cs[c + 1] += cs[c];
+    // stable fill (a camera's observations in increasing point order); cs[] is advanced and then restored
+    for (int i = 0; i < M; ++i) co[cs[oc[i]]++] = i;
+    for (int c = C; c > 0; --c) cs[c] = cs[c - 1];
+    cs[0] = 0;
+  }
+  int* fl = iw + ix.flags;
+  for (int i = 0; i < 16; ++i) fl[i] = 0;
+  fl[0] = 1; fl[1] = 1;
+  fl[6] = bad;   // malformed observation list: the scene is skipped with kSkipped (nothing to optimise safely)
+}
+
+template <typename T>
+__device__ __forceinline__ LmState<T>* bl_state(const BlParams* prm, const BlWork<T>& wk, long long p) {
+  return reinterpret_cast<LmState<T>*>(static_cast<T*>(prm->work) + size_t(p) * wk.total + wk.state);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) bl_init_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.x;
+  const BlWork<T> wk(prm->C, prm->N, prm->M);
+  const BlIdx ix(prm->C, prm->N, prm->M);
+  LmState<T>& S = *bl_state<T>(prm, wk, p);
+  if (threadIdx.x == 0) {
+    const toa_options& opt = prm->opt;
+    S.lambda = opt.damping_init; S.prev_lambda = 0; S.bad_factor = opt.bad_factor; S.rebuild = 1;
+    S.final_cost = kDblMax; S.final_nres = 0; S.final_ninl = 0; S.cost_ninl = 0; S.final_rerr = kDblMax;
+    S.stop = TOA_STOP_NONE; S.num_iters = 0; S.num_failures = 0; S.num_consec = 0;
+    S.cost_val = 0; S.cost_nres = 0;
+    S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
+    S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
+    S.acc_passes = 0; S.eval_passes = 0; S.solves = 0; S.problems = 0;
+    int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+    if (fl[6]) {   // malformed observation list: nothing is optimised, the Output of an untouched problem with kSkipped
+      S.stop = TOA_STOP_SKIPPED;
+      fl[0] = 0;
+      const toa_results& res = prm->res;
+      res.stop_reason[p] = TOA_STOP_SKIPPED;
+      res.num_iters[p] = 0;
+      res.final_cost[p] = kDblMax;
+      if (res.num_failures) res.num_failures[p] = 0;
+      if (res.num_consec_failures) res.num_consec_failures[p] = 0;
+      if (res.final_num_residuals) res.final_num_residuals[p] = 0;
+      if (res.final_rerr_dec) res.final_rerr_dec[p] = kDblMax;
+      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+      if (prm->counters) atomicAdd(&prm->counters[3], 1ull);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_obs_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  if (!fl[0]) return;
+  const bool do_acc = fl[1] != 0;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const T* intr = static_cast<const T*>(prm->intr) + size_t(p) * 4;
+  const T* X = static_cast<const T*>(prm->x) + size_t(p) * (size_t(12) * C + size_t(3) * N);
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  const int cm = prm->obs_cam[size_t(p) * M + i], pt = prm->obs_pt[size_t(p) * M + i];
+  const T* uv = static_cast<const T*>(prm->obs_uv) + (size_t(p) * M + i) * 2;
+  T Pm[12], q[3], r[2];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Pm[k] = X[12 * cm + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = X[size_t(12) * C + size_t(3) * pt + k];
+  if (do_acc) {
+    T Jc[2][6], Jp[2][3];
+    ba_obs<T, true>(Pm, q, intr[0], intr[1], intr[2], uv[0], uv[1], r, Jc, Jp);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[wk.Jc + size_t(6 * a + k) * M + i] = Jc[a][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w[wk.Jp + size_t(3 * a + k) * M + i] = Jp[a][k];
+      w[wk.r + size_t(a) * M + i] = r[a];
+    }
+  } else {
+    ba_obs<T, false>(Pm, q, intr[0], intr[1], intr[2], uv[0], uv[1], r, nullptr, nullptr);
+  }
+  w[wk.r2 + i] = r[0] * r[0] + r[1] * r[1];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* iw = prm->iwork + size_t(p) * ix.total;
+  if (!iw[ix.flags + 0]) return;
+  const bool do_acc = iw[ix.flags + 1] != 0;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  const int i0 = iw[ix.pt_start + j], i1 = iw[ix.pt_start + j + 1];
+  T cost = 0;
+  T v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int i = i0; i < i1; ++i) {
+    cost += w[wk.r2 + i];
+    if (do_acc) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const T j0 = w[wk.Jp + size_t(3 * a) * M + i], j1 = w[wk.Jp + size_t(3 * a + 1) * M + i], j2 = w[wk.Jp + size_t(3 * a + 2) * M + i];
+        const T ra = w[wk.r + size_t(a) * M + i];
+        v[0] += j0 * j0; v[1] += j1 * j1; v[2] += j2 * j2; v[3] += j0 * j1; v[4] += j0 * j2; v[5] += j1 * j2;
+        g[0] += j0 * ra; g[1] += j1 * ra; g[2] += j2 * ra;
+      }
+    }
+  }
+  w[wk.ptcost + j] = cost;
+  if (do_acc) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w[wk.Vd + 3 * j + k] = v[k]; w[wk.Voff + 3 * j + k] = v[3 + k]; w[wk.gp + 3 * j + k] = g[k]; }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_cam_kernel(const BlParams* __restrict__ prm) {
+  __shared__ T red[4][32];
+  const long long p = blockIdx.y;
+  const int c = blockIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* iw = prm->iwork + size_t(p) * ix.total;
+  if (!iw[ix.flags + 0] || !iw[ix.flags + 1]) return;   // build passes only
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = iw[ix.cam_start + c], k1 = iw[ix.cam_start + c + 1];
+  T G[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) G[t] = T(0);
+  for (int k = k0 + tid; k < k1; k += 256) {
+    const int i = iw[ix.cam_order + k];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      T w7[7];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) w7[d] = w[wk.Jc + size_t(6 * a + d) * M + i];
+      w7[6] = w[wk.r + size_t(a) * M + i];
+      int t = 0;
+#pragma unroll
+      for (int x = 0; x < 7; ++x)
+#pragma unroll
+        for (int y = x; y < 7; ++y) G[t++] += w7[x] * w7[y];
+    }
+  }
+  const T tot = wave_transposed_reduce32(G, lane);   // lane t < 28 holds this wave's total of sum t
+  if (lane < 32) red[wave][lane] = tot;
+  __syncthreads();
+  if (tid < 28) {
+    const T s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    int a = 0, rem = tid;  // tt(a, b) = a * 7 - a (a - 1) / 2 + (b - a)
+    while (rem >= 7 - a) { rem -= 7 - a; ++a; }
+    const int b = a + rem;
+    if (b < 6) { w[wk.U + 36 * c + 6 * a + b] = s; w[wk.U + 36 * c + 6 * b + a] = s; if (a == b) w[wk.Ud + 6 * c + a] = s; }
+    else if (a < 6) w[wk.gc + 6 * c + a] = s;
+  }
+}
+
+// fixed-order sum of arr[0 .. count) by the 256 threads of a block
+template <typename T>
+__device__ __forceinline__ T bl_block_sum(const T* arr, int count, T* red4) {
+  T v = 0;
+  for (int i = threadIdx.x; i < count; i += 256) v += arr[i];
+  return ba_block_sum<T>(v, red4);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_build_kernel(const BlParams* __restrict__ prm) {
+  __shared__ T red[8];
+  __shared__ int sflag;
+  const long long p = blockIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  if (!fl[0]) return;
+  const bool do_acc = fl[1] != 0;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  LmState<T>& S = *bl_state<T>(prm, wk, p);
+  const toa_options& opt = prm->opt;
+  const bool is_lm = opt.solver_type == 0;
+  const int tid = threadIdx.x;
+  const T cost_raw = bl_block_sum<T>(w + wk.ptcost, N, red);
+  __syncthreads();
+  if (tid == 0) {
+    if (do_acc) S.acc_passes++; else S.eval_passes++;
+    S.cost_val = normalize_cost(double(cost_raw), 2 * M, opt);
+    S.cost_nres = 2 * M;
+    S.cost_ninl = 2 * M;
+    sflag = (M > 0 && S.cost_val != kDblMax) ? 1 : 0;
+  }
+  __syncthreads();
+  bool built = sflag != 0;
+  if (built && do_acc) {
+    if (opt.grad_clipping != 0) {  // base.h:29-38
+      const T mm = opt.grad_clipping;
+      for (int i = tid; i < n; i += 256) w[wk.gc + i] = fmin(fmax(w[wk.gc + i], -mm), mm);
+      for (int i = tid; i < 3 * N; i += 256) w[wk.gp + i] = fmin(fmax(w[wk.gp + i], -mm), mm);
+    }
+    if (opt.check_min_H_diag > 0) {  // lm.h:82-86, every diagonal entry of H
+      T low = 0;
+      for (int i = tid; i < n; i += 256) low += fabs(w[wk.Ud + i]) < T(opt.check_min_H_diag) ? T(1) : T(0);
+      for (int i = tid; i < 3 * N; i += 256) low += fabs(w[wk.Vd + i]) < T(opt.check_min_H_diag) ? T(1) : T(0);
+      if (ba_block_sum<T>(low, red) > T(0)) built = false;
+    }
+  }
+  __syncthreads();
+  if (built && is_lm && S.lambda > T(0)) {  // lm.h:108-117, s in double; the points' diagonal is scaled in bl_psolve
+    const double s = S.rebuild ? 1.0 + double(S.lambda) : (1.0 + double(S.lambda)) / (1.0 + double(S.prev_lambda));
+    for (int i = tid; i < n; i += 256) w[wk.Ud + i] = T(double(w[wk.Ud + i]) * s);
+  }
+  if (tid == 0) { fl[3] = built ? 1 : 0; fl[4] = 0; fl[5] = 0; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_psolve_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  if (!fl[0] || !fl[3]) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  const LmState<T>& S = *bl_state<T>(prm, wk, p);
+  const toa_options& opt = prm->opt;
+  T a00 = w[wk.Vd + 3 * j], a11 = w[wk.Vd + 3 * j + 1], a22 = w[wk.Vd + 3 * j + 2];
+  if (opt.solver_type == 0 && S.lambda > T(0)) {
+    const double s = S.rebuild ? 1.0 + double(S.lambda) : (1.0 + double(S.lambda)) / (1.0 + double(S.prev_lambda));
+    a00 = T(double(a00) * s); a11 = T(double(a11) * s); a22 = T(double(a22) * s);
+    w[wk.Vd + 3 * j] = a00; w[wk.Vd + 3 * j + 1] = a11; w[wk.Vd + 3 * j + 2] = a22;
+  }
+  const T a01 = w[wk.Voff + 3 * j], a02 = w[wk.Voff + 3 * j + 1], a12 = w[wk.Voff + 3 * j + 2];
+  // a point no camera sees has V = 0: like the dense LDL^T's zero pivots it takes a zero step (pseudo-inverse)
+  const bool empty = a00 == T(0) && a11 == T(0) && a22 == T(0) && a01 == T(0) && a02 == T(0) && a12 == T(0);
+  T r00 = 0, r10 = 0, r11 = 0, r20 = 0, r21 = 0, r22 = 0;   // R^-1 (lower), V = R R^T... V = L L^T, R^-1 = L^-1
+  if (!empty) {
+    const T l00s = a00;
+    const T l00 = sqrt(l00s);
+    const T l10 = a01 / l00, l20 = a02 / l00;
+    const T l11s = a11 - l10 * l10;
+    const T l11 = sqrt(l11s);
+    const T l21 = (a12 - l20 * l10) / l11;
+    const T l22s = a22 - l20 * l20 - l21 * l21;
+    const T l22 = sqrt(l22s);
+    if (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0))) atomicAdd(&fl[4], 1);   // not positive definite: the solve fails
+    r00 = T(1) / l00; r11 = T(1) / l11; r22 = T(1) / l22;
+    r10 = -l10 * r00 * r11;
+    r21 = -l21 * r11 * r22;
+    r20 = -(l20 * r00 + l21 * r10) * r22;
+  }
+  T* Rj = w + wk.Vinv + 6 * j;
+  Rj[0] = r00; Rj[1] = r10; Rj[2] = r11; Rj[3] = r20; Rj[4] = r21; Rj[5] = r22;
+  const T g0 = w[wk.gp + 3 * j], g1 = w[wk.gp + 3 * j + 1], g2 = w[wk.gp + 3 * j + 2];
+  // q = V^-1 g_p = L^-T (L^-1 g_p)
+  const T y0 = r00 * g0, y1 = r10 * g0 + r11 * g1, y2 = r20 * g0 + r21 * g1 + r22 * g2;
+  w[wk.q + 3 * j] = r00 * y0 + r10 * y1 + r20 * y2;
+  w[wk.q + 3 * j + 1] = r11 * y1 + r21 * y2;
+  w[wk.q + 3 * j + 2] = r22 * y2;
+}
+
+// Block row c of the reduced camera system.  Thread c' (< C, in tiles of 256) owns block (c, c'); the camera's observations
+// are walked in list order in chunks of 64 whose per-observation factors T_i = J_c,i^T (J_p,i V_j^-1) (6 x 3) are staged
+// in LDS by the first 64 threads.  For observation i of point j, camera c' contributes iff it sees j: a binary search of
+// the point's (camera-sorted) list.  S(c, c') -= T_i (J_p,i'^T J_c,i'),   red_c -= T_i g_pj  [red = g_c - W V^-1 g_p].
+template <typename T>
+__global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restrict__ prm) {
+  __shared__ T Tl[64][18];
+  __shared__ int jl[64];
+  const long long p = blockIdx.y;
+  const int c = blockIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* iw = prm->iwork + size_t(p) * ix.total;
+  if (!iw[ix.flags + 0] || !iw[ix.flags + 3]) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  T* Sg = static_cast<T*>(prm->Sall) + size_t(p) * n * n;
+  T* rg = static_cast<T*>(prm->rhsall) + size_t(p) * n;
+  const int* oc = prm->obs_cam + size_t(p) * M;
+  const int tid = threadIdx.x;
+  const int k0 = iw[ix.cam_start + c], k1 = iw[ix.cam_start + c + 1];
+  for (int cbase = 0; cbase < C; cbase += 256) {
+    const int c2 = cbase + tid;
+    T Sb[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) Sb[a][b] = T(0);
+    T rv[6] = {0, 0, 0, 0, 0, 0};   // thread 0 of the first tile accumulates the row's W V^-1 g_p
+    for (int kk = k0; kk < k1; kk += 64) {
+      __syncthreads();
+      if (tid < 64 && kk + tid < k1) {
+        const int i = iw[ix.cam_order + kk + tid];
+        const int j = prm->obs_pt[size_t(p) * M + i];
+        jl[tid] = j;
+        const T* Rj = w + wk.Vinv + 6 * j;
+        const T r00 = Rj[0], r10 = Rj[1], r11 = Rj[2], r20 = Rj[3], r21 = Rj[4], r22 = Rj[5];
+        // V^-1 = R^-T R^-1 with R^-1 lower: rows
+        const T v00 = r00 * r00 + r10 * r10 + r20 * r20, v01 = r10 * r11 + r20 * r21, v02 = r20 * r22;
+        const T v11 = r11 * r11 + r21 * r21, v12 = r21 * r22, v22 = r22 * r22;
+        T A[2][3];   // J_p,i V^-1 (2 x 3)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const T p0 = w[wk.Jp + size_t(3 * a) * M + i], p1 = w[wk.Jp + size_t(3 * a + 1) * M + i], p2 = w[wk.Jp + size_t(3 * a + 2) * M + i];
+          A[a][0] = p0 * v00 + p1 * v01 + p2 * v02;
+          A[a][1] = p0 * v01 + p1 * v11 + p2 * v12;
+          A[a][2] = p0 * v02 + p1 * v12 + p2 * v22;
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+          const T jc0 = w[wk.Jc + size_t(d) * M + i], jc1 = w[wk.Jc + size_t(6 + d) * M + i];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) Tl[tid][3 * d + b] = jc0 * A[0][b] + jc1 * A[1][b];
+        }
+      }
+      __syncthreads();
+      const int cnt = min(64, k1 - kk);
+      if (c2 <= c) {   // the lower block triangle; block (c', c) is its transpose, written below: S is exactly symmetric
+        for (int s = 0; s < cnt; ++s) {
+          const int j = jl[s];
+          // does camera c2 see point j?  binary search of the point's list (sorted by camera)
+          int lo = iw[ix.pt_start + j], hi = iw[ix.pt_start + j + 1];
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (oc[mid] < c2) lo = mid + 1; else hi = mid;
+          }
+          if (lo < iw[ix.pt_start + j + 1] && oc[lo] == c2) {
+            const int i2 = lo;
+            T B[3][6];   // J_p,i2^T J_c,i2 (3 x 6)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const T p0 = w[wk.Jp + size_t(b) * M + i2], p1 = w[wk.Jp + size_t(3 + b) * M + i2];
+#pragma unroll
+              for (int d = 0; d < 6; ++d) B[b][d] = p0 * w[wk.Jc + size_t(d) * M + i2] + p1 * w[wk.Jc + size_t(6 + d) * M + i2];
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int d = 0; d < 6; ++d) Sb[a][d] -= Tl[s][3 * a] * B[0][d] + Tl[s][3 * a + 1] * B[1][d] + Tl[s][3 * a + 2] * B[2][d];
+          }
+          if (c2 == 0 && cbase == 0) {
+            const T g0 = w[wk.gp + 3 * j], g1 = w[wk.gp + 3 * j + 1], g2 = w[wk.gp + 3 * j + 2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) rv[a] -= Tl[s][3 * a] * g0 + Tl[s][3 * a + 1] * g1 + Tl[s][3 * a + 2] * g2;
+          }
+        }
+      }
+    }
+    if (c2 <= c) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+          T v = Sb[a][d];
+          if (c2 == c) {   // the diagonal block: symmetrise the sum of T_i B_i (equal in exact arithmetic) + U_c with its damped diagonal
+            v = (d <= a) ? Sb[a][d] : Sb[d][a];
+            v += (a == d) ? w[wk.Ud + 6 * c + a] : w[wk.U + 36 * c + 6 * a + d];
+          }
+          Sg[size_t(6 * c + a) * n + 6 * c2 + d] = v;
+          if (c2 != c) Sg[size_t(6 * c2 + d) * n + 6 * c + a] = v;
+        }
+      if (c2 == 0 && cbase == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) rg[6 * c + a] = w[wk.gc + 6 * c + a] + rv[a];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_back_kernel(const BlParams* __restrict__ prm, const int32_t* __restrict__ solve_ok) {
+  const long long p = blockIdx.y;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* iw = prm->iwork + size_t(p) * ix.total;
+  if (!iw[ix.flags + 0] || !iw[ix.flags + 3] || iw[ix.flags + 4] != 0 || !solve_ok[p]) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  const int* oc = prm->obs_cam + size_t(p) * M;
+  T u3[3] = {w[wk.gp + 3 * j], w[wk.gp + 3 * j + 1], w[wk.gp + 3 * j + 2]};
+  const T g2 = u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];
+  for (int i = iw[ix.pt_start + j]; i < iw[ix.pt_start + j + 1]; ++i) {
+    const T* dcc = static_cast<const T*>(prm->dcall) + size_t(p) * 6 * C + 6 * oc[i];
+    // W_i^T dc = J_p^T (J_c dc)
+    T e[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      T s = 0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) s += w[wk.Jc + size_t(6 * a + d) * M + i] * dcc[d];
+      e[a] = s;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) u3[b] += w[wk.Jp + size_t(b) * M + i] * e[0] + w[wk.Jp + size_t(3 + b) * M + i] * e[1];
+  }
+  const T* Rj = w + wk.Vinv + 6 * j;
+  const T y0 = Rj[0] * u3[0], y1 = Rj[1] * u3[0] + Rj[2] * u3[1], y2 = Rj[3] * u3[0] + Rj[4] * u3[1] + Rj[5] * u3[2];
+  const T e0 = -(Rj[0] * y0 + Rj[1] * y1 + Rj[3] * y2), e1 = -(Rj[2] * y1 + Rj[4] * y2), e2 = -(Rj[5] * y2);
+  w[wk.dp + 3 * j] = e0; w[wk.dp + 3 * j + 1] = e1; w[wk.dp + 3 * j + 2] = e2;
+  w[wk.pd2 + j] = e0 * e0 + e1 * e1 + e2 * e2;
+  w[wk.pg2 + j] = g2;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict__ prm, const int32_t* __restrict__ solve_ok, int timed_out) {
+  __shared__ T red[8];
+  const long long p = blockIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  if (!fl[0]) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  LmState<T>& S = *bl_state<T>(prm, wk, p);
+  const toa_options& opt = prm->opt;
+  const bool is_lm = opt.solver_type == 0;
+  const int tid = threadIdx.x;
+  const bool solved = fl[3] != 0 && fl[4] == 0 && solve_ok[p] != 0;
+  T d2s = 0, g2s = 0;
+  if (solved) {
+    T d2 = 0, g2 = 0;
+    for (int i = tid; i < N; i += 256) { d2 += w[wk.pd2 + i]; g2 += w[wk.pg2 + i]; }
+    const T* dcg = static_cast<const T*>(prm->dcall) + size_t(p) * n;
+    for (int i = tid; i < n; i += 256) { d2 += dcg[i] * dcg[i]; g2 += w[wk.gc + i] * w[wk.gc + i]; }
+    d2s = ba_block_sum<T>(d2, red);
+    g2s = ba_block_sum<T>(g2, red);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (fl[3]) S.solves++;
+    const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
+    int rc;  // 0 step, 1 solver failed for good, 2 early stop, -1 retry (same iteration)
+    if (solved) {
+      rc = 0;
+    } else {
+      S.num_consec = (S.num_consec + 1) & 0xff;
+      S.num_failures = (S.num_failures + 1) & 0xff;
+      if (S.cost_nres == 0) { S.stop = TOA_STOP_SKIPPED; rc = 2; }
+      else if (isnan(S.cost_val) || isinf(S.cost_val)) { S.stop = TOA_STOP_NAN_OR_INF; rc = 2; }
+      else if (opt.max_consec_failures > 0 && S.num_consec >= unsigned(opt.max_consec_failures)) {
+        if (S.final_cost < double(NumLimits<T>::max())) S.stop = TOA_STOP_MAX_CONSEC_NO_DECR;
+        rc = 1;
+      } else {
+        lm_bad_step(S, opt);
+        rc = (S.num_consec <= max_tries) ? -1 : 1;
+      }
+    }
+    int action = 0, cont = 1;
+    if (rc >= 0) {
+      int status = 0;
+      if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;
+      if (rc == 0) status = lm_judge_core<T>(S, opt, prm->res, p, double(d2s), opt.min_grad_norm2 > 0.0f ? double(g2s) : 0.0, true);
+      bool eval_only = false;
+      if (status & 1) {
+        action = 1; S.has_last_dx = 1; S.last_was_success = 1;
+        if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
+      } else {
+        if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
+        else if (status & 2) { action = 1; S.has_last_dx = 1; }
+        eval_only = (S.last_was_success == 0);
+        S.last_was_success = 0;
+      }
+      if (is_lm) S.rebuild = eval_only ? 0 : 1;
+      if (timed_out && S.stop == TOA_STOP_NONE) S.stop = TOA_STOP_TIMED_OUT;   // optimizer.h:302-305 (after the step was applied)
+      S.num_iters = S.num_iters + 1;
+      S.iter = S.iter + 1;
+      cont = (S.stop == TOA_STOP_NONE && S.iter < S.max_iters) ? 1 : 0;
+    }
+    fl[1] = (!is_lm || S.rebuild) ? 1 : 0;
+    fl[2] = action;
+    fl[0] = cont;
+    if (cont) atomicAdd(prm->any_active, 1);
+    if (!cont) {   // optimizer.h:313-327
+      const toa_results& res = prm->res;
+      if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;
+      res.stop_reason[p] = S.stop;
+      res.num_iters[p] = S.num_iters;
+      res.final_cost[p] = S.final_cost;
+      if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+      if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+      if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+      if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+      if (prm->counters) {
+        atomicAdd(&prm->counters[0], S.acc_passes);
+        atomicAdd(&prm->counters[1], S.eval_passes);
+        atomicAdd(&prm->counters[2], S.solves);
+        atomicAdd(&prm->counters[3], 1ull);
+      }
+    }
+  }
+}
+
+// x (+)= dx: SE3 on the cameras (sophus.h:24-26), Euclidean on the points (traits.h:184-190); action 2 rolls the last step back
+template <typename T>
+__global__ void __launch_bounds__(256) bl_update_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
+  const int C = prm->C, N = prm->N, M = prm->M;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  const int action = fl[2];
+  if (action == 0) return;
+  T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
+  T* X = static_cast<T*>(prm->x) + size_t(p) * (size_t(12) * C + size_t(3) * N);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < C) {
+    if (action == 1) {
+      T d[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { d[k] = static_cast<const T*>(prm->dcall)[size_t(p) * 6 * C + 6 * t + k]; w[wk.ldc + 6 * t + k] = d[k]; }
+      ba_se3_plus<T>(X + 12 * t, d, T(1));
+    } else {
+      ba_se3_plus<T>(X + 12 * t, w + wk.ldc + 6 * t, T(-1));
+    }
+  }
+  for (int i = t; i < 3 * N; i += gridDim.x * 256) {
+    if (action == 1) { const T d = w[wk.dp + i]; X[size_t(12) * C + i] += d; w[wk.ldp + i] = d; }
+    else X[size_t(12) * C + i] -= w[wk.ldp + i];
+  }
+}
+
+__global__ void bl_clear_action_kernel(const BlParams* __restrict__ prm) {
+  const BlIdx ix(prm->C, prm->N, prm->M);
+  const long long p = blockIdx.x * 64 + threadIdx.x;
+  if (p < prm->P) prm->iwork[size_t(p) * ix.total + ix.flags + 2] = 0;
+}
+
+template <typename T>
+int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms) {
+  const int C = prm.C, N = prm.N, M = prm.M, n = 6 * C;
+  const long long P = prm.P;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t b_work = al(size_t(P) * wk.total * sizeof(T)), b_iwork = al(size_t(P) * ix.total * sizeof(int)), b_ok = al(size_t(P) * sizeof(int32_t));
+  const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
+  const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v;
+  if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->aux) (void)hipFree(h->aux);
+    h->aux = nullptr;
+    h->aux_bytes = 0;
+    HIP_TRY(hipMalloc(&h->aux, need));
+    h->aux_bytes = need;
+  }
+  char* base = static_cast<char*>(h->aux);
+  prm.work = base;
+  prm.iwork = reinterpret_cast<int*>(base + b_work);
+  int32_t* ok = reinterpret_cast<int32_t*>(base + b_work + b_iwork);
+  prm.any_active = reinterpret_cast<int*>(base + b_work + b_iwork + b_ok);
+  prm.Sall = base + b_work + b_iwork + b_ok + 256;
+  prm.rhsall = static_cast<char*>(prm.Sall) + b_S;
+  prm.dcall = static_cast<char*>(prm.rhsall) + b_v;
+  HIP_TRY(hipMemsetAsync(prm.dcall, 0, b_v, h->stream));
+  static_assert(sizeof(BlParams) <= 1024, "parameter block too large");
+  if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
+  const BlParams* dev = static_cast<const BlParams*>(h->params_dev);
+  hipStream_t st = h->stream;
+  const unsigned gM = unsigned((M + 255) / 256), gN = unsigned((N + 255) / 256), gX = unsigned((std::max(N * 3 / 8, C) + 255) / 256);
+  hipLaunchKernelGGL(bl_index_kernel, dim3(unsigned(P)), dim3(64), 0, st, dev);
+  hipLaunchKernelGGL(bl_init_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
+  HIP_TRY(hipGetLastError());
+  // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
+  const long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (max_duration_ms > 0) {
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, st));
+  }
+  int rc_all = TOA_OK;
+  for (long long pass = 0; pass < max_passes; ++pass) {
+    int timed_out = 0;
+    if (max_duration_ms > 0) {   // the reference adds up the iterations' wall time (optimizer.h:302-305): device time here
+      HIP_TRY(hipEventRecord(t1, st));
+      HIP_TRY(hipEventSynchronize(t1));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+      timed_out = double(ms) > max_duration_ms ? 1 : 0;
+    }
+    HIP_TRY(hipMemsetAsync(prm.any_active, 0, sizeof(int), st));
+    hipLaunchKernelGGL(bl_obs_kernel<T>, dim3(gM, unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_point_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_cam_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_build_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_psolve_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_schur_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
+    HIP_TRY(hipGetLastError());
+    // reduced camera system: S dc = -red  (toa_large_solve: dx = -H^-1 g; scale 1: S is already damped).  A scene that is not
+    // running (or whose Build failed) still goes through the solver on whatever its S holds: its verdict is ignored.
+    if (n <= 128) {   // the workgroup LDL^T: one workgroup per matrix, the same arithmetic whatever the batch
+      if (int rc = toa_large_solve(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok)) { rc_all = rc; break; }
+    } else {
+      // rocSOLVER: ONE matrix per call — its batched Cholesky picks its blocking by batch size, and a scene solved alone must
+      // give the bits of its row in a batch (tests/test_gpu_ba_lists.py); scenes of this size are few per call
+      for (long long q = 0; q < P && rc_all == TOA_OK; ++q)
+        rc_all = toa_large_solve(h, dtype, n, 1, static_cast<T*>(prm.Sall) + size_t(q) * n * n, static_cast<T*>(prm.rhsall) + size_t(q) * n, 1.0,
+                                 static_cast<T*>(prm.dcall) + size_t(q) * n, ok + q);
+      if (rc_all != TOA_OK) break;
+    }
+    hipLaunchKernelGGL(bl_back_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok);
+    hipLaunchKernelGGL(bl_step_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok, timed_out);
+    hipLaunchKernelGGL(bl_update_kernel<T>, dim3(gX, unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_clear_action_kernel, dim3(unsigned((P + 63) / 64)), dim3(64), 0, st, dev);
+    HIP_TRY(hipGetLastError());
+    int active = 0;
+    HIP_TRY(hipMemcpyAsync(&active, prm.any_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (active == 0) break;
+  }
+  if (t0) (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  return rc_all;
+}
+
 }  // namespace toa
 
 using namespace toa;
@@ -812,4 +1541,34 @@ extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_poin
   prm.res.final_hessian = nullptr;   // the block Hessian is not exported
   prm.counters = reinterpret_cast<unsigned long long*>(counters_dev);
   return dtype == TOA_F32 ? launch_ba_any<float>(h, prm) : launch_ba_any<double>(h, prm);
+}
+
+extern "C" int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, int num_obs, int64_t P, const void* intr_dev,
+                                const int32_t* obs_cam_dev, const int32_t* obs_pt_dev, const void* obs_uv_dev, void* x_dev,
+                                const toa_options* options, const toa_results* results, uint64_t* counters_dev, double max_duration_ms) {
+  if (!h) return toa_fail(TOA_E_ARG, "null handle");
+  if (dtype != TOA_F32 && dtype != TOA_F64) return toa_fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+  if (num_cameras < 1 || num_cameras > 682) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: 1 <= num_cameras <= 682 (reduced camera system of at most 4092 unknowns)");
+  if (num_points < 1 || num_points > (1 << 22) || num_obs < 1 || num_obs > (1 << 26)) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: num_points / num_obs out of range");
+  if (P < 0 || P > 65535) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: P must be in [0, 65535]");
+  if (!intr_dev || !obs_cam_dev || !obs_pt_dev || !obs_uv_dev || !x_dev || !options || !results) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: null pointer");
+  if (!results->stop_reason || !results->num_iters || !results->final_cost)
+    return toa_fail(TOA_E_ARG, "toa_ba_lists_run: stop_reason, num_iters and final_cost outputs are required");
+  if (options->solver_type != 0 && options->solver_type != 1) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: solver_type must be 0 (LM) or 1 (GN)");
+  if (!options->use_ldlt) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run: use_ldlt=false is not available");
+  if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
+    return toa_fail(TOA_E_ARG, "toa_ba_lists_run: hist_stride must be >= max_iters + 2");
+  if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
+  if (h->loss != TOA_LOSS_L2)
+    return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run: bundle adjustment has no M-estimator and a loss is set on the handle (toa_set_loss); clear it first");
+  if (P == 0) return TOA_OK;
+  TOA_ON_DEVICE(h->device);
+  BlParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.intr = intr_dev; prm.obs_cam = obs_cam_dev; prm.obs_pt = obs_pt_dev; prm.obs_uv = obs_uv_dev; prm.x = x_dev;
+  prm.P = P; prm.C = num_cameras; prm.N = num_points; prm.M = num_obs;
+  prm.opt = *options; prm.res = *results;
+  prm.res.final_hessian = nullptr;
+  prm.counters = reinterpret_cast<unsigned long long*>(counters_dev);
+  return dtype == TOA_F32 ? ba_lists_run_t<float>(h, dtype, prm, max_duration_ms) : ba_lists_run_t<double>(h, dtype, prm, max_duration_ms);
 }

@@ -57,6 +57,14 @@ __global__ void __launch_bounds__(256) jet_eval_kernel(int fn, long long count, 
     case 33: r = fdim(x, y); break;     case 34: r = floor(x); break;        case 35: r = ceil(x); break;
     case 36: r = norm(x); break;        case 37: r = copysign(x, y); break;  case 38: r = T(2) / x + x / T(4) - T(3) * y; break;
     case 39: r = hypot(x, y, x * y); break;
+    case 40: r = BesselJ0(x); break;    case 41: r = BesselJ1(x); break;     case 42: r = BesselJn(3, x); break;
+    case 43: r = cyl_bessel_j(0, x) + cyl_bessel_j(2, y); break;
+    case 44: r = lerp(x, y, x * y); break;                                    case 45: r = midpoint(x, y); break;
+    case 46:   // classification / comparison on the scalar part: a bit mask in the value, no derivative
+      r = J(T((isfinite(x) ? 1 : 0) | (isinf(x) ? 2 : 0) | (isnan(x) ? 4 : 0) | (isnormal(x) ? 8 : 0) | (signbit(x) ? 16 : 0) |
+              (isless(x, y) ? 32 : 0) | (isgreater(x, y) ? 64 : 0) | (islessequal(x, y) ? 128 : 0) | (isgreaterequal(x, y) ? 256 : 0) |
+              (islessgreater(x, y) ? 512 : 0) | (isunordered(x, y) ? 1024 : 0) | (fpclassify(x) << 11)));
+      break;
     default: r = J(T(NAN)); break;
   }
   out[3 * i] = r.a; out[3 * i + 1] = r.v[0]; out[3 * i + 2] = r.v[1];
@@ -313,6 +321,7 @@ int toa_destroy(toa_handle h) {
   if (h->params_dev) (void)hipFree(h->params_dev);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->memo) (void)hipFree(h->memo);
+  if (h->aux) (void)hipFree(h->aux);
   if (h->blas && h->blas_destroy) (void)h->blas_destroy(h->blas);
   for (int i = 0; i < h->nwgraphs; ++i) (void)hipGraphExecDestroy(h->wgraphs[i].exec);
   delete h;
@@ -404,7 +413,7 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
 
 int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a, const void* b, void* out) {
   if (!h || !a || !b || !out || count < 0) return fail(TOA_E_ARG, "toa_jet_eval: null argument");
-  if (fn < 0 || fn > 39) return fail(TOA_E_ARG, "toa_jet_eval: unknown function id");
+  if (fn < 0 || fn > 46) return fail(TOA_E_ARG, "toa_jet_eval: unknown function id");
   if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
   if (count == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);

@@ -19,6 +19,7 @@ namespace toa {
 // call sin(t), sqrt(t), ... unqualified; the Jet overloads below would otherwise hide ::sin inside toa::)
 using ::sqrt; using ::sin; using ::cos; using ::tan; using ::atan; using ::atan2; using ::tanh;
 using ::exp; using ::log; using ::pow; using ::fabs; using std::abs;
+using ::isnan; using ::isinf; using ::isfinite; using ::signbit;   // (the Jet overloads below must not hide the scalar ones)
 using ::acos; using ::asin; using ::sinh; using ::cosh; using ::cbrt; using ::exp2; using ::log2; using ::log10;
 using ::log1p; using ::expm1; using ::hypot; using ::erf; using ::erfc; using ::floor; using ::ceil; using ::fmax;
 using ::fmin; using ::fdim; using ::fma; using ::copysign;
@@ -211,6 +212,61 @@ TOA_JET_FN Jet<T, N> pow(const Jet<T, N>& f, const Jet<T, N>& g) {              
   const T t1 = T(::pow(f.a, g.a)), t2 = g.a * T(::pow(f.a, g.a - T(1.0))), t3 = t1 * T(::log(f.a));
   Jet<T, N> r; r.a = t1; TOA_JET_LOOP r.v[i] = t2 * f.v[i] + t3 * g.v[i]; return r;
 }
+
+// ---- Bessel functions of the first kind (jet.h:919-1009): J0' = -J1, Jn' = (J(n-1) - J(n+1)) / 2  (dlmf.nist.gov/10.6) ----
+__device__ __forceinline__ double BesselJ0(double x) { return ::j0(x); }
+__device__ __forceinline__ double BesselJ1(double x) { return ::j1(x); }
+__device__ __forceinline__ double BesselJn(int n, double x) { return ::jn(n, x); }
+// (fp32 goes through the fp64 routines: the device library's jnf runs its recurrence forward and loses 3 digits near 0)
+__device__ __forceinline__ float BesselJ0(float x) { return float(::j0(double(x))); }
+__device__ __forceinline__ float BesselJ1(float x) { return float(::j1(double(x))); }
+__device__ __forceinline__ float BesselJn(int n, float x) { return float(::jn(n, double(x))); }
+TOA_JET_FN Jet<T, N> BesselJ0(const Jet<T, N>& f) { return jet_chain(f, BesselJ0(f.a), -BesselJ1(f.a)); }                    // :958
+TOA_JET_FN Jet<T, N> BesselJ1(const Jet<T, N>& f) { return jet_chain(f, BesselJ1(f.a), T(0.5) * (BesselJ0(f.a) - BesselJn(2, f.a))); }   // :969
+TOA_JET_FN Jet<T, N> BesselJn(int n, const Jet<T, N>& f) {                                                                    // :981
+  return jet_chain(f, BesselJn(n, f.a), T(0.5) * (BesselJn(n - 1, f.a) - BesselJn(n + 1, f.a)));
+}
+// std::cyl_bessel_j(v, x) for the INTEGER orders the device math library has (jet.h:999-1009; order 0: -J1 f')
+TOA_JET_FN Jet<T, N> cyl_bessel_j(int v, const Jet<T, N>& f) { return v == 0 ? BesselJ0(f) : BesselJn(v, f); }
+// ---- lerp / midpoint (jet.h:1171-1218, C++20): d lerp = (1 - t) da + t db + (b - a) dt; d midpoint = (da + db) / 2 ----
+TOA_JET_FN Jet<T, N> lerp(const Jet<T, N>& a, const Jet<T, N>& b, const Jet<T, N>& t) {
+  Jet<T, N> r;
+  r.a = a.a + t.a * (b.a - a.a);
+  TOA_JET_LOOP r.v[i] = (T(1) - t.a) * a.v[i] + t.a * b.v[i] + (b.a - a.a) * t.v[i];
+  return r;
+}
+TOA_JET_FN Jet<T, N> midpoint(const Jet<T, N>& a, const Jet<T, N>& b) {
+  Jet<T, N> r;
+  r.a = a.a * T(0.5) + b.a * T(0.5);                       // (overflow-safe, like std::midpoint)
+  TOA_JET_LOOP r.v[i] = a.v[i] * T(0.5) + b.v[i] * T(0.5);
+  return r;
+}
+// ---- classification and comparison on the SCALAR part only (jet.h:1011-1168) ----
+TOA_JET_FN bool isfinite(const Jet<T, N>& f) { return ::isfinite(f.a); }
+TOA_JET_FN bool isinf(const Jet<T, N>& f) { return ::isinf(f.a); }
+TOA_JET_FN bool isnan(const Jet<T, N>& f) { return f.a != f.a; }
+TOA_JET_FN bool isnormal(const Jet<T, N>& f) {
+  const T m = f.a < T(0) ? -f.a : f.a;
+  return ::isfinite(f.a) && m >= (sizeof(T) == 4 ? T(1.17549435e-38f) : T(2.2250738585072014e-308));
+}
+TOA_JET_FN bool signbit(const Jet<T, N>& f) { return ::signbit(f.a); }
+TOA_JET_FN int fpclassify(const Jet<T, N>& f) {                 // FP_NAN 0, FP_INFINITE 1, FP_ZERO 2, FP_SUBNORMAL 3, FP_NORMAL 4
+  if (f.a != f.a) return 0;
+  if (::isinf(f.a)) return 1;
+  if (f.a == T(0)) return 2;
+  return isnormal(f) ? 4 : 3;
+}
+TOA_JET_FN bool isless(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a < g.a; }
+TOA_JET_FN bool isgreater(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a > g.a; }
+TOA_JET_FN bool islessequal(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a <= g.a; }
+TOA_JET_FN bool isgreaterequal(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a >= g.a; }
+TOA_JET_FN bool islessgreater(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a < g.a || f.a > g.a; }
+TOA_JET_FN bool isunordered(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a != f.a || g.a != g.a; }
+// the deprecated spellings (jet.h:1130-1168)
+TOA_JET_FN bool IsFinite(const Jet<T, N>& f) { return isfinite(f); }
+TOA_JET_FN bool IsNaN(const Jet<T, N>& f) { return isnan(f); }
+TOA_JET_FN bool IsNormal(const Jet<T, N>& f) { return isnormal(f); }
+TOA_JET_FN bool IsInfinite(const Jet<T, N>& f) { return isinf(f); }
 
 #undef TOA_JET_FN
 #undef TOA_JET_LOOP

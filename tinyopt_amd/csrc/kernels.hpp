@@ -2053,6 +2053,8 @@ struct toa_context {
   size_t scratch_bytes = 0;
   void* memo = nullptr;        // fused kernel: one parked linearisation per resident wave (lm_device.hpp; grown on demand)
   size_t memo_bytes = 0;
+  void* aux = nullptr;         // bundle adjustment with visibility lists: its work arrays (`scratch` belongs to the solver it calls)
+  size_t aux_bytes = 0;
   // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (TOA_USE_GRAPH=1)
   struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
   WideGraph wgraphs[16];
