@@ -88,7 +88,7 @@ def run_single(args, ta, rank, world, local_rank):
     N > 1.  A step = one whole solve from x0 (`toa_lm_run`, benchmarks/options.h options); the line reports
     us per solve and per LM iteration (HIP events on the launch stream), the algorithmic GB/s of the data passes and the
     oracle on the same problem on one host core."""
-    from oracle import pyoracle
+    from tinyopt_amd import synth
     wl = args.workload
     opts = ta.Options.benchmark()
     pod = opts.to_pod()
@@ -99,7 +99,7 @@ def run_single(args, ta, rank, world, local_rank):
         bytes_per_pass = model.algorithmic_bytes_per_pass
     elif wl == "c5":
         n, npts, P = 6, 25000, 1
-        data, p0, pstar = pyoracle.synth_se3_reproj(P, npts, np.float64, seed=4 + rank)
+        data, p0, pstar = synth.synth_se3_reproj(P, npts, np.float64, seed=4 + rank)
         model = ta.SE3Reproj(torch.from_numpy(data).cuda(), npts)
         x0, xstar = torch.from_numpy(p0).cuda(), torch.from_numpy(pstar).cuda()
         m = 2 * npts
@@ -194,6 +194,7 @@ def run_single(args, ta, rank, world, local_rank):
                      "algorithmic_bytes_per_pass": bytes_per_pass, "kernel_us_all": kern_us},
     }
     if not args.no_cpu and world == 1:
+        from oracle import pyoracle   # the checker / CPU baseline only: the inputs above came from the package's own generators
         lib = pyoracle.load(pyoracle.build(march="native", out_dir=tempfile.mkdtemp(prefix="toa_oracle_")))
         x0h = x0.cpu().numpy()
         if wl == "c2":
@@ -234,11 +235,11 @@ BA_DESC = "bundle adjustment: 1024 scenes/GPU x 8 SE3 cameras x 256 points (4096
 def run_ba(args, ta, rank, world, local_rank):
     """batched bundle adjustment with the points eliminated (toa_ba_run).  The reference would run
     Optimize on the dense (6C + 3N)^2 system (math.h:232-240) — that is the CPU baseline (oracle/ba.hpp)."""
-    from oracle import pyoracle
+    from tinyopt_amd import synth
     P, C, N = (args.problems or 1024), 8, 256
     opts = ta.Options.benchmark()
     pod = opts.to_pod()
-    data, x0h, xsh = pyoracle.synth_ba(P, C, N, np.float64, seed=0x71940917 + rank)
+    data, x0h, xsh = synth.synth_ba(P, C, N, np.float64, seed=0x71940917 + rank)
     model = ta.BundleAdjustment(torch.from_numpy(data).cuda(), C, N)
     x0 = torch.from_numpy(x0h).cuda()
     ctx = ta.api.default_context(local_rank)
@@ -321,6 +322,7 @@ def run_ba(args, ta, rank, world, local_rank):
                      "kernel_ms_avg": kern_s * 1e3, "kernel_ms_all": kern_ms},
     }
     if not args.no_cpu and world == 1:
+        from oracle import pyoracle
         lib = pyoracle.load(pyoracle.build(march="native", out_dir=tempfile.mkdtemp(prefix="toa_oracle_")))
         S = args.cpu_problems or 6
         tc = time.perf_counter()
@@ -337,12 +339,112 @@ def run_ba(args, ta, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+BALISTS_DESC = "bundle adjustment with visibility lists: 4 scenes/GPU x 64 cameras x 5000 points x 6 observations per point (30 000 observations, 15 384 unknowns per scene), fp64"
+
+
+def run_balists(args, ta, rank, world, local_rank):
+    """SURVEY §8(f) rank 4 at a realistic shape: tens of cameras, each point seen by a few (toa_ba_lists_run).  A step = one
+    batched solve from x0 with the benchmark options.  The reference's route — tinyopt::Optimize on the dense (6C + 3N)^2
+    system (math.h:232-240): a 1.9 GB Hessian and ~1e12 flops per LDL^T per scene — is not runnable at this size; the CPU
+    baseline is the dense oracle on the same generator at 16 cameras x 300 points and is labelled as such."""
+    from tinyopt_amd import synth
+    P, C, N, K = (args.problems or 4), 64, 5000, 6
+    opts = ta.Options.benchmark()
+    pod = opts.to_pod()
+    intr, oc, op, ouv, x0h, xsh = synth.synth_ba_lists(P, C, N, K, np.float64, seed=0x71940917 + rank)
+    model = ta.BundleAdjustmentLists(torch.from_numpy(intr).cuda(), torch.from_numpy(oc).cuda(), torch.from_numpy(op).cuda(),
+                                     torch.from_numpy(ouv).cuda(), C, N)
+    x0 = torch.from_numpy(x0h).cuda()
+    ctx = ta.api.default_context(local_rank)
+    info = ctx.info()
+    x = x0.clone()
+    out = ta.Optimize(x, model, opts)
+    torch.cuda.synchronize()
+
+    def step():
+        x.copy_(x0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ta.Optimize(x, model, opts, out=out)
+        e1.record()
+        return e0, e1, out.num_iters.sum(dtype=torch.int64), (out.counters[0] + out.counters[1]).clone()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    iters_total = int(sum(int(r[2].item()) for r in recs))
+    passes_total = int(sum(int(r[3].item()) for r in recs))
+    kern_ms = [r[0].elapsed_time(r[1]) for r in recs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        sm = torch.tensor([iters_total], dtype=torch.int64, device="cuda")
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        iters_all = int(sm.item())
+    else:
+        iters_all = iters_total
+    assert bool((out.stop_reason >= 0).all()), "solve failed"
+    rms = float((out.final_cost / (2 * N * K)).sqrt().max())
+    assert rms < 0.5, f"reprojection rms {rms}"
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    bytes_per_pass = model.algorithmic_bytes_per_pass
+    kern_s = float(np.mean(kern_ms)) * 1e-3
+    achieved = bytes_per_pass * (passes_total / args.steps) / kern_s / 1e9
+    result = {
+        "metric": "LM iterations/s (bundle adjustment with visibility lists, Schur complement)", "value": iters_all / elapsed,
+        "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": BALISTS_DESC, "problems_per_gpu": P, "cameras": C, "points": N, "observations": N * K,
+                   "n": 6 * C + 3 * N, "m": 2 * N * K, "options": "benchmarks/options.h",
+                   "parallelism": f"scene-sharded x{world}, no data-path collective",
+                   "iters_per_problem": iters_all / args.steps / (P * world), "ms_per_lm_iteration": elapsed / max(iters_all / (P * world), 1) * 1e3,
+                   "final_reprojection_rms_px_max": rms, "device": info["name"], "num_cus": info["num_cus"]},
+        "roofline": {"bound": "latency", "kernel": "bl_* pipeline (10 launches + one host read-back per Build + Solve attempt; rocSOLVER potrf / potrs of the 384 x 384 reduced camera system)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
+                     "note": "launch / latency-bound at this size (a few scenes, ~1 MB of observations each): the figure of merit is ms per LM "
+                             "iteration; GB/s is reported for scale only",
+                     "kernel_ms_avg": kern_s * 1e3, "kernel_ms_all": kern_ms},
+    }
+    if not args.no_cpu and world == 1:
+        from oracle import pyoracle
+        lib = pyoracle.load(pyoracle.build(march="native", out_dir=tempfile.mkdtemp(prefix="toa_oracle_")))
+        Cs, Ns = 16, 300
+        ds, x0s, _ = synth.synth_ba(1, Cs, Ns, np.float64, seed=5)
+        tc = time.perf_counter()
+        r = pyoracle.ba_lm(ds, x0s, Cs, Ns, pod, history=False, lib=lib)
+        t_cpu = time.perf_counter() - tc
+        it_cpu = int(r["iters"].sum())
+        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                                  "sample": f"NOT the bench shape (a 15 384^2 dense Hessian is 1.9 GB and ~1e12 flops per LDL^T): the same generator at "
+                                            f"{Cs} cameras x {Ns} points, all visible ({6 * Cs + 3 * Ns} unknowns), solved the reference's way — dense "
+                                            f"Hessian + dense LDL^T (oracle/ba.hpp; math.h:232-240) — {it_cpu} LM iterations, {t_cpu:.1f} s, one thread",
+                                  "iters_per_problem": float(it_cpu)}
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS) + sorted(SINGLE) + ["ba"])
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS) + sorted(SINGLE) + ["ba", "balists"])
     ap.add_argument("--problems", type=int, default=0, help="override problems per GPU (debug; invalidates the metric)")
     ap.add_argument("--cpu-problems", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
@@ -365,6 +467,8 @@ def main():
         return run_single(args, ta, rank, world, local_rank)
     if args.workload == "ba":
         return run_ba(args, ta, rank, world, local_rank)
+    if args.workload == "balists":
+        return run_balists(args, ta, rank, world, local_rank)
     P, n, m, tdt, tag, desc = WORKLOADS[args.workload]
     if args.problems:
         P = args.problems

@@ -318,6 +318,19 @@ static void sharded() {
     REQUIRE(all_x[p] == xa[p] && x[p] == xa[p]);
     REQUIRE(out.stop_reason[p] == ref.stop_reason[p] && out.num_iters[p] == ref.num_iters[p] && out.final_cost[p] == ref.final_cost[p]);
   }
+  // error paths of the collective's boundary (reference behaviour for misuse: std::invalid_argument; here a thrown check())
+  auto throws = [](auto&& fn) { try { fn(); } catch (const std::exception&) { return true; } return false; };
+  std::vector<float> xw = x;
+  REQUIRE(throws([&] { (void)ShardedOptimize(xw, cost, options, comm, 9, &all_x); }));          // P_total does not match the shard this rank holds
+  REQUIRE(throws([&] { Communicator bad(ctx, id, /*nranks=*/1, /*rank=*/1); }));                  // rank out of range
+  REQUIRE(throws([&] { Communicator bad(ctx, id, /*nranks=*/0, /*rank=*/0); }));                  // empty communicator
+  {
+    toa_results lr{}, ar{};
+    REQUIRE(toa_gather(ctx.get(), comm.get(), TOA_F32, 1, 7, nullptr, &lr, 0, nullptr, &ar) != 0);   // the local arrays are required
+    REQUIRE(toa_gather(ctx.get(), comm.get(), TOA_F32, 1, 7, nullptr, nullptr, 3, nullptr, &ar) != 0); // root out of range
+    REQUIRE(toa_gather(ctx.get(), comm.get(), TOA_F32, 0, 7, nullptr, &lr, 0, nullptr, &ar) != 0);   // xdim < 1
+    REQUIRE(std::string(toa_last_error()).size() > 0);
+  }
   int64_t lo = -1, hi = -1;   // the block partition of SURVEY §8e: contiguous, sizes differ by at most one
   REQUIRE(toa_shard_range(100000, 3, 8, &lo, &hi) == 0 && lo == 37500 && hi == 50000);
   REQUIRE(toa_shard_range(11, 1, 2, &lo, &hi) == 0 && lo == 6 && hi == 11);

@@ -61,6 +61,39 @@ def test_gather_world2_gloo():
     assert np.array_equal(got["final_cost"], ids * 0.5)
 
 
+def test_gather_world4_uneven_gloo():
+    """Four ranks, shards of 4 + 4 + 3 + 3 problems and a wide x (the 2 / 4 / 8-GPU legs of the scaling run use exactly this
+    path when the native gather is not available): the root gets every field in problem-id order."""
+    P, n, world = 14, 50, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    ids = np.arange(P, dtype=np.float64)
+    assert np.array_equal(got["x"], (ids[:, None] * 10 + np.arange(n)[None, :]).astype(np.float32))
+    assert np.array_equal(got["stop_reason"], (ids % 5).astype(np.int32))
+    assert np.array_equal(got["num_iters"], (ids * 2).astype(np.int32))
+    assert np.array_equal(got["final_cost"], ids * 0.5)
+
+
+def test_bench_watchdog_line_is_a_complete_bench_line():
+    """bench.py at N > 1 arms a watchdog that prints the measured line if the result gather hangs: that line must carry the
+    same top-level keys as the normal one — `roofline` included, or the driver would record the scaling point as unmeasured."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    a = src.index("partial = {")
+    b = src.index("def _bail():")
+    block = src[a:b]
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"frac"', '"achieved"', '"peak"'):
+        assert key in block, key
+
+
 def test_gather_single_process_passthrough():
     from tinyopt_amd.dist import gather_output
     x = torch.zeros(4, 2)

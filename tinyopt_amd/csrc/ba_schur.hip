@@ -860,39 +860,57 @@ struct BlIdx {  // int offsets into a scene's index block
   }
 };
 
-// index structures of a scene, by ONE thread (setup, once per solve: O(M + N + C))
-__global__ void bl_index_kernel(const BlParams* __restrict__ prm) {
-  if (threadIdx.x != 0) return;
-  const long long p = blockIdx.x;
+// Index structures of a scene (setup, once per solve): pt_start (CSR over the point-sorted list), the cameras' observation
+// counts, and — a wave per camera, stable — each camera's observations in increasing point order.  (The first version did all
+// of it with ONE thread: 24.5 ms per call at 30 000 observations, 45 % of a 53 ms solve — profiles/r03_ab_log.md.)
+__global__ void __launch_bounds__(256) bl_index_a_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
   const int C = prm->C, N = prm->N, M = prm->M;
   const BlIdx ix(C, N, M);
   int* iw = prm->iwork + size_t(p) * ix.total;
   const int* oc = prm->obs_cam + size_t(p) * M;
   const int* op = prm->obs_pt + size_t(p) * M;
   int* ps = iw + ix.pt_start;
-  int* cs = iw + ix.cam_start;
-  int* co = iw + ix.cam_order;
-  int j = 0, bad = 0;
-  for (int i = 0; i < M; ++i) {
-    const int pt = op[i], cm = oc[i];
-    if (pt < 0 || pt >= N || cm < 0 || cm >= C) { bad = 1; break; }
-    if (i > 0 && (op[i - 1] > pt || (op[i - 1] == pt && oc[i - 1] >= cm))) { bad = 1; break; }   // sorted by (point, camera), no duplicates
-    while (j <= pt) ps[j++] = i;
-  }
-  while (j <= N) ps[j++] = M;
-  for (int c = 0; c <= C; ++c) cs[c] = 0;
-  if (!bad) {
-    for (int i = 0; i < M; ++i) cs[oc[i] + 1]++;
-    for (int c = 0; c < C; ++c) cs[c + 1] += cs[c];
-    // stable fill (a camera's observations in increasing point order); cs[] is advanced and then restored
-    for (int i = 0; i < M; ++i) co[cs[oc[i]]++] = i;
-    for (int c = C; c > 0; --c) cs[c] = cs[c - 1];
-    cs[0] = 0;
-  }
   int* fl = iw + ix.flags;
-  for (int i = 0; i < 16; ++i) fl[i] = 0;
-  fl[0] = 1; fl[1] = 1;
-  fl[6] = bad;   // malformed observation list: the scene is skipped with kSkipped (nothing to optimise safely)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int pt = op[i], cm = oc[i];
+  if (pt < 0 || pt >= N || cm < 0 || cm >= C) { atomicOr(&fl[6], 1); return; }
+  if (i > 0) {
+    const int pp = op[i - 1];
+    if (pp > pt || (pp == pt && oc[i - 1] >= cm)) { atomicOr(&fl[6], 1); return; }   // sorted by (point, camera), no duplicates
+    if (pp >= 0 && pp < pt) for (int j = pp + 1; j <= pt; ++j) ps[j] = i;          // the first observation of point pt (and of the empty points before it)
+  } else {
+    for (int j = 0; j <= pt; ++j) ps[j] = 0;
+  }
+  if (i == M - 1) for (int j = pt + 1; j <= N; ++j) ps[j] = M;
+  atomicAdd(&iw[ix.cam_start + cm + 1], 1);
+}
+__global__ void bl_index_b_kernel(const BlParams* __restrict__ prm) {   // exclusive scan of the cameras' counts: C <= 682 values
+  if (threadIdx.x != 0) return;
+  const long long p = blockIdx.x;
+  const BlIdx ix(prm->C, prm->N, prm->M);
+  int* cs = prm->iwork + size_t(p) * ix.total + ix.cam_start;
+  cs[0] = 0;
+  for (int c = 0; c < prm->C; ++c) cs[c + 1] += cs[c];
+}
+__global__ void __launch_bounds__(64) bl_index_c_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.y;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int M = prm->M;
+  const BlIdx ix(prm->C, prm->N, M);
+  int* iw = prm->iwork + size_t(p) * ix.total;
+  if (iw[ix.flags + 6]) return;
+  const int* oc = prm->obs_cam + size_t(p) * M;
+  int* co = iw + ix.cam_order;
+  int pos = iw[ix.cam_start + c];
+  for (int i0 = 0; i0 < M; i0 += 64) {
+    const int i = i0 + lane;
+    const bool mine = i < M && oc[i] == c;
+    const unsigned long long mask = __ballot(mine);
+    if (mine) co[pos + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    pos += __popcll(mask);
+  }
 }
 
 template <typename T>
@@ -916,6 +934,7 @@ __global__ void __launch_bounds__(64) bl_init_kernel(const BlParams* __restrict_
     S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
     S.acc_passes = 0; S.eval_passes = 0; S.solves = 0; S.problems = 0;
     int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+    fl[0] = 1; fl[1] = 1;
     if (fl[6]) {   // malformed observation list: nothing is optimised, the Output of an untouched problem with kSkipped
       S.stop = TOA_STOP_SKIPPED;
       fl[0] = 0;
@@ -1455,7 +1474,10 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const BlParams* dev = static_cast<const BlParams*>(h->params_dev);
   hipStream_t st = h->stream;
   const unsigned gM = unsigned((M + 255) / 256), gN = unsigned((N + 255) / 256), gX = unsigned((std::max(N * 3 / 8, C) + 255) / 256);
-  hipLaunchKernelGGL(bl_index_kernel, dim3(unsigned(P)), dim3(64), 0, st, dev);
+  HIP_TRY(hipMemsetAsync(prm.iwork, 0, b_iwork, st));   // flags, camera counts
+  hipLaunchKernelGGL(bl_index_a_kernel, dim3(gM, unsigned(P)), dim3(256), 0, st, dev);
+  hipLaunchKernelGGL(bl_index_b_kernel, dim3(unsigned(P)), dim3(64), 0, st, dev);
+  hipLaunchKernelGGL(bl_index_c_kernel, dim3(unsigned(C), unsigned(P)), dim3(64), 0, st, dev);
   hipLaunchKernelGGL(bl_init_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
   HIP_TRY(hipGetLastError());
   // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
