@@ -32,6 +32,7 @@ WORKLOADS = {
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
     # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
     "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, workgroup-per-problem kernel (64 <= n <= 128)"),
+    "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written tile-split MFMA Gram + rocSOLVER potrf/potrs"),
 }
 # single-problem configs of BASELINE.json (latency-bound: SURVEY §8d "report us/iter and GB/s"); replicas only at N > 1
 SINGLE = {
@@ -649,7 +650,11 @@ def main():
         # the lower block triangle, so that accounting would now credit flops nobody performs.)
         mfma_flop_per_pass = m * (n + 1) * (n + 2)
         nbl = (n + 15) // 16
-        mfma_issued_per_pass = 4 * ((((m + 3) // 4 + 3) // 4)) * (nbl * (nbl + 1) // 2) * 2048   # 4 waves x steps x tiles x 16*16*4*2
+        if n <= 128:
+            mfma_issued_per_pass = 4 * ((((m + 3) // 4 + 3) // 4)) * (nbl * (nbl + 1) // 2) * 2048   # 4 waves x steps x tiles x 16*16*4*2
+        else:   # large_gram_kernel: 64 x 64 blocks of the lower block triangle, 16 tiles each, every 4-row step
+            nb64 = (n + 63) // 64
+            mfma_issued_per_pass = ((m + 3) // 4) * (nb64 * (nb64 + 1) // 2) * 16 * 2048
     else:
         lay = ta.api.dense_row_layout(tdt, n, m)
         mfma_flop_per_pass = (lay["rows_padded"] // 4) * (lay["nb"] * (lay["nb"] + 1) // 2) * 2048
@@ -666,7 +671,7 @@ def main():
         except Exception:  # noqa: BLE001
             traffic = None
     result = {
-        "metric": "LM iterations/s (batched dense n<=50)" if not large else f"LM iterations/s (batched dense n={n}, 64 <= n <= 128 path)",
+        "metric": "LM iterations/s (batched dense n<=50)" if not large else f"LM iterations/s (batched dense n={n}, {'64 <= n <= 128' if n <= 128 else 'n > 128'} path)",
         "value": iters_all / elapsed,
         "unit": "LM iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -681,7 +686,7 @@ def main():
                    "iters_per_problem": iters_all / args.steps / (P * world),
                    "lm_iterations_per_step_per_gpu_min_max": rank_iters,
                    "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else "large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)",
+        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else ("large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)" if n <= 128 else "large_gram_kernel + the rest of the n > 128 pipeline (rows, reduce, pre, rocSOLVER potrf / potrs, post: the whole batched solve)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of the same workload and binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,

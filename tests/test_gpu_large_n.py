@@ -286,3 +286,29 @@ def test_large_n_batch_independence_and_determinism(ta, oracle):
     sub = slice(293, 300)
     xs_, os_ = _run_natural(ta, A[sub].copy(), b[sub].copy(), x0[sub].copy(), opts)
     assert np.array_equal(xs_, xa[sub]) and np.array_equal(os_.num_iters.cpu().numpy(), oa.num_iters.cpu().numpy()[sub])
+
+
+def test_hand_written_gram_beyond_128_follows_the_oracle(ta, oracle):
+    """TOA_LARGE_OWN_GRAM=1: H = J^T J of the n > 128 pipeline by large_gram_kernel (64 x 64 blocks of the lower block triangle on
+    the matrix cores, row chunks folded in fixed order) instead of the library GEMM: same trajectories as the oracle's."""
+    import os
+    P, n, m = 6, 160, 900
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=19)
+    opts = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
+    old = os.environ.get("TOA_LARGE_OWN_GRAM")
+    os.environ["TOA_LARGE_OWN_GRAM"] = "1"
+    try:
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, ta.DenseRowNatural(Ad, bd), opts, history=True)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["TOA_LARGE_OWN_GRAM"]
+        else:
+            os.environ["TOA_LARGE_OWN_GRAM"] = old
+    from parity import check_trajectories, gpu_dict
+    check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
+                                              cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
+    assert np.abs(x.cpu().numpy() - xs).max() < 2e-2

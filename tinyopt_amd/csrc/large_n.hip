@@ -252,6 +252,11 @@ struct LargeArgs {
   int gslots;
   int* info;
   unsigned long long* counters;
+  // hand-written Gram (large_gram_kernel): the rows kernel leaves the row scales s_i = 1 + 0.1 cos(a_i.x) here instead of
+  // writing J = diag(s) A; the Gram kernel re-reads A and forms J^T J on the matrix cores, partial Grams per row chunk
+  T* sc;        // [P][m]
+  T* gram_part; // [P][gram_R][pairs][64 * 64]
+  int own_gram, gram_R, gram_rows;   // row chunks per problem, rows per chunk (a multiple of 4)
 };
 
 template <typename T>
@@ -324,7 +329,8 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
       if (lane == 0) rp[i0 + k] = t[k] + T(0.1) * sn - bv[i0 + k];
       if (want_j) {
         const T sc = T(1) + T(0.1) * cs;
-        for (int j = lane; j < n; j += 64) Jp[size_t(i0 + k) * n + j] = sc * row[j];
+        if (a.own_gram) { if (lane == 0) a.sc[p * m + i0 + k] = sc; }
+        else for (int j = lane; j < n; j += 64) Jp[size_t(i0 + k) * n + j] = sc * row[j];
       }
     }
   }
@@ -387,8 +393,9 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
         const int c = rl + k * LPR;
         const V jv = av[k] * sc;
         gacc[k] += jv * ri;
-        if (live && c < nv) __builtin_nontemporal_store(jv, reinterpret_cast<V*>(Jp + size_t(i) * n) + c);
+        if (!a.own_gram && live && c < nv) __builtin_nontemporal_store(jv, reinterpret_cast<V*>(Jp + size_t(i) * n) + c);
       }
+      if (a.own_gram && live && rl == 0) a.sc[p * m + i] = sc;
     }
   }
   if (want_j) {  // fold the row groups of the wave (fixed order), then one partial vector per wave
@@ -408,6 +415,104 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
         if (c < nv) *reinterpret_cast<V*>(gp + c * VEC) = gacc[k];
       }
     }
+  }
+}
+
+// ---- H = J^T J for n > 128 on the matrix cores, hand-written (round 3, opt-in: see large_lm_run_t for the measured A/B;
+// the library GEMM computes the full square and needs J = diag(s) A written to and read back from HBM).  The Gram is cut into 64 x 64 blocks (I >= J: the
+// lower block triangle) and the rows into gram_R chunks; ONE WAVE owns (block pair, row chunk): 16 tiles of
+// v_mfma_*_16x16x4 accumulating in place, operands loaded straight into MFMA order (lane (k, c) of a 4-row step loads the
+// four columns 64 I + 4 c .. + 3 of row 4 s + k: one 16-byte load per operand block, the layout of DenseRowGram with
+// NBM = 4), scaled by the row's s_i in registers.  Partial blocks go to HBM and are summed over the row chunks in fixed
+// order by large_gram_reduce_kernel, which also mirrors the upper triangle.  Problems that are not running or do not
+// rebuild their Hessian this pass return at once: the host no longer needs their count.
+template <typename T>
+__device__ __forceinline__ void gram16(typename Mfma<T>::Acc (&acc)[16], const T (&wa)[4], const T (&wb)[4]) {
+  asm volatile("s_nop 1" : : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (sizeof(T) == 4) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * i + j]) : "v"(wa[i]), "v"(wb[j]));
+      else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[4 * i + j]) : "v"(wa[i]), "v"(wb[j]));
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) large_gram_kernel(const LargeArgs<T> a) {
+  using Acc = typename Mfma<T>::Acc;
+  const long long p = blockIdx.y;
+  if (!a.active[p]) return;
+  if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
+  const int n = a.n, m = a.m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, c = lane & 15;
+  const int R4 = (a.gram_R + 3) / 4;
+  const int pair = blockIdx.x / R4, chunk = (blockIdx.x % R4) * 4 + wave;
+  if (chunk >= a.gram_R) return;
+  int I = 0, rem = pair;                       // pair -> (I, J), I >= J, row-major over the lower block triangle
+  while (rem > I) { rem -= I + 1; ++I; }
+  const int J = rem;
+  const T* A = a.data + size_t(p) * m * (n + 1);
+  const T* scp = a.sc + size_t(p) * m;
+  const int row0 = chunk * a.gram_rows, row1 = min(m, row0 + a.gram_rows);
+  const int ca = 64 * I + 4 * c, cb = 64 * J + 4 * c;
+  const bool oka = ca < n, okb = cb < n;       // n is a multiple of 4: a lane's four columns are all inside or all outside
+  Acc acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = Acc{0, 0, 0, 0};
+  auto load = [&](const int row, T (&va)[4], T (&vb)[4], T& sv) __attribute__((always_inline)) {
+    const bool live = row < row1;
+    const T* rp = A + size_t(live ? row : row0) * n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { va[e] = (live && oka) ? rp[ca + e] : T(0); vb[e] = (live && okb) ? rp[cb + e] : T(0); }
+    sv = live ? scp[row] : T(0);
+  };
+  T va[4], vb[4], sv;
+  load(row0 + k, va, vb, sv);
+  for (int r = row0; r < row1; r += 4) {
+    T na[4], nb[4], ns;
+    load(r + 4 + k, na, nb, ns);               // the next step's operands, in flight during this step's MFMAs
+    T wa[4], wb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wa[e] = va[e] * sv; wb[e] = vb[e] * sv; }
+    gram16<T>(acc, wa, wb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nb[e]; }
+    sv = ns;
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the matrix pipe has drained before the accumulators are read
+#pragma unroll
+  for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
+  // G[64 I + 4 out_row + i][64 J + 4 c + j] = acc[4 i + j][reg]: four consecutive columns per lane and (i, reg)
+  const int npairs = ((n + 63) / 64) * ((n + 63) / 64 + 1) / 2;
+  T* blk = a.gram_part + ((size_t(p) * a.gram_R + chunk) * npairs + pair) * 4096;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int li = 4 * Mfma<T>::out_row(lane, reg) + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) blk[li * 64 + 4 * c + j] = acc[4 * i + j][reg];
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a) {
+  const long long p = blockIdx.y;
+  if (!a.active[p]) return;
+  if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
+  const int n = a.n;
+  const int pair = blockIdx.x;
+  int I = 0, rem = pair;
+  while (rem > I) { rem -= I + 1; ++I; }
+  const int J = rem;
+  const int npairs = ((n + 63) / 64) * ((n + 63) / 64 + 1) / 2;
+  T* H = a.Hnew + size_t(p) * n * n;
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int li = e >> 6, lj = e & 63, gi = 64 * I + li, gj = 64 * J + lj;
+    if (gi >= n || gj >= n) continue;
+    T s = 0;
+    for (int r = 0; r < a.gram_R; ++r) s += a.gram_part[((size_t(p) * a.gram_R + r) * npairs + pair) * 4096 + e];   // fixed order
+    H[size_t(gi) * n + gj] = s;
+    if (I != J) H[size_t(gj) * n + gi] = s;
   }
 }
 
@@ -693,7 +798,28 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
   const size_t b_ptr = al(size_t(P) * sizeof(void*));
-  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_J + b_r + b_sum + b_gpart + 2 * b_ptr;
+  // Hand-written Gram instead of the library GEMM: OPT-IN (TOA_LARGE_OWN_GRAM=1).  Measured on one MI355X, same box, 128
+  // problems x n = 256 x m = 8192 fp32 (profiles/r03_ab_log.md): 28.3 ms per batched solve against 24.1 ms with
+  // rocblas_sgemm_batched — the kernel issues 62 % of the full square's flops but runs at 43 TFLOP/s: one wave per 64 x 64
+  // block re-reads every row five times (5.4 GB per pass), and the library's tiles are at ~100 TFLOP/s.  What it needs to
+  // win is a row chunk staged ONCE in LDS and shared by all block pairs of a workgroup; until then the library stays the
+  // default.  Needs the 16-byte row alignment of the vectorised rows kernel.
+  const bool force_gemm = [] { const char* e = std::getenv("TOA_LARGE_OWN_GRAM"); return !(e && e[0] == '1'); }();   // (read per call: tests toggle it)
+  // (fp32 only: sixteen fp64 tiles are 128 accumulator registers, the kernel lands at one wave per SIMD and hipcc starts to
+  //  rotate accumulators between MFMAs — tools/isa_lint.py rejects it; fp64 keeps the library GEMM)
+  const bool own_gram = sizeof(T) == 4 && vec_ok && !force_gemm && n % 4 == 0;
+  const int nb64 = (n + 63) / 64, npairs = nb64 * (nb64 + 1) / 2;
+  int gram_R = 1, gram_rows = (m + 3) & ~3;
+  if (own_gram) {   // enough (pair, chunk) waves to fill the chip: ~16 per CU
+    const long long want_waves = (long long)h->num_cus * 16;
+    gram_R = int(std::max<long long>(1, std::min<long long>(32, (want_waves + P * npairs - 1) / (P * npairs))));
+    gram_rows = (((m + gram_R - 1) / gram_R) + 31) & ~31;
+    gram_R = (m + gram_rows - 1) / gram_rows;
+  }
+  const size_t b_sc = own_gram ? al(size_t(P) * m * sizeof(T)) : 0;
+  const size_t b_gp = own_gram ? al(size_t(P) * gram_R * npairs * 4096 * sizeof(T)) : 0;
+  const size_t b_Juse = own_gram ? 0 : b_J;   // J = diag(s) A is only materialised for the library GEMM
+  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
@@ -707,7 +833,9 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.g = reinterpret_cast<T*>(take(b_vec)); a.hd = reinterpret_cast<T*>(take(b_vec)); a.dx = reinterpret_cast<T*>(take(b_vec));
   a.ldx = reinterpret_cast<T*>(take(b_vec)); a.gnew = reinterpret_cast<T*>(take(b_vec)); a.rhs = reinterpret_cast<T*>(take(b_vec));
   a.H = reinterpret_cast<T*>(take(b_mat)); a.Hnew = reinterpret_cast<T*>(take(b_mat)); a.work = reinterpret_cast<T*>(take(b_mat));
-  a.J = reinterpret_cast<T*>(take(b_J)); a.r = reinterpret_cast<T*>(take(b_r));
+  a.J = reinterpret_cast<T*>(take(b_Juse)); a.r = reinterpret_cast<T*>(take(b_r));
+  a.sc = reinterpret_cast<T*>(take(b_sc)); a.gram_part = reinterpret_cast<T*>(take(b_gp));
+  a.own_gram = own_gram ? 1 : 0; a.gram_R = gram_R; a.gram_rows = gram_rows;
   a.summary = reinterpret_cast<int*>(take(b_sum));
   a.gpart = reinterpret_cast<T*>(take(b_gpart));
   a.gslots = gslots;
@@ -746,7 +874,12 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
         default: hipLaunchKernelGGL((large_rows_vec_kernel<T, 8>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
       }
     }
-    if (want_j > 0) {
+    if (own_gram) {
+      if constexpr (sizeof(T) == 4) {
+        hipLaunchKernelGGL(large_gram_kernel<T>, dim3(unsigned(npairs * ((gram_R + 3) / 4)), unsigned(P)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(npairs), unsigned(P)), dim3(256), 0, st, a);
+      }
+    } else if (want_j > 0) {
       hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
       int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
       if constexpr (sizeof(T) == 4) {
