@@ -563,18 +563,32 @@ BatchOutput OptimizeWithHostControls(std::vector<Scalar>& x, const Cost& cost, c
     for (int64_t p = 0; p < P; ++p) running[p] = running_before[p] && now.stop_reason[p] == kNone;
     std::vector<int32_t> req(P, 0);
     bool any = false;
-    if (active > 0 && (options.stop_callback || options.stop_callback2)) {
+    // The reference evaluates the callbacks inside Step on EVERY iteration (optimizer.h:529-534) and labels kMaxIters only after
+    // the loop, when stop_reason is still kNone (:320-321): a problem that used up its iterations in this very pass is
+    // consulted too, and a callback returning true makes it kUserStopped, not kMaxIters.
+    std::vector<char> just_max(P, 0);
+    bool consult = false, relabel = false;
+    for (int64_t p = 0; p < P; ++p) {
+      just_max[p] = running_before[p] && now.stop_reason[p] == kMaxIters;
+      consult = consult || running[p] || just_max[p];
+    }
+    if (consult && (options.stop_callback || options.stop_callback2)) {
       opt.StepInfo(err, dx2, g2, options.stop_callback2 ? &dxv : nullptr, options.stop_callback2 ? &gv : nullptr);
       for (int64_t p = 0; p < P; ++p) {
-        if (!running[p]) continue;
+        if (!running[p] && !just_max[p]) continue;
         bool stop = options.stop_callback && options.stop_callback(err[p], dx2[p], g2[p]);
         if (!stop && options.stop_callback2) {
           for (int j = 0; j < n; ++j) { dxf[j] = float(dxv[size_t(p) * n + j]); gf[j] = float(gv[size_t(p) * n + j]); }
           stop = options.stop_callback2(float(err[p]), dxf, gf);
         }
-        if (stop) { req[p] = kUserStopped; any = true; }
+        if (stop) {
+          if (just_max[p]) { now.stop_reason[p] = kUserStopped; relabel = true; }   // already finalised: only the label changes
+          else { req[p] = kUserStopped; any = true; }
+        }
       }
+      if (relabel) opt.SetStopReason(now.stop_reason);
     }
+    (void)active;
     duration_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const bool timed_out = options.max_duration_ms > 0 && duration_ms > options.max_duration_ms;
     if (timed_out)

@@ -267,6 +267,21 @@ static void stop_controls() {
     // after ONE iteration prev_lambda is still 0: Hessian() returns the damped diagonal as is (lm.h:157-171), reproduced
     REQUIRE(out.final_hessian.size() == 1 && std::abs(out.final_hessian[0] - 1.0001) < 1e-7);
   }
+  for (int trip = 0; trip < 2; ++trip) {  // the LAST allowed pass is shown to the callbacks too (optimizer.h:529-534 runs inside
+    // Step; kMaxIters is only labelled after the loop, :320-321).  max_iters = 1 -> 2 passes (:248-250): a callback that trips on
+    // the second gives kUserStopped, one that stays false gives kMaxIters
+    TestFn<double> cost(ctx, 1, 5);
+    double x = 1;
+    Options options;
+    options.min_error = 0;
+    options.min_grad_norm2 = 0;
+    options.max_iters = 1;
+    int calls = 0;
+    options.stop_callback2 = [&](float, const std::vector<float>&, const std::vector<float>&) { ++calls; return trip == 1 && calls == 2; };
+    const Output out = Optimize(x, cost, options);
+    REQUIRE(calls == 2 && out.num_iters == 2);
+    REQUIRE(out.stop_reason == (trip ? kUserStopped : kMaxIters));
+  }
   {  // stop_callback(err, |dx|^2, |g|^2), per problem of a batch: only the problems it names stop, the others converge
     Sqrt2<double> cost(ctx, 3);
     std::vector<double> x{1.0, -0.3, 3.2}, xr = x;

@@ -156,3 +156,29 @@ def test_stop_callback_per_problem_and_timeout(ta, oracle):
     assert (out.num_iters.cpu().numpy() == 1).all()
     assert bool(out.Succeeded().all()) and not bool(out.Converged().any())
     assert float((x - torch.from_numpy(x0).cuda()).abs().max()) > 1e-3       # the first step was applied
+
+
+def test_callbacks_are_consulted_on_the_last_allowed_iteration(ta):
+    """optimizer.h:529-534 evaluates the callbacks inside Step on every iteration; kMaxIters is only labelled after the loop
+    when nothing else stopped it (:320-321).  With max_iters = 1 the loop makes max_iters + 1 = 2 passes (:248-250): a callback
+    that trips on the second — the last allowed — pass gives kUserStopped; one that stays false gives kMaxIters, and has still
+    seen that last pass.  stop_callback2 receives err as a float (options.h:148-149)."""
+    for trip in (True, False):
+        seen = []
+
+        def cb(err, dx, g):
+            seen.append(err)
+            return trip and len(seen) == 2
+
+        o = ta.Options()
+        o.min_error = 0.0
+        o.min_grad_norm2 = 0.0
+        o.max_iters = 1
+        o.stop_callback2 = cb
+        x = torch.ones(1, 1, dtype=torch.float64, device="cuda")
+        out = ta.Optimize(x, ta.TestFn("x_minus_2", 1), o)
+        torch.cuda.synchronize()
+        assert len(seen) == 2 and int(out.num_iters[0]) == 2
+        assert all(e == float(np.float32(e)) for e in seen)
+        want = ta.StopReason.kUserStopped if trip else ta.StopReason.kMaxIters
+        assert int(out.stop_reason[0]) == int(want)

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
+
+import numpy as np
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -841,19 +843,28 @@ def _optimize_with_host_controls(x, cost, options: Options, history: bool, ctx: 
         running = out.stop_reason == int(StopReason.kNone)
         running &= running_before          # a row reports kNone until its problem stops
         req = torch.zeros(P, dtype=torch.int32)
-        if active and (options.stop_callback is not None or options.stop_callback2 is not None):
+        # The reference evaluates the callbacks inside Step on EVERY iteration (optimizer.h:529-534) and labels kMaxIters only
+        # after the loop, when stop_reason is still kNone (:320-321): a problem that used up its iterations in this very pass
+        # is consulted too, and a callback returning true makes it kUserStopped, not kMaxIters.
+        just_max = running_before & (out.stop_reason == int(StopReason.kMaxIters))
+        consult = running | just_max
+        if bool(consult.any()) and (options.stop_callback is not None or options.stop_callback2 is not None):
             err, dx2, g2, dxv, gv = opt.step_info(vectors=want_vec)
             err_h, dx2_h, g2_h = err.cpu().numpy(), dx2.cpu().numpy(), g2.cpu().numpy()
             dx_h = dxv.cpu().numpy() if want_vec else None
             g_h = gv.cpu().numpy() if want_vec else None
-            for p in torch.nonzero(running).flatten().tolist():
+            just_max_h = just_max.cpu().numpy()
+            for p in torch.nonzero(consult).flatten().tolist():
                 stop = False
                 if options.stop_callback is not None:
                     stop = bool(options.stop_callback(float(err_h[p]), float(dx2_h[p]), float(g2_h[p])))
-                if not stop and options.stop_callback2 is not None:
-                    stop = bool(options.stop_callback2(float(err_h[p]), dx_h[p].astype("float32"), g_h[p].astype("float32")))
+                if not stop and options.stop_callback2 is not None:   # stop_callback2(float(err), dx.cast<float>(), g.cast<float>())
+                    stop = bool(options.stop_callback2(float(np.float32(err_h[p])), dx_h[p].astype("float32"), g_h[p].astype("float32")))
                 if stop:
-                    req[p] = int(StopReason.kUserStopped)
+                    if just_max_h[p]:
+                        out.stop_reason[p] = int(StopReason.kUserStopped)   # already finalised: only the label changes
+                    else:
+                        req[p] = int(StopReason.kUserStopped)
         torch.cuda.synchronize(x.device)
         duration_ms += (time.perf_counter() - t0) * 1e3
         timed_out = options.max_duration_ms > 0 and duration_ms > options.max_duration_ms
