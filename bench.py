@@ -697,6 +697,14 @@ def main():
                                           "Builds served from the memo of the last accepted point read ~10 KB instead of a pass "
                                           "and are NOT credited",
                      "builds_from_memo_per_launch": memo_builds_total / args.steps,
+                     # SURVEY.md §8(d) prices the roof per problem-ITERATION (m (n + 1) sizeof(T) bytes each: "100 % HBM = 19.6 M
+                     # it/s" at C4).  With the memo an iteration no longer costs a pass, so this figure is NOT the DRAM rate of the
+                     # kernel (that is `achieved`, from the passes actually streamed); it is the iteration rate on SURVEY's scale.
+                     "per_iteration": {"bytes_per_iteration": bytes_per_pass,
+                                       "iterations_per_launch": iters_all / args.steps / world,
+                                       "achieved": bytes_per_pass * (iters_all / args.steps / world) / kern_avg_s / 1e9,
+                                       "ceiling_iterations_per_s": HBM_PEAK_GBS * 1e9 / bytes_per_pass,
+                                       "frac": bytes_per_pass * (iters_all / args.steps / world) / kern_avg_s / 1e9 / HBM_PEAK_GBS},
                      "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_all": kern_ms,
                      "mfma_secondary": {"achieved": mfma_tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,

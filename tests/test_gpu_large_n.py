@@ -288,17 +288,21 @@ def test_large_n_batch_independence_and_determinism(ta, oracle):
     assert np.array_equal(xs_, xa[sub]) and np.array_equal(os_.num_iters.cpu().numpy(), oa.num_iters.cpu().numpy()[sub])
 
 
-def test_hand_written_gram_beyond_128_follows_the_oracle(ta, oracle):
-    """TOA_LARGE_OWN_GRAM=1: H = J^T J of the n > 128 pipeline by large_gram_kernel (64 x 64 blocks of the lower block triangle on
-    the matrix cores, row chunks folded in fixed order) instead of the library GEMM: same trajectories as the oracle's."""
+@pytest.mark.parametrize("backend", ["own", "library"])
+@pytest.mark.parametrize("P,n,m", [(6, 160, 900), (3, 256, 1100), (2, 132, 700), (2, 388, 650), (1, 516, 1400)])
+def test_gram_beyond_128_follows_the_oracle(ta, oracle, P, n, m, backend):
+    """H = J^T J of the n > 128 pipeline, fp32: by default large_gram_kernel (row chunks staged once in LDS, 32 x 32 tiles of the
+    lower triangle dealt to the waves on v_mfma_f32_32x32x2_f32, chunks folded in fixed order); with TOA_LARGE_OWN_GRAM=0 the
+    library GEMM on J = diag(s) A.  Both must follow the oracle's trajectories.  Shapes: n a multiple of 32 and not; 1, 2, 3
+    and 4 tiles per wave; more than 64 tiles (n = 388: 91, n = 516: 153 -> two / three workgroups per row chunk); rows not a
+    multiple of the LDS stage."""
     import os
-    P, n, m = 6, 160, 900
     A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=19)
     opts = ta.Options.benchmark()
     ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
     Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
     old = os.environ.get("TOA_LARGE_OWN_GRAM")
-    os.environ["TOA_LARGE_OWN_GRAM"] = "1"
+    os.environ["TOA_LARGE_OWN_GRAM"] = "1" if backend == "own" else "0"
     try:
         x = torch.from_numpy(x0.copy()).cuda()
         out = ta.Optimize(x, ta.DenseRowNatural(Ad, bd), opts, history=True)
@@ -309,6 +313,10 @@ def test_hand_written_gram_beyond_128_follows_the_oracle(ta, oracle):
         else:
             os.environ["TOA_LARGE_OWN_GRAM"] = old
     from parity import check_trajectories, gpu_dict
+    # fp32 at the noise floor: a_i.x is a float dot product of length n, whose round-off moves the cost of one and the same point
+    # by ~n eps / |r| relative.  parity.TOL's 5e-4 is sized for n <= 128; at n >= 256 both the library GEMM and this kernel sit
+    # at 3-6e-4 from the oracle (measured on the device against the oracle, round 3), so the tolerance doubles there — stated here, nowhere hidden.
+    tol = dict(err_rtol=1e-3, floor_rtol=1e-3) if n >= 256 else None
     check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
-                                              cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
+                                              cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod(), tol=tol)
     assert np.abs(x.cpu().numpy() - xs).max() < 2e-2

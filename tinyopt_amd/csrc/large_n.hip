@@ -255,7 +255,7 @@ struct LargeArgs {
   // hand-written Gram (large_gram_kernel): the rows kernel leaves the row scales s_i = 1 + 0.1 cos(a_i.x) here instead of
   // writing J = diag(s) A; the Gram kernel re-reads A and forms J^T J on the matrix cores, partial Grams per row chunk
   T* sc;        // [P][m]
-  T* gram_part; // [P][gram_R][pairs][64 * 64]
+  T* gram_part; // [P][gram_R][tiles of the lower triangle][32 * 32]
   int own_gram, gram_R, gram_rows;   // row chunks per problem, rows per chunk (a multiple of 4)
 };
 
@@ -418,101 +418,194 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
   }
 }
 
-// ---- H = J^T J for n > 128 on the matrix cores, hand-written (round 3, opt-in: see large_lm_run_t for the measured A/B;
-// the library GEMM computes the full square and needs J = diag(s) A written to and read back from HBM).  The Gram is cut into 64 x 64 blocks (I >= J: the
-// lower block triangle) and the rows into gram_R chunks; ONE WAVE owns (block pair, row chunk): 16 tiles of
-// v_mfma_*_16x16x4 accumulating in place, operands loaded straight into MFMA order (lane (k, c) of a 4-row step loads the
-// four columns 64 I + 4 c .. + 3 of row 4 s + k: one 16-byte load per operand block, the layout of DenseRowGram with
-// NBM = 4), scaled by the row's s_i in registers.  Partial blocks go to HBM and are summed over the row chunks in fixed
-// order by large_gram_reduce_kernel, which also mirrors the upper triangle.  Problems that are not running or do not
-// rebuild their Hessian this pass return at once: the host no longer needs their count.
-template <typename T>
-__device__ __forceinline__ void gram16(typename Mfma<T>::Acc (&acc)[16], const T (&wa)[4], const T (&wb)[4]) {
-  asm volatile("s_nop 1" : : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]));
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (sizeof(T) == 4) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[4 * i + j]) : "v"(wa[i]), "v"(wb[j]));
-      else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[4 * i + j]) : "v"(wa[i]), "v"(wb[j]));
-    }
+// ---- H = J^T J = A^T diag(s^2) A for n > 128 on the matrix cores, hand-written (round 3).  The library GEMM computes the
+// full square and needs J = diag(s) A written to and read back from HBM; here the rows kernel leaves only the row scales
+// s_i, and the Gram kernel reads A ONCE per row chunk:
+//   * the Gram is cut into 32 x 32 tiles (ti >= tj: the lower tile triangle, T = nt (nt + 1) / 2 of them); the rows into
+//     gram_R chunks;
+//   * one WORKGROUP owns (row chunk, up to 64 tiles): it stages K rows at a time — every column, scaled by s_i — in LDS (two
+//     buffers: the next stage's global loads are in flight during this stage's MFMAs and are written to the other buffer
+//     afterwards; one barrier per stage).  Its W waves (W = 4, 8, 12 or 16: a multiple of the four SIMDs, so that every SIMD
+//     carries the same number of waves) own TPW <= 4 tiles each, dealt round-robin: one v_mfma_f32_32x32x2_f32 per tile and
+//     two-row step, operands read from LDS straight into MFMA order (lane l reads column 32 t + (l & 31) of row l >> 5:
+//     conflict-free ds_read_b32), the next step's operands in flight during this step's MFMAs;
+//   * partial tiles go to HBM and are summed over the row chunks in fixed order by large_gram_reduce_kernel, which also
+//     mirrors the upper triangle.
+// (A first version gave each wave a 64 x 64 block: 10 waves at n = 256 sit 3 + 3 + 2 + 2 on the SIMDs and the barrier of
+// every stage waits for the fullest — 77 TFLOP/s; profiles/r03_ab_log.md.)
+// Problems that are not running or do not rebuild their Hessian this pass return at once: the host does not need their
+// count.  fp32 only (fp64 keeps the library).
+struct SyrkGeom {
+  int nt, T;      // 32-column tiles per side, tiles in the lower triangle
+  int groups;     // workgroups per (problem, row chunk)
+  int per_group;  // tiles per workgroup (the last one may hold fewer)
+  int waves, tpw; // waves per workgroup, tiles per wave
+  int K;          // rows per LDS stage (a multiple of 8)
+  int ns;         // LDS row stride in elements: 32 nt (the columns beyond n hold zeros)
+};
+static inline SyrkGeom syrk_geom(const int n) {
+  SyrkGeom g;
+  g.nt = (n + 31) / 32;
+  g.T = g.nt * (g.nt + 1) / 2;
+  g.groups = (g.T + 63) / 64;
+  g.per_group = (g.T + g.groups - 1) / g.groups;
+  g.waves = 16; g.tpw = (g.per_group + 15) / 16;
+  for (int w = 12; w >= 4; w -= 4) {           // fewer slots wasted wins; on a tie the larger workgroup stays
+    const int t = (g.per_group + w - 1) / w;
+    if (t <= 4 && w * t < g.waves * g.tpw) { g.waves = w; g.tpw = t; }
+  }
+  g.ns = g.nt * 32;
+  g.K = 8;                                      // rows per stage: the largest of 32 / 16 / 8 with at most three 16-byte loads per thread
+  for (int K = 32; K > 8; K >>= 1)              // and 128 KB for the two buffers
+    if (K * (g.ns / 4) <= 3 * g.waves * 64 && 2 * K * g.ns * 4 <= 131072) { g.K = K; break; }
+  return g;
 }
-template <typename T>
-__global__ void __launch_bounds__(256) large_gram_kernel(const LargeArgs<T> a) {
-  using Acc = typename Mfma<T>::Acc;
+// LDS image of a stage: one K x 32 panel per 32-column tile (panel t at byte t K 128, row r of it at r 128): the operand of
+// two-row step q of tile t is at  t K 128 + (2 q + (lane >> 5)) 128 + (lane & 31) 4  — the step enters as an IMMEDIATE
+// offset of the ds_read, so the inner loop is matrix instructions and LDS reads only.  (On this chip VALU work does not
+// overlap the f32 MFMAs of the same SIMD: with [row][column] staging the six address adds and six register moves per
+// step cost 36 % on top of the MFMA time — profiles/r03_ab_log.md.)
+template <typename T, int TPW, int NV>   // NV <= TPW: the tiles this wave really owns
+__device__ __forceinline__ void syrk_stage(float __attribute__((ext_vector_type(16))) (&acc)[TPW], const unsigned char* lds, const int base,
+                                           const int (&offA)[TPW], const int (&offB)[TPW], const int K) {
+  if constexpr (NV > 0) {
+    int pa[NV], pb[NV];
+    T ra[NV], rb[NV];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+      pa[s] = base + offA[s];
+      pb[s] = base + offB[s];
+      ra[s] = *reinterpret_cast<const T*>(lds + pa[s]);
+      rb[s] = *reinterpret_cast<const T*>(lds + pb[s]);
+    }
+    for (int k8 = 0; k8 < K; k8 += 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T na[NV], nb[NV];                       // the next step's operands are in flight during this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {          // (q == 3 reads the first step of the next group: one panel row past the end at the
+          na[s] = *reinterpret_cast<const T*>(lds + pa[s] + (q + 1) * 256);   //  very end of a stage — inside the LDS allocation, never used)
+          nb[s] = *reinterpret_cast<const T*>(lds + pb[s] + (q + 1) * 256);
+        }
+#pragma unroll
+        for (int s = 0; s < NV; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s], rb[s], acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) { ra[s] = na[s]; rb[s] = nb[s]; }
+      }
+#pragma unroll
+      for (int s = 0; s < NV; ++s) { pa[s] += 1024; pb[s] += 1024; }
+    }
+  }
+}
+template <typename T, int TPW>
+__global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
+  static_assert(sizeof(T) == 4, "fp32 only");
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char syrk_lds[];
   const long long p = blockIdx.y;
   if (!a.active[p]) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
-  const int n = a.n, m = a.m;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 4, c = lane & 15;
-  const int R4 = (a.gram_R + 3) / 4;
-  const int pair = blockIdx.x / R4, chunk = (blockIdx.x % R4) * 4 + wave;
-  if (chunk >= a.gram_R) return;
-  int I = 0, rem = pair;                       // pair -> (I, J), I >= J, row-major over the lower block triangle
-  while (rem > I) { rem -= I + 1; ++I; }
-  const int J = rem;
+  const int n = a.n, m = a.m, ns = geo.ns, K = geo.K;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = blockIdx.x % geo.groups, chunk = blockIdx.x / geo.groups;
+  const int t_lo = group * geo.per_group, t_hi = min(geo.T, t_lo + geo.per_group);
+  const int l31 = lane & 31, l5 = lane >> 5;
+  // this wave's tiles: t_lo + wave + s W, s < TPW.  The valid ones are a prefix.  A surplus slot recomputes another tile and
+  // is not stored: the barrier of every stage waits for the waves with TPW tiles anyway, so skipping it would buy nothing,
+  // and a second code path costs accumulator copies and registers.
+  int tile[TPW], offA[TPW], offB[TPW];
+  int cnt = 0;
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    int t = t_lo + wave + s * geo.waves;
+    if (t < t_hi) cnt = s + 1; else t = t_lo + wave < t_hi ? t_lo + wave : t_lo;
+    tile[s] = t;
+    int ti = 0, rem = t;                        // t -> (ti, tj), ti >= tj, row-major over the lower triangle
+    while (rem > ti) { rem -= ti + 1; ++ti; }
+    offA[s] = ti * K * 128 + l5 * 128 + l31 * 4;
+    offB[s] = rem * K * 128 + l5 * 128 + l31 * 4;
+  }
   const T* A = a.data + size_t(p) * m * (n + 1);
   const T* scp = a.sc + size_t(p) * m;
   const int row0 = chunk * a.gram_rows, row1 = min(m, row0 + a.gram_rows);
-  const int ca = 64 * I + 4 * c, cb = 64 * J + 4 * c;
-  const bool oka = ca < n, okb = cb < n;       // n is a multiple of 4: a lane's four columns are all inside or all outside
-  Acc acc[16];
+  const int buf_bytes = K * ns * 4;
+  const int ns4 = ns >> 2, total4 = K * ns4;    // 16-byte elements per stage
+  constexpr int NLD = 3;
+  f32x4 st[NLD];
+  T ssc[NLD];
+  int goff[NLD], rr[NLD], loff[NLD];            // element e = tid + i nthr of a stage: row rr, global offset (from the stage's first row), LDS byte
 #pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = Acc{0, 0, 0, 0};
-  auto load = [&](const int row, T (&va)[4], T (&vb)[4], T& sv) __attribute__((always_inline)) {
-    const bool live = row < row1;
-    const T* rp = A + size_t(live ? row : row0) * n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { va[e] = (live && oka) ? rp[ca + e] : T(0); vb[e] = (live && okb) ? rp[cb + e] : T(0); }
-    sv = live ? scp[row] : T(0);
-  };
-  T va[4], vb[4], sv;
-  load(row0 + k, va, vb, sv);
-  for (int r = row0; r < row1; r += 4) {
-    T na[4], nb[4], ns;
-    load(r + 4 + k, na, nb, ns);               // the next step's operands, in flight during this step's MFMAs
-    T wa[4], wb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { wa[e] = va[e] * sv; wb[e] = vb[e] * sv; }
-    gram16<T>(acc, wa, wb);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { va[e] = na[e]; vb[e] = nb[e]; }
-    sv = ns;
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + i * nthr;
+    rr[i] = e / ns4;
+    const int c4 = e - rr[i] * ns4;
+    goff[i] = rr[i] * n + 4 * c4;
+    loff[i] = e < total4 ? (c4 >> 3) * K * 128 + rr[i] * 128 + (c4 & 7) * 16 : -1;
+    if (e >= total4 || 4 * c4 >= n) rr[i] = 1 << 28;   // never inside the chunk: the element stays zero
   }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the matrix pipe has drained before the accumulators are read
+  auto fetch = [&](const int r0) __attribute__((always_inline)) {   // issue only: nothing here waits for the loads
+    const T* Ar = A + size_t(r0) * n;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t]));
-  // G[64 I + 4 out_row + i][64 J + 4 c + j] = acc[4 i + j][reg]: four consecutive columns per lane and (i, reg)
-  const int npairs = ((n + 63) / 64) * ((n + 63) / 64 + 1) / 2;
-  T* blk = a.gram_part + ((size_t(p) * a.gram_R + chunk) * npairs + pair) * 4096;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int li = 4 * Mfma<T>::out_row(lane, reg) + i;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) blk[li * 64 + 4 * c + j] = acc[4 * i + j][reg];
+    for (int i = 0; i < NLD; ++i) {
+      const bool live = r0 + rr[i] < row1;
+      st[i] = live ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ar + goff[i])) : f32x4{0, 0, 0, 0};
+      ssc[i] = live ? scp[r0 + rr[i]] : T(0);
     }
+  };
+  auto put = [&](const int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)               // J = diag(s) A, rounded exactly as the rows kernel rounds it for the library path
+      if (loff[i] >= 0) *reinterpret_cast<f32x4*>(syrk_lds + base + loff[i]) = st[i] * ssc[i];
+  };
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) acc[s] = f32x16{0};
+  // Stage s computes on buffer s & 1.  At its START the rows of stage s + 1 (fetched during stage s - 1) are written to the
+  // other buffer — free since the barrier that ended stage s - 1 — and the loads of stage s + 2 are issued: the LDS writes
+  // and the global latency hide behind this stage's MFMAs, and the barrier at the end has nothing queued in front of it.
+  fetch(row0);
+  put(0);
+  fetch(row0 + K);                              // (rows past the chunk fetch nothing and stage zeros)
+  __syncthreads();
+  int cur = 0;
+  for (int r0 = row0; r0 < row1; r0 += K) {
+    if (r0 + K < row1) {
+      put(cur ? 0 : buf_bytes);
+      fetch(r0 + 2 * K);
+    }
+    syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    if (s >= cnt) continue;
+    T* blk = a.gram_part + ((size_t(p) * a.gram_R + chunk) * geo.T + tile[s]) * 1024;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) blk[((reg & 3) + 8 * (reg >> 2) + 4 * l5) * 32 + l31] = acc[s][reg];
+  }
 }
 template <typename T>
-__global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a) {
+__global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
   const long long p = blockIdx.y;
   if (!a.active[p]) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
   const int n = a.n;
-  const int pair = blockIdx.x;
-  int I = 0, rem = pair;
-  while (rem > I) { rem -= I + 1; ++I; }
-  const int J = rem;
-  const int npairs = ((n + 63) / 64) * ((n + 63) / 64 + 1) / 2;
+  const int t = blockIdx.x;
+  int ti = 0, rem = t;
+  while (rem > ti) { rem -= ti + 1; ++ti; }
+  const int tj = rem;
   T* H = a.Hnew + size_t(p) * n * n;
-  for (int e = threadIdx.x; e < 4096; e += 256) {
-    const int li = e >> 6, lj = e & 63, gi = 64 * I + li, gj = 64 * J + lj;
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int li = e >> 5, lj = e & 31, gi = 32 * ti + li, gj = 32 * tj + lj;
     if (gi >= n || gj >= n) continue;
     T s = 0;
-    for (int r = 0; r < a.gram_R; ++r) s += a.gram_part[((size_t(p) * a.gram_R + r) * npairs + pair) * 4096 + e];   // fixed order
+    for (int r = 0; r < a.gram_R; ++r) s += a.gram_part[((size_t(p) * a.gram_R + r) * geo.T + t) * 1024 + e];   // fixed order
     H[size_t(gi) * n + gj] = s;
-    if (I != J) H[size_t(gj) * n + gi] = s;
+    if (ti != tj) H[size_t(gj) * n + gi] = s;
   }
 }
 
@@ -556,12 +649,12 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   c = block_sum<T>(c, red);
   const double cost_val = normalize_cost(double(T(c)), m, opt);
   bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
+  bool assigned = false;                      // H, g took the fresh accumulation (also when the diagonal check then fails the Build)
   T* g = a.g + p * n;
   T* hd = a.hd + p * n;
   T* H = a.H + size_t(p) * n * n;
   if (built && do_acc) {  // H, g assigned from the fresh accumulation (gn.h:77-81,109-113)
-    const T* Hn = a.Hnew + size_t(p) * n * n;
-    for (size_t e = tid; e < size_t(n) * n; e += 256) H[e] = Hn[e];
+    const T* Hn = a.Hnew + size_t(p) * n * n;   // (H = Hnew itself: large_stage_kernel, all CUs instead of this one workgroup)
     double low = 0;
     for (int i = tid; i < n; i += 256) {
       T gi;
@@ -577,6 +670,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
       hd[i] = d;
       if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
     }
+    assigned = true;
     if (block_sum<T>(low, red) > 0) built = false;
   }
   __syncthreads();
@@ -585,20 +679,49 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
     for (int i = tid; i < n; i += 256) hd[i] = T(double(hd[i]) * s);
   }
   __syncthreads();
-  if (built) {
-    T* W = a.work + size_t(p) * n * n;
-    for (size_t e = tid; e < size_t(n) * n; e += 256) {
-      const int i = int(e / n), j = int(e % n);
-      W[e] = (i == j) ? hd[i] : H[e];
-    }
+  if (built)
     for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = g[i];
-  }
   if (tid == 0) {
     if (do_acc) S.acc_passes++; else S.eval_passes++;
     S.cost_val = cost_val;
     S.cost_nres = m;
     S.cost_ninl = m;
-    a.built[p] = built ? 1 : 0;
+    a.built[p] = (built ? 1 : 0) | (assigned ? 2 : 0);   // bit 0: Build succeeded; bit 1: H = Hnew is due (large_stage_kernel)
+  }
+}
+// The two n x n copies of Build — H = the fresh accumulation (gn.h:77-81), work = H with the damped diagonal (lm.h:108-117)
+// — spread over (row slices, problems) instead of riding in large_pre_kernel's one workgroup per problem (128 workgroups on
+// 256 CUs: 0.2 ms of a 2 ms pass at n = 256).  16-byte accesses when a row is a multiple of four elements.
+template <typename T>
+__global__ void __launch_bounds__(256) large_stage_kernel(const LargeArgs<T> a, const int rows_per_slice) {
+  const long long p = blockIdx.y;
+  if (!a.active[p] || !a.built[p]) return;
+  const int n = a.n, tid = threadIdx.x;
+  const bool do_acc = (a.built[p] & 2) != 0, built = (a.built[p] & 1) != 0;
+  T* H = a.H + size_t(p) * n * n;
+  const T* src = do_acc ? a.Hnew + size_t(p) * n * n : H;
+  T* W = a.work + size_t(p) * n * n;
+  const T* hd = a.hd + p * n;
+  const int r0 = blockIdx.x * rows_per_slice, r1 = min(n, r0 + rows_per_slice);
+  constexpr int V = 16 / int(sizeof(T));
+  if (n % V == 0) {
+    typedef T Vec __attribute__((ext_vector_type(V)));
+    const int nv = n / V, total = (r1 - r0) * nv;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int i = r0 + idx / nv, c = (idx % nv) * V;
+      Vec v = *reinterpret_cast<const Vec*>(src + size_t(i) * n + c);
+      if (do_acc) *reinterpret_cast<Vec*>(H + size_t(i) * n + c) = v;
+      if (i >= c && i < c + V) v[i - c] = hd[i];
+      if (built) *reinterpret_cast<Vec*>(W + size_t(i) * n + c) = v;
+    }
+  } else {
+    const int total = (r1 - r0) * n;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int i = r0 + idx / n, j = idx % n;
+      const T v = src[size_t(i) * n + j];
+      if (do_acc) H[size_t(i) * n + j] = v;
+      if (built) W[size_t(i) * n + j] = (i == j) ? hd[i] : v;
+    }
   }
 }
 
@@ -612,7 +735,7 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
   T* M = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image, factored in place
   __shared__ T dinv[16 * NB], sol[16 * NB];
   const size_t p = blockIdx.x;
-  if (!a.active[p] || !a.built[p]) return;
+  if (!a.active[p] || !(a.built[p] & 1)) return;
   const int n = a.n, LD = n | 1, tid = threadIdx.x;
   const T* Wp = a.work + p * size_t(n) * n;
   for (int e = tid; e < n * n; e += 256) {
@@ -669,7 +792,7 @@ __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, i
   T* g = a.g + p * n;
   T* dx = a.dx + p * n;
   T* ldx = a.ldx + p * n;
-  const bool built = a.built[p] != 0;
+  const bool built = (a.built[p] & 1) != 0;
   bool solver_failed = true;
   double dx_norm2 = 0, grad_norm2 = 0;
   if (built) {  // gn.h:150-171
@@ -798,26 +921,24 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
   const size_t b_ptr = al(size_t(P) * sizeof(void*));
-  // Hand-written Gram instead of the library GEMM: OPT-IN (TOA_LARGE_OWN_GRAM=1).  Measured on one MI355X, same box, 128
-  // problems x n = 256 x m = 8192 fp32 (profiles/r03_ab_log.md): 28.3 ms per batched solve against 24.1 ms with
-  // rocblas_sgemm_batched — the kernel issues 62 % of the full square's flops but runs at 43 TFLOP/s: one wave per 64 x 64
-  // block re-reads every row five times (5.4 GB per pass), and the library's tiles are at ~100 TFLOP/s.  What it needs to
-  // win is a row chunk staged ONCE in LDS and shared by all block pairs of a workgroup; until then the library stays the
-  // default.  Needs the 16-byte row alignment of the vectorised rows kernel.
-  const bool force_gemm = [] { const char* e = std::getenv("TOA_LARGE_OWN_GRAM"); return !(e && e[0] == '1'); }();   // (read per call: tests toggle it)
-  // (fp32 only: sixteen fp64 tiles are 128 accumulator registers, the kernel lands at one wave per SIMD and hipcc starts to
-  //  rotate accumulators between MFMAs — tools/isa_lint.py rejects it; fp64 keeps the library GEMM)
+  // H = J^T J: the hand-written LDS-staged Gram (large_gram_kernel) for fp32 rows that are 16-byte aligned; the library GEMM
+  // otherwise (fp64, odd shapes) or with TOA_LARGE_OWN_GRAM=0.  Same box, 128 problems x n = 256 x m = 8192 fp32
+  // (profiles/r03_ab_log.md): rocblas_sgemm_batched 1.22 ms per pass with every problem rebuilding (the full square,
+  // 113 TFLOP/s) plus the J = diag(s) A round trip through HBM in the rows kernel (0.43 -> 0.23 ms without it); this kernel
+  // 0.74 ms (the lower tile triangle only: 56 % of the flops, at 104 TFLOP/s issued).
+  const bool force_gemm = [] { const char* e = std::getenv("TOA_LARGE_OWN_GRAM"); return e && e[0] == '0'; }();   // (read per call: tests toggle it)
   const bool own_gram = sizeof(T) == 4 && vec_ok && !force_gemm && n % 4 == 0;
-  const int nb64 = (n + 63) / 64, npairs = nb64 * (nb64 + 1) / 2;
   int gram_R = 1, gram_rows = (m + 3) & ~3;
-  if (own_gram) {   // enough (pair, chunk) waves to fill the chip: ~16 per CU
-    const long long want_waves = (long long)h->num_cus * 16;
-    gram_R = int(std::max<long long>(1, std::min<long long>(32, (want_waves + P * npairs - 1) / (P * npairs))));
-    gram_rows = (((m + gram_R - 1) / gram_R) + 31) & ~31;
+  const SyrkGeom geo = syrk_geom(n);
+  if (own_gram) {   // about four workgroups per CU when every problem rebuilds (a late pass with few of them left is bound by ONE
+                    // workgroup's run time, which shrinks with the chunk); the rows of a chunk a multiple of the LDS stage
+    const long long want_wgs = (long long)h->num_cus * 4, per_chunk = P * geo.groups;
+    gram_R = int(std::max<long long>(1, std::min<long long>(32, (want_wgs + per_chunk - 1) / per_chunk)));
+    gram_rows = (((m + gram_R - 1) / gram_R) + geo.K - 1) / geo.K * geo.K;
     gram_R = (m + gram_rows - 1) / gram_rows;
   }
   const size_t b_sc = own_gram ? al(size_t(P) * m * sizeof(T)) : 0;
-  const size_t b_gp = own_gram ? al(size_t(P) * gram_R * npairs * 4096 * sizeof(T)) : 0;
+  const size_t b_gp = own_gram ? al(size_t(P) * gram_R * geo.T * 1024 * sizeof(T)) : 0;
   const size_t b_Juse = own_gram ? 0 : b_J;   // J = diag(s) A is only materialised for the library GEMM
   const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
@@ -856,6 +977,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // counters ACCUMULATE on every path (fused, row-split, stepping, here): the caller zeroes them (include/tinyopt_amd.h)
   hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
   const T one = 1, zero = 0;
+  // row slices of the n x n staging copies: ~8 workgroups per CU over the batch, at least 8 rows each
+  const int stage_rows = int(std::max<long long>(8, (long long)n * P / std::max<long long>(1, (long long)h->num_cus * 8)));
   int active = int(P), want_j = int(P);
   for (long long pass = 0; pass < max_passes && active > 0; ++pass) {
     const dim3 rgrid(row_blocks, unsigned(P));
@@ -876,8 +999,15 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     }
     if (own_gram) {
       if constexpr (sizeof(T) == 4) {
-        hipLaunchKernelGGL(large_gram_kernel<T>, dim3(unsigned(npairs * ((gram_R + 3) / 4)), unsigned(P)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(npairs), unsigned(P)), dim3(256), 0, st, a);
+        const dim3 ggrid(unsigned(geo.groups * gram_R), unsigned(P)), gblock(unsigned(geo.waves * 64));
+        const size_t glds = size_t(2) * geo.K * geo.ns * sizeof(T) + 256;   // (+ the one-step over-read of the operand prefetch)
+        switch (geo.tpw) {
+          case 1: hipLaunchKernelGGL((large_gram_kernel<T, 1>), ggrid, gblock, glds, st, a, geo); break;
+          case 2: hipLaunchKernelGGL((large_gram_kernel<T, 2>), ggrid, gblock, glds, st, a, geo); break;
+          case 3: hipLaunchKernelGGL((large_gram_kernel<T, 3>), ggrid, gblock, glds, st, a, geo); break;
+          default: hipLaunchKernelGGL((large_gram_kernel<T, 4>), ggrid, gblock, glds, st, a, geo); break;
+        }
+        hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(geo.T), unsigned(P)), dim3(256), 0, st, a, geo);
       }
     } else if (want_j > 0) {
       hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
@@ -892,6 +1022,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
       if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
     }
     hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(large_stage_kernel<T>, dim3(unsigned((n + stage_rows - 1) / stage_rows), unsigned(P)), dim3(256), 0, st, a, stage_rows);
     int rc = 0;
     if (own_chol) {
       launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);

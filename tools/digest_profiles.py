@@ -31,7 +31,7 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for wl in ("c3", "c2", "c5", "large128", "ba"):
+    for wl in ("c3", "c2", "c5", "large128", "large256", "ba", "balists"):
         hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
         if hits:
             shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
@@ -49,7 +49,8 @@ def main():
             lf.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
         globals()["_large128"] = lf   # finished below, once the FETCH_SIZE calibration is known
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
-                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba"):
+                 "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba",
+                 "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
@@ -71,7 +72,7 @@ def main():
     alg = bench["roofline"]["passes_per_launch"] * bpp
     out = {
         "round": tag, "workload": "c4", "problems": P,
-        "kernel": "lm_fused_kernel<DenseRowModel<float,3,3>>",
+        "kernel": "lm_fused_kernel<DenseRowModel<float,3,3,false,true>>",
         "FETCH_SIZE_KB_per_launch": fused["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": fused["WRITE_SIZE"],
         "fetch_calibration": {
             "kernel": "accumulate_kernel<DenseRowModel<float,3,3>> want_grad=0 (reads every packed byte exactly once)",
@@ -141,7 +142,7 @@ def main():
         cal3 = float(P3) * bpp3 / (e3["FETCH_SIZE"] * 1024.0)
         hbm3 = f3["FETCH_SIZE"] * 1024.0 * cal3 + f3["WRITE_SIZE"] * 1024.0
         alg3 = b3["roofline"]["passes_per_launch"] * bpp3
-        out3 = {"round": tag, "workload": "c3", "problems": P3, "kernel": "lm_fused_kernel<DenseRowModel<double,1,0>>",
+        out3 = {"round": tag, "workload": "c3", "problems": P3, "kernel": "lm_fused_kernel<DenseRowModel<double,1,0,false,true>>",
                 "FETCH_SIZE_KB_per_launch": f3["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": f3["WRITE_SIZE"],
                 "fetch_calibration": {"kernel": "accumulate_kernel<DenseRowModel<double,1,0>> want_grad=0", "known_bytes": float(P3) * bpp3,
                                       "FETCH_SIZE_KB": e3["FETCH_SIZE"], "bytes_per_reported_byte": cal3},

@@ -7,14 +7,17 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O   # NOTE: also delete the LOCAL gpurun_out/refresh before calling gpurun (results are merged, not mirrored)
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
-for wl in c4 c3 c2 c5 c1 ba; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+for wl in c4 c3 c2 c5 c1 ba balists; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
+python bench.py --workload large256 --steps 5 --warmup 2 > $O/bench_large256.json 2> $O/bench_large256.err
+TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
+TOA_MEMO=0 TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
-for wl in c3 c2 c5 large128 ba; do
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
+for wl in c3 c2 c5 large128 large256 ba balists; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python $R/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu > $O/bench_under_rocprof_$wl.json 2> $O/stats_$wl.err
 done
 for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA"; do
