@@ -2254,7 +2254,10 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     const char* env = std::getenv("TOA_COOP");
     const int steps_total = ((prm.m + 3) / 4);
     if (!(env && env[0] == '0') && prm.m >= 1024 && Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T)) {
-      int K = 4;                     // chunks per pass (TOA_COOP_K: experiments)
+      // chunks per pass: ~1024 rows each.  Same box, C4 (m = 2000), three interleaved rounds (profiles/r03_ab_log.md):
+      // K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays its own ramp of the
+      // load ring, so the coarsest split that still lets a sibling help wins.  (TOA_COOP_K: experiments)
+      int K = std::max(2, std::min(16, (prm.m + 512) / 1024));
       if (const char* ek = std::getenv("TOA_COOP_K")) { const int v = std::atoi(ek); if (v >= 2 && v <= 64) K = v; }
       const int period = 8;          // 8 = DenseRowGram::kDepth * U steps
       int cs = (steps_total + K - 1) / K;
