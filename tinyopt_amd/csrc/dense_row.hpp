@@ -942,7 +942,7 @@ struct DenseRowGram {
   template <bool WANT_H>
   __device__ __forceinline__ T pass_chunk(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
                                           const T* __restrict__ xs, const int lane_in, const int step0, const int step1) {
-    static_assert(!kSuper16, "the 64-row super-batches are not chunked");
+    if constexpr (kSuper16) return pass16<WANT_H>(prob, lay, n, xs, lane_in, step0, step1);   // (step0 a multiple of 16 there)
     // Opaque copy of the lane id: everything below that depends only on the lane and the layout is invariant across chunks,
     // passes and problems, and LICM would hoist it out of all three loops and pin it across the LDL^T and the state machine.
     int lane = lane_in;
@@ -1079,9 +1079,13 @@ struct DenseRowGram {
     return keep + dpp_row_ror<8>(send);
   }
 
+  // step0 / step1: the steps [step0, step1) only (a chunk of the cooperative tail, see pass_chunk: step0 a multiple of the
+  // 16-step super-batch, the buffer descriptor ends with the chunk); step1 < 0: the whole problem.
   template <bool WANT_H>
   __device__ __forceinline__ T pass16(const T* __restrict__ prob, const DenseRowLayout& lay, const int n, const T* __restrict__ xs,
-                                      const int lane) {
+                                      const int lane_in, const int step0 = 0, const int step1 = -1) {
+    int lane = lane_in;
+    if (step1 >= 0) asm volatile("" : "+v"(lane));   // (chunk form: keep the lane-only values out of the caller's loops, as pass_chunk does)
     const int k = lane >> 4, c = lane & 15;
     const int RS = lay.rs, rsm = lay.rsm;
     const bool active = c * NBM < rsm;
@@ -1107,12 +1111,13 @@ struct DenseRowGram {
     pc.inl = T(0);
     if (WANT_H) clear();
     T csum = 0;
-    const int steps = lay.m4 >> 2;
-    const unsigned prob_bytes = unsigned(lay.m4) * unsigned(RS) * unsigned(sizeof(T));
-    const i32x4 rsrc = make_rsrc(prob, prob_bytes);
+    const int last_step = step1 >= 0 ? step1 : (lay.m4 >> 2);
+    const int steps = last_step - step0;
+    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(4 * RS) * unsigned(sizeof(T)))));
+    const i32x4 rsrc = make_rsrc(prob, unsigned(last_step) * step_bytes_u);
+    const unsigned base = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(step0) * step_bytes_u)));
     const unsigned voff = active ? unsigned((k * RS + c * NBM) * int(sizeof(T))) : 0x80000000u;
     const unsigned vofft = unsigned((k * RS + rsm) * int(sizeof(T)));
-    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(4 * RS) * unsigned(sizeof(T)))));
     constexpr int NBATCH = 4;   // batches of U steps per super-batch
     Slots S[NBATCH];
     SlotsT St[NBATCH];
@@ -1132,7 +1137,7 @@ struct DenseRowGram {
     };
     static_for<NBATCH>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
-      issue_batch(S[j], St[j], rsrc, voff, vofft, unsigned(j * U) * step_bytes_u, step_bytes_u);
+      issue_batch(S[j], St[j], rsrc, voff, vofft, base + unsigned(j * U) * step_bytes_u, step_bytes_u);
     });
     static_for<NBATCH>(land);
     // Loop invariant at the back-edge: NO load is in flight (every batch of the next super-batch has landed and been folded
@@ -1154,7 +1159,7 @@ struct DenseRowGram {
         });
         __builtin_amdgcn_sched_barrier(0);
         // refill the registers this batch's MFMAs have just consumed with the same batch of the NEXT super-batch
-        const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + NBATCH * U + j * U) * step_bytes_u)));
+        const unsigned soff = unsigned(__builtin_amdgcn_readfirstlane(int(base + unsigned(s0 + NBATCH * U + j * U) * step_bytes_u)));
         issue_batch(S[j], St[j], rsrc, voff, vofft, soff, step_bytes_u);
         __builtin_amdgcn_sched_barrier(0);
       });

@@ -88,16 +88,19 @@ struct DenseRowModel {
   // cooperative passes (fused kernel only; see CoopCtl above): chunks per pass (0 = off), steps per chunk, and where the
   // workgroup's control block / the per-wave carves sit in LDS
   static constexpr bool kCoop = COOP;
-  static_assert(!(COOP && (ROBUST || DenseRowGram<T, NBM, THIN>::kSuper16)), "no cooperative form of the robust / 64-row super-batch passes");
-  int coop_K, coop_cs, coop_lds_per_wave, cur_p, helping, help_o, help_c;
+  static constexpr int kCoopPeriod = DenseRowGram<T, NBM, THIN>::kSuper16 ? 16 : 8;   // steps per super-batch / per turn of the load ring (kDepth * U)
+  static_assert(!(COOP && ROBUST), "no cooperative form of the robust passes");
+  int coop_K, coop_cs, coop_lds_per_wave, coop_tot_off, cur_p, helping, help_o, help_c;
   __device__ __forceinline__ void init(int n, int m_, const void* d) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
     loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
-    coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
+    coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; coop_tot_off = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
   }
-  __device__ __forceinline__ void coop_init(int K, int chunk_steps, int lds_per_wave) { coop_K = K; coop_cs = chunk_steps; coop_lds_per_wave = lds_per_wave; }
+  // tot_off: where in a wave's carve the chunk partials of ITS passes are summed — 0 = its LDL^T workspace M (free during a
+  // pass; the carve starts with it), or an area of its own when M is smaller than the Gram registers (n = 12 fp64)
+  __device__ __forceinline__ void coop_init(int K, int chunk_steps, int lds_per_wave, int tot_off) { coop_K = K; coop_cs = chunk_steps; coop_lds_per_wave = lds_per_wave; coop_tot_off = tot_off; }
   __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
 #ifdef TOA_ABL_REUSE  // ablation: every wave streams one of 64 problems (cache-resident data, same instruction stream)
   __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); rows_real = m; }
@@ -159,7 +162,7 @@ struct DenseRowModel {
       o = __builtin_amdgcn_readfirstlane(o);
       asm volatile("" : "+s"(c), "+s"(o));
       CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[o];
-      T* totp = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n).M;
+      T* totp = reinterpret_cast<T*>(smem + size_t(o) * coop_lds_per_wave + coop_tot_off);
       // fold in ticket order
       // (bounded: a protocol bug must end in a trapped launch, not in a GPU that never comes back — ~1 s of polling)
       for (int spin = 0; __hip_atomic_load(&S.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != c; ++spin) {
@@ -190,7 +193,7 @@ struct DenseRowModel {
       if (spin > (1 << 24)) asm volatile("s_trap 2");
     }
     if constexpr (WANT_H) {
-      if (coop_K > 1) gram.memo_load_inplace(L.M, lane);
+      if (coop_K > 1) gram.memo_load_inplace(reinterpret_cast<T*>(smem + size_t(w) * coop_lds_per_wave + coop_tot_off), lane);
       gram.fold_thin();
       return T(0);
     } else {
@@ -1203,6 +1206,7 @@ struct FusedParams {
   double loss_th2;
   void* memo;                    // mode 0, models with kMemo: one slot of memo_stride bytes per resident wave (null = off)
   unsigned long long memo_stride;
+  int coop_tot_off;              // cooperative passes: byte offset of the chunk-partial total in a wave's carve (0 = its M)
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
   int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
   int coop_cs;                   // steps (of 4 rows) per chunk, a multiple of the load ring's period
@@ -1250,7 +1254,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
   if constexpr (ModelCoop<Model>::value) {   // the workgroup's control block: every wave marks itself as an owner, no pass open
-    model.coop_init(prm_g->coop_K, prm_g->coop_cs, prm_g->lds_per_wave);
+    model.coop_init(prm_g->coop_K, prm_g->coop_cs, prm_g->lds_per_wave, prm_g->coop_tot_off);
     CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(4) * prm_g->lds_per_wave);
     if (lane == 0) {
       ctl->slot[wave].ticket = prm_g->coop_K;
@@ -1273,6 +1277,11 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     } else if (dry) {
       p = int(P);
     } else {
+      // (An "end game" that stops two — or three — waves of every workgroup from pulling once fewer than two problems per
+      //  workgroup are left, so that each remaining problem is worked by an owner plus helpers, was measured and rejected: C4
+      //  12.93 -> 12.60 M it/s with two pullers, 12.07 with one (profiles/r03_ab_log.md).  A helper shares the Accumulate
+      //  passes only; the solve, the step test and the evaluate-only passes stay with the owner, and two waves on one problem
+      //  are well short of twice as fast.)
       if (lane == 0) p = atomicAdd(queue, 1) + nwaves;
       p = __builtin_amdgcn_readfirstlane(p);
     }
@@ -2244,22 +2253,40 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   }
   prm.coop_K = 0;
   prm.coop_cs = 0;
+  prm.coop_tot_off = 0;
   if constexpr (ModelCoop<Model>::value) {
     prm.coop_K = 1;                       // one chunk = the classic pass, bit for bit
     prm.coop_cs = (prm.m + 3) / 4;
     pwg += 256;                           // the control block (the waves' carves are far below the LDS limit of a smaller grid)
     // Cooperative passes (CoopCtl): on for a SHAPE (never for a batch size or a position in the batch, so that a problem's
-    // bits do not depend on them), when a pass has enough rows to be worth sharing and the chunk total fits the LDL^T
-    // workspace it borrows during a pass.  TOA_COOP=0 switches it off (A/B).
+    // bits do not depend on them), when a pass has enough rows to be worth sharing.  The chunk total of a pass is summed in
+    // the owner's LDL^T workspace when the Gram registers fit it, in an area of its own otherwise (if that costs no
+    // resident workgroup).  TOA_COOP=0 switches it off (A/B).
     const char* env = std::getenv("TOA_COOP");
     const int steps_total = ((prm.m + 3) / 4);
-    if (!(env && env[0] == '0') && prm.m >= 1024 && Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T)) {
-      // chunks per pass: ~1024 rows each.  Same box, C4 (m = 2000), three interleaved rounds (profiles/r03_ab_log.md):
-      // K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays its own ramp of the
-      // load ring, so the coarsest split that still lets a sibling help wins.  (TOA_COOP_K: experiments)
-      int K = std::max(2, std::min(16, (prm.m + 512) / 1024));
+    constexpr bool super16 = Model::kCoopPeriod == 16;   // fp64 n <= 15: 64-row super-batches, 52 KB problems — share from 256 rows
+    bool room = Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T);
+    if (!(env && env[0] == '0') && prm.m >= (super16 ? 256 : 1024) && !room) {
+      const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
+      int w2 = 0;
+      if ((pw + mb) * 4 + 256 <= 160 * 1024) {
+        if (int rc = occupancy((pw + mb) * 4 + 256, &w2)) return rc;
+        if (w2 == wg_per_cu) {
+          prm.coop_tot_off = (int)pw;
+          pw += mb;
+          pwg = pw * 4 + 256;
+          prm.lds_per_wave = (int)pw;
+          room = true;
+        }
+      }
+    }
+    if (!(env && env[0] == '0') && prm.m >= (super16 ? 256 : 1024) && room) {
+      // chunks per pass: ~1024 rows each (256 for the super-batch form).  Same box, C4 (m = 2000), three interleaved rounds
+      // (profiles/r03_ab_log.md): K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays
+      // its own ramp of the load ring, so the coarsest split that still lets a sibling help wins.  (TOA_COOP_K: experiments)
+      int K = super16 ? std::max(2, std::min(16, (prm.m + 128) / 256)) : std::max(2, std::min(16, (prm.m + 512) / 1024));
       if (const char* ek = std::getenv("TOA_COOP_K")) { const int v = std::atoi(ek); if (v >= 2 && v <= 64) K = v; }
-      const int period = 8;          // 8 = DenseRowGram::kDepth * U steps
+      const int period = Model::kCoopPeriod;   // steps per ring turn / super-batch: chunk boundaries fall on it
       int cs = (steps_total + K - 1) / K;
       cs = (cs + period - 1) / period * period;
       prm.coop_cs = cs;
