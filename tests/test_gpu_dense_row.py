@@ -123,6 +123,13 @@ LM_CASES = [
     (np.float32, 12, 500, 16),
     (np.float64, 18, 80, 8),    # thin tail
     (np.float32, 34, 150, 8),   # thin tail
+    # fp64 n <= 15: the fused kernel's row-per-lane pass through LDS (pass16s) — odd and even row widths (even ones read their
+    # rows with LDS bank conflicts, not with different results), the full 16 columns, rows short of / past a 64-row super-batch
+    (np.float64, 2, 70, 8),
+    (np.float64, 7, 129, 8),
+    (np.float64, 13, 64, 8),
+    (np.float64, 14, 333, 8),
+    (np.float64, 15, 200, 8),
 ]
 
 

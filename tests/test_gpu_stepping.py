@@ -120,7 +120,9 @@ def test_stop_callback_per_problem_and_timeout(ta, oracle):
     xr = torch.from_numpy(x0.copy()).cuda()
     ref = ta.Optimize(xr, model, o, history=True)
     e1 = ref.errs.cpu().numpy()[:, 1]                 # cost seen at iteration 1
-    thr = float(np.sort(e1)[6])
+    se = np.sort(e1)
+    thr = float(0.5 * (se[6] + se[7]))                # between two costs: the fused kernel (reference run) and the stepping form
+                                                      # (callback run) sum a_i.x in different orders for fp64 n <= 15 (last bits)
     calls = []
 
     def cb(err, dx2, g2):

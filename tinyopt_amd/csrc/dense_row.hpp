@@ -201,6 +201,37 @@ __device__ __forceinline__ double horner_f64(double acc, double z, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(acc), "v"(z), "v"(c));
   return d;
 }
+// The same polynomial with every coefficient as the (one) scalar operand of its v_fma_f64: for a loop whose registers are
+// the bound (pass16s) — twelve coefficient pairs are 24 vector registers otherwise.  Same operations in the same order as
+// sincos_t: same bits.
+__device__ __forceinline__ double horner_f64_s(double acc, double z, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(acc), "v"(z), "s"(c));
+  return d;
+}
+__device__ __forceinline__ void sincos_t_s(double t, double* s, double* c) {
+  const double j = rint(t * 0.63661977236758134308);
+  double y = fma(-j, 1.5707963267948966, t);
+  y = fma(-j, 6.123233995736766e-17, y);
+  const double z = y * y;
+  double ps = horner_f64_s(z, 1.58962301576546568060e-10, -2.50507477628578072866e-8);
+  ps = horner_f64_s(ps, z, 2.75573136213857245213e-6);
+  ps = horner_f64_s(ps, z, -1.98412698295895385996e-4);
+  ps = horner_f64_s(ps, z, 8.33333333332211858878e-3);
+  ps = horner_f64_s(ps, z, -1.66666666666666307295e-1);
+  ps = fma(ps, z * y, y);
+  double pc = horner_f64_s(z, -1.13585365213876817300e-11, 2.08757008419747316778e-9);
+  pc = horner_f64_s(pc, z, -2.75573141792967388112e-7);
+  pc = horner_f64_s(pc, z, 2.48015872888517045348e-5);
+  pc = horner_f64_s(pc, z, -1.38888888888730564116e-3);
+  pc = horner_f64_s(pc, z, 4.16666666666665929218e-2);
+  pc = fma(pc, z * z, fma(-0.5, z, 1.0));
+  const int q = int(j) & 3;
+  const double sv = (q & 1) ? pc : ps;
+  const double cv = (q & 1) ? ps : pc;
+  *s = (q & 2) ? -sv : sv;
+  *c = ((q + 1) & 2) ? -cv : cv;
+}
 __device__ __forceinline__ void sincos_t(double t, double* s, double* c) {
   const double j = rint(t * 0.63661977236758134308);
   double y = fma(-j, 1.5707963267948966, t);
@@ -829,13 +860,15 @@ struct DenseRowGram {
   // ROBUST: every residual goes through the M-estimator `loss` (a separate instantiation of the loop, compiled only into
   // the kernels of DenseRowModel<.., ROBUST = true>: the plain kernels' instruction stream and register budget are
   // untouched).  Returns the cost (K2, and K1 with a loss); *ninl = inlier rows, or -1 when every residual is one.
-  template <bool WANT_H, bool ROBUST = false>
+  // STAGED (fp64 n <= 15 only): the row-per-lane pass through the wave's LDS stage (pass16s) instead of pass16.
+  template <bool WANT_H, bool ROBUST = false, bool STAGED = false>
   __device__ __forceinline__ T pass(const T* __restrict__ prob, const DenseRowLayout& lay, const int n,
                                     const T* __restrict__ xs, const int lane, const int loss = 0, const T th2 = T(0),
-                                    const int rows_real = 0, int* ninl = nullptr) {
+                                    const int rows_real = 0, int* ninl = nullptr, unsigned char* stage = nullptr) {
     if constexpr (!ROBUST) {
       if (ninl) *ninl = -1;
-      if constexpr (kSuper16) return pass16<WANT_H>(prob, lay, n, xs, lane);
+      if constexpr (kSuper16 && STAGED) return pass16s<WANT_H>(prob, lay, n, xs, lane, stage);
+      else if constexpr (kSuper16) return pass16<WANT_H>(prob, lay, n, xs, lane);
     }
     const int k = lane >> 4, c = lane & 15;
     const int RS = lay.rs, rsm = lay.rsm;
@@ -1177,6 +1210,128 @@ struct DenseRowGram {
       return T(0);
     }
     return wave_allreduce_sum(csum);
+  }
+
+  // ---- fp64, n <= 15, ROW PER LANE through LDS (round 3; lm_fused_kernel only: DenseRowModel<.., COOP = true> of these
+  // layouts) ---------------------------------------------------------------------------------------------------------------
+  // PMC of the pass above at C3 (profiles/r03_ab_log.md): 26 VALU instructions per 4-row step against ONE 64-cycle MFMA —
+  // the cross-lane reductions of a_i.x (a lane holds one element of a row) and the broadcasts back dominate the issue
+  // slots, and VALU work does not overlap the matrix pipe.  Here a super-batch of 64 rows goes
+  //   HBM -> registers (coalesced, element l + 64 i on lane l) -> LDS, linear
+  //   LDS -> lane r reads ROW r (RS doubles; conflict-free for odd RS): a_r.x is RS - 1 in-lane FMAs, ONE sin / cos per
+  //          row, J_r = s a_r in-lane — no cross-lane instruction at all
+  //   [J_r | r_r | 0] -> LDS, 128-byte rows, 16-byte granules XOR-swizzled by the row (the writer is a row, the reader a column)
+  //   LDS -> MFMA operand of step q straight from ds_read_b64 (lane (i, k): column i of row 4 q + k; the step enters the
+  //          address as an immediate)
+  // ~5 VALU instructions per step instead of 26.  The 8 KB stage of the wave is one region used three times per super-batch
+  // (raw rows, then the scaled rows over them): the LDS operations of a wave execute in order.
+  // The summation order of a_i.x changes (in-lane chain instead of a lane tree): results differ from pass16's in the last
+  // bits; every comparison with the oracle is by tolerance, and the launch-per-iteration forms keep pass16.
+  static constexpr int kStageBytes = 64 * 128;
+  // stage image: row r at byte r 128, its 16-byte granule g (columns 2 g, 2 g + 1) at position g ^ (r & 7) — for the raw rows
+  // and for the scaled rows alike, so [J | r] simply overwrites the row it was made from.  Columns >= RS are zero (the loads
+  // of lanes beyond the row's end return 0), which makes the whole pass independent of n: 16 columns, no branches.
+  template <bool WANT_H>
+  __device__ __forceinline__ T pass16s(const T* __restrict__ prob, const DenseRowLayout& lay, const int n, const T* __restrict__ xs,
+                                       const int lane, unsigned char* __restrict__ stage) {
+    static_assert(sizeof(T) == 8 && NBM == 1 && THIN == 0, "fp64, n <= 15");
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    const int RS = lay.rs;                      // n + 1 <= 16: the row [a_i | b_i]
+    const int k = lane >> 4, c = lane & 15;
+    const int steps = lay.m4 >> 2;
+    const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(4 * RS) * 8u)));
+    const i32x4 rsrc = make_rsrc(prob, unsigned(steps) * step_bytes_u);
+    const unsigned voff = c < RS ? unsigned((k * RS + c) * 8) : 0x80000000u;
+    RawVec<2> st[16];
+    if (WANT_H) clear();
+    T csum = 0;
+    // loop-invariant LDS addresses (bytes from the wave's stage)
+    const int wr0 = k * 128 + (((c >> 1) ^ k) << 4) + (c & 1) * 8;   // element (row 4 i + k, column c): wr0 + i 512 for even i, (wr0 ^ 64) + i 512 for odd
+    const int wr1 = wr0 ^ 64;                                        // (also the MFMA operand of step i: lane (c, k) reads column c of row 4 i + k)
+    const int myrow = lane * 128 + ((lane & 7) << 4);                // granule g of row `lane`: myrow ^ (g << 4)
+    const int myb = lane * 128 + ((((n >> 1) ^ (lane & 7))) << 4) + (n & 1) * 8;   // column n of row `lane`: b_i, later r_i
+    // x is wave-uniform: sixteen SGPR pairs (x_j = 0 for j >= n: b and the padding add nothing to a_i.x).  As vector registers
+    // they would cost the kernel its third wave per SIMD.
+    T xu[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const long long b = __double_as_longlong(xs[j]);
+      const unsigned lo = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b)))), hi = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b >> 32))));
+      xu[j] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    s16_issue<0>(st, rsrc, voff, 0u, step_bytes_u);
+    for (int s0 = 0; s0 < steps; s0 += 16) {
+      // ---- raw rows -> LDS, then the next super-batch's loads into the same registers
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s16_to_lds<0>(st, stage + wr0, stage + wr1);
+      __builtin_amdgcn_wave_barrier();
+      s16_issue<0>(st, rsrc, voff, unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 16) * step_bytes_u))), step_bytes_u);
+      // ---- my row
+      T a[16];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const T2 v = *reinterpret_cast<const T2*>(stage + (myrow ^ (g << 4)));
+        a[2 * g] = v[0];
+        a[2 * g + 1] = v[1];
+      }
+      const T bi = *reinterpret_cast<const T*>(stage + myb);
+      T t = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t = fma(a[j], xu[j], t);
+      T sn, cs;
+      sincos_t_s(t, &sn, &cs);
+      const T sc = T(1) + T(0.1) * cs;
+      const T res = (t + T(0.1) * sn) - bi;
+      if constexpr (!WANT_H) {
+        csum = fma(res, res, csum);
+      } else {
+        // ---- [J | r | 0] over the row it came from
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          *reinterpret_cast<T2*>(stage + (myrow ^ (g << 4))) = T2{sc * a[2 * g], sc * a[2 * g + 1]};
+        }
+        *reinterpret_cast<T*>(stage + myb) = res;   // (after the granule that holds column n: same lane, in order)
+        __builtin_amdgcn_wave_barrier();
+        // ---- sixteen steps on the matrix core
+        T op[16];                          // every operand read is issued before the first MFMA waits for its own
+#pragma unroll
+        for (int q = 0; q < 16; ++q) op[q] = *reinterpret_cast<const T*>(stage + ((q & 1) ? wr1 : wr0) + q * 512);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : "+a"(acc[0]) : "v"(op[q]));
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch past the end (zeros) before its registers die
+    s16_touch<0>(st);
+    if (WANT_H) {
+      mfma_retire();
+      return T(0);
+    }
+    return wave_allreduce_sum(csum);
+  }
+  // (the asm operands below cannot be named from inside a lambda: plain recursive templates)
+  template <int I>
+  static __device__ __forceinline__ void s16_issue(RawVec<2> (&st)[16], const i32x4 rsrc, const unsigned voff, const unsigned soff,
+                                                   const unsigned step_bytes) {
+    if constexpr (I < 16) {
+      st[I].template issue<I == 0, 0>(rsrc, voff, soff);
+      s16_issue<I + 1>(st, rsrc, voff, soff + step_bytes, step_bytes);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void s16_to_lds(RawVec<2> (&st)[16], unsigned char* even, unsigned char* odd) {
+    if constexpr (I < 16) {
+      asm volatile("" : "+v"(st[I].a));
+      *reinterpret_cast<u32x2*>(((I & 1) ? odd : even) + I * 512) = st[I].a;
+      s16_to_lds<I + 1>(st, even, odd);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void s16_touch(RawVec<2> (&st)[16]) {
+    if constexpr (I < 16) {
+      asm volatile("" : "+v"(st[I].a));
+      s16_touch<I + 1>(st);
+    }
   }
 
   // The same pass over rows in the NATURAL layout (large_fused.hip, 64 <= n <= 128): `A` = nrows rows of n elements,

@@ -126,10 +126,10 @@ int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, 
   // ... and the three layouts where the variant costs a resident wave per SIMD (tools/kernel_regs.py against the plain
   // variant: f32 (1,1) 80 -> 84 registers, f32 (1,2) 92 -> 100, f64 (2,4) 256 -> 260)
   constexpr bool kF32 = sizeof(InstT) == 4;
-  // fp64 n <= 15 (the 64-row super-batch pass, C3): the chunk form exists (pass16's step0 / step1) but loses — same box,
-  // 10 000 problems, m = 500: off 67.4 M it/s, K = 2: 64.7, K = 4: 63.3 (profiles/r03_ab_log.md): a pass is ~24 us, two
-  // ramps of the load ring and the LDS fold cost more than the workgroup-local sharing of the last round returns.
-  constexpr bool kCoop0 = !DenseRowGram<InstT, TOA_INST_NBM, 0>::kSuper16;
+  // fp64 n <= 15 (the 64-row super-batch layouts, C2 / C3): COOP selects the row-per-lane pass through LDS (pass16s), not the
+  // cooperative form — that one exists (pass16's step0 / step1) but loses: same box, 10 000 problems, m = 500: off 67.4 M it/s,
+  // K = 2: 64.7, K = 4: 63.3 (profiles/r03_ab_log.md).
+  constexpr bool kCoop0 = true;
   constexpr bool kCoop1 = !(kF32 && TOA_INST_NBM == 1);
   constexpr bool kCoop2 = !(kF32 && TOA_INST_NBM == 1);
   constexpr bool kCoop4 = !(!kF32 && TOA_INST_NBM == 2);

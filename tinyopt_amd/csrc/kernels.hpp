@@ -87,7 +87,12 @@ struct DenseRowModel {
   int ninl;        // inlier residuals of the last pass; -1 = all of them (no loss)
   // cooperative passes (fused kernel only; see CoopCtl above): chunks per pass (0 = off), steps per chunk, and where the
   // workgroup's control block / the per-wave carves sit in LDS
-  static constexpr bool kCoop = COOP;
+  // COOP on a 64-row super-batch layout (fp64, n <= 15) selects the fused kernel's OTHER special form instead: the row-per-lane
+  // pass through an LDS stage of the wave (DenseRowGram::pass16s).  (Its cooperative form was measured and rejected.)
+  static constexpr bool kStaged = COOP && DenseRowGram<T, NBM, THIN>::kSuper16;
+  static constexpr bool kCoop = COOP && !kStaged;
+  static constexpr size_t kStageBytes = kStaged ? size_t(DenseRowGram<T, NBM, THIN>::kStageBytes) : 0;
+  unsigned char* stage;   // kStaged: this wave's LDS stage
   static constexpr int kCoopPeriod = DenseRowGram<T, NBM, THIN>::kSuper16 ? 16 : 8;   // steps per super-batch / per turn of the load ring (kDepth * U)
   static_assert(!(COOP && ROBUST), "no cooperative form of the robust passes");
   int coop_K, coop_cs, coop_lds_per_wave, coop_tot_off, cur_p, helping, help_o, help_c;
@@ -97,6 +102,7 @@ struct DenseRowModel {
     data = static_cast<const T*>(d);
     loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
     coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; coop_tot_off = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
+    stage = nullptr;
   }
   // tot_off: where in a wave's carve the chunk partials of ITS passes are summed — 0 = its LDL^T workspace M (free during a
   // pass; the carve starts with it), or an area of its own when M is smaller than the Gram registers (n = 12 fp64)
@@ -246,7 +252,7 @@ struct DenseRowModel {
       cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
       nres = m;
     } else {
-      const T cl = gram.template pass<true, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
+      const T cl = gram.template pass<true, ROBUST, kStaged>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl, stage);
       cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
       if constexpr (ROBUST) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
       nres = m;
@@ -257,7 +263,7 @@ struct DenseRowModel {
       ninl = -1;
       cost = coop_pass<false>(L, n, lane);
     } else {
-      cost = gram.template pass<false, ROBUST>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl);
+      cost = gram.template pass<false, ROBUST, kStaged>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl, stage);
     }
     nres = m;
   }
@@ -1206,12 +1212,17 @@ struct FusedParams {
   double loss_th2;
   void* memo;                    // mode 0, models with kMemo: one slot of memo_stride bytes per resident wave (null = off)
   unsigned long long memo_stride;
+  int stage_off;                 // row-per-lane fp64 pass: byte offset of the wave's LDS stage in its carve
   int coop_tot_off;              // cooperative passes: byte offset of the chunk-partial total in a wave's carve (0 = its M)
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
   int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
   int coop_cs;                   // steps (of 4 rows) per chunk, a multiple of the load ring's period
 };
 
+template <typename M, typename = void>
+struct ModelStageBytes { static constexpr size_t value = 0; };
+template <typename M>
+struct ModelStageBytes<M, std::enable_if_t<(M::kStageBytes > 0)>> { static constexpr size_t value = M::kStageBytes; };
 template <typename M, typename = void>
 struct ModelCoop { static constexpr bool value = false; };
 template <typename M>
@@ -1250,6 +1261,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   Model model;
   model.init(n, prm_g->m, prm_g->data);
   model.set_loss(prm_g->loss, prm_g->loss_th2);
+  if constexpr (ModelStageBytes<Model>::value > 0) model.stage = reinterpret_cast<unsigned char*>(smem) + size_t(wave) * prm_g->lds_per_wave + prm_g->stage_off;
   T* X = static_cast<T*>(prm_g->x);
   const int xd = Model::kXdim ? Model::kXdim : n;  // stored parameters per problem (SE3: 12 for n = 6)
   int* queue = prm_g->queue;
@@ -2223,6 +2235,13 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     *out = w;
     return TOA_OK;
   };
+  prm.stage_off = 0;
+  if constexpr (ModelStageBytes<Model>::value > 0) {   // the LDS stage of the row-per-lane pass, part of every wave's carve
+    prm.stage_off = (int)pw;
+    pw += ModelStageBytes<Model>::value;
+    pwg = pw * 4;
+    prm.lds_per_wave = (int)pw;
+  }
   int wg_per_cu = 0;
   if (int rc = occupancy(pwg, &wg_per_cu)) return rc;
   prm.memo = nullptr;
