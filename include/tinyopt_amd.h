@@ -33,7 +33,9 @@ extern "C" {
 #define TOA_OK 0
 #define TOA_E_ARG (-1)     /* invalid argument (reference: std::invalid_argument, optimize.h:47,55,75) */
 #define TOA_E_HIP (-2)     /* HIP runtime error */
-#define TOA_E_NOMEM (-3)   /* device allocation failed (reference: bad_alloc -> kOutOfMemory) */
+#define TOA_E_NOMEM (-3)   /* device allocation failed.  toa_lm_run itself mirrors the reference (bad_alloc -> kOutOfMemory,
+                              optimizer.h:75-86): a workspace that cannot be allocated ends every problem with
+                              TOA_STOP_OUT_OF_MEMORY, x untouched, and the call returns TOA_OK */
 #define TOA_E_UNSUPPORTED (-4)
 #define TOA_E_RCCL (-5)    /* RCCL (collective) error */
 

@@ -320,3 +320,43 @@ def test_gram_beyond_128_follows_the_oracle(ta, oracle, P, n, m, backend):
     check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
                                               cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod(), tol=tol)
     assert np.abs(x.cpu().numpy() - xs).max() < 2e-2
+
+
+def test_workspace_that_cannot_be_allocated_is_kOutOfMemory(ta, oracle):
+    """optimizer.h:75-86: a system that cannot be allocated does not throw — the solve returns with StopReason::kOutOfMemory
+    (stop_reasons.h:20), x untouched.  TOA_TEST_SCRATCH_LIMIT_MB makes the workspace request fail as a full device would."""
+    import os
+    P, n, m = 3, 160, 400
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, np.float64, seed=2)
+    x = torch.from_numpy(x0.copy()).cuda()
+    os.environ["TOA_TEST_SCRATCH_LIMIT_MB"] = "0"
+    try:
+        out = ta.Optimize(x, ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()), ta.Options.benchmark())
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["TOA_TEST_SCRATCH_LIMIT_MB"]
+    assert (out.stop_reason.cpu().numpy() == int(ta.StopReason.kOutOfMemory)).all()
+    assert (out.num_iters.cpu().numpy() == 0).all() and not bool(out.Succeeded().any())
+    assert np.array_equal(x.cpu().numpy(), x0)
+    x2 = torch.from_numpy(x0.copy()).cuda()          # the handle is fine afterwards
+    out2 = ta.Optimize(x2, ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()), ta.Options.benchmark())
+    torch.cuda.synchronize()
+    assert bool(out2.Succeeded().all())
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 96, 500), (np.float64, 160, 600), (np.float32, 96, 600)])
+def test_use_ldlt_false_beyond_one_wavefront(ta, oracle, dtype, n, m):
+    """gn.h:157-162 / options.h:59: use_ldlt = false -> dx = -H.inverse() * g, unchecked.  For n >= 64 the launch-per-stage
+    pipeline with the library's general LU (rocSOLVER getrf / getrs), also where use_ldlt = true would take the persistent
+    64 <= n <= 128 kernel.  Same trajectories as the oracle's partial-pivot LU."""
+    P = 4
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=31)
+    opts = ta.Options.benchmark()
+    opts.hessian.use_ldlt = False
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()), opts, history=True)
+    torch.cuda.synchronize()
+    check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
+                                              cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), dtype, opts.to_pod())
+    assert np.abs(x.cpu().numpy() - xs).max() < (1e-2 if dtype == np.float32 else 1e-3)   # the planted solution, to the noise in b

@@ -641,7 +641,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");
     if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
     // the launch-per-stage pipeline indexes problems through grid.y (65 535); the persistent 64 <= n <= 128 kernel does not
-    if (P < 0 || (P > 65535 && !toa_large_fused_eligible(h, dtype, n, m)))
+    if (P < 0 || (P > 65535 && !(options && options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m))))
       return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: P must be in [0, 65535] for this n");
     if (!data) return fail(TOA_E_ARG, "null data pointer");
     if (mode != 0 || splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: toa_lm_run only");
@@ -655,15 +655,13 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     return fail(TOA_E_ARG, "toa_lm_run: stop_reason, num_iters and final_cost outputs are required");
   if (options->solver_type != 0 && options->solver_type != 1)
     return fail(TOA_E_ARG, "toa_lm_run: solver_type must be 0 (LM) or 1 (GN) on this path");  // optimize.h:75
-  if (!options->use_ldlt && n > 63)
-    return fail(TOA_E_UNSUPPORTED, "toa_lm_run: use_ldlt=false (gn.h:157-162) is implemented for n <= 63");
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return fail(TOA_E_ARG, "toa_lm_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return fail(TOA_E_ARG, "max_iters out of range");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   if (natural) {
-    if (h->loss != TOA_LOSS_L2 && !toa_large_fused_eligible(h, dtype, n, m))   // never silently: not wired into the n > 128 pipeline
+    if (h->loss != TOA_LOSS_L2 && !(options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)))   // never silently: not wired into the launch-per-stage pipeline
       return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is available for TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 only");
     return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   }
@@ -720,9 +718,22 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");
 }
 
+// The system (Hessians, work matrices) cannot be allocated: the reference does not throw — ResizeIfNeeded catches
+// std::bad_alloc and the solve returns with StopReason::kOutOfMemory, x untouched, nothing iterated (optimizer.h:75-86,
+// stop_reasons.h:20).  Same here: every problem's stop_reason becomes TOA_STOP_OUT_OF_MEMORY, num_iters 0, and the call
+// succeeds; toa_last_error() still names the allocation.
+static int oom_as_stop_reason(toa_handle h, int rc, int64_t P, const toa_results* results) {
+  if (rc != TOA_E_NOMEM || !results || !results->stop_reason || P <= 0) return rc;
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(results->stop_reason), int(TOA_STOP_OUT_OF_MEMORY), size_t(P), h->stream) != hipSuccess) return rc;
+  if (results->num_iters) (void)hipMemsetAsync(results->num_iters, 0, size_t(P) * sizeof(int32_t), h->stream);
+  if (results->num_failures) (void)hipMemsetAsync(results->num_failures, 0, size_t(P) * sizeof(int32_t), h->stream);
+  if (results->num_consec_failures) (void)hipMemsetAsync(results->num_consec_failures, 0, size_t(P) * sizeof(int32_t), h->stream);
+  return TOA_OK;
+}
+
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, void* x,
                const toa_options* options, const toa_results* results, uint64_t* counters) {
-  return lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1);
+  return oom_as_stop_reason(h, lm_run_impl(h, model, dtype, n, m, P, data, x, options, results, counters, -1), P, results);
 }
 
 size_t toa_lm_state_bytes(int dtype, int n, int64_t P) {

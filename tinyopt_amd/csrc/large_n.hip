@@ -31,6 +31,11 @@ struct RocApi {
   int (*spotrf)(rb_handle, int, int, float*, int, int64_t, int*, int) = nullptr;
   int (*dpotrf)(rb_handle, int, int, double*, int, int64_t, int*, int) = nullptr;
   int (*spotrs)(rb_handle, int, int, int, float*, int, int64_t, float*, int, int64_t, int) = nullptr;
+  // general LU for use_ldlt = false (gn.h:157-162: dx = -H.inverse() * g, unchecked)
+  int (*sgetrf)(rb_handle, int, int, float*, int, int64_t, int*, int64_t, int*, int) = nullptr;
+  int (*dgetrf)(rb_handle, int, int, double*, int, int64_t, int*, int64_t, int*, int) = nullptr;
+  int (*sgetrs)(rb_handle, int, int, int, float*, int, int64_t, const int*, int64_t, float*, int, int64_t, int) = nullptr;
+  int (*dgetrs)(rb_handle, int, int, int, double*, int, int64_t, const int*, int64_t, double*, int, int64_t, int) = nullptr;
   int (*dpotrs)(rb_handle, int, int, int, double*, int, int64_t, double*, int, int64_t, int) = nullptr;
   int (*sgemm)(rb_handle, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t,
                const float*, float*, int, int64_t, int) = nullptr;
@@ -72,6 +77,10 @@ RocApi& roc_api() {
     api.dpotrf = reinterpret_cast<decltype(api.dpotrf)>(sym(sol, "rocsolver_dpotrf_strided_batched"));
     api.spotrs = reinterpret_cast<decltype(api.spotrs)>(sym(sol, "rocsolver_spotrs_strided_batched"));
     api.dpotrs = reinterpret_cast<decltype(api.dpotrs)>(sym(sol, "rocsolver_dpotrs_strided_batched"));
+    api.sgetrf = reinterpret_cast<decltype(api.sgetrf)>(sym(sol, "rocsolver_sgetrf_strided_batched"));
+    api.dgetrf = reinterpret_cast<decltype(api.dgetrf)>(sym(sol, "rocsolver_dgetrf_strided_batched"));
+    api.sgetrs = reinterpret_cast<decltype(api.sgetrs)>(sym(sol, "rocsolver_sgetrs_strided_batched"));
+    api.dgetrs = reinterpret_cast<decltype(api.dgetrs)>(sym(sol, "rocsolver_dgetrs_strided_batched"));
     api.sgemm = reinterpret_cast<decltype(api.sgemm)>(sym(blas, "rocblas_sgemm_strided_batched"));
     api.dgemm = reinterpret_cast<decltype(api.dgemm)>(sym(blas, "rocblas_dgemm_strided_batched"));
     api.sgemm_b = reinterpret_cast<decltype(api.sgemm_b)>(sym(blas, "rocblas_sgemm_batched"));
@@ -85,6 +94,10 @@ RocApi& roc_api() {
 
 // Grow the context's scratch block (shared with the row-split path; contents are per-call) to at least `need` bytes.
 int ensure_scratch(toa_handle h, size_t need, const char* what) {
+  // TOA_TEST_SCRATCH_LIMIT_MB: a test hook — requests above the limit fail as an exhausted device would (read per call)
+  if (const char* e = std::getenv("TOA_TEST_SCRATCH_LIMIT_MB"))
+    if (need > size_t(std::atoll(e)) << 20)
+      return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace (TOA_TEST_SCRATCH_LIMIT_MB)");
   if (need <= h->scratch_bytes) return TOA_OK;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->scratch) (void)hipFree(h->scratch);
@@ -940,7 +953,12 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const size_t b_sc = own_gram ? al(size_t(P) * m * sizeof(T)) : 0;
   const size_t b_gp = own_gram ? al(size_t(P) * gram_R * geo.T * 1024 * sizeof(T)) : 0;
   const size_t b_Juse = own_gram ? 0 : b_J;   // J = diag(s) A is only materialised for the library GEMM
-  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp;
+  // use_ldlt = false (gn.h:157-162): dx = -H.inverse() * g "without any checks on invertibility" (options.h:59) — a general LU
+  // with partial pivoting from the library (what Eigen's inverse() is), its verdict ignored; the step is still refused if it is
+  // not finite, as everywhere else in this path
+  const bool lu = !opt.use_ldlt;
+  const size_t b_piv = lu ? al(size_t(P) * n * sizeof(int)) : 0;
+  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
@@ -962,12 +980,13 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.gslots = gslots;
   a.jptr = reinterpret_cast<const T**>(take(b_ptr));
   a.hptr = reinterpret_cast<T**>(take(b_ptr));
+  int* ipiv = reinterpret_cast<int*>(take(b_piv));
   if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
   // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = ldlt_image_bytes<T>(n);
-  const bool own_chol = !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
+  const bool own_chol = !lu && !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
   if (own_chol) {
     if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
   }
@@ -1026,6 +1045,15 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     int rc = 0;
     if (own_chol) {
       launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);
+    } else if (lu) {
+      if constexpr (sizeof(T) == 4) {
+        rc = api.sgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
+        if (rc == 0) rc = api.sgetrs(h->blas, kOpN, n, 1, a.work, n, int64_t(nn), ipiv, int64_t(n), a.rhs, n, int64_t(n), int(P));
+      } else {
+        rc = api.dgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
+        if (rc == 0) rc = api.dgetrs(h->blas, kOpN, n, 1, a.work, n, int64_t(nn), ipiv, int64_t(n), a.rhs, n, int64_t(n), int(P));
+      }
+      HIP_TRY(hipMemsetAsync(a.info, 0, size_t(P) * sizeof(int), st));   // unchecked: a singular pivot is not a failure by itself
     } else if constexpr (sizeof(T) == 4) {
       rc = api.spotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
       if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
@@ -1106,7 +1134,8 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                      const toa_results* results, uint64_t* counters) {
   // 64 <= n <= 128: the whole loop in one persistent kernel, Gram on the matrix cores (large_fused.hip)
-  if (toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
+  // (use_ldlt = false needs the library's general LU: the launch-per-stage pipeline below, for every n >= 64)
+  if (options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   toa::RocApi& api = toa::roc_api();
   if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
   if (dtype == TOA_F32)
