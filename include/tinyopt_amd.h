@@ -209,7 +209,7 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6].
- * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024 (P <= 65535 outside 64 <= n <= 128); data_dev: per problem A row-major [m][n] then b [m]
+ * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024 (any P: the n > 128 pipeline takes a large batch 65 535 problems at a time); data_dev: per problem A row-major [m][n] then b [m]
  *                           (problem stride m (n + 1) elements); x: [P][n]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;

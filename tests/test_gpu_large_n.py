@@ -360,3 +360,33 @@ def test_use_ldlt_false_beyond_one_wavefront(ta, oracle, dtype, n, m):
     check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
                                               cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), dtype, opts.to_pod())
     assert np.abs(x.cpu().numpy() - xs).max() < (1e-2 if dtype == np.float32 else 1e-3)   # the planted solution, to the noise in b
+
+
+def test_more_problems_than_one_grid_dimension(ta):
+    """The n > 128 pipeline indexes problems through grid.y (65 535): a larger batch goes through it slice by slice.  The last
+    problems of a 65 600-problem batch must come out as when they are solved on their own."""
+    P, n, m = 65600, 132, 180
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.rand(P, m, n, device="cuda", generator=g) * 2 - 1
+    xs = torch.rand(P, n, device="cuda", generator=g) * 2 - 1
+    t = torch.bmm(A, xs.unsqueeze(2)).squeeze(2)
+    b = t + 0.1 * torch.sin(t) + 1e-3 * (torch.rand(P, m, device="cuda", generator=g) * 2 - 1)
+    x0 = xs + 0.2 * (torch.rand(P, n, device="cuda", generator=g) * 2 - 1)
+    opts = ta.Options.benchmark()
+    x = x0.clone()
+    out = ta.Optimize(x, ta.DenseRowNatural(A, b), opts)
+    torch.cuda.synchronize()
+    ok = out.Succeeded()
+    assert float(ok.float().mean()) > 0.99 and bool((out.stop_reason != 0).all())   # (m is barely above n: a few starts may fail)
+    assert float((x - xs)[ok].abs().max()) < 5e-2
+    assert bool(ok[65535:].any())                                                    # the second slice did run
+    lo = 65500
+    x_t = x0[lo:].clone()
+    out_t = ta.Optimize(x_t, ta.DenseRowNatural(A[lo:].contiguous(), b[lo:].contiguous()), opts)
+    torch.cuda.synchronize()
+    # (not bit for bit on this path: the row chunking of the Gram and of J^T r is sized from the batch, so the sums of a small
+    #  batch run in another order — fp32 round-off, far below the noise in b)
+    both = ok[lo:] & out_t.Succeeded()
+    assert float(both.float().mean()) > 0.95
+    assert float((x_t - x[lo:])[both].abs().max()) < 2e-3
+    assert torch.allclose(out_t.final_cost[both], out.final_cost[lo:][both], rtol=2e-2)

@@ -640,9 +640,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
     if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");
     if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
-    // the launch-per-stage pipeline indexes problems through grid.y (65 535); the persistent 64 <= n <= 128 kernel does not
-    if (P < 0 || (P > 65535 && !(options && options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m))))
-      return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: P must be in [0, 65535] for this n");
+    if (P < 0) return fail(TOA_E_ARG, "P must be >= 0");   // (no upper limit: the launch-per-stage pipeline takes 65 535 problems per slice)
     if (!data) return fail(TOA_E_ARG, "null data pointer");
     if (mode != 0 || splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: toa_lm_run only");
   } else {

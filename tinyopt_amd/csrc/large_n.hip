@@ -1138,11 +1138,29 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
   if (options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   toa::RocApi& api = toa::roc_api();
   if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
-  if (dtype == TOA_F32)
-    return toa::large_lm_run_t<float>(h, api, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options,
-                                      *results, counters);
-  return toa::large_lm_run_t<double>(h, api, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options,
-                                     *results, counters);
+  // The pipeline's kernels index problems through grid.y (65 535): a larger batch goes through it slice by slice — the
+  // problems are independent, so the slices are just shorter batches (same bits), and the workspace is sized for one slice.
+  constexpr int64_t kSlice = 65535;
+  const size_t es = dtype == TOA_F32 ? 4 : 8;
+  for (int64_t p0 = 0; p0 < P || p0 == 0; p0 += kSlice) {
+    const int64_t Ps = std::min<int64_t>(kSlice, P - p0);
+    toa_results r = *results;
+    auto adv = [&](auto*& ptr, size_t per) { if (ptr) ptr += size_t(p0) * per; };
+    adv(r.stop_reason, 1); adv(r.num_iters, 1); adv(r.num_failures, 1); adv(r.num_consec_failures, 1);
+    adv(r.final_cost, 1); adv(r.final_num_residuals, 1); adv(r.final_rerr_dec, 1); adv(r.final_hessian, size_t(n) * n);
+    adv(r.errs, size_t(r.hist_stride)); adv(r.deltas2, size_t(r.hist_stride)); adv(r.successes, size_t(r.hist_stride));
+    adv(r.final_inlier_ratio, 1);
+    const char* d = static_cast<const char*>(data) + size_t(p0) * size_t(m) * (size_t(n) + 1) * es;
+    char* xs = static_cast<char*>(x) + size_t(p0) * size_t(n) * es;
+    int rc;
+    if (dtype == TOA_F32)
+      rc = toa::large_lm_run_t<float>(h, api, n, m, Ps, reinterpret_cast<const float*>(d), reinterpret_cast<float*>(xs), *options, r, counters);
+    else
+      rc = toa::large_lm_run_t<double>(h, api, n, m, Ps, reinterpret_cast<const double*>(d), reinterpret_cast<double*>(xs), *options, r, counters);
+    if (rc != TOA_OK) return rc;
+    if (P <= 0) break;
+  }
+  return TOA_OK;
 }
 
 int toa_large_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok) {
