@@ -812,6 +812,7 @@ int launch_ba_any(toa_handle h, BaParams& prm) {
 // Observations: sorted by (point, camera), each pair at most once.
 }  // namespace toa
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 namespace toa {
 struct BlParams {
   const void* intr;           // [P][4]: f cx cy 0
@@ -1513,9 +1514,8 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     } else {
       // rocSOLVER: ONE matrix per call — its batched Cholesky picks its blocking by batch size, and a scene solved alone must
       // give the bits of its row in a batch (tests/test_gpu_ba_lists.py); scenes of this size are few per call
-      for (long long q = 0; q < P && rc_all == TOA_OK; ++q)
-        rc_all = toa_large_solve(h, dtype, n, 1, static_cast<T*>(prm.Sall) + size_t(q) * n * n, static_cast<T*>(prm.rhsall) + size_t(q) * n, 1.0,
-                                 static_cast<T*>(prm.dcall) + size_t(q) * n, ok + q);
+      // (toa_large_solve_each: the calls go out over side streams, so the scenes' factorisations overlap)
+      rc_all = toa_large_solve_each(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok);
       if (rc_all != TOA_OK) break;
     }
     hipLaunchKernelGGL(bl_back_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok);

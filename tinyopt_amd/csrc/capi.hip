@@ -322,6 +322,12 @@ int toa_destroy(toa_handle h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->memo) (void)hipFree(h->memo);
   if (h->aux) (void)hipFree(h->aux);
+  for (int i = 0; i < h->nside; ++i) {
+    if (h->side_blas[i] && h->blas_destroy) (void)h->blas_destroy(h->side_blas[i]);
+    if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);
+    if (h->side_stream[i]) (void)hipStreamDestroy(h->side_stream[i]);
+  }
+  if (h->side_fork) (void)hipEventDestroy(h->side_fork);
   if (h->blas && h->blas_destroy) (void)h->blas_destroy(h->blas);
   for (int i = 0; i < h->nwgraphs; ++i) (void)hipGraphExecDestroy(h->wgraphs[i].exec);
   delete h;

@@ -2088,6 +2088,13 @@ struct toa_context {
   // large-n K3 (large_n.hip): rocBLAS handle created on the first n > 63 solve, and how to destroy it
   void* blas = nullptr;
   int (*blas_destroy)(void*) = nullptr;
+  // one-matrix-per-call solves spread over side streams (toa_large_solve_each): streams, their rocBLAS handles, events
+  static constexpr int kSide = 8;
+  hipStream_t side_stream[kSide] = {};
+  void* side_blas[kSide] = {};
+  hipEvent_t side_done[kSide] = {};
+  hipEvent_t side_fork = nullptr;
+  int nside = 0;
 };
 
 // large_fused.hip: the n in [64, 128] loop as one persistent kernel (called by toa_large_lm_run when eligible)

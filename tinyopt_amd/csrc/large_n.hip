@@ -186,6 +186,58 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
   return TOA_OK;
 }
 
+// The same solve with ONE matrix per library call — rocSOLVER's batched Cholesky picks its blocking from the batch size, and
+// a caller that promises "a problem solved alone gives the bits of its row in a batch" (bundle adjustment with visibility
+// lists) cannot use it — but the calls spread over up to eight side streams, each with a rocBLAS handle (and so a device
+// workspace) of its own: the P independent factorisations, one small workgroup-count each, overlap instead of queueing
+// behind one another on the context's stream.  Fork / join by events; everything else stays on the context's stream.
+template <typename T>
+int large_solve_each_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const T* g, double scale, T* dx, int32_t* ok) {
+  const size_t nn = size_t(n) * n;
+  const size_t b_work = (size_t(P) * nn * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_rhs = (size_t(P) * n * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_info = (size_t(P) * sizeof(int) + 255) & ~size_t(255);
+  if (int rc = ensure_scratch(h, b_work + b_rhs + b_info, "large-n solve")) return rc;
+  char* base = static_cast<char*>(h->scratch);
+  T* work = reinterpret_cast<T*>(base);
+  T* rhs = reinterpret_cast<T*>(base + b_work);
+  int* info = reinterpret_cast<int*>(base + b_work + b_rhs);
+  if (int rc = ensure_blas(h, api)) return rc;   // (also records how to destroy a handle)
+  const int K = int(std::min<int64_t>(toa_context::kSide, P));
+  while (h->nside < K) {
+    const int i = h->nside;
+    HIP_TRY(hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->side_done[i], hipEventDisableTiming));
+    if (api.create(&h->side_blas[i]) != 0) return toa_fail(TOA_E_HIP, "rocblas_create_handle failed");
+    if (api.set_stream(h->side_blas[i], h->side_stream[i]) != 0) return toa_fail(TOA_E_HIP, "rocblas_set_stream failed");
+    h->nside = i + 1;
+  }
+  if (!h->side_fork) HIP_TRY(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+  const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
+  hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, work, rhs, n, scale);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->side_fork, h->stream));
+  for (int i = 0; i < K; ++i) HIP_TRY(hipStreamWaitEvent(h->side_stream[i], h->side_fork, 0));
+  int rc = 0;
+  for (int64_t q = 0; q < P && rc == 0; ++q) {
+    void* hb = h->side_blas[q % K];
+    if constexpr (sizeof(T) == 4) {
+      rc = api.spotrf(hb, kFillUpper, n, work + q * nn, n, int64_t(nn), info + q, 1);
+      if (rc == 0) rc = api.spotrs(hb, kFillUpper, n, 1, work + q * nn, n, int64_t(nn), rhs + q * n, n, int64_t(n), 1);
+    } else {
+      rc = api.dpotrf(hb, kFillUpper, n, work + q * nn, n, int64_t(nn), info + q, 1);
+      if (rc == 0) rc = api.dpotrs(hb, kFillUpper, n, 1, work + q * nn, n, int64_t(nn), rhs + q * n, n, int64_t(n), 1);
+    }
+  }
+  for (int i = 0; i < K; ++i) {   // join (also after a failed call: nothing may still be running on the side when we return)
+    HIP_TRY(hipEventRecord(h->side_done[i], h->side_stream[i]));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->side_done[i], 0));
+  }
+  if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER potrf/potrs returned status " + std::to_string(rc));
+  hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, rhs, info, dx, ok, n);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
 
 // C = H^-1 for n > 63 (tinyopt::InvCov, math.h:41-91): Cholesky against the identity.
 template <typename T>
@@ -1129,6 +1181,14 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                                      static_cast<float*>(dx), ok);
   return toa::large_solve_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale,
                                     static_cast<double*>(dx), ok);
+}
+
+int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
+  toa::RocApi& api = toa::roc_api();
+  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n solve needs rocSOLVER: " + api.err);
+  if (dtype == TOA_F32)
+    return toa::large_solve_each_t<float>(h, api, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
+  return toa::large_solve_each_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);
 }
 
 int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
