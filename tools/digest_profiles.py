@@ -35,7 +35,27 @@ def main():
         hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
         if hits:
             shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
-    for txt in ("ad_ratio", "large_n_bench", "k3_crossover"):
+    # warm-only launch durations of the dominant kernel from the same rocprofv3 run (the *_kernel_stats.csv average includes
+    # the warm-up launches, the first of which pays lazy code loading): the timed launches are the LAST `steps` of the run
+    for sub, wl_tag in (("stats", "c4"), ("stats_c3", "c3"), ("stats_large128", "large128")):
+        tr = glob.glob(os.path.join(SRC, sub, "runc", "*_kernel_trace.csv"))
+        bj = os.path.join(SRC, "bench_under_rocprof.json" if wl_tag == "c4" else f"bench_under_rocprof_{wl_tag}.json")
+        if not tr or not os.path.exists(bj):
+            continue
+        line = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][-1])
+        ksub = "large_fused_kernel" if wl_tag == "large128" else "lm_fused_kernel"
+        rows = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+                       for r in csv.DictReader(open(tr[0])) if ksub in r["Kernel_Name"]))
+        durs = [d for _, d in rows]
+        warm = durs[-line["steps"]:]
+        with open(os.path.join(DST, f"{tag}_kernel_warm_{wl_tag}.json"), "w") as f:
+            json.dump({"round": tag, "workload": wl_tag, "kernel": ksub, "source": "rocprofv3 --kernel-trace of `bench.py --no-cpu` (the run behind "
+                       f"{tag}_kernel_stats{'' if wl_tag == 'c4' else '_' + wl_tag}.csv)", "launches_in_run": len(durs), "all_ms": durs,
+                       "timed_launches": len(warm), "warm_avg_ms": sum(warm) / len(warm),
+                       "bench_line_kernel_ms_avg_hip_events": line["roofline"].get("kernel_ms_avg"),
+                       "ratio_rocprof_over_hip_events": (sum(warm) / len(warm)) / line["roofline"]["kernel_ms_avg"] if line["roofline"].get("kernel_ms_avg") else None,
+                       "bench_line_value": line["value"], "bench_line_frac": line["roofline"]["frac"]}, f, indent=1)
+    for txt in ("ad_ratio", "large_n_bench", "k3_crossover", "probe_phases", "coop_sweep"):
         if os.path.exists(os.path.join(SRC, txt + ".txt")):
             shutil.copy(os.path.join(SRC, txt + ".txt"), os.path.join(DST, f"{tag}_{txt}.txt"))
     if os.path.isdir(os.path.join(SRC, "pmc_large128")):   # counters of the n = 128 workgroup-per-problem kernel
@@ -104,6 +124,20 @@ def main():
             with open(os.path.join(DST, name), "w") as f:
                 json.dump(outl, f, indent=1)
         print("large128", {k: outl[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
+    # ---- SQ counters of the hand-written Gram (n > 128) and of the C3 launch: raw per-launch averages
+    for sub, kernel_sub, name in (("pmc_large256", "large_gram_kernel", "large256"), ("pmc_sq_c3", kern, "sq_c3")):
+        if os.path.isdir(os.path.join(SRC, sub)):
+            acc = {}
+            for d in sorted(glob.glob(os.path.join(SRC, sub, "*"))):
+                try:
+                    c, durs = counters(d, kernel_sub)
+                except IndexError:
+                    continue
+                acc.update(c)
+                acc.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs[:40]
+            with open(os.path.join(DST, f"{tag}_pmc_{name}.json"), "w") as f:
+                json.dump({"round": tag, "kernel": kernel_sub, "counters_per_launch_avg": {k: v for k, v in acc.items() if not k.startswith("_")},
+                           "fetch_calibration_bytes_per_reported_byte": cal, "kernel_ms_under_pmc": acc.get("_kernel_ms", {})}, f, indent=1)
     # ---- HBM traffic of the bundle-adjustment kernel (work arrays included: they do not fit the L2s)
     if os.path.isdir(os.path.join(SRC, "pmc_ba")) and os.path.exists(os.path.join(DST, f"{tag}_bench_ba.json")):
         bb = json.loads(open(os.path.join(DST, f"{tag}_bench_ba.json")).read())

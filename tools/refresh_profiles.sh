@@ -15,6 +15,8 @@ TOA_MEMO=0 TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_memo0
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1
+(python tools/probe.py c4; python tools/probe.py c3) > $O/probe_phases.txt 2>&1
+bash tools/coop_sweep.sh > $O/coop_sweep.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
 for wl in c3 c2 c5 large128 large256 ba balists; do
@@ -35,6 +37,16 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 for C in "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA" FETCH_SIZE; do
   tag=$(echo $C | tr " " "_" | cut -c1-48)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_large128/$tag -- python $R/bench.py --workload large128 --steps 5 --warmup 1 --no-cpu > /dev/null 2>&1
+done
+# the hand-written Gram of the n > 128 pipeline
+for C in "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA" FETCH_SIZE; do
+  tag=$(echo $C | tr " " "_" | cut -c1-48)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_large256/$tag -- python $R/bench.py --workload large256 --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+done
+# issue mix of the C3 launch
+for C in "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_MFMA"; do
+  tag=$(echo $C | tr " " "_" | cut -c1-48)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_sq_c3/$tag -- python $R/tools/prof_phase.py fused c3 > /dev/null 2>&1
 done
 # HBM traffic of the bundle-adjustment kernel (its per-scene work arrays do not fit the L2s)
 for C in FETCH_SIZE WRITE_SIZE; do
