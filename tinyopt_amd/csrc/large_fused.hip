@@ -70,8 +70,235 @@ __device__ __forceinline__ double wg_sum(const double v, double* red) {  // fixe
 
 // ROBUST: every residual through the handle's M-estimator (robust_norms.h:20-26: cost += l, the row's J^T J and J^T r scaled by
 // s) — a separate instantiation, so the plain kernel's instruction stream and registers are untouched.
-template <typename T, int NB, bool ROBUST = false>
+// ---- TS = true (round 3, fp32, rows a multiple of four columns): the TILE-SPLIT data pass ---------------------------------
+// The row-split pass above gives every wave the whole Gram (36 tiles = 144 accumulator registers at n = 128; the kernel
+// needs 404 registers: one workgroup per CU, one wave per SIMD, every wait exposed, and 65 us of fold + LDL^T + step per
+// iteration with the matrix cores idle).  Here the rows of a stage (64 at a time) are prepared ONCE by the workgroup —
+// four threads per row: a_i.x, one sin / cos, J_i = s_i a_i — and written to LDS as one [64][16] panel per 16-column block;
+// then every wave runs ITS quarter of the tiles (tile t belongs to wave t mod 4) over all 64 rows, operands straight from
+// the panels (the step enters the ds_read as an immediate) — 9 accumulator tiles per wave, no fold at all, under 256
+// registers: two workgroups share a CU and one's Build / LDL^T / step hides behind the other's Gram.  The two stage buffers
+// live in the LDS image of the factorisation, which is only filled after the pass.  J^T r: the wave that owns block b (b mod 4)
+// forms it on the VALU from the same operands and the stage's residuals; ||r||^2 by the row workers.
+template <int NB>
+struct TsTiles {   // tile t = (bi, bj), bi <= bj, row-major over the upper block triangle
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr int bi_of(int t) { int bi = 0; while (t >= NB - bi) { t -= NB - bi; ++bi; } return bi; }
+  static constexpr int bj_of(int t) { int bi = 0; while (t >= NB - bi) { t -= NB - bi; ++bi; } return bi + t; }
+  static constexpr int kSlots = (NT + 3) / 4;
+};
+template <int NB, int W, int S = 0>
+__device__ __forceinline__ void ts_step(float __attribute__((ext_vector_type(4))) (&acc)[TsTiles<NB>::kSlots], const float (&w)[NB]) {
+  constexpr int t = W + 4 * S;
+  if constexpr (S < TsTiles<NB>::kSlots && t < TsTiles<NB>::NT) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[S]) : "v"(w[TsTiles<NB>::bi_of(t)]), "v"(w[TsTiles<NB>::bj_of(t)]));
+    ts_step<NB, W, S + 1>(acc, w);
+  }
+}
+
+
+
+template <int I>
+__device__ __forceinline__ void ts_issue(RawVec<4> (&pre)[8], const i32x4 rs, const unsigned voff, const unsigned soff) {
+  if constexpr (I < 8) {
+    pre[I].template issue<I == 0, I * 64>(rs, voff, soff);
+    ts_issue<I + 1>(pre, rs, voff, soff);
+  }
+}
+template <int I>
+__device__ __forceinline__ void ts_touch(RawVec<4> (&pre)[8]) {
+  if constexpr (I < 8) {
+    asm volatile("" : "+v"(pre[I].a));
+    ts_touch<I + 1>(pre);
+  }
+}
+// The tile-split data pass as a function of its own (NOT inlined): inside the kernel body hipcc's allocation of the whole
+// persistent loop (state machine, blocked LDL^T, cost-only pass) pushed these accumulators around — copies right behind an
+// MFMA, which tools/isa_lint.py rejects — and past 256 registers.  As a callee it has its own allocation.  Leaves: H (full,
+// symmetric, undamped) in Hs, the raw J^T r in gout (LDS), this wave's part of ||r||^2 in costw[wave].
+// WANT_H = false: the cost-only pass — the SAME row arithmetic (so that the cost of a point is the same number whether it
+// comes from an accumulate or an evaluate-only pass: with pass_natural's sums for the one and these for the other, last-bit
+// differences at the noise floor cost 1.2 extra iterations per problem), no stage, no barrier, no matrix-core work.
+template <int NB, bool WANT_H>
+__device__ __noinline__ void ts_data_pass(const float* __restrict__ A_in, const float* __restrict__ bv_in, const int n_in, const int m_in,
+                                          const float* xs, float* __restrict__ Hs_in, float* gout, float* costw) {
+  typedef float T;
+  // the arguments of a non-inlined function arrive in VECTOR registers: make the uniform ones scalar again (a buffer
+  // descriptor built from a "divergent" pointer costs a waterfall loop around every load)
+  auto uni = [](const void* q) __attribute__((always_inline)) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b)))), hi = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b >> 32))));
+    return reinterpret_cast<void*>((static_cast<unsigned long long>(hi) << 32) | lo);
+  };
+  const float* A = static_cast<const float*>(uni(A_in));
+  const float* bv = static_cast<const float*>(uni(bv_in));
+  float* Hs = static_cast<float*>(uni(Hs_in));
+  const int n = __builtin_amdgcn_readfirstlane(n_in), m = __builtin_amdgcn_readfirstlane(m_in);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float Acc __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  constexpr int NT = TsTiles<NB>::NT, kTsSlots = TsTiles<NB>::kSlots;
+  constexpr int R = 64, PANEL = R * 64, STAGE = NB * PANEL + R * 4;   // bytes: NB panels of [64][16] floats + the stage's residuals
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rrow = tid >> 2, rj = tid & 3, n4 = n >> 2;
+  const int k = lane >> 4, ci = lane & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  static_assert(NB == 8, "the rotation scheme below is for eight column blocks");
+  // Tile ownership by ROTATION: wave W works in virtual blocks v = physical block (v + 2 W) mod 8 and every wave runs the same
+  // nine virtual tiles — (0,0) (1,1) (0,1) (1,2) (0,2) (1,3) (0,3) (1,4) and (x, x + 4) — whose four rotations are exactly the
+  // 36 unordered block pairs (the pairs at distance 4 have only two distinct rotations: waves 0, 1 take x = 0, waves 2, 3 x = 1).
+  constexpr int kVa[9] = {0, 1, 0, 1, 0, 1, 0, 1, -1}, kVb[9] = {0, 1, 1, 2, 2, 3, 3, 4, -1};
+  const int xsp = wave_u < 2 ? 0 : 1;
+  int voff[5];
+#pragma unroll
+  for (int v = 0; v < 5; ++v) voff[v] = ((v + 2 * wave_u) & 7) * PANEL;
+  const int soffa = ((xsp + 2 * wave_u) & 7) * PANEL, soffb = ((xsp + 4 + 2 * wave_u) & 7) * PANEL;
+  Acc ts_acc[kTsSlots];
+  T ts_g[2] = {T(0), T(0)};
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  // rows through bounds-checked buffer loads (a row past the end returns zeros: no branches), 16 bytes per lane, the eight
+  // loads of a thread as immediates off ONE offset; issued by hand (dense_row.hpp: hipcc does not count asm loads)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, int(unsigned(m) * unsigned(n) * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bv), 0, int(unsigned(m) * 4u), 0x00020000);
+  u4 pre[8];
+  T pre_b = 0;
+  const unsigned row_bytes = unsigned(n) * 4u;
+  const unsigned vofs0 = unsigned(rrow) * row_bytes + unsigned(rj) * 16u;
+  auto fetch = [&](const int r0) __attribute__((always_inline)) {
+    const int soff = __builtin_amdgcn_readfirstlane(int(unsigned(r0) * row_bytes));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, int(vofs0) + i * 64, soff, 0);
+    pre_b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (r0 + rrow) * 4, 0, 0));   // (the builtin returns the raw dword)
+  };
+  T csum = 0;
+  const char* xl = lds_raw + 2 * STAGE;            // x, copied here by the caller (an LDS address this function can name)
+  auto rowwork = [&](char* st) __attribute__((always_inline)) {
+    f2 t2 = {0, 0};
+    f4 av[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_memcpy(&av[i], &pre[i], 16);
+      if (i == 7 && 4 * (rj + 28) >= n) av[i] = f4{0, 0, 0, 0};   // (n < 128, n >= 116: only the last group can run into the next row)
+      const f4 xv = *reinterpret_cast<const f4*>(xl + (rj + 4 * i) * 16);
+      t2 = f2{av[i][0], av[i][1]} * f2{xv[0], xv[1]} + t2;    // v_pk_fma_f32
+      t2 = f2{av[i][2], av[i][3]} * f2{xv[2], xv[3]} + t2;
+    }
+    T t = t2[0] + t2[1];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    T sn, cs;
+    sincos_t(t, &sn, &cs);
+    const T sc = T(1) + T(0.1f) * cs;
+    const T resv = (t + T(0.1f) * sn) - pre_b;   // (a row past the end: a = 0, b = 0 -> 0)
+    if constexpr (WANT_H) {
+      char* wp = st + rrow * 64 + rj * 16;       // float4 idx = rj + 4 i -> block i, position rj of the row's 64 bytes
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f4*>(wp + i * PANEL) = av[i] * sc;
+    }
+    if (rj == 0) {
+      if constexpr (WANT_H) reinterpret_cast<T*>(st + NB * PANEL)[rrow] = resv;
+      csum = fmaf(resv, resv, csum);
+    }
+  };
+#pragma unroll
+  for (int sl = 0; sl < kTsSlots; ++sl) ts_acc[sl] = Acc{0, 0, 0, 0};
+  fetch(0);
+  int cur = 0;
+  for (int r0 = 0; r0 < m; r0 += R) {
+    char* st = lds_raw + cur * STAGE;
+    rowwork(st);                       // stage r0 -> buffer cur (free since the barrier that ended stage r0 - R)
+    if (r0 + R < m) fetch(r0 + R);     // the next stage's rows are in flight during this stage's MFMAs
+    if constexpr (!WANT_H) continue;
+    __syncthreads();
+    const char* op = st + (k * 64 + ci * 4);
+    const T* rs = reinterpret_cast<const T*>(st + NB * PANEL) + k;
+    // operands of the VIRTUAL blocks 0..4 (physical block (v + 2 wave) mod 8), of this wave's ninth tile, and the step's
+    // residuals; the NEXT step's are in flight during this step's MFMAs (two register sets, alternating: no copies)
+    auto load_ops = [&](const int q, T (&w)[5], T& sa, T& sb, T& rr) __attribute__((always_inline)) {
+#pragma unroll
+      for (int v = 0; v < 5; ++v) w[v] = *reinterpret_cast<const T*>(op + voff[v] + q * 256);
+      sa = *reinterpret_cast<const T*>(op + soffa + q * 256);
+      sb = *reinterpret_cast<const T*>(op + soffb + q * 256);
+      rr = rs[4 * q];
+    };
+    // ONE MFMA site per register set for all four waves (hipcc keeps a separate accumulator set per site it finds over the same
+    // accumulators only when their tile lists differ — these two are textually identical).  s_nop: VALU write -> MFMA read wait
+    // states for operands hipcc may have moved through the VALU.
+    auto mfma9 = [&](const T (&w)[5], const T sa, const T sb, const T rr) __attribute__((always_inline)) {
+      asm volatile("s_nop 1\n\t"
+                   "v_mfma_f32_16x16x4_f32 %0, %9, %9, %0\n\t"     // (0, 0)
+                   "v_mfma_f32_16x16x4_f32 %1, %10, %10, %1\n\t"   // (1, 1)
+                   "v_mfma_f32_16x16x4_f32 %2, %9, %10, %2\n\t"    // (0, 1)
+                   "v_mfma_f32_16x16x4_f32 %3, %10, %11, %3\n\t"   // (1, 2)
+                   "v_mfma_f32_16x16x4_f32 %4, %9, %11, %4\n\t"    // (0, 2)
+                   "v_mfma_f32_16x16x4_f32 %5, %10, %12, %5\n\t"   // (1, 3)
+                   "v_mfma_f32_16x16x4_f32 %6, %9, %12, %6\n\t"    // (0, 3)
+                   "v_mfma_f32_16x16x4_f32 %7, %10, %13, %7\n\t"   // (1, 4)
+                   "v_mfma_f32_16x16x4_f32 %8, %14, %15, %8"         // (x, x + 4): x = 0 for waves 0, 1; 1 for waves 2, 3
+                   : "+a"(ts_acc[0]), "+a"(ts_acc[1]), "+a"(ts_acc[2]), "+a"(ts_acc[3]), "+a"(ts_acc[4]), "+a"(ts_acc[5]), "+a"(ts_acc[6]),
+                     "+a"(ts_acc[7]), "+a"(ts_acc[8])
+                   : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(sa), "v"(sb));
+      ts_g[0] = fmaf(w[0], rr, ts_g[0]);   // J^T r of the physical blocks 2 wave and 2 wave + 1
+      ts_g[1] = fmaf(w[1], rr, ts_g[1]);
+    };
+    T wA[5], saA, sbA, rrA, wB[5], saB, sbB, rrB;
+    load_ops(0, wA, saA, sbA, rrA);
+    for (int q = 0; q < R / 4; q += 2) {
+      load_ops(q + 1, wB, saB, sbB, rrB);
+      mfma9(wA, saA, sbA, rrA);
+      load_ops(q + 2 < R / 4 ? q + 2 : 0, wA, saA, sbA, rrA);   // (the last one re-reads step 0: harmless)
+      mfma9(wB, saB, sbB, rrB);
+    }
+    cur ^= 1;
+  }
+  // ||r||^2: the row workers' partial sums, one per wave (summed in fixed order by the caller)
+  csum += __shfl_xor(csum, 4); csum += __shfl_xor(csum, 8); csum += __shfl_xor(csum, 16); csum += __shfl_xor(csum, 32);
+  if (lane == 0) costw[wave] = csum;
+  if constexpr (!WANT_H) return;
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the matrix pipe has drained before an accumulator is read
+#pragma unroll
+  for (int sl = 0; sl < kTsSlots; ++sl) asm volatile("" : "+a"(ts_acc[sl]));
+  // every tile is final in the registers of the wave that owns it: straight to the L2-resident H (mirrored)
+#pragma unroll
+  for (int sl = 0; sl < 9; ++sl) {
+    const int va = sl < 8 ? kVa[sl] : xsp, vb = sl < 8 ? kVb[sl] : xsp + 4;
+    const int pa = (va + 2 * wave_u) & 7, pb = (vb + 2 * wave_u) & 7;
+    const int qj = 16 * pb + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = 16 * pa + Mfma<T>::out_row(lane, r);
+      const T v = ts_acc[sl][r];
+      if (qi < n && qj < n) {
+        Hs[qi * n + qj] = v;
+        if (pa != pb) Hs[qj * n + qi] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {   // J^T r of the physical block b = 2 wave + u: the four row groups' partials, then lanes 0..15
+    const int b = 2 * wave_u + u;
+    T gi = ts_g[u];
+    gi += __shfl_xor(gi, 16);
+    gi += __shfl_xor(gi, 32);
+    const int q = 16 * b + lane;
+    if (b < NB && lane < 16 && q < n) gout[q] = gi;
+  }
+}
+template <typename T, int NB, bool ROBUST, bool TS>
+__device__ __forceinline__ void large_fused_body(const LfArgs<T>& a);
+template <typename T, int NB, bool ROBUST = false, bool TS = false>
 __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
+  large_fused_body<T, NB, ROBUST, false>(a);
+}
+// the tile-split form must stay under 256 registers (two waves per SIMD = two workgroups per CU): ask for it
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) large_fused_ts_kernel(const LfArgs<T> a) {
+  large_fused_body<T, NB, false, true>(a);
+}
+template <typename T, int NB, bool ROBUST, bool TS>
+__device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
+  static_assert(!TS || (sizeof(T) == 4 && !ROBUST), "tile-split pass: fp32, no M-estimator");
 #ifdef TOA_LF_TIMING
   unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
   long long ck_pass = 0;
@@ -83,10 +310,11 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
   constexpr int NV = 16 * NB;  // padded vector length (>= n)
   // ring depth of the cost-only pass (see there).  fp64 with NB >= 5: the deeper ring's registers do not fit beside the rest
   // of the kernel, and hipcc then parks in-flight load destinations in AGPRs (tools/isa_lint.py rejects that code)
-  constexpr int kEvalDepth = sizeof(T) == 4 ? 4 : (NB <= 4 ? 3 : 2);
+  constexpr int kEvalDepth = TS ? 2 : (sizeof(T) == 4 ? 4 : (NB <= 4 ? 3 : 2));   // (TS: the kernel lives under 256 registers)
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   T* Aimg = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image of the damped matrix, factored in place
-  __shared__ T xs[NV], g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
+  __shared__ __attribute__((aligned(16))) T xs[NV];
+  __shared__ T g[NV], hd[NV], dx[NV], ldx[NV], rhs[NV], diag[NV];
   __shared__ T gfold[4][NV];
   __shared__ T costw[4];
   __shared__ int ninlw[4];
@@ -140,7 +368,19 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       // ---------------- data pass: this wave's rows ----------------
       {
         Gram gram;
-        if (do_acc) {
+        if constexpr (TS) {
+          if (do_acc) {
+            for (int i = tid; i < NV; i += 256) reinterpret_cast<T*>(lds_raw + 2 * (NB * 64 * 64 + 64 * 4))[i] = xs[i];   // x where the callee can name it
+            __syncthreads();
+            ts_data_pass<NB, true>(A, bv, n, m, xs, Hs, g, costw);
+            if (lane == 0) ninlw[wave] = 0;
+          } else {
+            for (int i = tid; i < NV; i += 256) reinterpret_cast<T*>(lds_raw + 2 * (NB * 64 * 64 + 64 * 4))[i] = xs[i];
+            __syncthreads();
+            ts_data_pass<NB, false>(A, bv, n, m, xs, Hs, g, costw);
+            if (lane == 0) ninlw[wave] = 0;
+          }
+        } else if (do_acc) {
           // fp64 with NB >= 7: 28 / 36 tiles of 8 registers do not fit the register file — two passes over the rows, half of
           // the tiles each (the pass is matrix-core bound: 32 flop / byte against a ridge of 10, reading the rows twice is free)
           constexpr bool kTwoPass = sizeof(T) == 8 && NB >= 7;
@@ -183,7 +423,19 @@ __global__ void __launch_bounds__(256) large_fused_kernel(const LfArgs<T> a) {
       const double cost_val = normalize_cost(double(T((costw[0] + costw[1]) + (costw[2] + costw[3]))), m, opt);
       bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
       const int LD = n | 1;
-      if (built && do_acc) {
+      if constexpr (TS) {
+        if (built && do_acc) {   // no fold: ts_data_pass has left the finished H in the L2-resident copy and the raw J^T r in g; the image
+                                 // may overwrite the stage buffers now (every wave is past the barrier above)
+          for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            const T v = Hs[e];
+            Aimg[i * LD + j] = v;
+            if (i == j) hd[i] = v;
+          }
+          if (opt.grad_clipping != 0)
+            for (int i = tid; i < n; i += 256) { const T mm = opt.grad_clipping; g[i] = fmin(fmax(g[i], -mm), mm); }  // base.h:29-38
+        }
+      } else if (built && do_acc) {
         // H = sum of the four partial Grams, to the L2-resident copy Hs (kept undamped for eval-only iterations and the
         // final export) AND straight into the LDS image the factorisation works on
 #pragma unroll 3
@@ -486,13 +738,15 @@ int large_accumulate_dispatch(toa_handle h, int n, int m, int64_t P, const T* da
   }
 }
 
-template <typename T, int NB, bool ROBUST>
+template <typename T, int NB, bool ROBUST, bool TS = false>
 int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt, const toa_results& res,
                          uint64_t* counters) {
   using Acc = typename Mfma<T>::Acc;
   constexpr int NT = NB * (NB + 1) / 2;
-  auto kern = large_fused_kernel<T, NB, ROBUST>;
-  const size_t lds = ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15);  // + the slack WgLdlt's unconditional reads may touch
+  void (*kern)(const LfArgs<T>);
+  if constexpr (TS) kern = large_fused_ts_kernel<T, NB>; else kern = large_fused_kernel<T, NB, ROBUST, false>;
+  size_t lds = ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15);  // + the slack WgLdlt's unconditional reads may touch
+  if (TS) lds = std::max(lds, size_t(2) * (size_t(NB) * 64 * 64 + 64 * 4) + size_t(16 * NB) * sizeof(T));   // the two stage buffers of the tile-split pass (+ x) live in the image
   int wg_per_cu = 0;
   for (int i = 0; i < h->ncfg; ++i)
     if (h->cfg[i].fn == (const void*)kern && h->cfg[i].lds == lds && h->cfg[i].wg_per_cu > 0) wg_per_cu = h->cfg[i].wg_per_cu;
@@ -543,6 +797,14 @@ int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* 
     // destinations (tools/isa_lint.py rejects that code) — refused rather than built
     if constexpr (sizeof(T) == 8 && NB >= 7) return toa_fail(TOA_E_UNSUPPORTED, "toa_set_loss with fp64 natural-layout rows: n <= 96");
     else return launch_large_fused_r<T, NB, true>(h, n, m, P, data, x, opt, res, counters);
+  }
+  if constexpr (sizeof(T) == 4 && NB == 8) {   // (NB = 4: ten tiles do not divide by four waves, and hipcc copies accumulators between the
+                                               //  waves' unequal tile lists right behind an MFMA — tools/isa_lint.py rejects that code)
+    // the tile-split data pass (two workgroups per CU): rows of whole 16-byte column groups, 16-byte aligned.  TOA_LF_TS=0: the
+    // row-split pass (A/B; it also serves every other shape)
+    static const bool ts_off = [] { const char* e = std::getenv("TOA_LF_TS"); return e && e[0] == '0'; }();
+    if (!ts_off && n % 4 == 0 && (size_t(m) * (size_t(n) + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0)
+      return launch_large_fused_r<T, NB, false, true>(h, n, m, P, data, x, opt, res, counters);
   }
   return launch_large_fused_r<T, NB, false>(h, n, m, P, data, x, opt, res, counters);
 }
