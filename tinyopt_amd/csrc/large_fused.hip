@@ -121,7 +121,7 @@ __device__ __forceinline__ void ts_touch(RawVec<4> (&pre)[8]) {
 // differences at the noise floor cost 1.2 extra iterations per problem), no stage, no barrier, no matrix-core work.
 template <int NB, bool WANT_H>
 __device__ __noinline__ void ts_data_pass(const float* __restrict__ A_in, const float* __restrict__ bv_in, const int n_in, const int m_in,
-                                          const float* xs, float* __restrict__ Hs_in, float* gout, float* costw) {
+                                          const float* xs, float* __restrict__ Hs_in, float* gout, float* costw, float* hd_out) {
   typedef float T;
   // the arguments of a non-inlined function arrive in VECTOR registers: make the uniform ones scalar again (a buffer
   // descriptor built from a "divergent" pointer costs a waterfall loop around every load)
@@ -259,7 +259,12 @@ __device__ __noinline__ void ts_data_pass(const float* __restrict__ A_in, const 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the matrix pipe has drained before an accumulator is read
 #pragma unroll
   for (int sl = 0; sl < kTsSlots; ++sl) asm volatile("" : "+a"(ts_acc[sl]));
-  // every tile is final in the registers of the wave that owns it: straight to the L2-resident H (mirrored)
+  // every tile is final in the registers of the wave that owns it: straight to the L2-resident H (kept undamped for eval-only
+  // iterations and the export) AND to the LDS image of the factorisation, which may overwrite the stage buffers once every
+  // wave is past its last MFMA (the barrier); the undamped diagonal to hd (lm.h:108-117 acts on that copy)
+  __syncthreads();
+  T* Aimg = reinterpret_cast<T*>(lds_raw);
+  const int LD = n | 1;
 #pragma unroll
   for (int sl = 0; sl < 9; ++sl) {
     const int va = sl < 8 ? kVa[sl] : xsp, vb = sl < 8 ? kVb[sl] : xsp + 4;
@@ -271,7 +276,9 @@ __device__ __noinline__ void ts_data_pass(const float* __restrict__ A_in, const 
       const T v = ts_acc[sl][r];
       if (qi < n && qj < n) {
         Hs[qi * n + qj] = v;
-        if (pa != pb) Hs[qj * n + qi] = v;
+        Aimg[qi * LD + qj] = v;
+        if (pa != pb) { Hs[qj * n + qi] = v; Aimg[qj * LD + qi] = v; }
+        else if (qi == qj) hd_out[qi] = v;
       }
     }
   }
@@ -372,12 +379,12 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
           if (do_acc) {
             for (int i = tid; i < NV; i += 256) reinterpret_cast<T*>(lds_raw + 2 * (NB * 64 * 64 + 64 * 4))[i] = xs[i];   // x where the callee can name it
             __syncthreads();
-            ts_data_pass<NB, true>(A, bv, n, m, xs, Hs, g, costw);
+            ts_data_pass<NB, true>(A, bv, n, m, xs, Hs, g, costw, hd);
             if (lane == 0) ninlw[wave] = 0;
           } else {
             for (int i = tid; i < NV; i += 256) reinterpret_cast<T*>(lds_raw + 2 * (NB * 64 * 64 + 64 * 4))[i] = xs[i];
             __syncthreads();
-            ts_data_pass<NB, false>(A, bv, n, m, xs, Hs, g, costw);
+            ts_data_pass<NB, false>(A, bv, n, m, xs, Hs, g, costw, hd);
             if (lane == 0) ninlw[wave] = 0;
           }
         } else if (do_acc) {
@@ -424,17 +431,11 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
       bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
       const int LD = n | 1;
       if constexpr (TS) {
-        if (built && do_acc) {   // no fold: ts_data_pass has left the finished H in the L2-resident copy and the raw J^T r in g; the image
-                                 // may overwrite the stage buffers now (every wave is past the barrier above)
-          for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, j = e - i * n;
-            const T v = Hs[e];
-            Aimg[i * LD + j] = v;
-            if (i == j) hd[i] = v;
-          }
-          if (opt.grad_clipping != 0)
-            for (int i = tid; i < n; i += 256) { const T mm = opt.grad_clipping; g[i] = fmin(fmax(g[i], -mm), mm); }  // base.h:29-38
-        }
+        // no fold: ts_data_pass has left the finished H in the L2-resident copy AND in the image, the undamped diagonal in hd, the
+        // raw J^T r in g.  (A pass whose cost turns out invalid has overwritten them too — like the reference, whose Build
+        // accumulates into H_ before it looks at the cost, lm.h:59-80.)
+        if (built && do_acc && opt.grad_clipping != 0)
+          for (int i = tid; i < n; i += 256) { const T mm = opt.grad_clipping; g[i] = fmin(fmax(g[i], -mm), mm); }  // base.h:29-38
       } else if (built && do_acc) {
         // H = sum of the four partial Grams, to the L2-resident copy Hs (kept undamped for eval-only iterations and the
         // final export) AND straight into the LDS image the factorisation works on
