@@ -43,7 +43,7 @@ def main():
         if not tr or not os.path.exists(bj):
             continue
         line = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][-1])
-        ksub = "large_fused_kernel" if wl_tag == "large128" else "lm_fused_kernel"
+        ksub = "large_fused" if wl_tag == "large128" else "lm_fused_kernel"
         rows = sorted(((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
                        for r in csv.DictReader(open(tr[0])) if ksub in r["Kernel_Name"]))
         durs = [d for _, d in rows]
@@ -62,7 +62,7 @@ def main():
         lf = {}
         for d in sorted(glob.glob(os.path.join(SRC, "pmc_large128", "*"))):
             try:
-                c, durs = counters(d, "large_fused_kernel")
+                c, durs = counters(d, "large_fused")
             except IndexError:
                 continue
             lf.update(c)
@@ -112,7 +112,7 @@ def main():
         hs = bl["roofline"]["hbm_secondary"]
         alg_l = hs["passes_per_launch"] * hs["algorithmic_bytes_per_pass"]
         hbm_l = lf["FETCH_SIZE"] * 1024.0 * cal if "FETCH_SIZE" in lf else None
-        outl = {"round": tag, "workload": "large128", "problems": bl["config"]["problems_per_gpu"], "kernel": "large_fused_kernel<float, 8>",
+        outl = {"round": tag, "workload": "large128", "problems": bl["config"]["problems_per_gpu"], "kernel": "large_fused_ts_kernel<float, 8> (tile-split data pass, two workgroups per CU)",
                 "counters_per_launch": {k: v for k, v in lf.items() if not k.startswith("_")},
                 "fetch_calibration_bytes_per_reported_byte": cal,
                 "fetch_calibration_note": "the C4 calibration (wide coalesced streams report 1/2 on gfx950); reads only — the kernel's writes "
