@@ -405,6 +405,18 @@ def run_balists(args, ta, rank, world, local_rank):
     bytes_per_pass = model.algorithmic_bytes_per_pass
     kern_s = float(np.mean(kern_ms)) * 1e-3
     achieved = bytes_per_pass * (passes_total / args.steps) / kern_s / 1e9
+    traffic_bl, traffic_src = None, None
+    try:   # HBM bytes per batched solve, summed over every kernel of the pipeline (separate --pmc passes, tools/pmc_sum.sh; not this run)
+        with open(os.path.join(ROOT, "profiles", "pmc_latest_balists.json")) as f:
+            pm = json.load(f)
+        if pm.get("problems") == P:
+            traffic_bl = pm.get("hbm_bytes_per_launch")
+            traffic_src = ("profiles/pmc_latest_balists.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over all kernels of the pipeline, same workload; "
+                           "~80x the input bytes, ~5x the intermediates it must write and read once (J_c, J_p, r per observation, the reduced system per scene): "
+                           "the Schur-complement kernel gathers 64-128 byte records of other cameras' observations; the pipeline is latency-bound at this "
+                           "size, see the note)")
+    except Exception:  # noqa: BLE001
+        pass
     result = {
         "metric": "LM iterations/s (bundle adjustment with visibility lists, Schur complement)", "value": iters_all / elapsed,
         "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -415,8 +427,8 @@ def run_balists(args, ta, rank, world, local_rank):
                    "iters_per_problem": iters_all / args.steps / (P * world), "ms_per_lm_iteration": elapsed / max(iters_all / (P * world), 1) * 1e3,
                    "final_reprojection_rms_px_max": rms, "device": info["name"], "num_cus": info["num_cus"]},
         "roofline": {"bound": "latency", "kernel": "bl_* pipeline (10 launches + one host read-back per Build + Solve attempt; rocSOLVER potrf / potrs of the 384 x 384 reduced camera system)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bl,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
                      "note": "launch / latency-bound at this size (a few scenes, ~1 MB of observations each): the figure of merit is ms per LM "
                              "iteration; GB/s is reported for scale only",
                      "kernel_ms_avg": kern_s * 1e3, "kernel_ms_all": kern_ms},

@@ -834,13 +834,16 @@ struct BlParams {
 };
 
 template <typename T>
-struct BlWork {  // element offsets into a scene's scratch block (T); obs arrays are component-major ([k][M]) for coalescing
+struct BlWork {  // element offsets into a scene's scratch block (T)
   size_t Jc, Jp, r, r2, ptcost, Vd, Voff, gp, Vinv, q, dp, ldp, U, gc, Ud, ldc, pd2, pg2, state, total;
   __host__ __device__ BlWork(int C, int N, int M) {
     size_t o = 0;
     const size_t n = size_t(6) * C;
     auto take = [&](size_t k) { const size_t at = o; o += (k + 7) & ~size_t(7); return at; };
-    Jc = take(size_t(12) * M); Jp = take(size_t(6) * M); r = take(size_t(2) * M); r2 = take(M);
+    // per observation ONE 128-byte record [J_c (2 x 6) | r (2) | pad] and ONE 64-byte record [J_p (2 x 3) | pad]: the camera-wise
+    // kernels (bl_cam, bl_schur) GATHER observations, and component-major arrays cost them a 64-byte HBM fetch per 8-byte
+    // component (PMC: 374 + 244 MB per solve in those two kernels for ~6 MB of records per scene and pass)
+    Jc = take(size_t(16) * M); Jp = take(size_t(8) * M); r = Jc; r2 = take(M);
     ptcost = take(N); Vd = take(size_t(3) * N); Voff = take(size_t(3) * N); gp = take(size_t(3) * N); Vinv = take(size_t(6) * N);
     q = take(size_t(3) * N); dp = take(size_t(3) * N); ldp = take(size_t(3) * N);
     U = take(size_t(36) * C); gc = take(n); Ud = take(n); ldc = take(n);
@@ -980,10 +983,10 @@ __global__ void __launch_bounds__(256) bl_obs_kernel(const BlParams* __restrict_
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) w[wk.Jc + size_t(6 * a + k) * M + i] = Jc[a][k];
+      for (int k = 0; k < 6; ++k) w[wk.Jc + size_t(i) * 16 + (6 * a + k)] = Jc[a][k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) w[wk.Jp + size_t(3 * a + k) * M + i] = Jp[a][k];
-      w[wk.r + size_t(a) * M + i] = r[a];
+      for (int k = 0; k < 3; ++k) w[wk.Jp + size_t(i) * 8 + (3 * a + k)] = Jp[a][k];
+      w[wk.Jc + size_t(i) * 16 + 12 + (a)] = r[a];
     }
   } else {
     ba_obs<T, false>(Pm, q, intr[0], intr[1], intr[2], uv[0], uv[1], r, nullptr, nullptr);
@@ -1011,8 +1014,8 @@ __global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restric
     if (do_acc) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const T j0 = w[wk.Jp + size_t(3 * a) * M + i], j1 = w[wk.Jp + size_t(3 * a + 1) * M + i], j2 = w[wk.Jp + size_t(3 * a + 2) * M + i];
-        const T ra = w[wk.r + size_t(a) * M + i];
+        const T j0 = w[wk.Jp + size_t(i) * 8 + (3 * a)], j1 = w[wk.Jp + size_t(i) * 8 + (3 * a + 1)], j2 = w[wk.Jp + size_t(i) * 8 + (3 * a + 2)];
+        const T ra = w[wk.Jc + size_t(i) * 16 + 12 + (a)];
         v[0] += j0 * j0; v[1] += j1 * j1; v[2] += j2 * j2; v[3] += j0 * j1; v[4] += j0 * j2; v[5] += j1 * j2;
         g[0] += j0 * ra; g[1] += j1 * ra; g[2] += j2 * ra;
       }
@@ -1047,8 +1050,8 @@ __global__ void __launch_bounds__(256) bl_cam_kernel(const BlParams* __restrict_
     for (int a = 0; a < 2; ++a) {
       T w7[7];
 #pragma unroll
-      for (int d = 0; d < 6; ++d) w7[d] = w[wk.Jc + size_t(6 * a + d) * M + i];
-      w7[6] = w[wk.r + size_t(a) * M + i];
+      for (int d = 0; d < 6; ++d) w7[d] = w[wk.Jc + size_t(i) * 16 + (6 * a + d)];
+      w7[6] = w[wk.Jc + size_t(i) * 16 + 12 + (a)];
       int t = 0;
 #pragma unroll
       for (int x = 0; x < 7; ++x)
@@ -1216,14 +1219,14 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
         T A[2][3];   // J_p,i V^-1 (2 x 3)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const T p0 = w[wk.Jp + size_t(3 * a) * M + i], p1 = w[wk.Jp + size_t(3 * a + 1) * M + i], p2 = w[wk.Jp + size_t(3 * a + 2) * M + i];
+          const T p0 = w[wk.Jp + size_t(i) * 8 + (3 * a)], p1 = w[wk.Jp + size_t(i) * 8 + (3 * a + 1)], p2 = w[wk.Jp + size_t(i) * 8 + (3 * a + 2)];
           A[a][0] = p0 * v00 + p1 * v01 + p2 * v02;
           A[a][1] = p0 * v01 + p1 * v11 + p2 * v12;
           A[a][2] = p0 * v02 + p1 * v12 + p2 * v22;
         }
 #pragma unroll
         for (int d = 0; d < 6; ++d) {
-          const T jc0 = w[wk.Jc + size_t(d) * M + i], jc1 = w[wk.Jc + size_t(6 + d) * M + i];
+          const T jc0 = w[wk.Jc + size_t(i) * 16 + (d)], jc1 = w[wk.Jc + size_t(i) * 16 + (6 + d)];
 #pragma unroll
           for (int b = 0; b < 3; ++b) Tl[tid][3 * d + b] = jc0 * A[0][b] + jc1 * A[1][b];
         }
@@ -1244,9 +1247,9 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
             T B[3][6];   // J_p,i2^T J_c,i2 (3 x 6)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-              const T p0 = w[wk.Jp + size_t(b) * M + i2], p1 = w[wk.Jp + size_t(3 + b) * M + i2];
+              const T p0 = w[wk.Jp + size_t(i2) * 8 + (b)], p1 = w[wk.Jp + size_t(i2) * 8 + (3 + b)];
 #pragma unroll
-              for (int d = 0; d < 6; ++d) B[b][d] = p0 * w[wk.Jc + size_t(d) * M + i2] + p1 * w[wk.Jc + size_t(6 + d) * M + i2];
+              for (int d = 0; d < 6; ++d) B[b][d] = p0 * w[wk.Jc + size_t(i2) * 16 + (d)] + p1 * w[wk.Jc + size_t(i2) * 16 + (6 + d)];
             }
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -1304,11 +1307,11 @@ __global__ void __launch_bounds__(256) bl_back_kernel(const BlParams* __restrict
     for (int a = 0; a < 2; ++a) {
       T s = 0;
 #pragma unroll
-      for (int d = 0; d < 6; ++d) s += w[wk.Jc + size_t(6 * a + d) * M + i] * dcc[d];
+      for (int d = 0; d < 6; ++d) s += w[wk.Jc + size_t(i) * 16 + (6 * a + d)] * dcc[d];
       e[a] = s;
     }
 #pragma unroll
-    for (int b = 0; b < 3; ++b) u3[b] += w[wk.Jp + size_t(b) * M + i] * e[0] + w[wk.Jp + size_t(3 + b) * M + i] * e[1];
+    for (int b = 0; b < 3; ++b) u3[b] += w[wk.Jp + size_t(i) * 8 + (b)] * e[0] + w[wk.Jp + size_t(i) * 8 + (3 + b)] * e[1];
   }
   const T* Rj = w + wk.Vinv + 6 * j;
   const T y0 = Rj[0] * u3[0], y1 = Rj[1] * u3[0] + Rj[2] * u3[1], y2 = Rj[3] * u3[0] + Rj[4] * u3[1] + Rj[5] * u3[2];
