@@ -390,3 +390,36 @@ def test_more_problems_than_one_grid_dimension(ta):
     assert float(both.float().mean()) > 0.95
     assert float((x_t - x[lo:])[both].abs().max()) < 2e-3
     assert torch.allclose(out_t.final_cost[both], out.final_cost[lo:][both], rtol=2e-2)
+
+
+@pytest.mark.parametrize("n,m", [(128, 600), (124, 332), (116, 1000), (120, 448)])
+def test_tile_split_pass_follows_the_oracle_and_the_row_split_pass(ta, oracle, n, m):
+    """fp32, 112 < n <= 128: the tile-split data pass of the 64 <= n <= 128 kernel (rows staged once in LDS, nine tiles per wave by
+    block rotation, two workgroups per CU) — every n that takes it (the last 16-byte column group of a row may run into the next
+    row: n = 116, 120, 124), row counts that are and are not a multiple of the 64-row stage.  Same trajectories as the oracle's,
+    and the same outcome as the row-split pass (TOA_LF_TS=0) up to fp32 round-off."""
+    import os
+    P = 5
+    assert (m * (n + 1)) % 4 == 0
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=41)
+    opts = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
+    res = {}
+    old = os.environ.get("TOA_LF_TS")
+    try:
+        for ts in ("1", "0"):
+            os.environ["TOA_LF_TS"] = ts
+            x = torch.from_numpy(x0.copy()).cuda()
+            out = ta.Optimize(x, ta.DenseRowNatural(Ad, bd), opts, history=True)
+            torch.cuda.synchronize()
+            res[ts] = (x.cpu().numpy(), out)
+            check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
+                                                      cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
+    finally:
+        if old is None:
+            os.environ.pop("TOA_LF_TS", None)
+        else:
+            os.environ["TOA_LF_TS"] = old
+    assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-3
+    assert np.allclose(res["1"][1].final_cost.cpu().numpy(), res["0"][1].final_cost.cpu().numpy(), rtol=1e-3)

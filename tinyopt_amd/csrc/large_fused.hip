@@ -803,7 +803,7 @@ int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* 
                                                //  waves' unequal tile lists right behind an MFMA — tools/isa_lint.py rejects that code)
     // the tile-split data pass (two workgroups per CU): rows of whole 16-byte column groups, 16-byte aligned.  TOA_LF_TS=0: the
     // row-split pass (A/B; it also serves every other shape)
-    static const bool ts_off = [] { const char* e = std::getenv("TOA_LF_TS"); return e && e[0] == '0'; }();
+    const bool ts_off = [] { const char* e = std::getenv("TOA_LF_TS"); return e && e[0] == '0'; }();   // (read per call: tests toggle it)
     if (!ts_off && n % 4 == 0 && (size_t(m) * (size_t(n) + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0)
       return launch_large_fused_r<T, NB, false, true>(h, n, m, P, data, x, opt, res, counters);
   }
