@@ -819,6 +819,214 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
   for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = sol[i];
   if (tid == 0) a.info[p] = 0;
 }
+// ---- (H + lambda diag H) sol = g for 128 < n <= 1024 (fp64: 512) without the library (round 3) ---------------------------------
+// rocSOLVER's batched potrf + potrs is ~30 launches per solve (two potf2 kernels of 0.2 ms, ten forward and four backward
+// substitution launches, syr2k, small GEMMs): 0.75 ms of a 1.5 ms pass at n = 256 and 65 % of a bundle-adjustment pass with 384
+// camera unknowns — latency, not flops (n^3 / 3 = 5.6 Mflop).  Here ONE workgroup factors its matrix in place (row-major lower
+// triangle of `work`, L2-resident) by panels of 32 columns and solves, in one launch for the whole batch:
+//   diagonal block   wave 0, a row per lane in registers: 32 unrolled Cholesky columns, pivots and column entries by broadcast
+//   panel below      a thread per row: x L_kk^T = a (32-step substitution against the block in LDS); the rows stay in LDS
+//   trailing update  a thread per COLUMN j (its panel row in registers), rows i >= j: A_ij -= L_i . L_j (coalesced across lanes)
+//   substitutions    the same panels: the block by wave 0 (lane r owns unknown r), the rest by a thread per row / column
+// Cholesky without pivoting, as the library path: a pivot that is not positive (or not finite) fails the solve (info != 0).
+// Every sum has a fixed order: a matrix solved alone gives the bits of its row in a batch.
+template <typename T>
+__device__ __forceinline__ T chol_bcast(const T v, const int src) {
+  if constexpr (sizeof(T) == 4) {
+    return __shfl(v, src, 64);
+  } else {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl(int(unsigned(b)), src, 64), hi = __shfl(int(b >> 32), src, 64);
+    return __longlong_as_double((long long)(((unsigned long long)unsigned(hi) << 32) | unsigned(lo)));
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T> a) {
+  constexpr int B = 32, LS = B + 1;
+  extern __shared__ __attribute__((aligned(16))) char chol_lds[];
+  T* Ld = reinterpret_cast<T*>(chol_lds);          // [B][LS]   the factored diagonal block
+  T* Lp = Ld + B * LS;                             // [n][LS]   the panel's rows below it (row i of the matrix at Lp[i - k1])
+  T* ys = Lp + size_t(a.n) * LS;                   // [n]       right-hand side / solution
+  __shared__ int fail;
+  const size_t p = blockIdx.x;
+  if (!a.active[p] || !(a.built[p] & 1)) return;
+  const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* A = a.work + p * size_t(n) * n;
+  for (int i = tid; i < n; i += 256) ys[i] = a.rhs[p * n + i];
+  if (tid == 0) fail = 0;
+  __syncthreads();
+#ifdef TOA_CHOL_TIMING
+  unsigned long long tkc[6] = {0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define CH_TICK(i) { const unsigned long long now_ = wall_clock64(); tkc[i] += now_ - tprev; tprev = now_; }
+#else
+#define CH_TICK(i)
+#endif
+  for (int k0 = 0; k0 < n; k0 += B) {
+    const int bs = min(B, n - k0), k1 = k0 + bs;
+    // ---- diagonal block: wave 0, lane r holds row r of the block (columns past the diagonal are never read)
+    if (wave == 0) {
+      T r[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? A[size_t(k0 + lane) * n + k0 + c] : T(0);
+      bool bad = false;
+      T* colj = ys + n;                                  // 64 scratch entries behind the right-hand side: column j of the block, lane by lane
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        colj[lane] = r[j];                               // (through LDS, not lane broadcasts: 500 readlanes into scalar registers
+        __builtin_amdgcn_wave_barrier();                 //  made hipcc spill hundreds of them)
+        const T d = colj[j];                             // the pivot: entry (j, j) after the updates of columns < j
+        const bool live = j < bs;
+        if (live && !(d > T(0) && d <= NumLimits<T>::max())) bad = true;
+        const T l = sqrt(live && d > T(0) ? d : T(1));
+        r[j] = r[j] / l;                                 // lane j: l itself; lanes > j: L_ij
+        __builtin_amdgcn_wave_barrier();
+        colj[lane] = r[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = j + 1; c < B; ++c) r[c] = fma(-r[j], colj[c], r[c]);   // L_cj from lane c (lanes < c hold zeros there and are not stored)
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane < bs) {
+#pragma unroll
+        for (int c = 0; c < B; ++c)
+          if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
+      }
+      if (bad && lane == 0) fail = 1;
+    }
+    __syncthreads();
+    CH_TICK(0)
+    if (fail) break;
+    // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update)
+    for (int i = k1 + tid; i < n; i += 256) {
+      T x[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) x[c] = c < bs ? A[size_t(i) * n + k0 + c] : T(0);
+#pragma unroll
+      for (int c = 0; c < B; ++c) {
+        asm volatile("" ::: "memory");   // (the block's entries are read where they are used: hoisted out of the row loop they are 528 registers)
+        if (c < bs) {
+          T v = x[c];
+#pragma unroll
+          for (int t = 0; t < c; ++t) v = fma(-x[t], Ld[c * LS + t], v);
+          x[c] = v / Ld[c * LS + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < B; ++c) {
+        if (c < bs) A[size_t(i) * n + k0 + c] = x[c];
+        Lp[size_t(i - k1) * LS + c] = x[c];
+      }
+    }
+    __syncthreads();
+    CH_TICK(1)
+    // ---- trailing update: 64-column blocks; a lane per column j (its own panel row in registers), the rows below in batches of
+    // eight dealt to the four waves in turn (a wave per column block left the first wave with 7/16 of the work)
+    for (int cb = k1; cb < n; cb += 64) {
+      const int j = cb + lane;
+      const bool jv = j < n;
+      T lj[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) lj[c] = Lp[size_t((jv ? j : n - 1) - k1) * LS + c];
+      auto fetch8 = [&](const int i0, T (&av)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u; av[u] = (jv && i < n && i >= j) ? A[size_t(i) * n + j] : T(0); }
+      };
+      T av[8];                                           // eight rows' entries, the NEXT batch's in flight during this batch's products
+      fetch8(cb + 8 * wave, av);
+      for (int i0 = cb + 8 * wave; i0 < n; i0 += 32) {
+        T an[8];
+        fetch8(i0 + 32, an);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u;
+          const T* li = Lp + size_t((i < n ? i : n - 1) - k1) * LS;   // (the same address in every lane: an LDS broadcast)
+          T s = 0;
+#pragma unroll
+          for (int c = 0; c < B; ++c) s = fma(li[c], lj[c], s);
+          if (jv && i < n && i >= j) A[size_t(i) * n + j] = av[u] - s;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = an[u];
+      }
+    }
+    __syncthreads();
+    CH_TICK(2)
+  }
+  if (fail) {
+    if (tid == 0) a.info[p] = 1;
+    return;
+  }
+  // ---- L y = b
+  for (int k0 = 0; k0 < n; k0 += B) {
+    const int bs = min(B, n - k0), k1 = k0 + bs;
+    if (wave == 0) {
+      T y = lane < bs ? ys[k0 + lane] : T(0);
+      T lr[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) lr[c] = (lane < bs && c <= lane) ? A[size_t(k0 + lane) * n + k0 + c] : T(1);
+#pragma unroll
+      for (int c = 0; c < B; ++c) {
+        const T yc = chol_bcast(y / lr[c], c);           // (lane c: its unknown; the value of the others is unused)
+        if (lane == c) y = yc;
+        else if (lane > c) y = fma(-lr[c], yc, y);
+      }
+      if (lane < bs) ys[k0 + lane] = y;
+    }
+    __syncthreads();
+    for (int i = k1 + tid; i < n; i += 256) {
+      T s = ys[i];
+      const T* Li = A + size_t(i) * n + k0;
+      T lv[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) lv[c] = c < bs ? Li[c] : T(0);   // (all 32 loads in flight)
+#pragma unroll
+      for (int c = 0; c < B; ++c) s = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], s);
+      ys[i] = s;
+    }
+    __syncthreads();
+  }
+  CH_TICK(3)
+  // ---- L^T x = y
+  for (int k0 = ((n - 1) / B) * B; k0 >= 0; k0 -= B) {
+    const int bs = min(B, n - k0);
+    if (wave == 0) {
+      T xv = lane < bs ? ys[k0 + lane] : T(0);
+      T lcol[B];                                         // column `lane` of L_kk: entries (c, lane), c >= lane (all loads in flight,
+#pragma unroll                                           //  coalesced across lanes; inside the loop below they were 64 dependent round trips)
+      for (int c = 0; c < B; ++c) lcol[c] = (lane < bs && c < bs && c >= lane) ? A[size_t(k0 + c) * n + k0 + lane] : T(0);
+      T ldiag = T(1);
+#pragma unroll
+      for (int c = 0; c < B; ++c) ldiag = (c == lane && c < bs) ? lcol[c] : ldiag;
+#pragma unroll
+      for (int c = B - 1; c >= 0; --c) {
+        const T xc = chol_bcast(xv / ldiag, c);          // lane c: its unknown (for c >= bs: 0 / 1)
+        if (lane == c) xv = xc;
+        else if (lane < c) xv = fma(-lcol[c], xc, xv);   // L_c,lane: the entry of L^T this lane's equation holds for unknown c
+      }
+      if (lane < bs) ys[k0 + lane] = xv;
+    }
+    __syncthreads();
+    for (int j = tid; j < k0; j += 256) {                // the unknowns above: x_j -= sum_c L_(k0+c),j x_(k0+c)  (coalesced across lanes)
+      T s = ys[j];
+      T lv[B];
+#pragma unroll
+      for (int c = 0; c < B; ++c) lv[c] = c < bs ? A[size_t(k0 + c) * n + j] : T(0);
+#pragma unroll
+      for (int c = 0; c < B; ++c) s = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], s);
+      ys[j] = s;
+    }
+    __syncthreads();
+  }
+  CH_TICK(4)
+#ifdef TOA_CHOL_TIMING
+  if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01);
+#endif
+  for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = ys[i];
+  if (tid == 0) a.info[p] = 0;
+}
+template <typename T>
+inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 33 + size_t(n) + 64) * sizeof(T) + 64; }
+
 template <typename T>
 inline size_t ldlt_image_bytes(int n) { return ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15); }
 template <typename T>
@@ -1042,6 +1250,13 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   if (own_chol) {
     if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
   }
+  // beyond 128 unknowns: the one-workgroup blocked Cholesky + substitutions (large_chol_solve_kernel) while its panel fits the
+  // LDS (fp32: n <= 1024, fp64: n <= 512); the library beyond, for use_ldlt = false, and with TOA_FORCE_ROCSOLVER=1
+  const size_t chol2_lds = chol_solve_lds_bytes<T>(n);
+  const bool own_chol2 = !own_chol && !lu && !force_lib && n > 128 && chol2_lds + 2048 <= size_t(h->max_lds);
+  if (own_chol2) {
+    if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T>, chol2_lds)) return rc;
+  }
   HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
@@ -1097,6 +1312,8 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     int rc = 0;
     if (own_chol) {
       launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);
+    } else if (own_chol2) {
+      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(256), chol2_lds, st, a);
     } else if (lu) {
       if constexpr (sizeof(T) == 4) {
         rc = api.sgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
@@ -1151,12 +1368,13 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
   a.info = reinterpret_cast<int*>(base + b_work + b_rhs);
   a.active = reinterpret_cast<int*>(base + b_work + b_rhs + b_i);  // every matrix is solved
   a.built = a.active;
-  const size_t chol_lds = ldlt_image_bytes<T>(n);
-  if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
+  const size_t chol_lds = n <= 128 ? ldlt_image_bytes<T>(n) : chol_solve_lds_bytes<T>(n);
+  if (int rc = ensure_lds_attr(h, n <= 128 ? ldlt_solve_fn<T>(n) : (const void*)large_chol_solve_kernel<T>, chol_lds)) return rc;
   hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P);
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
-  launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
+  if (n <= 128) launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
+  else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
   hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
@@ -1169,7 +1387,9 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                     int32_t* ok) {
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
-  if (!force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) {  // the workgroup LDL^T (ldlt_wg.hpp), up to its measured crossover with the library
+  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 64) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
+  const bool own2 = n > 128 && P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds);   // the one-workgroup blocked Cholesky (fp32: n <= 1024, fp64: n <= 512)
+  if (!force_lib && ((n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) || own2)) {  // the workgroup LDL^T (ldlt_wg.hpp) / blocked Cholesky; the library beyond
     if (dtype == TOA_F32)
       return toa::large_solve_own_t<float>(h, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
     return toa::large_solve_own_t<double>(h, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);
@@ -1184,6 +1404,11 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 }
 
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
+  {  // our own kernels are batch-independent by construction (one workgroup per matrix, fixed-order sums): one launch for all
+    static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 64) * (dtype == TOA_F32 ? 4 : 8) + 64;
+    if (!force_lib && (n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds)))) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
+  }
   toa::RocApi& api = toa::roc_api();
   if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n solve needs rocSOLVER: " + api.err);
   if (dtype == TOA_F32)
