@@ -872,18 +872,17 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       T* colj = ys + n;                                  // 64 scratch entries behind the right-hand side: column j of the block, lane by lane
 #pragma unroll
       for (int j = 0; j < B; ++j) {
-        colj[lane] = r[j];                               // (through LDS, not lane broadcasts: 500 readlanes into scalar registers
-        __builtin_amdgcn_wave_barrier();                 //  made hipcc spill hundreds of them)
+        colj[lane] = r[j];                               // column j before its scaling, lane by lane (through LDS, not lane broadcasts:
+        __builtin_amdgcn_wave_barrier();                 //  500 readlanes into scalar registers made hipcc spill hundreds of them)
         const T d = colj[j];                             // the pivot: entry (j, j) after the updates of columns < j
         const bool live = j < bs;
-        if (live && !(d > T(0) && d <= NumLimits<T>::max())) bad = true;
-        const T l = sqrt(live && d > T(0) ? d : T(1));
-        r[j] = r[j] / l;                                 // lane j: l itself; lanes > j: L_ij
-        __builtin_amdgcn_wave_barrier();
-        colj[lane] = r[j];
-        __builtin_amdgcn_wave_barrier();
+        const bool pos = d > T(0) && d <= NumLimits<T>::max();
+        if (live && !pos) bad = true;
+        const T dd = (live && pos) ? d : T(1);
+        const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj (ONE LDS round trip per column)
 #pragma unroll
-        for (int c = j + 1; c < B; ++c) r[c] = fma(-r[j], colj[c], r[c]);   // L_cj from lane c (lanes < c hold zeros there and are not stored)
+        for (int c = j + 1; c < B; ++c) r[c] = fma(-t, colj[c], r[c]);   // (lanes < c hold zeros there and are not stored)
+        r[j] = r[j] / sqrt(dd);                          // lane j: l itself; lanes > j: L_ij
         __builtin_amdgcn_wave_barrier();
       }
       if (lane < bs) {
@@ -964,9 +963,12 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       T lr[B];
 #pragma unroll
       for (int c = 0; c < B; ++c) lr[c] = (lane < bs && c <= lane) ? A[size_t(k0 + lane) * n + k0 + c] : T(1);
+      T rinv = T(1);                                     // 1 / L_rr of this lane's row: the division leaves the dependent chain
+#pragma unroll
+      for (int c = 0; c < B; ++c) rinv = (c == lane && lane < bs) ? T(1) / lr[c] : rinv;
 #pragma unroll
       for (int c = 0; c < B; ++c) {
-        const T yc = chol_bcast(y / lr[c], c);           // (lane c: its unknown; the value of the others is unused)
+        const T yc = chol_bcast(y * rinv, c);            // (lane c: its unknown; the value of the others is unused)
         if (lane == c) y = yc;
         else if (lane > c) y = fma(-lr[c], yc, y);
       }
@@ -997,9 +999,10 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       T ldiag = T(1);
 #pragma unroll
       for (int c = 0; c < B; ++c) ldiag = (c == lane && c < bs) ? lcol[c] : ldiag;
+      ldiag = T(1) / ldiag;
 #pragma unroll
       for (int c = B - 1; c >= 0; --c) {
-        const T xc = chol_bcast(xv / ldiag, c);          // lane c: its unknown (for c >= bs: 0 / 1)
+        const T xc = chol_bcast(xv * ldiag, c);          // lane c: its unknown (for c >= bs: 0)
         if (lane == c) xv = xc;
         else if (lane < c) xv = fma(-lcol[c], xc, xv);   // L_c,lane: the entry of L^T this lane's equation holds for unknown c
       }
