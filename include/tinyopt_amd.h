@@ -65,9 +65,11 @@ extern "C" {
  * differentiated on the device by dual numbers over the right perturbation; n == m == 6; x: [P][12] poses;
  * data_dev: [P][12] = prior_inv (rotation matrix row-major, translation) */
 #define TOA_MODEL_SE3_PRIOR 9
-/* DenseRow beyond one wavefront (n up to 1024): rows in natural layout, J^T J by a batched library
- * GEMM (at this width the residual block is a real dense contraction), the solve by rocSOLVER's batched Cholesky,
- * the LM state machine in small kernels between them (tinyopt_amd/csrc/large_n.hip).  toa_lm_run only. */
+/* DenseRow beyond one wavefront (n up to 1024): rows in natural layout.  64 <= n <= 128: one persistent
+ * workgroup-per-problem kernel (csrc/large_fused.hip).  Beyond: J^T J by a hand-written LDS-staged MFMA Gram (fp32; the
+ * library GEMM for fp64), the solve by a one-workgroup blocked Cholesky (fp32 n <= 1024, fp64 n <= 512; rocSOLVER's batched
+ * potrf + potrs beyond and for use_ldlt = 0), the LM state machine in small kernels between them (csrc/large_n.hip).
+ * toa_lm_run only. */
 #define TOA_MODEL_DENSE_ROW_NATURAL 10
 
 /* The DenseRow residual written as r(x) ONLY and differentiated on the device for wide parameter blocks (13 <= n <= 63,
@@ -226,7 +228,8 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
  *      dx = -H^-1 g by pivoted LDL^T with Eigen's acceptance rule (info()==Success && isPositive()).
  *      dx_dev: [P][n] T; ok_dev: [P] int32 (1 = solved, 0 = "not positive definite" => solver failure).
  *      n <= 63: one wavefront per matrix.  64 <= n <= 128: one workgroup per matrix (blocked LDL^T, trailing updates
- *      on the matrix cores).  Beyond, up to 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs) — the measured crossover. */
+ *      on the matrix cores).  128 < n <= 1024 (fp64: 512), P <= 65535: one workgroup per matrix, blocked Cholesky through L2.
+ *      Beyond, up to 4096 (P <= 65535): rocSOLVER batched Cholesky (potrf + potrs). */
 int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, const void* g_dev,
                      double scale, void* dx_dev, int32_t* ok_dev);
 
@@ -348,8 +351,9 @@ int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t
 /* ---- bundle adjustment with VISIBILITY LISTS: tens to hundreds of cameras, each point observed by a few of them — the shape
  *      Eigen's SimplicialLDLT path exists for (math.h:266-277; README.md:30,165-167 "sparse is slow").  Same unknowns, update
  *      rules, state machine, StopReasons and Output fields as toa_ba_run; the observations arrive as a LIST instead of a dense
- *      C x N mask, and the reduced camera system (6 C unknowns, in HBM) is solved by the workgroup LDL^T up to 128 unknowns and
- *      by rocSOLVER's batched Cholesky (potrf + potrs, opened with dlopen) beyond — up to 682 cameras.  A pipeline of small
+ *      C x N mask, and the reduced camera system (6 C unknowns, in HBM) is solved by the workgroup LDL^T up to 128 unknowns, by
+ *      the one-workgroup blocked Cholesky up to 512 (85 cameras in fp64; 170 in fp32) and by rocSOLVER's potrf + potrs (opened
+ *      with dlopen, one scene per call) beyond — up to 682 cameras.  A pipeline of small
  *      kernels per Build + Solve attempt (csrc/ba_schur.hip, "bl_*"); every sum has a fixed order.  The host reads one integer
  *      back per pass (it blocks until the solve is done; not graph-capturable), which is also where max_duration_ms is
  *      honoured: > 0 ends every scene still running with kTimedOut once the launches' device time exceeds it
