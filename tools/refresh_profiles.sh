@@ -10,6 +10,9 @@ python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 
 for wl in c4 c3 c2 c5 c1 ba balists; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
 python bench.py --workload large256 --steps 5 --warmup 2 > $O/bench_large256.json 2> $O/bench_large256.err
+TOA_FORCE_ROCSOLVER=1 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu > $O/bench_large256_rocsolver.json 2>/dev/null
+TOA_FORCE_ROCSOLVER=1 python bench.py --workload balists --no-cpu > $O/bench_balists_rocsolver.json 2>/dev/null
+TOA_LF_TS=0 python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu > $O/bench_large128_rowsplit.json 2>/dev/null
 TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
 TOA_MEMO=0 TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
@@ -52,5 +55,7 @@ done
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_ba/$C -- python $R/bench.py --workload ba --steps 5 --warmup 1 --no-cpu > /dev/null 2>&1
 done
+# HBM traffic of the whole BA-lists pipeline (every kernel, per batched solve)
+cd $R; bash tools/pmc_sum.sh balists "bl_|rocsolver|rocblas|Cijk|large_" 6 --workload balists --steps 3 --warmup 2 > $O/pmcsum_balists.txt 2>&1; cp gpurun_out/pmcsum_balists.json $O/
 find $O -name "*.csv" | wc -l
 du -sh $O
