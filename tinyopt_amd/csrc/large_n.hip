@@ -918,34 +918,29 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
     }
     __syncthreads();
     CH_TICK(1)
-    // ---- trailing update: 64-column blocks; a lane per column j (its own panel row in registers), the rows below in batches of
-    // eight dealt to the four waves in turn (a wave per column block left the first wave with 7/16 of the work)
-    for (int cb = k1; cb < n; cb += 64) {
-      const int j = cb + lane;
-      const bool jv = j < n;
-      T lj[B];
+    // ---- trailing update A22 -= L21 L21^T on the matrix cores: 16 x 16 tiles of the lower triangle dealt to the four waves, both
+    // operands straight from the panel in LDS (row stride 33: conflict-free), eight v_mfma_*_16x16x4 per tile, then a
+    // read-modify-write of the tile in the L2-resident matrix.  (A lane per column with the rows in batches of eight — VALU, one
+    // dependent global round trip per batch — took 122 us of a 376 us n = 256 solve.)
+    {
+      using Acc = typename Mfma<T>::Acc;
+      const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
+      const int l15 = lane & 15, kq = lane >> 4;
+      for (int t = wave; t < ntile; t += 4) {
+        int ti = 0, rem = t;                             // t -> (ti, tj), ti >= tj, row-major over the lower triangle
+        while (rem > ti) { rem -= ti + 1; ++ti; }
+        const int tj = rem;
+        const T* pa = Lp + size_t(16 * ti + l15) * LS + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
+        const T* pb = Lp + size_t(16 * tj + l15) * LS + kq;
+        Acc acc = {0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < B; ++c) lj[c] = Lp[size_t((jv ? j : n - 1) - k1) * LS + c];
-      auto fetch8 = [&](const int i0, T (&av)[8]) __attribute__((always_inline)) {
+        for (int q = 0; q < B / 4; ++q) acc = Mfma<T>::fma(pa[4 * q], pb[4 * q], acc);
+        asm volatile("s_nop 9" : "+a"(acc));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u; av[u] = (jv && i < n && i >= j) ? A[size_t(i) * n + j] : T(0); }
-      };
-      T av[8];                                           // eight rows' entries, the NEXT batch's in flight during this batch's products
-      fetch8(cb + 8 * wave, av);
-      for (int i0 = cb + 8 * wave; i0 < n; i0 += 32) {
-        T an[8];
-        fetch8(i0 + 32, an);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u;
-          const T* li = Lp + size_t((i < n ? i : n - 1) - k1) * LS;   // (the same address in every lane: an LDS broadcast)
-          T s = 0;
-#pragma unroll
-          for (int c = 0; c < B; ++c) s = fma(li[c], lj[c], s);
-          if (jv && i < n && i >= j) A[size_t(i) * n + j] = av[u] - s;
+        for (int reg = 0; reg < 4; ++reg) {
+          const int gi = k1 + 16 * ti + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj + l15;
+          if (gi < n && gj <= gi) A[size_t(gi) * n + gj] -= acc[reg];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = an[u];
       }
     }
     __syncthreads();
