@@ -1,6 +1,5 @@
-"""K3 for n > 63 (rocSOLVER batched Cholesky behind toa_solve_damped): parity with a float64
-host solve of the same damped systems, and agreement with the one-wavefront path where both apply."""
-import numpy as np
+"""K3 for n > 63 behind toa_solve_damped (workgroup LDL^T up to 128 unknowns, one-workgroup blocked Cholesky up to 1024 / 512,
+rocSOLVER beyond) and the LM loop for 64 <= n <= 1024: parity with a float64 host solve / the oracle."""import numpy as np
 import pytest
 import torch
 
@@ -423,3 +422,40 @@ def test_tile_split_pass_follows_the_oracle_and_the_row_split_pass(ta, oracle, n
             os.environ["TOA_LF_TS"] = old
     assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-3
     assert np.allclose(res["1"][1].final_cost.cpu().numpy(), res["0"][1].final_cost.cpu().numpy(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol,n", [(np.float64, 1e-9, 129), (np.float64, 1e-9, 256), (np.float64, 1e-9, 384), (np.float64, 1e-9, 500),
+                                         (np.float32, 3e-3, 160), (np.float32, 3e-3, 257), (np.float32, 3e-3, 512), (np.float32, 5e-3, 1000)])
+def test_blocked_cholesky_beyond_128_matches_host(ta, dtype, tol, n):
+    """128 < n <= 1024 (fp64: 512): the one-workgroup blocked Cholesky + substitutions (large_chol_solve_kernel) behind
+    toa_solve_damped — sizes that are and are not multiples of the 32-column panel — against a float64 host solve."""
+    P = 3
+    H, g = _spd_batch(P, n, dtype, seed=n)
+    scale = 1.0 + 1e-3
+    dx, ok = ta.solve_damped(torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda(), scale)
+    torch.cuda.synchronize()
+    assert ok.cpu().numpy().tolist() == [1] * P
+    Hd = H.astype(np.float64).copy()
+    idx = np.arange(n)
+    Hd[:, idx, idx] = (H[:, idx, idx].astype(np.float64) * scale).astype(dtype).astype(np.float64)
+    ref = -np.linalg.solve(Hd, g.astype(np.float64)[..., None])[..., 0]
+    err = np.abs(dx.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < tol, err
+
+
+def test_blocked_cholesky_failure_and_batch_independence(ta):
+    """A matrix that is not positive definite fails ITS solve only (gn.h:150-171: nullopt -> failed solve), wherever the bad
+    pivot sits (first panel, a later panel's diagonal block); and a matrix solved alone gives the bits of its row in a batch."""
+    P, n = 5, 300
+    H, g = _spd_batch(P, n, np.float64, seed=17)
+    H[1, 10, 10] = -1.0
+    H[3, 290, 290] = -1.0e3
+    Hd, gd = torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda()
+    dx, ok = ta.solve_damped(Hd, gd, 1.0)
+    torch.cuda.synchronize()
+    assert ok.cpu().numpy().tolist() == [1, 0, 1, 0, 1]
+    assert float(dx[1].abs().max()) == 0.0 and float(dx[3].abs().max()) == 0.0
+    for q in (0, 2, 4):
+        dq, okq = ta.solve_damped(Hd[q:q + 1].contiguous(), gd[q:q + 1].contiguous(), 1.0)
+        torch.cuda.synchronize()
+        assert int(okq[0]) == 1 and torch.equal(dq[0], dx[q])
