@@ -1,5 +1,6 @@
 """K3 for n > 63 behind toa_solve_damped (workgroup LDL^T up to 128 unknowns, one-workgroup blocked Cholesky up to 1024 / 512,
-rocSOLVER beyond) and the LM loop for 64 <= n <= 1024: parity with a float64 host solve / the oracle."""import numpy as np
+rocSOLVER beyond) and the LM loop for 64 <= n <= 1024: parity with a float64 host solve / the oracle."""
+import numpy as np
 import pytest
 import torch
 
