@@ -1182,16 +1182,23 @@ __global__ void __launch_bounds__(256) bl_psolve_kernel(const BlParams* __restri
 // the point's (camera-sorted) list.  S(c, c') -= T_i (J_p,i'^T J_c,i'),   red_c -= T_i g_pj  [red = g_c - W V^-1 g_p].
 template <typename T>
 __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restrict__ prm) {
-  __shared__ T Tl[64][18];
-  __shared__ int jl[64];
-  // the cameras that see each staged observation's point (the head of the point's list, sorted by camera) and where the list
-  // starts: a thread looking for "does camera c' see this point" scans these in LDS — a binary search of the list in global
-  // memory was three dependent round trips per observation and thread (0.78 ms per pass at 64 cameras, 42 % of the pipeline)
-  constexpr int kListCap = 12;
-  __shared__ short cl[64][kListCap];
-  __shared__ int l0[64], ln[64];
-  __shared__ T gl[64][3];   // g_p of each staged observation's point (read per observation by the thread that forms W V^-1 g_p: from
-                            // global memory that was one dependent round trip per observation for the whole wave)
+  // One workgroup per camera c forms block row c of S (lower block triangle, mirrored) and of the reduced right-hand side.
+  // Per staged chunk of 32 of the camera's observations (point j each):
+  //   T_s  = J_c,s^T (J_p,s V_j^-1)                 6 x 3   thread s
+  //   B_se = J_p,i2^T J_c,i2 for the e-th observer i2 of point j   3 x 6   thread (s, e), the first kFast observers of a point
+  //   S(c, c2) -= T_s B_se  with c2 = camera of i2: lane (a d, e) adds component (a, d) of the e-th observer's product into the
+  //   LDS row of that observer's camera. The six lanes of one (a, d) sit in ONE wave (9 components x 6 entries = 54 lanes per wave),
+  //   a point's observers are distinct cameras, and a wave's LDS operations are in order — so no two lanes ever race on an address,
+  //   every sum runs over s in the same fixed order, there are no atomics, and 216 of 256 lanes do 3 FMAs per observation.
+  // (A thread per block (c, c2) with the product in registers — round 3's first version — executed the 108-FMA block product
+  //  for ~6 of its wave's 64 lanes per observation: 0.66 ms per pass at 64 cameras, divergence, not memory.)
+  constexpr int kS = 32, kFast = 6, kListCap = 12, kTile = 64;
+  __shared__ T Tl[kS][18];
+  __shared__ T Bl[kS][kFast][18];
+  __shared__ T Srow[kTile][36];
+  __shared__ T gl[kS][3];
+  __shared__ short cl[kS][kListCap];
+  __shared__ int jl[kS], l0[kS], ln[kS];
   const long long p = blockIdx.y;
   const int c = blockIdx.x;
   const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
@@ -1205,28 +1212,24 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
   const int* oc = prm->obs_cam + size_t(p) * M;
   const int tid = threadIdx.x;
   const int k0 = iw[ix.cam_start + c], k1 = iw[ix.cam_start + c + 1];
-  for (int cbase = 0; cbase < C; cbase += 256) {
-    const int c2 = cbase + tid;
-    T Sb[6][6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < 6; ++b) Sb[a][b] = T(0);
-    T rv[6] = {0, 0, 0, 0, 0, 0};   // thread 0 of the first tile accumulates the row's W V^-1 g_p
-    for (int kk = k0; kk < k1; kk += 64) {
+  const int lane = tid & 63, ent = lane % kFast;
+  const bool live = lane < 54;
+  const int ad = live ? 9 * (tid >> 6) + lane / kFast : 0, a = ad / 6, d = ad % 6;   // component (a, d), list entries ent, ent + 6, ...
+  T rva = T(0);   // lanes (a, d = 0, entry 0): row a of W V^-1 g_p
+  for (int cbase = 0; cbase <= c; cbase += kTile) {                  // camera tiles of the lower block triangle
+    for (int e = tid; e < kTile * 36; e += 256) (&Srow[0][0])[e] = T(0);
+    for (int kk = k0; kk < k1; kk += kS) {
       __syncthreads();
-      if (tid < 64 && kk + tid < k1) {
+      if (tid < kS && kk + tid < k1) {
         const int i = iw[ix.cam_order + kk + tid];
         const int j = prm->obs_pt[size_t(p) * M + i];
         jl[tid] = j;
-        {
-          const int a0 = iw[ix.pt_start + j], a1 = iw[ix.pt_start + j + 1];
-          l0[tid] = a0;
-          ln[tid] = a1 - a0;
-          gl[tid][0] = w[wk.gp + 3 * j]; gl[tid][1] = w[wk.gp + 3 * j + 1]; gl[tid][2] = w[wk.gp + 3 * j + 2];
+        const int a0 = iw[ix.pt_start + j], a1 = iw[ix.pt_start + j + 1];
+        l0[tid] = a0;
+        ln[tid] = a1 - a0;
+        gl[tid][0] = w[wk.gp + 3 * j]; gl[tid][1] = w[wk.gp + 3 * j + 1]; gl[tid][2] = w[wk.gp + 3 * j + 2];
 #pragma unroll
-          for (int e = 0; e < kListCap; ++e) cl[tid][e] = short(a0 + e < a1 ? oc[a0 + e] : 32767);
-        }
+        for (int e = 0; e < kListCap; ++e) cl[tid][e] = short(a0 + e < a1 ? oc[a0 + e] : 32767);
         const T* Rj = w + wk.Vinv + 6 * j;
         const T r00 = Rj[0], r10 = Rj[1], r11 = Rj[2], r20 = Rj[3], r21 = Rj[4], r22 = Rj[5];
         // V^-1 = R^-T R^-1 with R^-1 lower: rows
@@ -1234,79 +1237,73 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
         const T v11 = r11 * r11 + r21 * r21, v12 = r21 * r22, v22 = r22 * r22;
         T A[2][3];   // J_p,i V^-1 (2 x 3)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const T p0 = w[wk.Jp + size_t(i) * 8 + (3 * a)], p1 = w[wk.Jp + size_t(i) * 8 + (3 * a + 1)], p2 = w[wk.Jp + size_t(i) * 8 + (3 * a + 2)];
-          A[a][0] = p0 * v00 + p1 * v01 + p2 * v02;
-          A[a][1] = p0 * v01 + p1 * v11 + p2 * v12;
-          A[a][2] = p0 * v02 + p1 * v12 + p2 * v22;
+        for (int q = 0; q < 2; ++q) {
+          const T p0 = w[wk.Jp + size_t(i) * 8 + (3 * q)], p1 = w[wk.Jp + size_t(i) * 8 + (3 * q + 1)], p2 = w[wk.Jp + size_t(i) * 8 + (3 * q + 2)];
+          A[q][0] = p0 * v00 + p1 * v01 + p2 * v02;
+          A[q][1] = p0 * v01 + p1 * v11 + p2 * v12;
+          A[q][2] = p0 * v02 + p1 * v12 + p2 * v22;
         }
 #pragma unroll
-        for (int d = 0; d < 6; ++d) {
-          const T jc0 = w[wk.Jc + size_t(i) * 16 + (d)], jc1 = w[wk.Jc + size_t(i) * 16 + (6 + d)];
+        for (int dd = 0; dd < 6; ++dd) {
+          const T jc0 = w[wk.Jc + size_t(i) * 16 + (dd)], jc1 = w[wk.Jc + size_t(i) * 16 + (6 + dd)];
 #pragma unroll
-          for (int b = 0; b < 3; ++b) Tl[tid][3 * d + b] = jc0 * A[0][b] + jc1 * A[1][b];
+          for (int b = 0; b < 3; ++b) Tl[tid][3 * dd + b] = jc0 * A[0][b] + jc1 * A[1][b];
         }
       }
       __syncthreads();
-      const int cnt = min(64, k1 - kk);
-      if (c2 <= c) {   // the lower block triangle; block (c', c) is its transpose, written below: S is exactly symmetric
-        for (int s = 0; s < cnt; ++s) {
-          const int j = jl[s];
-          // does camera c2 see point j?  the head of the point's list (sorted by camera) is in LDS; a longer list falls back to
-          // the binary search of its tail in global memory
-          int found = -1;
+      const int cnt = min(kS, k1 - kk);
+      if (tid < kS * kFast) {   // B_se for the first kFast observers of every staged point
+        const int s_ = tid / kFast, e_ = tid % kFast;
+        if (s_ < cnt && e_ < ln[s_]) {
+          const int i2 = l0[s_] + e_;
 #pragma unroll
-          for (int e = 0; e < kListCap; ++e) found = (int(cl[s][e]) == c2) ? e : found;
-          int i2 = found >= 0 ? l0[s] + found : -1;
-          if (found < 0 && ln[s] > kListCap && int(cl[s][kListCap - 1]) < c2) {
-            int lo = l0[s] + kListCap, hi = l0[s] + ln[s];
-            const int end = hi;
-            while (lo < hi) {
-              const int mid = (lo + hi) >> 1;
-              if (oc[mid] < c2) lo = mid + 1; else hi = mid;
-            }
-            if (lo < end && oc[lo] == c2) i2 = lo;
-          }
-          if (i2 >= 0) {
-            T B[3][6];   // J_p,i2^T J_c,i2 (3 x 6)
+          for (int b = 0; b < 3; ++b) {
+            const T p0 = w[wk.Jp + size_t(i2) * 8 + (b)], p1 = w[wk.Jp + size_t(i2) * 8 + (3 + b)];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-              const T p0 = w[wk.Jp + size_t(i2) * 8 + (b)], p1 = w[wk.Jp + size_t(i2) * 8 + (3 + b)];
-#pragma unroll
-              for (int d = 0; d < 6; ++d) B[b][d] = p0 * w[wk.Jc + size_t(i2) * 16 + (d)] + p1 * w[wk.Jc + size_t(i2) * 16 + (6 + d)];
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-              for (int d = 0; d < 6; ++d) Sb[a][d] -= Tl[s][3 * a] * B[0][d] + Tl[s][3 * a + 1] * B[1][d] + Tl[s][3 * a + 2] * B[2][d];
-          }
-          if (c2 == 0 && cbase == 0) {
-            const T g0 = gl[s][0], g1 = gl[s][1], g2 = gl[s][2];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) rv[a] -= Tl[s][3 * a] * g0 + Tl[s][3 * a + 1] * g1 + Tl[s][3 * a + 2] * g2;
+            for (int dd = 0; dd < 6; ++dd) Bl[s_][e_][6 * b + dd] = p0 * w[wk.Jc + size_t(i2) * 16 + (dd)] + p1 * w[wk.Jc + size_t(i2) * 16 + (6 + dd)];
           }
         }
       }
-    }
-    if (c2 <= c) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-          T v = Sb[a][d];
-          if (c2 == c) {   // the diagonal block: symmetrise the sum of T_i B_i (equal in exact arithmetic) + U_c with its damped diagonal
-            v = (d <= a) ? Sb[a][d] : Sb[d][a];
-            v += (a == d) ? w[wk.Ud + 6 * c + a] : w[wk.U + 36 * c + 6 * a + d];
+      __syncthreads();
+      if (live) {
+        for (int s_ = 0; s_ < cnt; ++s_) {
+          const int len = ln[s_];
+          const T t0 = Tl[s_][3 * a], t1 = Tl[s_][3 * a + 1], t2 = Tl[s_][3 * a + 2];
+          for (int e_ = ent; e_ < len; e_ += kFast) {
+            int c2;
+            if (e_ < kListCap) c2 = int(cl[s_][e_]); else c2 = oc[l0[s_] + e_];
+            if (c2 > c || c2 < cbase || c2 >= cbase + kTile) continue;
+            T b0, b1, b2;
+            if (e_ < kFast) {
+              b0 = Bl[s_][e_][d]; b1 = Bl[s_][e_][6 + d]; b2 = Bl[s_][e_][12 + d];
+            } else {   // a point seen by more cameras than the fast path stages: its entry straight from the records
+              const int i2 = l0[s_] + e_;
+              const T jc0 = w[wk.Jc + size_t(i2) * 16 + (d)], jc1 = w[wk.Jc + size_t(i2) * 16 + (6 + d)];
+              b0 = w[wk.Jp + size_t(i2) * 8 + 0] * jc0 + w[wk.Jp + size_t(i2) * 8 + 3] * jc1;
+              b1 = w[wk.Jp + size_t(i2) * 8 + 1] * jc0 + w[wk.Jp + size_t(i2) * 8 + 4] * jc1;
+              b2 = w[wk.Jp + size_t(i2) * 8 + 2] * jc0 + w[wk.Jp + size_t(i2) * 8 + 5] * jc1;
+            }
+            Srow[c2 - cbase][ad] -= t0 * b0 + t1 * b1 + t2 * b2;
           }
-          Sg[size_t(6 * c + a) * n + 6 * c2 + d] = v;
-          if (c2 != c) Sg[size_t(6 * c2 + d) * n + 6 * c + a] = v;
+          if (cbase == 0 && ent == 0 && d == 0) rva -= t0 * gl[s_][0] + t1 * gl[s_][1] + t2 * gl[s_][2];
         }
-      if (c2 == 0 && cbase == 0) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) rg[6 * c + a] = w[wk.gc + 6 * c + a] + rv[a];
       }
     }
+    __syncthreads();
+    for (int e = tid; e < kTile * 36; e += 256) {
+      const int c2 = cbase + e / 36, q = e % 36, qa = q / 6, qd = q % 6;
+      if (c2 > c || c2 >= C) continue;
+      T v = Srow[c2 - cbase][q];
+      if (c2 == c) {   // the diagonal block: symmetrise the sum of T_i B_i (equal in exact arithmetic) + U_c with its damped diagonal
+        v = (qd <= qa) ? Srow[c2 - cbase][qa * 6 + qd] : Srow[c2 - cbase][qd * 6 + qa];
+        v += (qa == qd) ? w[wk.Ud + 6 * c + qa] : w[wk.U + 36 * c + 6 * qa + qd];
+      }
+      Sg[size_t(6 * c + qa) * n + 6 * c2 + qd] = v;
+      if (c2 != c) Sg[size_t(6 * c2 + qd) * n + 6 * c + qa] = v;
+    }
+    __syncthreads();
   }
+  if (live && ent == 0 && d == 0) rg[6 * c + a] = w[wk.gc + 6 * c + a] + rva;
 }
 
 template <typename T>
