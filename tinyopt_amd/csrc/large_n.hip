@@ -840,19 +840,20 @@ __device__ __forceinline__ T chol_bcast(const T v, const int src) {
     return __longlong_as_double((long long)(((unsigned long long)unsigned(hi) << 32) | unsigned(lo)));
   }
 }
+constexpr int kCholThreads = 512;
 template <typename T>
-__global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T> a) {
-  constexpr int B = 32, LS = B + 1;
+__global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const LargeArgs<T> a) {
+  constexpr int B = 32, LS = B + 1, NT = kCholThreads, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char chol_lds[];
   T* Ld = reinterpret_cast<T*>(chol_lds);          // [B][LS]   the factored diagonal block
   T* Lp = Ld + B * LS;                             // [n][LS]   the panel's rows below it (row i of the matrix at Lp[i - k1])
-  T* ys = Lp + size_t(a.n) * LS;                   // [n]       right-hand side / solution
+  T* ys = Lp + size_t(a.n) * LS;                   // [n]       right-hand side / solution (+ 64 scratch entries, + 32 reciprocals of the block's diagonal)
   __shared__ int fail;
   const size_t p = blockIdx.x;
   if (!a.active[p] || !(a.built[p] & 1)) return;
   const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* A = a.work + p * size_t(n) * n;
-  for (int i = tid; i < n; i += 256) ys[i] = a.rhs[p * n + i];
+  for (int i = tid; i < n; i += NT) ys[i] = a.rhs[p * n + i];
   if (tid == 0) fail = 0;
   __syncthreads();
 #ifdef TOA_CHOL_TIMING
@@ -889,6 +890,10 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
 #pragma unroll
         for (int c = 0; c < B; ++c)
           if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
+        T dg = T(1);
+#pragma unroll
+        for (int c = 0; c < B; ++c) dg = c == lane ? r[c] : dg;
+        ys[n + 64 + lane] = T(1) / dg;                   // the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
       }
       if (bad && lane == 0) fail = 1;
     }
@@ -896,7 +901,7 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
     CH_TICK(0)
     if (fail) break;
     // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update)
-    for (int i = k1 + tid; i < n; i += 256) {
+    for (int i = k1 + tid; i < n; i += NT) {
       T x[B];
 #pragma unroll
       for (int c = 0; c < B; ++c) x[c] = c < bs ? A[size_t(i) * n + k0 + c] : T(0);
@@ -907,7 +912,7 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
           T v = x[c];
 #pragma unroll
           for (int t = 0; t < c; ++t) v = fma(-x[t], Ld[c * LS + t], v);
-          x[c] = v / Ld[c * LS + c];
+          x[c] = v * ys[n + 64 + c];
         }
       }
 #pragma unroll
@@ -926,21 +931,39 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       using Acc = typename Mfma<T>::Acc;
       const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
       const int l15 = lane & 15, kq = lane >> 4;
-      for (int t = wave; t < ntile; t += 4) {
-        int ti = 0, rem = t;                             // t -> (ti, tj), ti >= tj, row-major over the lower triangle
-        while (rem > ti) { rem -= ti + 1; ++ti; }
-        const int tj = rem;
-        const T* pa = Lp + size_t(16 * ti + l15) * LS + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
-        const T* pb = Lp + size_t(16 * tj + l15) * LS + kq;
-        Acc acc = {0, 0, 0, 0};
+      for (int t = wave; t < ntile; t += 2 * NW) {       // two tiles per trip: their eight old values are in flight under the MFMAs
+        int ti[2], tj[2];
 #pragma unroll
-        for (int q = 0; q < B / 4; ++q) acc = Mfma<T>::fma(pa[4 * q], pb[4 * q], acc);
-        asm volatile("s_nop 9" : "+a"(acc));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int gi = k1 + 16 * ti + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj + l15;
-          if (gi < n && gj <= gi) A[size_t(gi) * n + gj] -= acc[reg];
+        for (int u = 0; u < 2; ++u) {                    // t -> (ti, tj), ti >= tj, row-major over the lower triangle
+          int row = 0, rem = t + u * NW;
+          while (rem > row) { rem -= row + 1; ++row; }
+          ti[u] = row; tj[u] = rem;
         }
+        const bool two = t + NW < ntile;
+        T old[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
+            old[u][reg] = ((u == 0 || two) && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
+          }
+        Acc acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const T* pa = Lp + size_t(16 * ti[u] + l15) * LS + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
+          const T* pb = Lp + size_t(16 * tj[u] + l15) * LS + kq;
+#pragma unroll
+          for (int q = 0; q < B / 4; ++q) acc[u] = Mfma<T>::fma(pa[4 * q], pb[4 * q], acc[u]);
+        }
+        asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
+            if ((u == 0 || two) && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
+          }
       }
     }
     __syncthreads();
@@ -970,7 +993,7 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       if (lane < bs) ys[k0 + lane] = y;
     }
     __syncthreads();
-    for (int i = k1 + tid; i < n; i += 256) {
+    for (int i = k1 + tid; i < n; i += NT) {
       T s = ys[i];
       const T* Li = A + size_t(i) * n + k0;
       T lv[B];
@@ -1004,7 +1027,7 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
       if (lane < bs) ys[k0 + lane] = xv;
     }
     __syncthreads();
-    for (int j = tid; j < k0; j += 256) {                // the unknowns above: x_j -= sum_c L_(k0+c),j x_(k0+c)  (coalesced across lanes)
+    for (int j = tid; j < k0; j += NT) {                // the unknowns above: x_j -= sum_c L_(k0+c),j x_(k0+c)  (coalesced across lanes)
       T s = ys[j];
       T lv[B];
 #pragma unroll
@@ -1019,11 +1042,11 @@ __global__ void __launch_bounds__(256) large_chol_solve_kernel(const LargeArgs<T
 #ifdef TOA_CHOL_TIMING
   if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01);
 #endif
-  for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = ys[i];
+  for (int i = tid; i < n; i += NT) a.rhs[p * n + i] = ys[i];
   if (tid == 0) a.info[p] = 0;
 }
 template <typename T>
-inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 33 + size_t(n) + 64) * sizeof(T) + 64; }
+inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 33 + size_t(n) + 64 + 32) * sizeof(T) + 64; }
 
 template <typename T>
 inline size_t ldlt_image_bytes(int n) { return ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15); }
@@ -1311,7 +1334,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     if (own_chol) {
       launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);
     } else if (own_chol2) {
-      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(256), chol2_lds, st, a);
+      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(kCholThreads), chol2_lds, st, a);
     } else if (lu) {
       if constexpr (sizeof(T) == 4) {
         rc = api.sgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
@@ -1372,7 +1395,7 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
   if (n <= 128) launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
-  else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(256), chol_lds, h->stream, a);
+  else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(kCholThreads), chol_lds, h->stream, a);
   hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
@@ -1385,7 +1408,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                     int32_t* ok) {
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
-  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 64) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
+  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
   const bool own2 = n > 128 && P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds);   // the one-workgroup blocked Cholesky (fp32: n <= 1024, fp64: n <= 512)
   if (!force_lib && ((n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) || own2)) {  // the workgroup LDL^T (ldlt_wg.hpp) / blocked Cholesky; the library beyond
     if (dtype == TOA_F32)
@@ -1404,7 +1427,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
   {  // our own kernels are batch-independent by construction (one workgroup per matrix, fixed-order sums): one launch for all
     static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
-    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 64) * (dtype == TOA_F32 ? 4 : 8) + 64;
+    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
     if (!force_lib && (n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds)))) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   }
   toa::RocApi& api = toa::roc_api();
