@@ -843,11 +843,12 @@ __device__ __forceinline__ T chol_bcast(const T v, const int src) {
 constexpr int kCholThreads = 512;
 template <typename T>
 __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const LargeArgs<T> a) {
-  constexpr int B = 32, LS = B + 1, NT = kCholThreads, NW = NT / 64;
+  constexpr int B = 32, LS = B + 1, LSP = B + 4, NT = kCholThreads, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char chol_lds[];
   T* Ld = reinterpret_cast<T*>(chol_lds);          // [B][LS]   the factored diagonal block
-  T* Lp = Ld + B * LS;                             // [n][LS]   the panel's rows below it (row i of the matrix at Lp[i - k1])
-  T* ys = Lp + size_t(a.n) * LS;                   // [n]       right-hand side / solution (+ 64 scratch entries, + 32 reciprocals of the block's diagonal)
+  T* Lp = Ld + B * LS;                             // [n][LSP]  the panel's rows below it (row i of the matrix at Lp[i - k1]); row stride 36:
+                                                   //           the MFMA operand reads (16 rows x 4 columns per instruction) hit every bank once (fp32) / twice (fp64)
+  T* ys = Lp + size_t(a.n) * LSP;                  // [n]       right-hand side / solution (+ 64 scratch entries, + 32 reciprocals of the block's diagonal)
   __shared__ int fail;
   const size_t p = blockIdx.x;
   if (!a.active[p] || !(a.built[p] & 1)) return;
@@ -883,17 +884,24 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
         const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj (ONE LDS round trip per column)
 #pragma unroll
         for (int c = j + 1; c < B; ++c) r[c] = fma(-t, colj[c], r[c]);   // (lanes < c hold zeros there and are not stored)
-        r[j] = r[j] / sqrt(dd);                          // lane j: l itself; lanes > j: L_ij
         __builtin_amdgcn_wave_barrier();
       }
+      // the scaling by 1 / sqrt(d_j), once for all columns: lane j takes the root of ITS pivot (one sqrt and one division per lane,
+      // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors go round through LDS
+      T dj = T(1);
+#pragma unroll
+      for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
+      const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
+      colj[lane] = rs;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < B; ++c) r[c] *= colj[c];       // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
+      __builtin_amdgcn_wave_barrier();
       if (lane < bs) {
 #pragma unroll
         for (int c = 0; c < B; ++c)
           if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
-        T dg = T(1);
-#pragma unroll
-        for (int c = 0; c < B; ++c) dg = c == lane ? r[c] : dg;
-        ys[n + 64 + lane] = T(1) / dg;                   // the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
+        ys[n + 64 + lane] = rs;                          // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
       }
       if (bad && lane == 0) fail = 1;
     }
@@ -918,51 +926,54 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
 #pragma unroll
       for (int c = 0; c < B; ++c) {
         if (c < bs) A[size_t(i) * n + k0 + c] = x[c];
-        Lp[size_t(i - k1) * LS + c] = x[c];
+        Lp[size_t(i - k1) * LSP + c] = x[c];
       }
     }
     __syncthreads();
     CH_TICK(1)
     // ---- trailing update A22 -= L21 L21^T on the matrix cores: 16 x 16 tiles of the lower triangle dealt to the four waves, both
-    // operands straight from the panel in LDS (row stride 33: conflict-free), eight v_mfma_*_16x16x4 per tile, then a
+    // operands straight from the panel in LDS (row stride 36: conflict-free), eight v_mfma_*_16x16x4 per tile, then a
     // read-modify-write of the tile in the L2-resident matrix.  (A lane per column with the rows in batches of eight — VALU, one
     // dependent global round trip per batch — took 122 us of a 376 us n = 256 solve.)
     {
       using Acc = typename Mfma<T>::Acc;
       const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
       const int l15 = lane & 15, kq = lane >> 4;
-      for (int t = wave; t < ntile; t += 2 * NW) {       // two tiles per trip: their eight old values are in flight under the MFMAs
-        int ti[2], tj[2];
+      constexpr int U = sizeof(T) == 8 ? 2 : 4;
+      for (int t = wave; t < ntile; t += U * NW) {       // U tiles per trip: their old values are in flight under the MFMAs
+        int ti[U], tj[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                    // t -> (ti, tj), ti >= tj, row-major over the lower triangle
+        for (int u = 0; u < U; ++u) {                    // t -> (ti, tj), ti >= tj, row-major over the lower triangle
           int row = 0, rem = t + u * NW;
           while (rem > row) { rem -= row + 1; ++row; }
           ti[u] = row; tj[u] = rem;
         }
-        const bool two = t + NW < ntile;
-        T old[2][4];
+        T old[U][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            old[u][reg] = ((u == 0 || two) && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
+            old[u][reg] = (t + u * NW < ntile && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
           }
-        Acc acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        Acc acc[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const T* pa = Lp + size_t(16 * ti[u] + l15) * LS + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
-          const T* pb = Lp + size_t(16 * tj[u] + l15) * LS + kq;
+        for (int u = 0; u < U; ++u) acc[u] = Acc{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T* pa = Lp + size_t(16 * ti[u] + l15) * LSP + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
+          const T* pb = Lp + size_t(16 * tj[u] + l15) * LSP + kq;
 #pragma unroll
           for (int q = 0; q < B / 4; ++q) acc[u] = Mfma<T>::fma(pa[4 * q], pb[4 * q], acc[u]);
         }
-        asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
+        if constexpr (U == 4) asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+        else asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            if ((u == 0 || two) && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
+            if (t + u * NW < ntile && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
           }
       }
     }
@@ -1046,7 +1057,7 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   if (tid == 0) a.info[p] = 0;
 }
 template <typename T>
-inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 33 + size_t(n) + 64 + 32) * sizeof(T) + 64; }
+inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 36 + size_t(n) + 64 + 32) * sizeof(T) + 64; }
 
 template <typename T>
 inline size_t ldlt_image_bytes(int n) { return ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15); }
@@ -1408,7 +1419,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                     int32_t* ok) {
   static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
   const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
-  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
+  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
   const bool own2 = n > 128 && P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds);   // the one-workgroup blocked Cholesky (fp32: n <= 1024, fp64: n <= 512)
   if (!force_lib && ((n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) || own2)) {  // the workgroup LDL^T (ldlt_wg.hpp) / blocked Cholesky; the library beyond
     if (dtype == TOA_F32)
@@ -1427,7 +1438,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
   {  // our own kernels are batch-independent by construction (one workgroup per matrix, fixed-order sums): one launch for all
     static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
-    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 34 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
+    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
     if (!force_lib && (n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds)))) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   }
   toa::RocApi& api = toa::roc_api();
