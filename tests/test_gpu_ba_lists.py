@@ -71,6 +71,27 @@ def _sparse_scene(oracle, P, ncam, npts, per_point, seed):
     return data, x0, xs
 
 
+def test_lists_beyond_one_camera_tile_match_dense_oracle(ta, oracle):
+    """72 cameras: `bl_schur_kernel` walks its block row in camera tiles of 64, so cameras 64..71 take the second tile; 9 observers
+    per point also take the entries past the six whose products are staged in LDS.  Against the dense oracle (792 unknowns)."""
+    ncam, npts = 72, 120
+    data, x0, xs = _sparse_scene(oracle, 1, ncam, npts, 9, seed=77)
+    opts = ta.Options()
+    ref = oracle.ba_lm(data, x0, ncam, npts, opts.to_pod())
+    model = ta.BundleAdjustmentLists.from_dense(torch.from_numpy(data).cuda(), ncam, npts)
+    assert model.nobs == 9 * npts
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    assert (out.stop_reason.cpu().numpy() >= 0).all() and (ref["stop"] >= 0).all()
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    st = check_trajectories(gpu_dict(out, x), refd, np.float64, opts.to_pod(), tol=dict(x_tol=1e-5, cost_rtol=1e-8), label="BA lists 72x120")
+    assert st["full"] + st["ties"] == 1
+    k = int(min(out.num_iters.min().item(), ref["iters"].min()))
+    assert np.allclose(out.deltas2.cpu().numpy()[:, :k], ref["deltas2"][:, :k], rtol=1e-6)
+
+
 def test_lists_large_scene_properties(ta, oracle):
     """64 cameras x 5000 points, 6 observations per point (30 000 observations, 15 384 unknowns)."""
     ncam, npts, P = 64, 5000, 2
