@@ -797,9 +797,11 @@ int launch_ba_any(toa_handle h, BaParams& prm) {
 //   bl_cam      workgroup / camera     U_c = sum J_c^T J_c, g_c = sum J_c^T r over the camera's observations, fixed-order fold
 //   bl_build    workgroup / scene      cost, validity, clipping, diagonal check, Marquardt scale (lm.h:59-120)
 //   bl_psolve   thread / point         damp V_j, V_j^-1 (Cholesky), q_j = V_j^-1 g_pj
-//   bl_schur    workgroup / camera c   block row c of  S = U - sum_j W_cj V_j^-1 W_c'j^T  and of  g_c - W V^-1 g_p : thread c'
-//                                      owns block (c, c'), the camera's observations are walked in order (no atomics)
-//   solve       toa_large_solve        S dc = -(g_c - W V^-1 g_p): workgroup LDL^T up to 128 unknowns, rocSOLVER potrf beyond
+//   bl_schur    workgroup / camera c   block row c of  S = U - sum_j W_cj V_j^-1 W_c'j^T  and of  g_c - W V^-1 g_p : block
+//                                      products staged in LDS, lane (component, observer) accumulates into the LDS row of the
+//                                      observer's camera; the camera's observations are walked in order (no atomics)
+//   solve       toa_large_solve_each   S dc = -(g_c - W V^-1 g_p): workgroup LDL^T up to 128 unknowns, the one-workgroup blocked
+//                                      Cholesky up to 512 (fp64) / 1024 (fp32), rocSOLVER potrf beyond
 //   bl_back     thread / point         dp_j = -V_j^-1 (g_pj + sum W_ij^T dc), |dx|^2, |g|^2 partials
 //   bl_step     workgroup / scene      the rest of Step + the loop body of OptimizeAcc (optimizer.h:266-310, 370-539): the same
 //                                      scalar state machine as every other path (lm_judge_core, lm_good_step / lm_bad_step)
