@@ -100,14 +100,18 @@ def lint_inflight(func, insts):
                         state = state[1:]
             else:
                 touched = touched_vregs(op, rest.split("<")[0])
+                sink_load = op == "buffer_load_ubyte"   # L2 prefetches into a register nobody reads (dense_row.hpp q_prefetch)
                 for dst, loff in state:
                     hit = touched & set(dst)
+                    if hit and sink_load and insts[index_of[loff]][1] == "buffer_load_ubyte" and min(hit) == min(dst):
+                        continue   # one prefetch overwriting the sink of another: write after write of a value never read
                     if hit:
                         problems.add(f"{func[:90]}: `{op} {rest.split('<')[0].strip()}` (+{off:#x}) touches v{min(hit)} while the load issued at +{loff:#x} is in flight")
                 if VMEM.match(op):
                     # only the hand-written pipeline's loads (`buffer_load ... offen` from the asm statements) are
                     # protected; every other vector-memory access just occupies a vmcnt slot behind them
-                    prot = op.startswith("buffer_load") and "offen" in rest
+                    # (an LDS-DMA load, `... offen lds`, has no register destination: its first operand is the address)
+                    prot = op.startswith("buffer_load") and "offen" in rest and not re.search(r"\blds\b", rest)
                     dst = tuple(sorted(vregs(rest.split(",")[0]))) if prot else ()
                     state = state + ((dst, off if prot else 0),)
                     while state and not state[0][0]:   # unprotected accesses older than every protected one retire first
