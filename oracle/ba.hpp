@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "lm_oracle.hpp"
+#include "robust.hpp"
 #include "se3.hpp"
 
 namespace oracle {
@@ -39,10 +40,15 @@ struct Plus {
   }
 };
 
+// loss / th2: an M-estimator on each observation's squared norm n2 = |r|^2 (what a tinyopt user writes inside the cost functor,
+// losses/robust_norms.h:20-26 "JtJ * dx = Jt*res*s", docs/API.md:396-411): cost += l(n2), the observation's J^T J and J^T r
+// scaled by s = dl/dn2, both of its residuals inliers when n2 <= th2 (cost.h:84-95).  loss 0 = plain squared L2.
 template <typename T>
 struct Acc {
   int C, N;
   const T* data;
+  int loss = 0;
+  T th2 = T(0);
   // r (2), Jc (2x6 row-major), Jp (2x3 row-major) of one observation
   void obs(const Params<T>& x, int c, int j, T* r, T* Jc, T* Jp) const {
     const T* P = x.v.data() + 12 * c;
@@ -78,14 +84,17 @@ struct Acc {
     const int n = 6 * C + 3 * N;
     const T* vis = data + 8 + size_t(C) * N * 2;
     T cost = 0;
-    int nres = 0;
+    int nres = 0, ninl = 0;
     for (int c = 0; c < C; ++c)
       for (int j = 0; j < N; ++j) {
         if (vis[size_t(c) * N + j] == T(0)) continue;
         T r[2], Jc[12], Jp[6];
         obs(x, c, j, r, g ? Jc : nullptr, g ? Jp : nullptr);
-        cost += r[0] * r[0] + r[1] * r[1];
+        const T n2 = r[0] * r[0] + r[1] * r[1];
+        const auto ls = robust::Apply<T>(loss, n2, th2);   // loss 0: {n2, 1}
+        cost += ls.l;
         nres += 2;
+        ninl += (loss == 0 || n2 <= th2) ? 2 : 0;
         if (!g) continue;
         int idx[9];
         for (int k = 0; k < 6; ++k) idx[k] = 6 * c + k;
@@ -95,12 +104,13 @@ struct Acc {
           for (int k = 0; k < 6; ++k) J9[k] = Jc[6 * row + k];
           for (int k = 0; k < 3; ++k) J9[6 + k] = Jp[3 * row + k];
           for (int a = 0; a < 9; ++a) {
-            g[idx[a]] += J9[a] * r[row];
-            if (H) for (int b = 0; b < 9; ++b) H[size_t(idx[b]) * n + idx[a]] += J9[a] * J9[b];
+            const T sJ = ls.s * J9[a];
+            g[idx[a]] += sJ * r[row];
+            if (H) for (int b = 0; b < 9; ++b) H[size_t(idx[b]) * n + idx[a]] += sJ * J9[b];
           }
         }
       }
-    return Cost(double(cost), nres);
+    return Cost(double(cost), nres, nres ? float(ninl) / float(nres) : 1.0f);
   }
 };
 

@@ -248,7 +248,8 @@ static void ba_lm_t(int64_t P, int C, int N, const T* data, T* x, const Options&
     X.C = C; X.N = N;
     X.v.assign(x + p * xs, x + (p + 1) * xs);
     Optimizer<T> opt(o, 6 * C + 3 * N);
-    Output out = opt.OptimizeAcc(X, ba::Acc<T>{C, N, data + p * ds}, ba::Plus<T>());
+    Output out = opt.OptimizeAcc(X, ba::Acc<T>{C, N, data + p * ds, g_loss_kind, T(g_loss_th2)}, ba::Plus<T>());
+    if (g_inlier_out) g_inlier_out[p] = out.final_cost.inlier_ratio;
     std::memcpy(x + p * xs, X.v.data(), sizeof(T) * xs);
     if (stop) stop[p] = out.stop_reason;
     if (iters) iters[p] = out.num_iters;

@@ -451,9 +451,19 @@ def synth_ba(P, ncam, npts, dtype, seed=0x71940917, noise_px=0.5, pose_pert=0.02
     return data.astype(dtype), x0.astype(dtype), xs.astype(dtype)
 
 
-def ba_lm(data, x0, ncam, npts, pod: ToaOptions, history=True, lib=None):
-    """Bundle adjustment solved the reference's way: dense (6C + 3N)^2 Hessian + dense LDL^T (oracle/ba.hpp)."""
+def ba_lm(data, x0, ncam, npts, pod: ToaOptions, history=True, lib=None, loss=None, th2=0.0):
+    """Bundle adjustment solved the reference's way: dense (6C + 3N)^2 Hessian + dense LDL^T (oracle/ba.hpp).
+    loss / th2: an M-estimator on every observation's squared norm (losses/robust_norms.h:20-26); adds "inlier_ratio"."""
     lib = lib or load()
+    if loss is not None:
+        inl = np.ones(np.asarray(x0).shape[0], np.float32)
+        lib.oracle_set_loss(LOSS_KINDS[loss], float(th2), _p(inl))
+        try:
+            r = ba_lm(data, x0, ncam, npts, pod, history=history, lib=lib)
+        finally:
+            lib.oracle_set_loss(0, 0.0, None)
+        r["inlier_ratio"] = inl
+        return r
     x = np.array(x0, copy=True)
     P = x.shape[0]
     stop = np.zeros(P, np.int32); iters = np.zeros(P, np.int32); fails = np.zeros(P, np.int32)

@@ -51,11 +51,12 @@ __device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign
 // four waves run different problems at their own pace), no HBM traffic.
 struct CoopSlot {          // one per wave, written by the OWNER except ticket (everybody) and turn (whoever folds)
   int p;                   // problem of the open pass
-  int kind;                // 1: accumulate (Gram), 0: evaluate-only (sum of squares)
-  int ticket;              // next chunk to hand out; >= K: no open pass
+  int ticket;              // next chunk of the open ACCUMULATE pass to hand out; >= K: no open pass.  Evaluate-only passes never
+                           // touch it (the owner walks their chunks itself), so whatever ticket a helper draws — however long
+                           // ago it looked at the counter — belongs to an accumulate pass of this slot, and the acquire half of
+                           // the fetch-add shows it that pass's problem and x
   int turn;                // next chunk whose partial may be folded; == K: the pass is complete
-  double cost;             // evaluate-only: the running sum (holds a T)
-  int pad_[2];
+  int pad_[5];
 };
 struct CoopCtl {
   CoopSlot slot[4];
@@ -126,26 +127,38 @@ struct DenseRowModel {
   // the n = 50 kernel from 156 to 196 registers, 3 -> 2 waves / SIMD), so the kernel may contain exactly one.
   //   owner   (helping == 0): opens a pass on its own slot, takes its tickets like everybody else, waits for the last fold,
   //           reads the total back into the Gram registers;
-  //   helper  (helping == 1, only ever through the WANT_H instantiation — see lm_fused_kernel's "ghost problem"): this wave
+  //   helper  (helping == 1 — see lm_fused_kernel's "ghost problem"): this wave
   //           has no problem left; it serves the siblings' open ACCUMULATE passes until none of them is active.  (Evaluate-
-  //           only passes — one in seven at C4 — are chunked and folded the same way but never shared: a second kind of
-  //           chunk in this loop costs the kernel its third wave per SIMD.)
+  //           only passes — one in seven at C4 — are the same chunks summed in the same order by the owner alone, coop_eval:
+  //           a second kind of chunk in this loop costs the kernel its third wave per SIMD.)
   // The shape of the loop is what hipcc's register allocation tolerated (A/B log, profiles/r03_ab_log.md): do-while, the
   // scalars that cross the pass re-derived behind optimisation barriers, the total read back through in-out asm operands.
-  // Returns the cost of an evaluate-only pass.
-  template <bool WANT_H>
-  __device__ __forceinline__ T coop_pass(WaveLds<T>& L, const int n, const int lane) {
+  __device__ __forceinline__ T coop_eval(WaveLds<T>& L, const int n, const int lane) {
+    // Evaluate-only pass: the same chunks, summed in the same order, by the owner alone — no ticket, no slot.  (A helper
+    // that looked at this slot's counter during the previous accumulate pass and draws its ticket only now must never land
+    // in a pass of a different kind — ADVICE r03: the counter therefore stays closed across evaluate-only passes.)
+    const int st = lay.m4 >> 2;
+    T tot = T(0);
+    for (int c = 0; c < coop_K; ++c) {
+      reg_fence();
+      const T part = gram.template pass_chunk<false>(prob, lay, n, L.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
+      reg_fence();
+      tot = c == 0 ? part : tot + part;
+    }
+    return tot;
+  }
+  __device__ __forceinline__ void coop_acc(WaveLds<T>& L, const int n, const int lane) {
+    constexpr bool WANT_H = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    const bool help = WANT_H && helping != 0;
     const int st = lay.m4 >> 2;
+    const bool help = helping != 0;
     int c, o;
     if (!help) {
       o = w;
       CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[w];
       if (lane == 0) {
         S.p = cur_p;
-        S.kind = WANT_H ? 1 : 0;
         S.turn = 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // x (L.xs) and the fields above, before the counter opens
@@ -175,14 +188,10 @@ struct DenseRowModel {
         __builtin_amdgcn_s_sleep(2);
         if (spin > (1 << 24)) asm volatile("s_trap 2");
       }
-      if (WANT_H) {
-        if (coop_K > 1) {   // (one chunk per pass: the registers ARE the total)
-          if (c == 0) gram.memo_save(totp, lane);
-          else gram.memo_add(totp, lane);
-        }
-      } else if (lane == 0) {
-        T* cs = reinterpret_cast<T*>(&S.cost);
-        *cs = c == 0 ? part : *cs + part;
+      (void)part;
+      if (coop_K > 1) {   // (one chunk per pass: the registers ARE the total)
+        if (c == 0) gram.memo_save(totp, lane);
+        else gram.memo_add(totp, lane);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&S.turn, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -198,16 +207,11 @@ struct DenseRowModel {
       __builtin_amdgcn_s_sleep(2);
       if (spin > (1 << 24)) asm volatile("s_trap 2");
     }
-    if constexpr (WANT_H) {
-      if (coop_K > 1) gram.memo_load_inplace(reinterpret_cast<T*>(smem + size_t(w) * coop_lds_per_wave + coop_tot_off), lane);
-      gram.fold_thin();
-      return T(0);
-    } else {
-      return *reinterpret_cast<const T*>(&S.cost);
-    }
+    if (coop_K > 1) gram.memo_load_inplace(reinterpret_cast<T*>(smem + size_t(w) * coop_lds_per_wave + coop_tot_off), lane);
+    gram.fold_thin();
   }
-  // A wave whose queue is dry looks for a sibling's open ACCUMULATE pass and takes a ticket of it (kind is written before
-  // the counter opens and cannot change while tickets of that pass are outstanding).  false: no sibling is active any more.
+  // A wave whose queue is dry looks for a sibling's open ACCUMULATE pass and takes a ticket of it (only accumulate passes
+  // ever open the counter: a ticket drawn late still names a chunk of an accumulate pass).  false: no sibling is active any more.
   __device__ __forceinline__ bool coop_find(const int lane) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
@@ -225,7 +229,6 @@ struct DenseRowModel {
         if (__hip_atomic_load(&ctl->active[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
         any = true;
         if (__hip_atomic_load(&ctl->slot[q].ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= coop_K) continue;
-        if (__hip_atomic_load(&ctl->slot[q].kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
         int cc = 0;
         if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         cc = __builtin_amdgcn_readfirstlane(cc);
@@ -243,7 +246,7 @@ struct DenseRowModel {
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     if constexpr (kCoop) {
       ninl = -1;
-      (void)coop_pass<true>(L, n, lane);
+      coop_acc(L, n, lane);
       if (helping) {   // the ghost problem of a wave whose queue is dry (lm_fused_kernel): "no residuals" ends it at once
         cost = T(0);
         nres = 0;
@@ -261,7 +264,7 @@ struct DenseRowModel {
   __device__ __forceinline__ void evaluate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     if constexpr (kCoop) {
       ninl = -1;
-      cost = coop_pass<false>(L, n, lane);
+      cost = coop_eval(L, n, lane);
     } else {
       cost = gram.template pass<false, ROBUST, kStaged>(prob, lay, n, L.xs, lane, loss, th2, rows_real, &ninl, stage);
     }
@@ -1301,7 +1304,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     if (p >= P) {
       // The queue is dry.  A wave of a cooperative model does not leave yet: it looks for a sibling's open Accumulate pass,
       // takes a chunk ticket of it (DenseRowModel::coop_find) and runs a GHOST problem through the very same state-machine
-      // code — whose single Accumulate call is where the chunk loop lives (DenseRowModel::coop_pass: hipcc tolerates
+      // code — whose single Accumulate call is where the chunk loop lives (DenseRowModel::coop_acc: hipcc tolerates
       // exactly one MFMA loop per kernel).  That call works the ticket (and the pass's remaining ones) off, then reports
       // "no residuals", which ends the ghost at once (kSkipped, optimizer.h:372-375) with nothing written anywhere (p < 0);
       // the wave comes back here for the next ticket until no sibling is active any more.
