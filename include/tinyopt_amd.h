@@ -244,8 +244,10 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
  *      TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 (fp64: 96) — refused beyond, never ignored: each row's r_i^2;
  *      TOA_MODEL_CIRCLE_FIT / DENSE_ROW_AD6: each item's ||r||^2): cost += l, the item's J^T J and J^T r scaled by
  *      s = dl/dn2, inliers (n2 <= th2) reported through final_inlier_ratio (cost.h:84-95).  kind = TOA_LOSS_* (TOA_LOSS_L2
- *      = off, the default); th2 = squared threshold.  TOA_MODEL_SE3_REPROJ keeps its loss in its data header; the other
- *      families have none. */
+ *      = off, the default); th2 = squared threshold.  TOA_MODEL_SE3_REPROJ keeps its loss in its data header.  Both
+ *      bundle-adjustment forms (toa_ba_run, toa_ba_lists_run) honour it per OBSERVATION (round 4): n2 = the squared norm of the
+ *      observation's two reprojection residuals, both of them inliers when n2 <= th2.  The other families have none and
+ *      refuse a handle that carries one. */
 int toa_set_loss(toa_handle h, int kind, double th2);
 
 /* ---- the dual numbers alone (replaces ceres::Jet<T, N>, include/tinyopt/3rdparty/ceres/jet.h:216-1400, as the residual

@@ -18,6 +18,14 @@ Appendix A and the reference headers directly — NOT from anything under oracle
     Options defaults          include/tinyopt/optimizers/options.h:43-139
     SolveLDLT                 include/tinyopt/math.h:232-240  (+ Eigen 3.4 LDLT, restated from its published algorithm)
     the cost callbacks        tests/optimize_easy.cpp:35-221 (Rosenbrock, plateau, Powell — manual Accumulate callbacks)
+                              tests/optimize_hard.cpp:34-102 (Beale, Himmelblau — residual VECTORS: the AD bridge folds them,
+                              diff/optimize_autodiff.h:151-164: grad = J^T r, H = J^T J, Cost(||r||^2, r.size()))
+
+Round 4 (VERDICT r03 "weak" #1 ii): the branches the first 30 cases left to one reading — use_step_quality_approx (lm.h:126-129),
+grad_clipping (base.h:29-38 through lm.h:79), check_min_H_diag (lm.h:82-86), use_ldlt = false (gn.h:157-162), the three
+NormalizeCost flags (base.h:41-45), vector-residual costs with num_residuals > 1 — and "float32" cases: the same reading in
+doubles, held against the fp32 oracle / device with fp32 tolerances, emitted only when every decision is further than 1e-3
+from flipping and the trace is short enough to stay clear of the fp32 noise floor.
 
 It emits tests/golden/reference_traces.json: per case the options, the start, and per loop pass the cost, |dx|^2, the
 accept flag, lambda AFTER the pass, x AFTER the pass, whether the pass rebuilt the linear system, plus the final Output.
@@ -185,7 +193,7 @@ def rosenbrock(v, want):
     if want:
         g = [-2.0 * term1 - 400.0 * x * term2, 200.0 * term2]
         H = [[2.0 - 400.0 * y + 1200.0 * x * x, -400.0 * x], [-400.0 * x, 200.0]]
-    return term1 * term1 + 100.0 * term2 * term2, g, H
+    return term1 * term1 + 100.0 * term2 * term2, g, H, 1
 
 
 def plateau(v, want):
@@ -201,7 +209,7 @@ def plateau(v, want):
         h11 = cx * ex * (cy - 4.0 * dy * sy + (2.0 - 4.0 * dy * dy) * cy)
         h01 = ex * (sx + 2.0 * dx * cx) * (sy + 2.0 * dy * cy)
         H = [[h00, h01], [h01, h11]]
-    return cost, g, H
+    return cost, g, H, 1
 
 
 def powell(v, want):
@@ -218,10 +226,65 @@ def powell(v, want):
         H[1][1] += d3; H[1][2] += -2.0 * d3; H[2][1] += -2.0 * d3; H[2][2] += 4.0 * d3
         d4 = 120.0 * t4 * t4
         H[0][0] += d4; H[0][3] += -d4; H[3][0] += -d4; H[3][3] += d4
-    return t1 * t1 + 5.0 * t2 * t2 + math.pow(t3, 4) + math.pow(t4, 4) * 10.0, g, H
+    return t1 * t1 + 5.0 * t2 * t2 + math.pow(t3, 4) + math.pow(t4, 4) * 10.0, g, H, 1
 
 
-FUNCS = {"rosenbrock": rosenbrock, "plateau": plateau, "powell": powell}
+def _from_residuals(r, J, want):
+    """What the AD bridge makes of a residual vector (optimize_autodiff.h:151-164): grad = J^T r, H = J^T J (all n x n
+    entries), cost = r.squaredNorm() over r.size() residuals."""
+    m, n = len(r), len(J[0])
+    cost = 0.0
+    for v in r:
+        cost += v * v
+    g = H = None
+    if want:
+        g = [0.0] * n
+        H = [[0.0] * n for _ in range(n)]
+        for a in range(n):
+            for i in range(m):
+                g[a] += J[i][a] * r[i]
+            for b in range(n):
+                for i in range(m):
+                    H[a][b] += J[i][a] * J[i][b]
+    return cost, g, H, m
+
+
+def beale(v, want):                       # tests/optimize_hard.cpp:34-63
+    x, y = v
+    r = [1.5 - x + x * y, 2.25 - x + x * y * y, 2.625 - x + x * y * y * y]
+    J = [[-1.0 + y, x], [-1.0 + y * y, 2.0 * x * y], [-1.0 + y * y * y, 3.0 * x * y * y]]
+    return _from_residuals(r, J, want)
+
+
+def himmelblau(v, want):                  # tests/optimize_hard.cpp:72-102
+    x, y = v
+    r = [x * x + y - 11.0, x + y * y - 7.0]
+    J = [[2.0 * x, 1.0], [1.0, 2.0 * y]]
+    return _from_residuals(r, J, want)
+
+
+FUNCS = {"rosenbrock": rosenbrock, "plateau": plateau, "powell": powell, "beale": beale, "himmelblau": himmelblau}
+
+
+def solve_general(H, b):
+    """gn.h:162: `-H.inverse() * g` without any checks, here as Gaussian elimination with partial pivoting (a singular H gives
+    inf / nan, which Step turns into kSystemHasNaNOrInf, optimizer.h:416-425 — no fixture goes there)."""
+    n = len(H)
+    A = [row[:] + [b[i]] for i, row in enumerate(H)]
+    for k in range(n):
+        piv = max(range(k, n), key=lambda i: abs(A[i][k]))
+        A[k], A[piv] = A[piv], A[k]
+        for i in range(k + 1, n):
+            f = A[i][k] / A[k][k]
+            for j in range(k, n + 1):
+                A[i][j] -= f * A[k][j]
+    x = [0.0] * n
+    for i in range(n - 1, -1, -1):
+        s_ = A[i][n]
+        for j in range(i + 1, n):
+            s_ -= A[i][j] * x[j]
+        x[i] = s_ / A[i][i]
+    return x
 
 
 # ---- the solver (lm.h / gn.h / base.h) -----------------------------------------------------------------------------------
@@ -254,9 +317,9 @@ class Solver:
         if not lm or self.rebuild:                          # lm.h:61-93 / gn.h:117-147
             self.H = [[0.0] * n for _ in range(n)]          # clear()
             self.g = [0.0] * n
-            c, g, H = fn(x, True)
+            c, g, H, nres = fn(x, True)
             self.H, self.g = [r[:] for r in H], g[:]
-            self.cost, self.nres = self.normalize(perturb(c), 1), 1
+            self.cost, self.nres = self.normalize(perturb(c), nres), nres
             if not self.valid():
                 return False
             if o.grad_clipping != 0:                        # base.h:29-38
@@ -265,8 +328,8 @@ class Solver:
             if o.check_min_H_diag > 0 and any(abs(self.H[i][i]) < o.check_min_H_diag for i in range(n)):
                 return False
         else:                                               # lm.h:94-105: Evaluate(x, acc, save = true)
-            c, _, _ = fn(x, False)
-            self.cost, self.nres = self.normalize(perturb(c), 1), 1
+            c, _, _, nres = fn(x, False)
+            self.cost, self.nres = self.normalize(perturb(c), nres), nres
             if not self.valid():
                 return False
         if lm and self.lam > 0.0:                           # lm.h:107-117, s is a double
@@ -280,7 +343,9 @@ class Solver:
             return None
         if self.o.use_ldlt:
             return solve_ldlt(self.H, [-v for v in self.g])
-        raise NotImplementedError("fixtures use the LDLT branch")
+        if self.n == 1:                                     # gn.h:157-161 (Dims == 1)
+            return [-(1.0 / self.H[0][0]) * self.g[0] if self.H[0][0] > f32(1e-7) else 0.0]
+        return solve_general(self.H, [-v for v in self.g])  # gn.h:162
 
     def clampl(self, v):
         return min(max(v, self.o.damping_range[0]), self.o.damping_range[1])
@@ -472,6 +537,52 @@ CASES = [
     ("powell", [3.0, -1.0, 0.0, 1.0], dict(max_iters=40, max_consec_failures=0, solver="gn"), "GaussNewton on the singular problem"),
 ]
 
+RB = dict(max_iters=200, min_rerr_dec=0, max_consec_failures=20)          # the Rosenbrock test's options
+PW = dict(max_iters=200, max_consec_failures=0, min_error=1e-30, min_rerr_dec=1e-30, damping_init=1e-1)   # Powell's
+BL = dict(max_iters=200, max_consec_failures=0, min_error=1e-30, damping_init=1e-3)                       # Beale's (optimize_hard.cpp:51-55)
+HB = dict(max_iters=200, max_consec_failures=0, min_error=1e-30)                                           # Himmelblau's (:90-93)
+CASES += [
+    # ---- round 4: the option branches one reading had pinned so far
+    ("rosenbrock", [-1.0, 1.2], dict(RB, use_step_quality_approx=True), "step-quality damping (lm.h:126-129)"),
+    ("rosenbrock", [-1.4, 0.8], dict(RB, use_step_quality_approx=True), "step-quality damping, another start"),
+    ("rosenbrock", [-0.7, 1.1], dict(RB, use_step_quality_approx=True, damping_init=1.0), "step-quality damping from heavy damping"),
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, use_step_quality_approx=True), "step-quality damping on Powell"),
+    ("plateau", [2.9, 3.2], dict(damping_init=1e-6, use_step_quality_approx=True, max_consec_failures=8), "step-quality damping through rejected steps"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, grad_clipping=50.0), "gradient clipping (base.h:29-38): |g| starts at 216 / 88"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, grad_clipping=5.0), "hard gradient clipping"),
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, grad_clipping=20.0), "gradient clipping on Powell (g up to 306)"),
+    ("beale", [1.0, 1.0], dict(BL, grad_clipping=2.0), "gradient clipping on a residual-vector cost"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, check_min_H_diag=250.0), "lm.h:82-86: H(1,1) = 200 < 250 at every point => Build fails => kSolverFailed"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, check_min_H_diag=150.0), "min-diagonal check that passes at the start and bites where H(0,0) gets small"),
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, check_min_H_diag=5.0), "min-diagonal check on Powell: H(0,0) = 2 + 120 t4^2 falls under 5 near the solution"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, use_ldlt=False), "gn.h:157-162: -H.inverse() * g, unchecked"),
+    ("rosenbrock", [-0.5, 0.5], dict(RB, use_ldlt=False), "unchecked inverse from a start with an indefinite Hessian"),
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, use_ldlt=False), "unchecked inverse on Powell (n = 4)"),
+    ("plateau", [2.8, 3.3], dict(damping_init=1e-6, use_ldlt=False, max_consec_failures=8), "unchecked inverse on the plateau"),
+    ("himmelblau", [3.5, 2.5], dict(HB, use_ldlt=False), "unchecked inverse, residual-vector cost"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, use_squared_norm=False), "base.h:42: cost = sqrt(c)"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, downscale_by_2=True), "base.h:43: cost *= 0.5"),
+    ("rosenbrock", [-1.2, 1.0], dict(RB, use_squared_norm=False, downscale_by_2=True), "both"),
+    ("beale", [1.0, 1.0], dict(BL, normalize=True), "base.h:44: cost /= num_residuals (3)"),
+    ("himmelblau", [3.5, 2.5], dict(HB, normalize=True, downscale_by_2=True, use_squared_norm=False), "all three flags, 2 residuals"),
+    ("beale", [1.0, 1.0], dict(BL), "tests/optimize_hard.cpp:34-63 as is (residual vector, 3 residuals)"),
+    ("beale", [2.0, 0.0], dict(BL), "Beale, another start"),
+    ("beale", [0.5, 1.5], dict(BL, max_consec_failures=5), "Beale with the default failure limit"),
+    ("himmelblau", [3.5, 2.5], dict(HB), "tests/optimize_hard.cpp:72-102 as is (2 residuals)"),
+    ("himmelblau", [-3.0, 3.0], dict(HB), "Himmelblau towards another of its four minima"),
+    ("himmelblau", [0.0, 0.0], dict(HB, damping_init=1e-2), "Himmelblau from the saddle region"),
+    ("beale", [1.0, 1.0], dict(BL, solver="gn"), "GaussNewton on a residual-vector cost"),
+]
+# the same reading against the fp32 instantiations: short traces, decisions far from a flip
+F32_CASES = [
+    ("rosenbrock", [-1.2, 1.0], dict(RB, max_iters=10), "float32: the first iterations of the Rosenbrock test"),
+    ("rosenbrock", [-0.9, 1.3], dict(RB, max_iters=8, use_step_quality_approx=True), "float32 with step-quality damping"),
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, max_iters=8), "float32 Powell"),
+    ("beale", [1.0, 1.0], dict(BL, max_iters=6), "float32 Beale (residual vector)"),
+    ("himmelblau", [3.5, 2.5], dict(HB, max_iters=4, normalize=True), "float32 Himmelblau, normalised cost"),
+    ("plateau", [2.8, 3.3], dict(damping_init=1e-6, max_iters=10), "float32 plateau: rejected steps"),
+]
+
 
 # seeded random starts around the reference starts (the same options as the reference tests): more routes through the
 # rejected-step / eval-only / failed-solve branches than any hand-picked list
@@ -492,11 +603,12 @@ def decisions(out):
 
 def main():
     cases = []
-    for name, x0, kw, comment in CASES:
+    for name, x0, kw, comment, dtype in [c + ("float64",) for c in CASES] + [c + ("float32",) for c in F32_CASES]:
         opt = Options(**kw)
         out = optimize(name, x0, opt)
         robust = True
-        for eps in (1e-13, -1e-13):
+        peps, need_margin = (1e-13, 1e-9) if dtype == "float64" else (3e-4, 1e-3)
+        for eps in (peps, -peps):
             ctr = [0]
 
             def perturb(c, eps=eps, ctr=ctr):
@@ -507,7 +619,7 @@ def main():
         # After a rejected step the loop rolls x back (x + dx - dx) and accumulates again THERE: err - final_cost is exactly 0
         # when both roundings cancel (=> "not good", structurally), and a last-bit coin toss when they do not.  Only traces
         # whose every decision is either that exact zero or further than 1e-9 (relative) from flipping are emitted.
-        if out["min_margin"] < 1e-9:
+        if out["min_margin"] < need_margin:
             robust = False
         nrej = sum(1 for s in out["successes"][1:] if not s)
         neval = sum(1 for t in out["trace"] if not t["rebuilt"])
@@ -518,7 +630,7 @@ def main():
             continue
         o = {k: (v if not isinstance(v, tuple) else list(v)) for k, v in vars(opt).items()}
         cases.append(dict(
-            function=name, x0=x0, options=o, comment=comment,
+            function=name, x0=x0, options=o, comment=comment, dtype=dtype,
             errs=out["errs"], deltas2=out["deltas2"], successes=[int(s) for s in out["successes"]],
             stop_reason=out["stop"], num_iters=out["num_iters"], num_failures=out["num_failures"], num_consec_failures=out["num_consec"],
             final_cost=out["final_cost"], final_rerr_dec=out["final_rerr_dec"], x=out["x"], final_hessian=out["final_hessian"],

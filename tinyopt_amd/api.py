@@ -345,11 +345,12 @@ class CircleFit(_LossMixin):
         return self.m * 2 * self.packed.element_size()
 
 
-class BundleAdjustmentLists:
+class BundleAdjustmentLists(_LossMixin):
     """Bundle adjustment with VISIBILITY LISTS (`toa_ba_lists_run`): tens to hundreds of SE3 cameras, each point observed by a
     few of them — what the reference would hand to Eigen's SimplicialLDLT (math.h:266-277; README.md:30,165-167).  Same x as
     ``BundleAdjustment`` ([P, 12 C + 3 N]); the observations are a list sorted by (point, camera):
-    intr [P, 4] = (f, cx, cy, 0), obs_cam / obs_pt [P, M] int32, obs_uv [P, M, 2].  ``Options.max_duration_ms`` is honoured."""
+    intr [P, 4] = (f, cx, cy, 0), obs_cam / obs_pt [P, M] int32, obs_uv [P, M, 2].  ``Options.max_duration_ms`` is honoured.
+    ``.with_loss("huber", th)`` puts every observation's squared reprojection error through an M-estimator (round 4)."""
     model_id = None
 
     def __init__(self, intr: torch.Tensor, obs_cam: torch.Tensor, obs_pt: torch.Tensor, obs_uv: torch.Tensor, ncam: int, npts: int):
@@ -541,12 +542,13 @@ class DenseRowAD:
         return self.m * (self.n + 1) * self.packed.element_size()
 
 
-class BundleAdjustment:
+class BundleAdjustment(_LossMixin):
     """C SE3 cameras x N 3-D points, pinhole reprojection residuals: the multi-pose problem behind
     config C5's single-pose block.  x: [P, 12*C + 3*N] = poses (rotation matrix row-major + translation) then points;
     data: [P, 8 + 3*C*N] = [f, cx, cy, 0... | uv (C, N, 2) | vis (C, N)].  Solved with the points eliminated (Schur
     complement on the reduced camera system, `toa_ba_run`); the reference would run Optimize on the full dense /
-    SimplicialLDLT system (math.h:232-277).  Output.final_hessian is not produced."""
+    SimplicialLDLT system (math.h:232-277).  Output.final_hessian is not produced.  ``.with_loss("cauchy", th)``: every
+    observation's squared reprojection error through an M-estimator (losses/robust_norms.h:32-316; round 4)."""
     model_id = None
 
     def __init__(self, data: torch.Tensor, ncam: int, npts: int):
@@ -703,7 +705,7 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
         elif zero_counters:
             out.counters.zero_()
         res = _results_pod(out)
-        _apply_loss(ctx, cost)   # no M-estimator here: clears whatever an earlier launch left on the handle
+        _apply_loss(ctx, cost)
         check(ctx.lib.toa_ba_run(ctx.h, _dtype_code(x.dtype), cost.ncam, cost.npts, P, cost.packed.data_ptr(), x.data_ptr(),
                                  C.byref(pod), C.byref(res), out.counters.data_ptr()))
         return out

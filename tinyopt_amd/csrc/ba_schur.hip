@@ -34,13 +34,15 @@ struct BaParams {
   int lds_wave;               // bytes of the WaveLds carve (wave 0's LDL^T workspace + vectors + LmState)
   int lds_gpart;              // byte offset of the per-wave camera sums
   int lds_part2;              // byte offset of a second partial-Gram buffer (n*n + 128 elements), 0 = none (LDS budget)
+  int loss;                   // TOA_LOSS_* of the handle (toa_set_loss; the ROBUST instantiation of the kernel only)
+  double loss_th2;
 };
 
 template <typename T>
 struct BaWork {  // element offsets into a scene's scratch block
-  size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, ptsb, total;
+  size_t W, Voff, hdp, gp, Rinv, q, dp, ldp, ptsb, wgt, total;
   int nb64;
-  __host__ __device__ BaWork(int C, int N) {
+  __host__ __device__ BaWork(int C, int N, bool robust = false) {
     size_t o = 0;
     // W_cj = J_c^T J_p (6 x 3, element e = 3 dof + b): points in tiles of 64 (one wave's worth), element-major inside a tile —
     // block (c, j) element e at ((c nb64 + j / 64) 18 + e) 64 + j % 64.  The lanes of a wave (consecutive points) then touch
@@ -57,6 +59,7 @@ struct BaWork {  // element offsets into a scene's scratch block
     dp = o; o += size_t(N) * 3;
     ldp = o; o += size_t(N) * 3;
     ptsb = o; o += size_t(N) * 3;     // the points of the last BUILD (eval-only iterations solve with that system while x sits at a trial point)
+    wgt = o; if (robust) o += size_t(C) * N;   // M-estimator scale s of every observation at the last build (0 = not seen): W is re-formed, not stored
     total = (o + 63) & ~size_t(63);
   }
 };
@@ -193,7 +196,11 @@ __device__ __forceinline__ void ba_obs_wrows(const T* P, const T* q, const T f, 
 #define BA_TICK_START
 #define BA_TICK(i)
 #endif
-template <typename T, int NBM, int THIN>
+// ROBUST: every observation's |r|^2 goes through the handle's M-estimator (toa_set_loss; losses/robust_norms.h:20-26 "JtJ * dx =
+// Jt*res*s"): cost += l, the observation's rows of [J_c | J_p | r] scaled by sqrt(s) before the Grams, W scaled by s where it
+// is re-formed, inliers = observations with |r|^2 <= th^2 (cost.h:84-95).  A separate instantiation (its own translation unit,
+// -DTOA_BA_ROBUST_TU): the estimators' exp / log / atan2 would cost the plain kernel registers it does not have.
+template <typename T, int NBM, int THIN, bool ROBUST>
 __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParams* __restrict__ prm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,8 +209,10 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   unsigned long long tk_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const long long p = blockIdx.x;
-  const BaWork<T> wk(C, N);
+  const BaWork<T> wk(C, N, ROBUST);
   const int nb64 = wk.nb64;
+  const int loss = ROBUST ? prm->loss : TOA_LOSS_L2;
+  const T th2 = T(prm->loss_th2);
   // W is 18 values per observation: written once and read twice per iteration it was 3/4 of the kernel's HBM traffic (the 151 MB
   // of the resident scenes' W do not fit the L2s; PMC: 6.0 GB per launch against 0.28 GB of algorithmic bytes).  Where all the
   // Schur columns of a lane belong to ONE camera (NBM divides 6, no thin Z columns) W is never stored: the Schur loop and the
@@ -237,6 +246,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   GT* work = (GT*)(static_cast<T*>(prm->work) + size_t(p) * wk.total);
   GT* Wb = work + wk.W; GT* Voff = work + wk.Voff; GT* hdp = work + wk.hdp; GT* gp = work + wk.gp;
   GT* Rinv = work + wk.Rinv; GT* qv = work + wk.q; GT* dp = work + wk.dp; GT* ldp = work + wk.ldp; GT* ptsb = work + wk.ptsb;
+  GT* wgt = work + wk.wgt;
   const DenseRowLayout lay = DenseRowLayout::make(n, 4);
 
   if (wave == 0) {
@@ -260,7 +270,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
     const bool do_acc = !is_lm || S.rebuild;
     BA_TICK_START
     // ================= Accumulate / Evaluate (gn.h:97-113) =================
-    T csum = 0, nvis = 0;
+    T csum = 0, nvis = 0, ninl = 0;
     if (do_acc)
       for (int i = tid; i < 12 * C; i += 256) poses_b[i] = poses[i];   // read again only behind later barriers
     for (int c = 0; c < C; ++c) {
@@ -284,6 +294,26 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
             for (int k = 0; k < 3; ++k) Jp[a][k] = T(0);
           }
           if (seen) ba_obs<T, true>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, Jc, Jp);
+          T lobs = T(0);
+          if constexpr (ROBUST) {
+            const T n2 = r[0] * r[0] + r[1] * r[1];
+            T l, sw;
+            robust_norm(loss, n2, th2, l, sw);
+            lobs = seen ? l : T(0);                         // (l(0) is not 0 for every estimator: an unseen pair has no cost)
+            ninl += (seen && n2 <= th2) ? T(2) : T(0);
+            const T sq = r_sqrt(sw);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) Jc[a][k] *= sq;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) Jp[a][k] *= sq;
+            }
+            const T rs0 = r[0] * sq, rs1 = r[1] * sq;
+            if constexpr (kRecomputeW) wgt[size_t(c) * N + j] = seen ? sw : T(0);
+            r[0] = rs0; r[1] = rs1;
+            csum += lobs;
+          }
           // camera block: upper Gram of [Jc | r] (7 x 7), as Se3ReprojModel
 #pragma unroll
           for (int row = 0; row < 2; ++row) {
@@ -326,8 +356,15 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           }
         } else if (seen) {
           ba_obs<T, false>(Pm, q, f, cx, cy, uv[(size_t(c) * N + j) * 2], uv[(size_t(c) * N + j) * 2 + 1], r, nullptr, nullptr);
+          if constexpr (ROBUST) {
+            const T n2 = r[0] * r[0] + r[1] * r[1];
+            T l, sw;
+            robust_norm(loss, n2, th2, l, sw);
+            csum += l;
+            ninl += n2 <= th2 ? T(2) : T(0);
+          }
         }
-        csum += r[0] * r[0] + r[1] * r[1];
+        if constexpr (!ROBUST) csum += r[0] * r[0] + r[1] * r[1];
         nvis += seen ? T(2) : T(0);
       }
       if (do_acc) {  // this wave's totals of the camera's 28 sums: one transposed reduction, parked in LDS until every camera is done
@@ -354,13 +391,15 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
     BA_TICK(0)
     const T cost_raw = ba_block_sum<T>(csum, red);
     const int nres = int(ba_block_sum<T>(nvis, red));
+    int ninl_all = nres;
+    if constexpr (ROBUST) ninl_all = int(ba_block_sum<T>(ninl, red));
     __syncthreads();
     // ================= rest of Build (lm.h:59-120): validity, clipping, diagonal check, Marquardt damping =================
     if (tid == 0) {
       if (do_acc) S.acc_passes++; else S.eval_passes++;
       S.cost_val = normalize_cost(double(cost_raw), nres, opt);
       S.cost_nres = nres;
-      S.cost_ninl = nres;
+      S.cost_ninl = ninl_all;
       flags[3] = (nres > 0 && S.cost_val != kDblMax) ? 1 : 0;
     }
     __syncthreads();
@@ -469,7 +508,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
             const size_t ob = size_t(cam_ok ? cam_l : 0) * N + jj;
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2) pv.pt[b2] = ptsb[3 * jj + b2];
-            const T vs = vis[ob];
+            const T vs = ROBUST ? wgt[ob] : vis[ob];   // ROBUST: the observation's scale s at the build (0 = not seen)
             pv.vs = (live && cam_ok) ? vs : T(0);
           } else {
 #pragma unroll
@@ -498,7 +537,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
             for (int i = 0; i < NBM; ++i) {
               const bool use = seen && col0 + i < n && col0 + i < lay.nmr;
 #pragma unroll
-              for (int b2 = 0; b2 < 3; ++b2) wrec[i][b2] = use ? wrec[i][b2] : T(0);
+              for (int b2 = 0; b2 < 3; ++b2) wrec[i][b2] = use ? (ROBUST ? wrec[i][b2] * cur.vs : wrec[i][b2]) : T(0);
             }
           }
 #pragma unroll
@@ -615,12 +654,13 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
             T Pm[12], Jc[2][6], Jp[2][3], rr[2];
 #pragma unroll
             for (int i = 0; i < 12; ++i) Pm[i] = poses_b[12 * c + i];
-            const bool seen = vis[size_t(c) * N + j] != T(0);
+            const T sobs = ROBUST ? wgt[size_t(c) * N + j] : vis[size_t(c) * N + j];
+            const bool seen = sobs != T(0);
             ba_obs<T, true>(Pm, qb, f, T(0), T(0), T(0), T(0), rr, Jc, Jp);   // the Jacobians do not depend on cx, cy, u, v
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
 #pragma unroll
-              for (int b = 0; b < 3; ++b) { const T w0 = ba_w<T>(Jc[0][kk], Jc[1][kk], Jp[0][b], Jp[1][b]); wl[3 * kk + b] = seen ? w0 : T(0); }
+              for (int b = 0; b < 3; ++b) { const T w0 = ba_w<T>(Jc[0][kk], Jc[1][kk], Jp[0][b], Jp[1][b]); wl[3 * kk + b] = seen ? (ROBUST ? w0 * sobs : w0) : T(0); }
           } else {
             GCT* Wd = Wb + (size_t(c) * nb64 + (j >> 6)) * (18 * 64) + (j & 63);
             // the block's 18 loads go out together (left to itself hipcc reuses ONE register pair: 18 round trips)
@@ -719,7 +759,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
     if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
     if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
     if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
-    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
     if (prm->counters) {
       atomicAdd(&prm->counters[0], S.acc_passes);
       atomicAdd(&prm->counters[1], S.eval_passes);
@@ -729,7 +769,7 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
   }
 }
 
-template <typename T, int NBM, int THIN>
+template <typename T, int NBM, int THIN, bool ROBUST>
 int launch_ba(toa_handle h, BaParams& prm) {
   const int n = 6 * prm.C;
   size_t pw = WaveLds<T>::bytes(n);
@@ -748,7 +788,7 @@ int launch_ba(toa_handle h, BaParams& prm) {
 #endif
   }
   if (lds > size_t(160 * 1024)) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: LDS footprint exceeds 160 KiB");
-  const BaWork<T> wk(prm.C, prm.N);
+  const BaWork<T> wk(prm.C, prm.N, ROBUST);
   const size_t need = size_t(prm.P) * wk.total * sizeof(T);
   if (need > h->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -761,28 +801,36 @@ int launch_ba(toa_handle h, BaParams& prm) {
   prm.work = h->scratch;
   static_assert(sizeof(BaParams) <= 1024, "parameter block too large");
   if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
-  auto kern = ba_schur_kernel<T, NBM, THIN>;
+  auto kern = ba_schur_kernel<T, NBM, THIN, ROBUST>;
   if (int rc = ensure_lds_attr(h, (const void*)kern, lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(unsigned(prm.P)), dim3(256), lds, h->stream, (const BaParams*)h->params_dev);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
 
-template <typename T>
+template <typename T, bool ROBUST>
 int launch_ba_any(toa_handle h, BaParams& prm) {
   const DenseRowLayout lay = DenseRowLayout::make(6 * prm.C, 4);
   switch (lay.nbm * 8 + lay.thin) {
-    case 8 + 0: return launch_ba<T, 1, 0>(h, prm);    // C = 1, 2
-    case 8 + 3: return launch_ba<T, 1, 3>(h, prm);    // C = 3
-    case 16 + 0: return launch_ba<T, 2, 0>(h, prm);   // C = 4, 5
-    case 24 + 0: return launch_ba<T, 3, 0>(h, prm);   // C = 6, 7
-    case 24 + 1: return launch_ba<T, 3, 1>(h, prm);   // C = 8
-    case 32 + 0: return launch_ba<T, 4, 0>(h, prm);   // C = 9, 10
+    case 8 + 0: return launch_ba<T, 1, 0, ROBUST>(h, prm);    // C = 1, 2
+    case 8 + 3: return launch_ba<T, 1, 3, ROBUST>(h, prm);    // C = 3
+    case 16 + 0: return launch_ba<T, 2, 0, ROBUST>(h, prm);   // C = 4, 5
+    case 24 + 0: return launch_ba<T, 3, 0, ROBUST>(h, prm);   // C = 6, 7
+    case 24 + 1: return launch_ba<T, 3, 1, ROBUST>(h, prm);   // C = 8
+    case 32 + 0: return launch_ba<T, 4, 0, ROBUST>(h, prm);   // C = 9, 10
   }
   return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: no kernel for this camera count");
 }
+// the ROBUST instantiations live in their own translation unit (the same source with -DTOA_BA_ROBUST_TU)
+int toa_ba_launch_robust(toa_handle h, int dtype, BaParams& prm);
+#ifdef TOA_BA_ROBUST_TU
+int toa_ba_launch_robust(toa_handle h, int dtype, BaParams& prm) {
+  return dtype == TOA_F32 ? launch_ba_any<float, true>(h, prm) : launch_ba_any<double, true>(h, prm);
+}
+#endif
 
 
+#ifndef TOA_BA_ROBUST_TU   // (everything below exists once, in the plain translation unit)
 // =====================================================================================================================
 // Bundle adjustment with VISIBILITY LISTS (round 3): tens to hundreds of cameras, each point seen by a few of them.
 //
@@ -833,11 +881,13 @@ struct BlParams {
   void* Sall;                 // [P][6C][6C] reduced camera systems, [P][6C] right-hand sides and solutions: contiguous over the
   void* rhsall;               // batch so that ONE call of the batched solver serves every scene
   void* dcall;
+  int loss;                   // TOA_LOSS_* of the handle (toa_set_loss): each observation's |r|^2 through the M-estimator
+  double loss_th2;
 };
 
 template <typename T>
 struct BlWork {  // element offsets into a scene's scratch block (T)
-  size_t Jc, Jp, r, r2, ptcost, Vd, Voff, gp, Vinv, q, dp, ldp, U, gc, Ud, ldc, pd2, pg2, state, total;
+  size_t Jc, Jp, r, r2, inl, ptcost, ptinl, Vd, Voff, gp, Vinv, q, dp, ldp, U, gc, Ud, ldc, pd2, pg2, state, total;
   __host__ __device__ BlWork(int C, int N, int M) {
     size_t o = 0;
     const size_t n = size_t(6) * C;
@@ -845,8 +895,8 @@ struct BlWork {  // element offsets into a scene's scratch block (T)
     // per observation ONE 128-byte record [J_c (2 x 6) | r (2) | pad] and ONE 64-byte record [J_p (2 x 3) | pad]: the camera-wise
     // kernels (bl_cam, bl_schur) GATHER observations, and component-major arrays cost them a 64-byte HBM fetch per 8-byte
     // component (PMC: 374 + 244 MB per solve in those two kernels for ~6 MB of records per scene and pass)
-    Jc = take(size_t(16) * M); Jp = take(size_t(8) * M); r = Jc; r2 = take(M);
-    ptcost = take(N); Vd = take(size_t(3) * N); Voff = take(size_t(3) * N); gp = take(size_t(3) * N); Vinv = take(size_t(6) * N);
+    Jc = take(size_t(16) * M); Jp = take(size_t(8) * M); r = Jc; r2 = take(M); inl = take(M);
+    ptcost = take(N); ptinl = take(N); Vd = take(size_t(3) * N); Voff = take(size_t(3) * N); gp = take(size_t(3) * N); Vinv = take(size_t(6) * N);
     q = take(size_t(3) * N); dp = take(size_t(3) * N); ldp = take(size_t(3) * N);
     U = take(size_t(36) * C); gc = take(n); Ud = take(n); ldc = take(n);
     pd2 = take(N); pg2 = take(N);
@@ -979,21 +1029,39 @@ __global__ void __launch_bounds__(256) bl_obs_kernel(const BlParams* __restrict_
   for (int k = 0; k < 12; ++k) Pm[k] = X[12 * cm + k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) q[k] = X[size_t(12) * C + size_t(3) * pt + k];
+  // M-estimator (toa_set_loss; losses/robust_norms.h:20-26 "JtJ * dx = Jt*res*s"): the observation's cost is l(|r|^2) and its
+  // rows of [J_c | J_p | r] are stored scaled by sqrt(s), s = dl/dn2 — every later kernel (bl_point, bl_cam, bl_schur, bl_back)
+  // contracts the stored rows, so J^T J, J^T r and W all come out scaled by s without knowing about the loss
+  const int loss = prm->loss;
+  const T th2 = T(prm->loss_th2);
   if (do_acc) {
     T Jc[2][6], Jp[2][3];
     ba_obs<T, true>(Pm, q, intr[0], intr[1], intr[2], uv[0], uv[1], r, Jc, Jp);
+    const T n2 = r[0] * r[0] + r[1] * r[1];
+    T l = n2, sq = T(1);
+    if (loss != TOA_LOSS_L2) {
+      T sw;
+      robust_norm(loss, n2, th2, l, sw);
+      sq = r_sqrt(sw);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) w[wk.Jc + size_t(i) * 16 + (6 * a + k)] = Jc[a][k];
+      for (int k = 0; k < 6; ++k) w[wk.Jc + size_t(i) * 16 + (6 * a + k)] = loss != TOA_LOSS_L2 ? sq * Jc[a][k] : Jc[a][k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) w[wk.Jp + size_t(i) * 8 + (3 * a + k)] = Jp[a][k];
-      w[wk.Jc + size_t(i) * 16 + 12 + (a)] = r[a];
+      for (int k = 0; k < 3; ++k) w[wk.Jp + size_t(i) * 8 + (3 * a + k)] = loss != TOA_LOSS_L2 ? sq * Jp[a][k] : Jp[a][k];
+      w[wk.Jc + size_t(i) * 16 + 12 + (a)] = loss != TOA_LOSS_L2 ? sq * r[a] : r[a];
     }
+    w[wk.r2 + i] = l;
+    w[wk.inl + i] = (loss == TOA_LOSS_L2 || n2 <= th2) ? T(2) : T(0);   // cost.h:84-95: both residuals of an inlier observation
   } else {
     ba_obs<T, false>(Pm, q, intr[0], intr[1], intr[2], uv[0], uv[1], r, nullptr, nullptr);
+    const T n2 = r[0] * r[0] + r[1] * r[1];
+    T l = n2;
+    if (loss != TOA_LOSS_L2) { T sw; robust_norm(loss, n2, th2, l, sw); }
+    w[wk.r2 + i] = l;
+    w[wk.inl + i] = (loss == TOA_LOSS_L2 || n2 <= th2) ? T(2) : T(0);
   }
-  w[wk.r2 + i] = r[0] * r[0] + r[1] * r[1];
 }
 
 template <typename T>
@@ -1009,10 +1077,11 @@ __global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restric
   if (j >= N) return;
   T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
   const int i0 = iw[ix.pt_start + j], i1 = iw[ix.pt_start + j + 1];
-  T cost = 0;
+  T cost = 0, inl = 0;
   T v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int i = i0; i < i1; ++i) {
     cost += w[wk.r2 + i];
+    inl += w[wk.inl + i];
     if (do_acc) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -1024,6 +1093,7 @@ __global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restric
     }
   }
   w[wk.ptcost + j] = cost;
+  w[wk.ptinl + j] = inl;
   if (do_acc) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { w[wk.Vd + 3 * j + k] = v[k]; w[wk.Voff + 3 * j + k] = v[3 + k]; w[wk.gp + 3 * j + k] = g[k]; }
@@ -1100,11 +1170,13 @@ __global__ void __launch_bounds__(256) bl_build_kernel(const BlParams* __restric
   const int tid = threadIdx.x;
   const T cost_raw = bl_block_sum<T>(w + wk.ptcost, N, red);
   __syncthreads();
+  const T inl_sum = prm->loss != TOA_LOSS_L2 ? bl_block_sum<T>(w + wk.ptinl, N, red) : T(2 * M);   // (exact in T: small integers)
+  __syncthreads();
   if (tid == 0) {
     if (do_acc) S.acc_passes++; else S.eval_passes++;
     S.cost_val = normalize_cost(double(cost_raw), 2 * M, opt);
     S.cost_nres = 2 * M;
-    S.cost_ninl = 2 * M;
+    S.cost_ninl = int(inl_sum);
     sflag = (M > 0 && S.cost_val != kDblMax) ? 1 : 0;
   }
   __syncthreads();
@@ -1423,7 +1495,7 @@ __global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict
       if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
       if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
       if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
-      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+      if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
       if (prm->counters) {
         atomicAdd(&prm->counters[0], S.acc_passes);
         atomicAdd(&prm->counters[1], S.eval_passes);
@@ -1578,8 +1650,6 @@ extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_poin
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return toa_fail(TOA_E_ARG, "toa_ba_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
-  if (h->loss != TOA_LOSS_L2)   // sticky handle state must not be ignored silently (include/tinyopt_amd.h, toa_set_loss)
-    return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: bundle adjustment has no M-estimator and a loss is set on the handle (toa_set_loss); clear it first");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   BaParams prm;
@@ -1588,7 +1658,10 @@ extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_poin
   prm.opt = *options; prm.res = *results;
   prm.res.final_hessian = nullptr;   // the block Hessian is not exported
   prm.counters = reinterpret_cast<unsigned long long*>(counters_dev);
-  return dtype == TOA_F32 ? launch_ba_any<float>(h, prm) : launch_ba_any<double>(h, prm);
+  prm.loss = h->loss;
+  prm.loss_th2 = h->loss_th2;
+  if (h->loss != TOA_LOSS_L2) return toa_ba_launch_robust(h, dtype, prm);   // the handle's M-estimator (toa_set_loss)
+  return dtype == TOA_F32 ? launch_ba_any<float, false>(h, prm) : launch_ba_any<double, false>(h, prm);
 }
 
 extern "C" int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, int num_obs, int64_t P, const void* intr_dev,
@@ -1607,8 +1680,6 @@ extern "C" int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int nu
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return toa_fail(TOA_E_ARG, "toa_ba_lists_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
-  if (h->loss != TOA_LOSS_L2)
-    return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run: bundle adjustment has no M-estimator and a loss is set on the handle (toa_set_loss); clear it first");
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   BlParams prm;
@@ -1618,5 +1689,10 @@ extern "C" int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int nu
   prm.opt = *options; prm.res = *results;
   prm.res.final_hessian = nullptr;
   prm.counters = reinterpret_cast<unsigned long long*>(counters_dev);
+  prm.loss = h->loss;
+  prm.loss_th2 = h->loss_th2;
   return dtype == TOA_F32 ? ba_lists_run_t<float>(h, dtype, prm, max_duration_ms) : ba_lists_run_t<double>(h, dtype, prm, max_duration_ms);
 }
+#else
+}  // namespace toa
+#endif  // TOA_BA_ROBUST_TU
