@@ -399,7 +399,10 @@ def optimize(name, x0, opt, max_iters_arg=-1, perturb=lambda c: c):
         solver_failed = True
         dx = None
         max_tries = max(1, o.max_consec_failures) if o.max_consec_failures > 0 else 255
+        spins = 0
         while out["num_consec"] <= max_tries:
+            spins += 1
+            assert spins < 2000, "the reference itself would never leave this loop (uint8_t counter): not a usable fixture"
             if S.build(x, fn, perturb):
                 d = S.solve()
                 if d is not None:
@@ -550,11 +553,18 @@ CASES += [
     ("plateau", [2.9, 3.2], dict(damping_init=1e-6, use_step_quality_approx=True, max_consec_failures=8), "step-quality damping through rejected steps"),
     ("rosenbrock", [-1.2, 1.0], dict(RB, grad_clipping=50.0), "gradient clipping (base.h:29-38): |g| starts at 216 / 88"),
     ("rosenbrock", [-1.2, 1.0], dict(RB, grad_clipping=5.0), "hard gradient clipping"),
+    ("rosenbrock", [-0.9, 1.3], dict(RB, grad_clipping=50.0), "gradient clipping, another start"),
+    ("rosenbrock", [-1.5, 0.7], dict(RB, grad_clipping=30.0), "gradient clipping, another start"),
+    ("rosenbrock", [-1.1, 0.9], dict(RB, grad_clipping=100.0), "gradient clipping, another start"),
+    ("rosenbrock", [-1.3, 1.1], dict(RB, use_step_quality_approx=True), "step-quality damping, another start"),
+    ("rosenbrock", [-0.8, 0.9], dict(RB, use_step_quality_approx=True), "step-quality damping, another start"),
     ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, grad_clipping=20.0), "gradient clipping on Powell (g up to 306)"),
     ("beale", [1.0, 1.0], dict(BL, grad_clipping=2.0), "gradient clipping on a residual-vector cost"),
     ("rosenbrock", [-1.2, 1.0], dict(RB, check_min_H_diag=250.0), "lm.h:82-86: H(1,1) = 200 < 250 at every point => Build fails => kSolverFailed"),
     ("rosenbrock", [-1.2, 1.0], dict(RB, check_min_H_diag=150.0), "min-diagonal check that passes at the start and bites where H(0,0) gets small"),
-    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, check_min_H_diag=5.0), "min-diagonal check on Powell: H(0,0) = 2 + 120 t4^2 falls under 5 near the solution"),
+    # (with max_consec_failures = 0 a Build that keeps failing never leaves Step's retry loop: `num_consec_failures <= 255` holds
+    #  for every uint8_t, optimizer.h:356-358 — the fixture gives the loop a limit)
+    ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, check_min_H_diag=5.0, max_consec_failures=6), "min-diagonal check on Powell: H(0,0) = 2 + 120 t4^2 falls under 5 near the solution"),
     ("rosenbrock", [-1.2, 1.0], dict(RB, use_ldlt=False), "gn.h:157-162: -H.inverse() * g, unchecked"),
     ("rosenbrock", [-0.5, 0.5], dict(RB, use_ldlt=False), "unchecked inverse from a start with an indefinite Hessian"),
     ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, use_ldlt=False), "unchecked inverse on Powell (n = 4)"),
@@ -579,7 +589,7 @@ F32_CASES = [
     ("rosenbrock", [-0.9, 1.3], dict(RB, max_iters=8, use_step_quality_approx=True), "float32 with step-quality damping"),
     ("powell", [3.0, -1.0, 0.0, 1.0], dict(PW, max_iters=8), "float32 Powell"),
     ("beale", [1.0, 1.0], dict(BL, max_iters=6), "float32 Beale (residual vector)"),
-    ("himmelblau", [3.5, 2.5], dict(HB, max_iters=4, normalize=True), "float32 Himmelblau, normalised cost"),
+    ("himmelblau", [3.5, 2.5], dict(HB, max_iters=2, normalize=True), "float32 Himmelblau, normalised cost (stopped before the fp32 noise floor decides the stop test)"),
     ("plateau", [2.8, 3.3], dict(damping_init=1e-6, max_iters=10), "float32 plateau: rejected steps"),
 ]
 

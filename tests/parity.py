@@ -170,6 +170,8 @@ def check_against_trace(c, got, label=""):
     again at that point (optimizer.h:283-287, :266), so `err < final_cost` (:428-429) compares two numbers that are equal in
     exact arithmetic — 0 exactly when (x + dx) - dx restored x bit for bit, a last-bit coin toss otherwise.  Then: same
     point evaluated on both sides, its cost equal to the last accepted cost to 1e-12, everything before identical."""
+    f32 = c.get("dtype", "float64") == "float32"   # the double-precision reading against an fp32 run: FloatEpsilon-class tolerances
+    rt, rt2, xt = (2e-3, 2e-2, 5e-3) if f32 else (1e-8, 1e-6, 1e-8)
     k = len(c["errs"])
     e, d2 = np.asarray(c["errs"]), np.asarray(c["deltas2"])
     kg = int(got["iters"])
@@ -183,8 +185,9 @@ def check_against_trace(c, got, label=""):
             div = i
             break
     upto = kk if div is None else div + 1
-    assert np.allclose(ge[:upto], e[:upto], rtol=1e-8, atol=1e-12 * scale), (label, "cost history", div)
+    assert np.allclose(ge[:upto], e[:upto], rtol=rt, atol=(1e-6 if f32 else 1e-12) * scale), (label, "cost history", div)
     if div is not None:
+        assert not f32, (label, "an fp32 fixture is only emitted when every decision is 1e-3 from flipping", div)
         assert div >= 2, (label, "parted before any step was rejected", div)
         acc_f = [i for i in range(div) if fs[i] or i == 0][-1]
         assert abs(e[div] - e[acc_f]) <= 1e-12 * abs(e[acc_f]) and abs(ge[div] - ge[acc_f]) <= 1e-12 * abs(ge[acc_f]), \
@@ -194,9 +197,9 @@ def check_against_trace(c, got, label=""):
     assert kg == c["num_iters"], (label, "iters", kg, c["num_iters"])
     assert int(got["fails"]) == c["num_failures"], (label, "fails", int(got["fails"]), c["num_failures"])
     if k:
-        assert np.allclose(np.asarray(got["deltas2"])[:k], d2, rtol=1e-6, atol=1e-12 * max(d2.max(), 1e-300)), (label, "|dx|^2 history")
+        assert np.allclose(np.asarray(got["deltas2"])[:k], d2, rtol=rt2, atol=(1e-6 if f32 else 1e-12) * max(d2.max(), 1e-300)), (label, "|dx|^2 history")
     xs = np.asarray(c["x"])
-    assert np.abs(np.asarray(got["x"]) - xs).max() <= 1e-8 * max(1.0, np.abs(xs).max()), (label, "x")
+    assert np.abs(np.asarray(got["x"]) - xs).max() <= xt * max(1.0, np.abs(xs).max()), (label, "x")
     if c["final_cost"] < 1e300:
-        assert abs(float(got["cost"]) - c["final_cost"]) <= 1e-8 * abs(c["final_cost"]) + 1e-12 * scale, (label, "final cost")
+        assert abs(float(got["cost"]) - c["final_cost"]) <= rt * abs(c["final_cost"]) + (1e-6 if f32 else 1e-12) * scale, (label, "final cost")
     return "full"

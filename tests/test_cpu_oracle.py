@@ -168,11 +168,17 @@ def test_oracle_follows_the_second_reading(oracle):
     The C++ oracle must take the same decisions and produce the same numbers: two readings, not one."""
     from parity import check_against_trace, load_reference_traces
     cases = load_reference_traces()
-    assert len(cases) >= 24
+    assert len(cases) >= 55
     kinds, ties = set(), 0
+    branches = set()
     for c, pod in cases:
         hs = c["options"]["max_iters"] + 3
-        r = oracle.testfn_lm(c["function"], np.array([c["x0"]], dtype=np.float64), pod, hist_stride=hs)
+        o = c["options"]
+        branches |= {k for k in ("use_step_quality_approx", "downscale_by_2", "normalize", "check_final_cost") if o[k]}
+        branches |= {k for k in ("grad_clipping", "check_min_H_diag") if o[k] != 0}
+        branches |= ({"use_ldlt=false"} if not o["use_ldlt"] else set()) | ({"sqrt cost"} if not o["use_squared_norm"] else set())
+        branches |= {c["function"], c.get("dtype", "float64")}
+        r = oracle.testfn_lm(c["function"], np.array([c["x0"]], dtype=np.dtype(c.get("dtype", "float64"))), pod, hist_stride=hs)
         got = dict(errs=r["errs"][0], deltas2=r["deltas2"][0], succ=r["succ"][0], stop=r["stop"][0], iters=r["iters"][0],
                    fails=r["fails"][0], x=r["x"][0], cost=r["cost"][0])
         if check_against_trace(c, got, label=f"{c['function']} {c['x0']} ({c['comment']})") == "tie":
@@ -185,4 +191,7 @@ def test_oracle_follows_the_second_reading(oracle):
             kinds.add("rejected")
     # the fixture set covers what it claims to cover
     assert {"eval-only", "rejected", -3, 1, 5, 6, 7} <= kinds, kinds
+    # round 4: the option branches, the residual-vector costs and the fp32 instantiation are held to the second reading too
+    assert {"use_step_quality_approx", "grad_clipping", "check_min_H_diag", "use_ldlt=false", "sqrt cost", "downscale_by_2", "normalize",
+            "beale", "himmelblau", "float32"} <= branches, branches
     assert ties <= len(cases) // 8, f"{ties} of {len(cases)} cases parted at a round-off tie"
