@@ -379,14 +379,39 @@ int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, i
  *      scalars as T,  r[q]  the item's residuals; every function of ceres::Jet (jet.h:557-1400: sin, exp, pow, atan2, ...)
  *      is in scope.  toa_model_compile builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> with hiprtc
  *      (opened with dlopen on first use; ~2-3 s, once) and loads the code object: no rebuild of the library.
- *        num_params <= 12 (the register Gram); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
+ *        num_params <= 12: the register Gram of JetModel (13 .. 63: see toa_model_compile_ex below); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
  *        m = num_items * residuals_per_item residuals per problem.  log_out (optional): the compiler's diagnostics.
  *        toa_jit_lm_run / toa_jit_accumulate: the contracts of toa_lm_run / toa_accumulate.  The handle's M-estimator
  *        (toa_set_loss) applies to each item's squared residual norm, as for TOA_MODEL_CIRCLE_FIT. */
 typedef struct toa_jit_model_s* toa_jit_model;
 int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per_item, int scalars_per_item, int header_scalars,
                       const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
-int toa_model_destroy(toa_jit_model m);
+/*      Round 4 — the general form.
+ *        num_params up to 63: beyond 12 the model is JetRowModel (chunked Jets evaluated in matrix-core operand order, the path
+ *          of TOA_MODEL_DENSE_ROW_AD): a Euclidean residual functor with ONE residual per item, no M-estimator.
+ *        manifold = TOA_MANIFOLD_SE3: x is ONE pose stored as R (row-major 9) + t (3) = 12 scalars, num_params = 6 (its tangent
+ *          in Sophus order upsilon, omega); the body reads the pose through x[0..11] — Jets over the right perturbation
+ *          x * exp(delta) at delta = 0 (optimize_autodiff.h:48-77, 3rdparty/traits/sophus.h:13-27) — and may call
+ *          se3_log<S, T>(R, t, xi); the update is pose <- pose * exp(delta).  tests/sophus.cpp:26-44 `Optimize(pose, lambda)`.
+ *        kind = TOA_JIT_ACCUMULATE: a manual Accumulate callback (docs/API.md:37-57, tests/optimize_easy.cpp:35-79) — the body
+ *          fills r[q] and, `if (want_grad)`, the Jacobian rows J[q][a] itself (plain T, no AD); x[j], h[k], p[k] as before.
+ *        A compiled model is cached on disk (code object keyed by the generated source, the library's headers, the hiprtc
+ *          version and the device architecture): toa_jit_set_cache_dir(dir), default $XDG_CACHE_HOME/tinyopt_amd or
+ *          $HOME/.cache/tinyopt_amd; "" = off, NULL = the default again.  The library's headers are embedded in it: no source tree is needed at run time. */
+#define TOA_MANIFOLD_EUCLID 0
+#define TOA_MANIFOLD_SE3 1
+#define TOA_JIT_RESIDUAL 0
+#define TOA_JIT_ACCUMULATE 1
+typedef struct toa_jit_spec {
+  int32_t dtype, num_params, residuals_per_item, scalars_per_item, header_scalars;
+  int32_t manifold;   /* TOA_MANIFOLD_* */
+  int32_t kind;       /* TOA_JIT_* */
+  int32_t reserved[9];
+} toa_jit_spec;
+int toa_model_compile_ex(toa_handle h, const toa_jit_spec* spec, const char* body, toa_jit_model* out, char* log_out, size_t log_cap);
+int toa_jit_set_cache_dir(const char* dir);
+int toa_jit_model_info(toa_jit_model m, int* from_cache, int* xdim);   /* from_cache: 1 = the code object came from the disk cache */
+int toa_model_destroy(toa_jit_model m);   /* waits for the model's last launch before the code is unloaded */
 int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
                    const toa_options* options, const toa_results* results, uint64_t* counters_dev);
 int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, const void* x_dev,

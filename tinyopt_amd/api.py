@@ -401,23 +401,55 @@ class JitResidual:
                              n=3, item_scalars=2, dtype=torch.float64)
         out = ta.Optimize(x, fit.bind(points), options)        # points: [P, items, 2] on the GPU
 
-    hiprtc builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> (2-3 s, once per JitResidual) and the
-    code object is loaded into the process: no rebuild of libtinyopt_amd.so.  n <= 12."""
+    hiprtc builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> (2-3 s the first time; the code object is
+    cached on disk — ``JitResidual.set_cache_dir`` — so a second construction of the same residual, in this or another process,
+    takes milliseconds: ``from_cache``) and the code object is loaded into the process: no rebuild of libtinyopt_amd.so, and no
+    source tree next to it (the kernel headers are embedded in the library).
+
+    Round 4:
+      * ``n`` up to 63 — beyond 12 parameters the functor is evaluated on chunked Jets in matrix-core operand order (the path
+        of ``DenseRowAD``): one residual per item, Euclidean, no loss;
+      * ``manifold="se3"`` — x is ONE pose [P, 12] (rotation matrix row-major + translation), n = 6; the body reads the pose
+        through ``x[0..11]`` (Jets over the right perturbation, optimize_autodiff.h:48-77 + sophus.h:13-27) and may call
+        ``se3_log<S, T>(R, t, xi)``; the update is pose <- pose * exp(delta).  tests/sophus.cpp:26-44 as a string::
+
+            prior = ta.JitResidual(SE3_PRIOR_BODY, n=6, item_scalars=0, residuals_per_item=6, header_scalars=12, manifold="se3")
+
+      * ``kind="accumulate"`` — a manual Accumulate callback (docs/API.md:37-57): the body fills ``r[q]`` and, inside
+        ``if (want_grad) { ... }``, its own Jacobian rows ``J[q][a]`` (plain T, no AD)."""
+
+    MANIFOLDS = {"euclid": 0, "se3": 1}
+    KINDS = {"residual": 0, "accumulate": 1}
 
     def __init__(self, body: str, n: int, item_scalars: int, residuals_per_item: int = 1, header_scalars: int = 0,
-                 dtype: torch.dtype = torch.float64, ctx: Optional["Context"] = None):
+                 dtype: torch.dtype = torch.float64, ctx: Optional["Context"] = None, manifold: str = "euclid", kind: str = "residual"):
+        from ._capi import ToaJitSpec
         self.ctx = ctx or default_context()
         self.n, self.kR, self.kD, self.kH, self.dtype = int(n), int(residuals_per_item), int(item_scalars), int(header_scalars), dtype
+        self.manifold, self.kind = manifold, kind
+        self.xdim = 12 if manifold == "se3" else self.n
         self._h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
-        rc = self.ctx.lib.toa_model_compile(self.ctx.h, _dtype_code(dtype), self.n, self.kR, self.kD, self.kH, body.encode(),
-                                            C.byref(self._h), log, len(log))
+        spec = ToaJitSpec()
+        spec.dtype, spec.num_params, spec.residuals_per_item = _dtype_code(dtype), self.n, self.kR
+        spec.scalars_per_item, spec.header_scalars = self.kD, self.kH
+        spec.manifold, spec.kind = self.MANIFOLDS[manifold], self.KINDS[kind]
+        rc = self.ctx.lib.toa_model_compile_ex(self.ctx.h, C.byref(spec), body.encode(), C.byref(self._h), log, len(log))
         self.compile_log = log.value.decode(errors="replace")
         check(rc)
+        fc = C.c_int(0)
+        check(self.ctx.lib.toa_jit_model_info(self._h, C.byref(fc), None))
+        self.from_cache = bool(fc.value)
 
-    def bind(self, data: torch.Tensor, header: Optional[torch.Tensor] = None) -> "JitModel":
-        """data: [P, items, item_scalars] (and header: [P, header_scalars]) on the GPU -> the ``cost`` of Optimize(x, cost)."""
-        return JitModel(self, data, header)
+    @staticmethod
+    def set_cache_dir(path: Optional[str], ctx: Optional["Context"] = None) -> None:
+        """Where compiled code objects are kept (default: $XDG_CACHE_HOME/tinyopt_amd or ~/.cache/tinyopt_amd); "" = no cache."""
+        check((ctx or default_context()).lib.toa_jit_set_cache_dir(None if path is None else path.encode()))   # None: back to the default
+
+    def bind(self, data: Optional[torch.Tensor], header: Optional[torch.Tensor] = None, items: int = 1) -> "JitModel":
+        """data: [P, items, item_scalars] (and header: [P, header_scalars]) on the GPU -> the ``cost`` of Optimize(x, cost).
+        data = None for a functor with item_scalars = 0 (e.g. a pose prior: everything is in the header)."""
+        return JitModel(self, data, header, items)
 
     def close(self) -> None:
         if self._h:
@@ -435,10 +467,14 @@ class JitModel(_LossMixin):
     """A JitResidual bound to its problem data ([P][header | items x item_scalars], the layout of the built-in Jet families)."""
     model_id = None
 
-    def __init__(self, res: JitResidual, data: torch.Tensor, header: Optional[torch.Tensor] = None):
+    def __init__(self, res: JitResidual, data: Optional[torch.Tensor], header: Optional[torch.Tensor] = None, items: int = 1):
+        if data is None:   # a functor whose items carry no data of their own (item_scalars = 0): `items` evaluations of the header
+            assert res.kD == 0 and header is not None
+            data = torch.zeros(header.shape[0], int(items), 0, dtype=res.dtype, device=header.device)
         assert data.dim() == 3 and data.shape[2] == res.kD and data.is_cuda and data.dtype == res.dtype
         self.res = res
         self.P, self.items, self.n, self.dtype = data.shape[0], data.shape[1], res.n, res.dtype
+        self.xdim = res.xdim
         self.m = self.items * res.kR
         flat = data.reshape(self.P, -1)
         if res.kH:

@@ -20,7 +20,11 @@
 #include <vector>
 #endif
 
+#ifdef __HIPCC_RTC__   // run-time compilation (jit.hip): the headers are handed to hiprtc by NAME, embedded in the library
+#include "tinyopt_amd.h"
+#else
 #include "../../include/tinyopt_amd.h"
+#endif
 #include "dense_row.hpp"
 #include "jet.hpp"
 #include "ldlt_blocked.hpp"
@@ -915,14 +919,46 @@ struct Se3ReprojModel {
 //   kH header scalars per problem;  template <class S> static void eval(const S* x, const T* header,
 //   const T* item, S* r).   Data per problem: [kH | items x kD].
 // A user family = one functor + one line in inst.hip (INTEGRATION.md "bring your own functor").
+//
+// MANIFOLD (round 4; TOA_MANIFOLD_*): 0 = Euclidean parameters, x (+)= dx (traits.h:184-190).  1 = ONE SE3 pose stored as
+//   R (row-major 9) + t (3) = 12 scalars, tangent kN = 6 in Sophus order (upsilon, omega): the functor sees the pose through
+//   x[0..11] — Jets seeded over the RIGHT perturbation x * exp(delta) at delta = 0, what OptimizeWithAutoDiff does for a user
+//   type (optimize_autodiff.h:48-77 with 3rdparty/traits/sophus.h:13-27; tests/sophus.cpp:26-44 `Optimize(pose, lambda)`);
+//   the update is pose <- pose * exp(delta).
+// A functor with `kManual = true` is a manual Accumulate callback instead (docs/API.md:37-57, tests/optimize_easy.cpp:35-79:
+//   the user writes the Jacobian rows, no AD):  template <bool WANT_GRAD> eval_manual(const T* x, header, item, T* r, T (*J)[kN]).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename F>
+template <typename F, typename = void>
+struct FunctorManual { static constexpr bool value = false; };
+template <typename F>
+struct FunctorManual<F, std::enable_if_t<F::kManual>> { static constexpr bool value = true; };
+
+// the pose as Jet<T, 6> over the right perturbation at delta = 0: R (I + [omega]x), t + R upsilon (exact to first order)
+template <typename T>
+__device__ __forceinline__ void se3_seed_pose(const T* x, Jet<T, 6>* xj) {
+  using J6 = Jet<T, 6>;
+  J6 d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = J6(T(0), k);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xj[3 * i + 0] = x[3 * i + 0] + (d[5] * x[3 * i + 1] - d[4] * x[3 * i + 2]);
+    xj[3 * i + 1] = x[3 * i + 1] + (d[3] * x[3 * i + 2] - d[5] * x[3 * i + 0]);
+    xj[3 * i + 2] = x[3 * i + 2] + (d[4] * x[3 * i + 0] - d[3] * x[3 * i + 1]);
+    xj[9 + i] = x[9 + i] + (d[0] * x[3 * i] + d[1] * x[3 * i + 1] + d[2] * x[3 * i + 2]);
+  }
+}
+
+template <typename T, typename F, int MANIFOLD = 0>
 struct JetModel {
   using Scalar = T;
   static constexpr int kNpad = 16;
-  static constexpr int kXdim = 0;
+  static constexpr int kXdim = MANIFOLD == 1 ? 12 : 0;
   static constexpr int kN = F::kN, kW = F::kN + 1, kG = kW * (kW + 1) / 2;
+  static constexpr int kX = MANIFOLD == 1 ? 12 : F::kN;   // stored scalars of x
+  static constexpr bool kManual = FunctorManual<F>::value;
   static_assert(F::kN >= 1 && F::kN <= 12, "register Gram: kN <= 12");
+  static_assert(MANIFOLD == 0 || F::kN == 6, "an SE3 pose has a 6-dimensional tangent");
   const T* data;
   const T* d;
   int items, it0, it1;
@@ -941,13 +977,16 @@ struct JetModel {
     it0 = 0; it1 = items;
   }
   __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }  // one chunk (stepping form)
-  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const { euclid_plus_eq(L, dv, sign, lane); }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
+    if constexpr (MANIFOLD == 1) Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
+    else euclid_plus_eq(L, dv, sign, lane);
+  }
 
   template <bool WANT_H>
   __device__ __forceinline__ T pass(const WaveLds<T>& L, int lane) {
-    T x[kN];
+    T x[kX];
 #pragma unroll
-    for (int i = 0; i < kN; ++i) x[i] = L.xs[i];
+    for (int i = 0; i < kX; ++i) x[i] = L.xs[i];
     if (WANT_H) {
 #pragma unroll
       for (int i = 0; i < kG; ++i) G[i] = T(0);
@@ -959,15 +998,30 @@ struct JetModel {
     for (int i = it0 + lane; i < it1; i += 64) {
       const T* item = itemsp + size_t(i) * F::kD;
       if (WANT_H) {
-        Jet<T, kN> xj[kN], r[F::kR];
+        T rv[F::kR], Jv[F::kR][kN];   // residuals and their Jacobian rows
+        if constexpr (kManual) {
+          F::template eval_manual<true>(x, d, item, rv, Jv);          // the user's own derivatives (docs/API.md:37-57)
+        } else {
+          Jet<T, kN> xj[kX], r[F::kR];
+          if constexpr (MANIFOLD == 1) {
+            se3_seed_pose<T>(x, xj);                                  // optimize_autodiff.h:48-55, 73-77
+          } else {
 #pragma unroll
-        for (int k = 0; k < kN; ++k) xj[k] = Jet<T, kN>(x[k], k);   // optimize_autodiff.h:56-69
-        F::template eval<Jet<T, kN>>(xj, d, item, r);
+            for (int k = 0; k < kN; ++k) xj[k] = Jet<T, kN>(x[k], k);   // optimize_autodiff.h:56-69
+          }
+          F::template eval<Jet<T, kN>>(xj, d, item, r);
+#pragma unroll
+          for (int q = 0; q < F::kR; ++q) {
+            rv[q] = r[q].a;
+#pragma unroll
+            for (int a = 0; a < kN; ++a) Jv[q][a] = r[q].v[a];        // J.row(i) = res[i].v   (:127-148)
+          }
+        }
         T s = T(1);
         if (robust) {   // the item's ||r||^2 through the M-estimator: cost += l, its J^T J and J^T r scaled by s
           T n2 = 0, l;
 #pragma unroll
-          for (int q = 0; q < F::kR; ++q) n2 += r[q].a * r[q].a;
+          for (int q = 0; q < F::kR; ++q) n2 += rv[q] * rv[q];
           robust_norm(loss, n2, th2, l, s);
           csum += l;
           inl += n2 <= th2 ? T(F::kR) : T(0);
@@ -976,8 +1030,8 @@ struct JetModel {
         for (int q = 0; q < F::kR; ++q) {
           T w[kW];
 #pragma unroll
-          for (int a = 0; a < kN; ++a) w[a] = r[q].v[a];             // J.row(i) = res[i].v   (:127-148)
-          w[kN] = r[q].a;
+          for (int a = 0; a < kN; ++a) w[a] = Jv[q][a];
+          w[kN] = rv[q];
 #pragma unroll
           for (int a = 0; a < kW; ++a) {
             const T sw = s * w[a];
@@ -987,7 +1041,8 @@ struct JetModel {
         }
       } else {
         T r[F::kR];
-        F::template eval<T>(x, d, item, r);
+        if constexpr (kManual) F::template eval_manual<false>(x, d, item, r, static_cast<T(*)[kN]>(nullptr));
+        else F::template eval<T>(x, d, item, r);
         T n2 = 0;
 #pragma unroll
         for (int q = 0; q < F::kR; ++q) n2 += r[q] * r[q];

@@ -19,7 +19,11 @@
 #pragma once
 #include <type_traits>
 
+#ifdef __HIPCC_RTC__   // run-time compilation (jit.hip): the headers are handed to hiprtc by NAME, embedded in the library
+#include "tinyopt_amd.h"
+#else
 #include "../../include/tinyopt_amd.h"
+#endif
 #include "ldlt_blocked.hpp"
 #include "ldlt_lds.hpp"
 #include "ldlt_regs.hpp"

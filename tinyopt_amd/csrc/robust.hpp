@@ -8,7 +8,11 @@
 
 #include <cfloat>
 
+#ifdef __HIPCC_RTC__   // run-time compilation (jit.hip): the headers are handed to hiprtc by NAME, embedded in the library
+#include "tinyopt_amd.h"
+#else
 #include "../../include/tinyopt_amd.h"
+#endif
 
 namespace toa {
 
