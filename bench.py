@@ -461,6 +461,8 @@ def main():
     ap.add_argument("--problems", type=int, default=0, help="override problems per GPU (debug; invalidates the metric)")
     ap.add_argument("--cpu-problems", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
+    ap.add_argument("--tuning", default="", help="A/B arms of the library as toa_tuning fields, e.g. coop_off=1,memo_off=1 (recorded in the line; "
+                                                 "the default line is measured with none)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -476,6 +478,8 @@ def main():
 
     import tinyopt_amd as ta
 
+    if args.tuning:   # typed per-handle state (include/tinyopt_amd.h toa_tuning): the library reads no environment variable
+        ta.api.default_context(local_rank).set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
     if args.workload in SINGLE:
         return run_single(args, ta, rank, world, local_rank)
     if args.workload == "ba":

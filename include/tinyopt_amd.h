@@ -162,6 +162,38 @@ typedef struct toa_context* toa_handle;
 
 /* ---- lifetime (replaces: `lm::Optimizer<H_t> optimizer(options)` construction, optimize.h:50-53) ---- */
 int toa_create(toa_handle* out, int device, void* stream);
+
+/* ---- ABI version.  4 (round 4): counters_dev arrays are [TOA_NUM_COUNTERS = 8] uint64 (they were [4] up to version 2 — a caller
+ *      that still allocates 4 entries would be written out of bounds by the memo counter), toa_tuning / toa_jit_spec exist.
+ *      The host mirrors (include/tinyopt_amd/tinyopt.hpp, tinyopt_amd/_capi.py) refuse a library whose version differs. */
+#define TOA_ABI_VERSION 4
+int toa_abi_version(void);
+
+/* ---- tuning (per handle).  The arms of the A/B logs (profiles/r0N_ab_log.md) and of the bit-identity tests, as typed state
+ *      instead of environment variables: the product path reads NO environment variable.  All-zero = the library's choices;
+ *      toa_set_tuning(h, NULL) restores them.  Nothing here changes a result beyond round-off (memo, coop: not at all —
+ *      tests/test_gpu_memo.py, tests/test_gpu_coop.py). */
+typedef struct toa_tuning {
+  int32_t memo_off;              /* lm_fused_kernel: do not park / read back the last accepted linearisation */
+  int32_t coop_off;              /* lm_fused_kernel: one chunk per pass, no cooperative tail */
+  int32_t coop_chunks;           /* 0 = ~1024 rows per chunk; else 2 .. 64 chunks per pass */
+  int32_t max_workgroups;        /* 0 = every resident slot; else a cap on lm_fused_kernel's grid (experiments) */
+  int32_t wide_no_autosplit;     /* never pick the row-split / team forms automatically (one wavefront per problem) */
+  int32_t wide_multilaunch;      /* row-split form: one (partial, step) launch pair per iteration instead of the persistent kernel */
+  int32_t wide_no_team;          /* row-split form: no one-workgroup-per-problem team kernel */
+  int32_t wide_team_max_per_cu;  /* 0 = automatic; problems per CU up to which the team form is chosen */
+  int32_t wide_graph;            /* launch-per-iteration form replayed from a hipGraph */
+  int32_t large_row_split;       /* 64 <= n <= 128: the row-split data pass instead of the tile-split one */
+  int32_t large_pipeline;        /* the launch-per-stage pipeline for every n > 63 */
+  int32_t large_library_gram;    /* n > 128: rocBLAS batched GEMM instead of the hand-written MFMA Gram */
+  int32_t large_library_solver;  /* rocSOLVER potrf / potrs wherever a solver of our own would run (also toa_solve_damped for n <= 63) */
+  int32_t fail_workspace_alloc;  /* TEST HOOK: the n > 128 workspace request fails as on a full device (kOutOfMemory path) */
+  int32_t reserved[18];
+} toa_tuning;
+int toa_set_tuning(toa_handle h, const toa_tuning* t);
+int toa_get_tuning(toa_handle h, toa_tuning* out);
+/* debug: per-problem start / end stamps of every lm_fused_kernel launch appended to `path` as text (tools/timeline.py); NULL = off */
+int toa_debug_timeline(toa_handle h, const char* path);
 int toa_destroy(toa_handle h);
 const char* toa_last_error(void);
 /* Device properties the measurement needs (CU count, clock, name). */
@@ -282,7 +314,7 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      iteration after a rejected step accumulates again at the rolled-back point (optimizer.h:283-287, :266).  The fused
  *      kernel of the DenseRow families parks the Gram registers of every accepted point (one slot per resident wave) and,
  *      when the roll-back restored x BIT FOR BIT, reads them back instead of streaming the rows again; g, H and the cost
- *      are the bits a second pass would have produced (tests/test_gpu_memo.py; TOA_MEMO=0 switches the memo off).
+ *      are the bits a second pass would have produced (tests/test_gpu_memo.py; toa_tuning::memo_off switches the memo off).
  *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128: that
  *      regime reads two integers back per pass (it blocks the host and cannot be captured in a hipGraph); 64 <= n <= 128
  *      is one persistent kernel like the rest. */

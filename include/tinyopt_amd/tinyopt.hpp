@@ -128,8 +128,17 @@ inline void check(int rc) {
 // RAII over toa_handle: one per host thread per GPU (the reference's Optimizer_ is equally stateful).
 class Context {
  public:
-  explicit Context(int device = 0, void* stream = nullptr) { check(toa_create(&h_, device, stream)); }
+  explicit Context(int device = 0, void* stream = nullptr) {
+    // the header and the library must agree on the layout of what crosses the boundary (counters_dev is [TOA_NUM_COUNTERS = 8]
+    // since ABI 4; a header compiled against an older library — or the reverse — must not run)
+    if (toa_abi_version() != TOA_ABI_VERSION)
+      throw std::runtime_error("tinyopt_amd: libtinyopt_amd.so has ABI version " + std::to_string(toa_abi_version()) + ", this header expects " +
+                               std::to_string(TOA_ABI_VERSION));
+    check(toa_create(&h_, device, stream));
+  }
   ~Context() { toa_destroy(h_); }
+  // A/B arms of the library as typed per-handle state (toa_tuning; nullptr = the library's own choices)
+  void set_tuning(const toa_tuning* t) const { check(toa_set_tuning(h_, t)); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   toa_handle get() const { return h_; }
@@ -296,11 +305,19 @@ class JitModel;
 template <typename Scalar>
 class JitResidual {
  public:
-  JitResidual(const Context& ctx, const std::string& body, int n, int item_scalars, int residuals_per_item = 1, int header_scalars = 0)
-      : ctx_(&ctx), n_(n), kR_(residuals_per_item), kD_(item_scalars), kH_(header_scalars) {
+  // manifold: TOA_MANIFOLD_EUCLID, or TOA_MANIFOLD_SE3 — x is ONE pose stored as 12 scalars (R row-major, t), n = 6, the body reads
+  //   it through x[0..11] and may call se3_log<S, T>(R, t, xi)  (tests/sophus.cpp:26-44 `Optimize(pose, lambda)`);
+  // kind: TOA_JIT_RESIDUAL (differentiated on the device), or TOA_JIT_ACCUMULATE — a manual Accumulate callback: the body fills
+  //   r[q] and, inside `if (want_grad)`, its own Jacobian rows J[q][a]  (docs/API.md:37-57);
+  // n up to 63 (beyond 12: one residual per item, Euclidean).  Compiled code objects are cached on disk (toa_jit_set_cache_dir).
+  JitResidual(const Context& ctx, const std::string& body, int n, int item_scalars, int residuals_per_item = 1, int header_scalars = 0,
+              int manifold = TOA_MANIFOLD_EUCLID, int kind = TOA_JIT_RESIDUAL)
+      : ctx_(&ctx), n_(n), kR_(residuals_per_item), kD_(item_scalars), kH_(header_scalars), xdim_(manifold == TOA_MANIFOLD_SE3 ? 12 : n) {
     std::vector<char> log(1 << 16);
-    const int rc = toa_model_compile(ctx.get(), dtype_of<Scalar>(), n, residuals_per_item, item_scalars, header_scalars, body.c_str(), &h_,
-                                     log.data(), log.size());
+    toa_jit_spec spec{};
+    spec.dtype = dtype_of<Scalar>(); spec.num_params = n; spec.residuals_per_item = residuals_per_item;
+    spec.scalars_per_item = item_scalars; spec.header_scalars = header_scalars; spec.manifold = manifold; spec.kind = kind;
+    const int rc = toa_model_compile_ex(ctx.get(), &spec, body.c_str(), &h_, log.data(), log.size());
     log_ = log.data();
     check(rc);
   }
@@ -316,11 +333,12 @@ class JitResidual {
   int residuals_per_item() const { return kR_; }
   int item_scalars() const { return kD_; }
   int header_scalars() const { return kH_; }
+  int xdim() const { return xdim_; }   // stored scalars of x per problem (12 for an SE3 pose)
 
  private:
   const Context* ctx_;
   toa_jit_model h_ = nullptr;
-  int n_, kR_, kD_, kH_;
+  int n_, kR_, kD_, kH_, xdim_;
   std::string log_;
 };
 template <typename Scalar>
@@ -334,7 +352,7 @@ class JitModel : public LossTag {
   int64_t P() const { return P_; }
   int n() const { return res_->n(); }
   int m() const { return items_ * res_->residuals_per_item(); }
-  int xdim() const { return res_->n(); }
+  int xdim() const { return res_->xdim(); }
   int items() const { return items_; }
   const Scalar* data() const { return data_.data(); }
   const Context& ctx() const { return res_->ctx(); }

@@ -150,6 +150,40 @@ static void circle_jit() {
   REQUIRE(threw);
 }
 
+// tests/sophus.cpp:26-44 — `Optimize(pose, [&](const auto& x) { return (prior_inv * x).log(); })` — with the lambda as source
+// text and the manifold as a tag (round 4), and tests/optimize_easy.cpp:35-79 as a manual Accumulate body (the user's Jacobian)
+static void jit_manifold_and_manual() {
+  Context ctx(0);
+  const char* se3_prior =
+      "S RA[9], tA[3];\n"
+      "for (int i = 0; i < 3; ++i) {\n"
+      "  for (int j = 0; j < 3; ++j) RA[3 * i + j] = x[j] * h[3 * i] + x[3 + j] * h[3 * i + 1] + x[6 + j] * h[3 * i + 2];\n"
+      "  tA[i] = x[9] * h[3 * i] + x[10] * h[3 * i + 1] + x[11] * h[3 * i + 2] + h[9 + i];\n"
+      "}\n"
+      "se3_log<S, T>(RA, tA, r);\n";
+  JitResidual<double> prior(ctx, se3_prior, /*n=*/6, /*item_scalars=*/0, /*residuals_per_item=*/6, /*header_scalars=*/12, TOA_MANIFOLD_SE3);
+  // prior_inv: a rotation of 0.5 rad about z and a translation; the optimum is its inverse
+  const double c = std::cos(0.5), sn = std::sin(0.5);
+  std::vector<double> prior_inv{c, -sn, 0, sn, c, 0, 0, 0, 1, 0.3, -0.2, 0.7};
+  std::vector<double> pose{1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  const auto out = Optimize(pose, prior.bind(1, 1, prior_inv.data()), Options());
+  REQUIRE(out.Succeeded(0) && out.Converged(0));
+  // pose = prior_inv^-1: R = Rz(-0.5), t = -R t0
+  REQUIRE(std::abs(pose[0] - c) < 1e-6 && std::abs(pose[1] - sn) < 1e-6 && std::abs(pose[3] + sn) < 1e-6 && std::abs(pose[8] - 1) < 1e-6);
+  REQUIRE(std::abs(pose[9] + (c * 0.3 + sn * -0.2)) < 1e-6 && std::abs(pose[10] + (-sn * 0.3 + c * -0.2)) < 1e-6 && std::abs(pose[11] + 0.7) < 1e-6);
+  const char* rosen =
+      "r[0] = T(1) - x[0];\n"
+      "r[1] = T(10) * (x[1] - x[0] * x[0]);\n"
+      "if (want_grad) { J[0][0] = T(-1); J[0][1] = T(0); J[1][0] = T(-20) * x[0]; J[1][1] = T(10); }\n";
+  JitResidual<double> acc(ctx, rosen, 2, 0, 2, 1, TOA_MANIFOLD_EUCLID, TOA_JIT_ACCUMULATE);
+  std::vector<double> v{-1.2, 1.0}, hdr{0.0};
+  Options o;
+  o.max_iters = 200; o.min_rerr_dec = 0; o.max_consec_failures = 20;      // tests/optimize_easy.cpp:60-63
+  const auto o2 = Optimize(v, acc.bind(1, 1, hdr.data()), o);
+  REQUIRE(o2.Succeeded(0));
+  REQUIRE(std::abs(v[0] - 1) < 1e-5 && std::abs(v[1] - 1) < 1e-5);
+}
+
 // tests/cov.cpp:20-47 — Gaussian prior with sigma = 4.2: covariance from the final Hessian recovers sigma
 static void prior_cov() {
   Context ctx(0);
@@ -361,6 +395,7 @@ int main() {
   sqrt2<float>();
   circle();
   circle_jit();
+  jit_manifold_and_manual();
   prior_cov();
   run<double>(5, 12, 200, 1e-7);
   run<float>(3, 50, 600, 2e-3);

@@ -4,9 +4,7 @@ wave whose work queue is dry takes tickets of its workgroup siblings' passes.  W
   * whoever computes the chunks, the bits are the same: run-to-run, for any batch size, for any position in the batch —
     also when most waves of a launch have nothing of their own and help from the first microsecond;
   * the chunked sum is a legitimate evaluation of the same Accumulate callback: trajectories equal the oracle's (tie-aware),
-    for every chunk count, exactly as with the single-chunk pass (TOA_COOP=0)."""
-import os
-
+    for every chunk count, exactly as with the single-chunk pass (toa_tuning::coop_off)."""
 import numpy as np
 import pytest
 import torch
@@ -14,26 +12,6 @@ import torch
 from parity import check_trajectories, gpu_dict
 
 pytestmark = pytest.mark.gpu
-
-
-class _env:
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        for k, v in self.kw.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _run(ta, model, x0, opts):
@@ -72,14 +50,14 @@ def test_every_chunk_count_follows_the_oracle(ta, oracle, K):
     opts = ta.Options.benchmark()
     ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
     model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
-    with _env(TOA_COOP="0" if K == 0 else "1", TOA_COOP_K=None if K == 0 else K):
+    with ta.api.default_context().tuning(coop_off=int(K == 0), coop_chunks=K):       # toa_tuning: typed per-handle state, no environment
         x, out = _run(ta, model, torch.from_numpy(x0).cuda(), opts)
     check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
                                               cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
 
 
 def test_single_chunk_pass_is_the_classic_pass(ta):
-    """Below 1024 rows (and with TOA_COOP=0) a pass is ONE chunk: the same instruction stream over the same rows as the
+    """Below 1024 rows (and with toa_tuning::coop_off) a pass is ONE chunk: the same instruction stream over the same rows as the
     launch-per-iteration form's data pass, so the stepping form still reproduces the fused kernel bit for bit."""
     P, n, m = 80, 50, 600
     model, x0, _ = ta.DenseRow.synthetic(P, n, m, torch.float32)

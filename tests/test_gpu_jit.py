@@ -121,7 +121,9 @@ def test_compile_errors_and_limits(ta):
         ta.JitResidual("r[0] = undefined_symbol(x[0]);", n=1, item_scalars=1)
     assert "undefined_symbol" in str(e.value)                       # the compiler's diagnostic reaches the caller
     with pytest.raises(ta.ToaError):
-        ta.JitResidual("r[0] = x[0];", n=13, item_scalars=1)           # the register Gram stops at 12 parameters
+        ta.JitResidual("r[0] = x[0];", n=64, item_scalars=1)           # one wavefront per problem: 63 parameters at most
+    with pytest.raises(ta.ToaError):
+        ta.JitResidual("r[0] = x[0];", n=7, item_scalars=1, manifold="se3")   # an SE3 pose has a 6-dimensional tangent
     res = ta.JitResidual("r[0] = x[0] * x[0] - p[0];", n=1, item_scalars=1)     # sqrt: the smallest possible model
     data = torch.full((3, 1, 1), 2.0, dtype=torch.float64, device="cuda")
     x = torch.tensor([[1.0], [-0.3], [3.2]], dtype=torch.float64, device="cuda")
@@ -205,7 +207,9 @@ def test_se3_pose_prior_supplied_as_source(ta, oracle, dtype, tdt):
     assert np.linalg.norm(resid, axis=1).max() < (1e-5 if dtype == np.float64 else 2e-3)
     assert torch.equal(out.stop_reason, outb.stop_reason) and torch.equal(out.num_iters, outb.num_iters)
     k = int(out.num_iters.min())
-    assert np.allclose(out.errs.cpu().numpy()[:, :k], outb.errs.cpu().numpy()[:, :k], rtol=1e-9 if dtype == np.float64 else 2e-3, atol=1e-12)
+    # (fp32: the last costs are round-off of a residual that is zero at the solution — compared on the scale of the first cost)
+    assert np.allclose(out.errs.cpu().numpy()[:, :k], outb.errs.cpu().numpy()[:, :k], rtol=1e-9 if dtype == np.float64 else 2e-3,
+                       atol=1e-12 if dtype == np.float64 else 1e-6)
     R = x.cpu().numpy()[:, :9].reshape(P, 3, 3)
     assert np.abs(np.einsum("pij,pkj->pik", R, R) - np.eye(3)).max() < (1e-12 if dtype == np.float64 else 1e-5)   # stays on the manifold
 

@@ -52,12 +52,12 @@ def test_library_path_agrees_with_wavefront_path_below_64(ta, monkeypatch):
         "import sys, json, numpy as np, torch; sys.path.insert(0, %r); import tinyopt_amd as ta\n"
         "rng = np.random.default_rng(3); n = 50; P = 5\n"
         "J = rng.uniform(-1, 1, size=(P, 150, n)); H = np.einsum('pki,pkj->pij', J, J); g = rng.uniform(-1, 1, size=(P, n))\n"
+        "ta.api.default_context().set_tuning(large_library_solver=FORCE_LIB)\n"
         "dx, ok = ta.solve_damped(torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda(), 1.0001)\n"
         "print(json.dumps({'dx': dx.cpu().numpy().tolist(), 'ok': ok.cpu().numpy().tolist()}))\n" % root)
     outs = []
     for force in ("0", "1"):
-        env = dict(os.environ, TOA_FORCE_ROCSOLVER=force)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code.replace("FORCE_LIB", force)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     a, b = np.array(outs[0]["dx"]), np.array(outs[1]["dx"])
@@ -292,7 +292,7 @@ def test_large_n_batch_independence_and_determinism(ta, oracle):
 @pytest.mark.parametrize("P,n,m", [(6, 160, 900), (3, 256, 1100), (2, 132, 700), (2, 388, 650), (1, 516, 1400)])
 def test_gram_beyond_128_follows_the_oracle(ta, oracle, P, n, m, backend):
     """H = J^T J of the n > 128 pipeline, fp32: by default large_gram_kernel (row chunks staged once in LDS, 32 x 32 tiles of the
-    lower triangle dealt to the waves on v_mfma_f32_32x32x2_f32, chunks folded in fixed order); with TOA_LARGE_OWN_GRAM=0 the
+    lower triangle dealt to the waves on v_mfma_f32_32x32x2_f32, chunks folded in fixed order); with toa_tuning::large_library_gram the
     library GEMM on J = diag(s) A.  Both must follow the oracle's trajectories.  Shapes: n a multiple of 32 and not; 1, 2, 3
     and 4 tiles per wave; more than 64 tiles (n = 388: 91, n = 516: 153 -> two / three workgroups per row chunk); rows not a
     multiple of the LDS stage."""
@@ -301,17 +301,10 @@ def test_gram_beyond_128_follows_the_oracle(ta, oracle, P, n, m, backend):
     opts = ta.Options.benchmark()
     ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
     Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
-    old = os.environ.get("TOA_LARGE_OWN_GRAM")
-    os.environ["TOA_LARGE_OWN_GRAM"] = "1" if backend == "own" else "0"
-    try:
+    with ta.api.default_context().tuning(large_library_gram=int(backend != "own")):
         x = torch.from_numpy(x0.copy()).cuda()
         out = ta.Optimize(x, ta.DenseRowNatural(Ad, bd), opts, history=True)
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ["TOA_LARGE_OWN_GRAM"]
-        else:
-            os.environ["TOA_LARGE_OWN_GRAM"] = old
     from parity import check_trajectories, gpu_dict
     # fp32 at the noise floor: a_i.x is a float dot product of length n, whose round-off moves the cost of one and the same point
     # by ~n eps / |r| relative.  parity.TOL's 5e-4 is sized for n <= 128; at n >= 256 both the library GEMM and this kernel sit
@@ -324,17 +317,14 @@ def test_gram_beyond_128_follows_the_oracle(ta, oracle, P, n, m, backend):
 
 def test_workspace_that_cannot_be_allocated_is_kOutOfMemory(ta, oracle):
     """optimizer.h:75-86: a system that cannot be allocated does not throw — the solve returns with StopReason::kOutOfMemory
-    (stop_reasons.h:20), x untouched.  TOA_TEST_SCRATCH_LIMIT_MB makes the workspace request fail as a full device would."""
+    (stop_reasons.h:20), x untouched.  toa_tuning::fail_workspace_alloc makes the workspace request fail as a full device would."""
     import os
     P, n, m = 3, 160, 400
     A, b, x0, _ = oracle.synth_dense_row(P, n, m, np.float64, seed=2)
     x = torch.from_numpy(x0.copy()).cuda()
-    os.environ["TOA_TEST_SCRATCH_LIMIT_MB"] = "0"
-    try:
+    with ta.api.default_context().tuning(fail_workspace_alloc=1):
         out = ta.Optimize(x, ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()), ta.Options.benchmark())
         torch.cuda.synchronize()
-    finally:
-        del os.environ["TOA_TEST_SCRATCH_LIMIT_MB"]
     assert (out.stop_reason.cpu().numpy() == int(ta.StopReason.kOutOfMemory)).all()
     assert (out.num_iters.cpu().numpy() == 0).all() and not bool(out.Succeeded().any())
     assert np.array_equal(x.cpu().numpy(), x0)
@@ -397,7 +387,7 @@ def test_tile_split_pass_follows_the_oracle_and_the_row_split_pass(ta, oracle, n
     """fp32, 112 < n <= 128: the tile-split data pass of the 64 <= n <= 128 kernel (rows staged once in LDS, nine tiles per wave by
     block rotation, two workgroups per CU) — every n that takes it (the last 16-byte column group of a row may run into the next
     row: n = 116, 120, 124), row counts that are and are not a multiple of the 64-row stage.  Same trajectories as the oracle's,
-    and the same outcome as the row-split pass (TOA_LF_TS=0) up to fp32 round-off."""
+    and the same outcome as the row-split pass (toa_tuning::large_row_split) up to fp32 round-off."""
     import os
     P = 5
     assert (m * (n + 1)) % 4 == 0
@@ -406,21 +396,14 @@ def test_tile_split_pass_follows_the_oracle_and_the_row_split_pass(ta, oracle, n
     ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
     Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()
     res = {}
-    old = os.environ.get("TOA_LF_TS")
-    try:
-        for ts in ("1", "0"):
-            os.environ["TOA_LF_TS"] = ts
+    for ts in ("1", "0"):
+        with ta.api.default_context().tuning(large_row_split=int(ts == "0")):
             x = torch.from_numpy(x0.copy()).cuda()
             out = ta.Optimize(x, ta.DenseRowNatural(Ad, bd), opts, history=True)
             torch.cuda.synchronize()
-            res[ts] = (x.cpu().numpy(), out)
-            check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
-                                                      cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
-    finally:
-        if old is None:
-            os.environ.pop("TOA_LF_TS", None)
-        else:
-            os.environ["TOA_LF_TS"] = old
+        res[ts] = (x.cpu().numpy(), out)
+        check_trajectories(gpu_dict(out, x), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"],
+                                                  cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]), np.float32, opts.to_pod())
     assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-3
     assert np.allclose(res["1"][1].final_cost.cpu().numpy(), res["0"][1].final_cost.cpu().numpy(), rtol=1e-3)
 

@@ -3,7 +3,7 @@ still at hand is served from that Gram instead of a second pass over the rows (o
 a rejected step accumulates again at the rolled-back point; optimizer.h:358-393: a failed solve re-enters Build at the same x).
 
 What must hold: (i) every result — x, StopReason, iteration and failure counts, the whole cost / |dx|^2 / accept history, the
-exported Hessian — is BIT-IDENTICAL with the memo on and off (TOA_MEMO=0), also through option sets that keep a problem
+exported Hessian — is BIT-IDENTICAL with the memo on and off (toa_tuning::memo_off), also through option sets that keep a problem
 bouncing between rejected steps; (ii) the work is really saved: passes streamed + Builds served from the memo == passes
 streamed without it; (iii) the oracle (which always re-accumulates) still agrees."""
 import os
@@ -18,17 +18,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _solve(ta, model, x0, opts, memo):
-    old = os.environ.get("TOA_MEMO")
-    os.environ["TOA_MEMO"] = "1" if memo else "0"
-    try:
+    with ta.api.default_context().tuning(memo_off=0 if memo else 1):     # toa_tuning (the product reads no environment variable)
         x = torch.from_numpy(x0).cuda()
         out = ta.Optimize(x, model, opts, history=True)
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            del os.environ["TOA_MEMO"]
-        else:
-            os.environ["TOA_MEMO"] = old
     return x.cpu().numpy(), out
 
 
@@ -81,7 +74,7 @@ def test_results_do_not_depend_on_the_memo(ta, oracle, dtype, n, m, P, over):
     _assert_identical(x_off, o_off, x_on, o_on)
     c_off = o_off.counters.cpu().numpy()
     c_on = o_on.counters.cpu().numpy()
-    assert c_off[4] == 0, "TOA_MEMO=0 must stream every Build"
+    assert c_off[4] == 0, "toa_tuning::memo_off must stream every Build"
     assert c_on[0] + c_on[4] == c_off[0], "a Build is either streamed or served from the memo"
     assert c_on[1] == c_off[1] and c_on[2] == c_off[2] and c_on[3] == c_off[3] == P
     # the oracle always re-accumulates: the trajectories must still be its own

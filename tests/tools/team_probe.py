@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Team form (one workgroup per small problem) against one wavefront per problem, batches of C2-sized problems.
-Run twice: plain, and with TOA_NO_AUTOSPLIT=1 (forces one wavefront per problem)."""
+Run twice: plain, and with argv[1] = 1 (toa_tuning::wide_no_autosplit: forces one wavefront per problem)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import tinyopt_amd as ta
 
+ta.api.default_context().set_tuning(wide_no_autosplit=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 for n, m in ((6, 1000), (12, 2000)):
     for P in (1, 16, 64, 128, 256, 512, 1024, 2048):
         model, x0, xs = ta.DenseRow.synthetic(P, n, m, torch.float64)

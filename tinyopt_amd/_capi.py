@@ -58,6 +58,15 @@ class ToaResults(C.Structure):
 
 
 # every symbol include/tinyopt_amd.h declares: name -> (restype, argtypes)
+ABI_VERSION = 4   # include/tinyopt_amd.h TOA_ABI_VERSION
+
+
+class ToaTuning(C.Structure):   # include/tinyopt_amd.h toa_tuning
+    _fields_ = [(k, C.c_int32) for k in ("memo_off", "coop_off", "coop_chunks", "max_workgroups", "wide_no_autosplit", "wide_multilaunch",
+                                         "wide_no_team", "wide_team_max_per_cu", "wide_graph", "large_row_split", "large_pipeline",
+                                         "large_library_gram", "large_library_solver", "fail_workspace_alloc")] + [("reserved", C.c_int32 * 18)]
+
+
 class ToaJitSpec(C.Structure):   # include/tinyopt_amd.h toa_jit_spec
     _fields_ = [("dtype", C.c_int32), ("num_params", C.c_int32), ("residuals_per_item", C.c_int32), ("scalars_per_item", C.c_int32),
                 ("header_scalars", C.c_int32), ("manifold", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32 * 9)]
@@ -104,6 +113,10 @@ PROTOTYPES = {
     "toa_ba_lists_run": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, C.POINTER(ToaOptions),
                                    C.POINTER(ToaResults), _P, C.c_double]),
     "toa_model_compile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    "toa_abi_version": (C.c_int, []),
+    "toa_set_tuning": (C.c_int, [_P, C.POINTER(ToaTuning)]),
+    "toa_get_tuning": (C.c_int, [_P, C.POINTER(ToaTuning)]),
+    "toa_debug_timeline": (C.c_int, [_P, C.c_char_p]),
     "toa_model_compile_ex": (C.c_int, [_P, C.POINTER(ToaJitSpec), C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "toa_jit_set_cache_dir": (C.c_int, [C.c_char_p]),
     "toa_jit_model_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -131,6 +144,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.toa_abi_version()
+    if got != ABI_VERSION:   # (e.g. counters_dev grew from [4] to [8] uint64 with version 4: a stale mirror would be written out of bounds)
+        raise RuntimeError(f"{LIB_PATH} has ABI version {got}, this Python mirror expects {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 

@@ -163,6 +163,38 @@ class Context:
                                           int(reps), C.byref(out)))
         return out.value
 
+    def set_tuning(self, **kw) -> None:
+        """The A/B arms of the library (include/tinyopt_amd.h toa_tuning) as typed per-handle state: ``ctx.set_tuning(memo_off=1)``;
+        no arguments = the library's own choices.  The product reads no environment variable."""
+        t = _capi.ToaTuning()
+        for k, v in kw.items():
+            if k == "reserved" or not hasattr(t, k):
+                raise ValueError(f"unknown tuning field {k!r}")
+            setattr(t, k, int(v))
+        check(self.lib.toa_set_tuning(self.h, C.byref(t) if kw else None))
+
+    def get_tuning(self) -> dict:
+        t = _capi.ToaTuning()
+        check(self.lib.toa_get_tuning(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_ if k != "reserved"}
+
+    def tuning(self, **kw):
+        """``with ctx.tuning(coop_off=1): ...`` — the fields set for the block, the previous state restored after it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = self.get_tuning()
+            self.set_tuning(**{**old, **kw})
+            try:
+                yield self
+            finally:
+                self.set_tuning(**old) if any(old.values()) else self.set_tuning()
+        return cm()
+
+    def debug_timeline(self, path: Optional[str]) -> None:
+        check(self.lib.toa_debug_timeline(self.h, path.encode() if path else None))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.toa_destroy(self.h)

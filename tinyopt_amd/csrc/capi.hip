@@ -434,6 +434,27 @@ int toa_jet_eval(toa_handle h, int fn, int dtype, int64_t count, const void* a, 
   return TOA_OK;
 }
 
+int toa_abi_version(void) { return TOA_ABI_VERSION; }
+
+int toa_set_tuning(toa_handle h, const toa_tuning* t) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  if (!t) { h->tune = toa_tuning{}; return TOA_OK; }
+  if (t->coop_chunks != 0 && (t->coop_chunks < 2 || t->coop_chunks > 64)) return fail(TOA_E_ARG, "toa_set_tuning: coop_chunks must be 0 or in [2, 64]");
+  if (t->max_workgroups < 0 || t->wide_team_max_per_cu < 0) return fail(TOA_E_ARG, "toa_set_tuning: negative count");
+  h->tune = *t;
+  return TOA_OK;
+}
+int toa_get_tuning(toa_handle h, toa_tuning* out) {
+  if (!h || !out) return fail(TOA_E_ARG, "toa_get_tuning: null argument");
+  *out = h->tune;
+  return TOA_OK;
+}
+int toa_debug_timeline(toa_handle h, const char* path) {
+  if (!h) return fail(TOA_E_ARG, "null handle");
+  h->timeline_path = path ? path : "";
+  return TOA_OK;
+}
+
 int toa_set_loss(toa_handle h, int kind, double th2) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (kind < TOA_LOSS_L2 || kind > TOA_LOSS_BLAKE_ZISSERMAN) return fail(TOA_E_ARG, "toa_set_loss: unknown loss kind");
@@ -588,8 +609,8 @@ int toa_solve_damped(toa_handle h, int dtype, int n, int64_t P, const void* H, c
                      int32_t* ok) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   // n <= 63: one wavefront per matrix (register / LDS LDL^T); 64 <= n <= 4096: rocSOLVER batched Cholesky (large_n.hip).
-  // TOA_FORCE_ROCSOLVER=1 sends small matrices down the library path too (tools/k3_crossover.py measures both).
-  static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+  // toa_tuning::large_library_solver sends small matrices down the library path too (tools/k3_crossover.py measures both).
+  const bool force_lib = h->tune.large_library_solver != 0;
   const bool large = n > 63 || force_lib;
   if (large) {
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
@@ -700,10 +721,10 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   //   or, for small problems (n <= 15, 512..4096 rows), the team form: one workgroup per problem has no co-residency
   //   requirement, so it also pays for whole batches of them — measured (tests/tools/team_probe.py, C2-sized problems):
   //   89-100 us for 1..256 problems against 131-144 us with one wavefront per problem; the crossover is one problem per
-  //   compute unit at n = 6 x 1000 rows and two at n = 12 x 2000.  TOA_TEAM_MAX_PER_CU overrides, TOA_NO_AUTOSPLIT disables.
+  //   compute unit at n = 6 x 1000 rows and two at n = 12 x 2000.  toa_tuning::wide_team_max_per_cu overrides, toa_tuning::wide_no_autosplit disables.
   if (splits == -1) {
-    static const bool no_auto = std::getenv("TOA_NO_AUTOSPLIT") != nullptr;
-    static const long long team_env = [] { const char* e = std::getenv("TOA_TEAM_MAX_PER_CU"); return e ? atoll(e) : 0ll; }();
+    const bool no_auto = h->tune.wide_no_autosplit != 0;
+    const long long team_env = h->tune.wide_team_max_per_cu;
     const long long team_per_cu = team_env > 0 ? team_env : ((long long)m * (n + 1) >= 20000 ? 2 : 1);
     const bool few = P * 4 <= h->num_cus && m >= 512;
     const bool team = n <= 15 && m >= 512 && m <= 4096 && P <= team_per_cu * h->num_cus;

@@ -1259,7 +1259,7 @@ struct FusedParams {
   toa_results res;
   unsigned long long* counters;  // [4] or null
   int* queue;                    // [0] pop counter, [16] waves that have left the kernel (separate cache lines)
-  unsigned long long* timeline;  // debug (TOA_TIMELINE=file): [P][2] start / end of every problem in 100 MHz ticks
+  unsigned long long* timeline;  // debug (toa_debug_timeline): [P][2] start / end of every problem in 100 MHz ticks
   int lds_per_wave;
   int mode;                      // 0: whole solve; 1: begin (state <- x0, lm_init); 2: ONE loop pass per problem (stepping form);
                                  // 3: finalise the problems named in stop_request with that StopReason (host-side stop controls)
@@ -2126,6 +2126,8 @@ struct toa_context {
   void* params_dev = nullptr;  // device copy of the fused kernel's parameter block
   int loss = TOA_LOSS_L2;      // toa_set_loss: the M-estimator of this handle's cost functor (DenseRow / Jet families)
   double loss_th2 = 0;
+  toa_tuning tune = {};        // toa_set_tuning: A/B arms (all-zero = the library's choices)
+  std::string timeline_path;   // toa_debug_timeline
   unsigned char params_shadow[1024] = {0};  // what params_dev holds (or will hold, in stream order): see upload_params
   size_t params_shadow_bytes = 0;
   void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
@@ -2134,7 +2136,7 @@ struct toa_context {
   size_t memo_bytes = 0;
   void* aux = nullptr;         // bundle adjustment with visibility lists: its work arrays (`scratch` belongs to the solver it calls)
   size_t aux_bytes = 0;
-  // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (TOA_USE_GRAPH=1)
+  // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (toa_tuning::wide_graph)
   struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
   WideGraph wgraphs[16];
   int nwgraphs = 0;
@@ -2316,9 +2318,8 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if constexpr (ModelMemo<Model>::value) {
     // One parked linearisation per resident wave (the Gram registers of the last accepted point: ~10 KB at n = 50, 2 KB at
     // n = 12 fp64): the re-accumulation that follows a rejected step reads it back instead of streaming the problem's rows
-    // again.  TOA_MEMO=0 switches it off (A/B, and the test that the results do not depend on it).
-    const char* env = std::getenv("TOA_MEMO");
-    memo_on = !(env && env[0] == '0');
+    // again.  toa_tuning::memo_off switches it off (A/B, and the test that the results do not depend on it).
+    memo_on = !h->tune.memo_off;
     if (memo_on) {
       // a small Gram is parked in LDS when that costs no resident workgroup (C3: parking in HBM after every accepted step
       // measured 1.5 % of the launch for a workload that never rejects a step)
@@ -2345,12 +2346,12 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     // Cooperative passes (CoopCtl): on for a SHAPE (never for a batch size or a position in the batch, so that a problem's
     // bits do not depend on them), when a pass has enough rows to be worth sharing.  The chunk total of a pass is summed in
     // the owner's LDL^T workspace when the Gram registers fit it, in an area of its own otherwise (if that costs no
-    // resident workgroup).  TOA_COOP=0 switches it off (A/B).
-    const char* env = std::getenv("TOA_COOP");
+    // resident workgroup).  toa_tuning::coop_off switches it off (A/B).
+    const bool coop_on = !h->tune.coop_off;
     const int steps_total = ((prm.m + 3) / 4);
     constexpr bool super16 = Model::kCoopPeriod == 16;   // fp64 n <= 15: 64-row super-batches, 52 KB problems — share from 256 rows
     bool room = Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T);
-    if (!(env && env[0] == '0') && prm.m >= (super16 ? 256 : 1024) && !room) {
+    if (coop_on && prm.m >= (super16 ? 256 : 1024) && !room) {
       const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
       int w2 = 0;
       if ((pw + mb) * 4 + 256 <= 160 * 1024) {
@@ -2364,12 +2365,12 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
         }
       }
     }
-    if (!(env && env[0] == '0') && prm.m >= (super16 ? 256 : 1024) && room) {
+    if (coop_on && prm.m >= (super16 ? 256 : 1024) && room) {
       // chunks per pass: ~1024 rows each (256 for the super-batch form).  Same box, C4 (m = 2000), three interleaved rounds
       // (profiles/r03_ab_log.md): K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays
-      // its own ramp of the load ring, so the coarsest split that still lets a sibling help wins.  (TOA_COOP_K: experiments)
+      // its own ramp of the load ring, so the coarsest split that still lets a sibling help wins.  (toa_tuning::coop_chunks: experiments)
       int K = super16 ? std::max(2, std::min(16, (prm.m + 128) / 256)) : std::max(2, std::min(16, (prm.m + 512) / 1024));
-      if (const char* ek = std::getenv("TOA_COOP_K")) { const int v = std::atoi(ek); if (v >= 2 && v <= 64) K = v; }
+      if (h->tune.coop_chunks >= 2 && h->tune.coop_chunks <= 64) K = h->tune.coop_chunks;
       const int period = Model::kCoopPeriod;   // steps per ring turn / super-batch: chunk boundaries fall on it
       int cs = (steps_total + K - 1) / K;
       cs = (cs + period - 1) / period * period;
@@ -2383,10 +2384,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if (grid < 1) grid = 1;
   // (Sizing the grid to P / rounds waves so that every round is full was tried: at the BASELINE shard size 625 workgroups
   // instead of 768 are ~2 % slower, tools/grid_ab.sh — more resident waves hide more latency than full rounds save.)
-  {
-    static const char* cap_env = std::getenv("TOA_MAX_WGS");  // experiments only
-    if (cap_env && std::atoll(cap_env) > 0 && grid > std::atoll(cap_env)) grid = std::atoll(cap_env);
-  }
+  if (h->tune.max_workgroups > 0 && grid > h->tune.max_workgroups) grid = h->tune.max_workgroups;   // experiments only
   if constexpr (ModelMemo<Model>::value) {
     if (memo_on && prm.memo_lds_off == 0) {
       const size_t stride = (Model::kMemoBytes + 255) & ~size_t(255);
@@ -2407,7 +2405,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   // stream-ordered upload of the parameter block (kept out of the kernarg segment so that its ~60
   // scalars are loaded on demand instead of being pinned in SGPRs across the hot loop)
   if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
-  static const char* tl_path = std::getenv("TOA_TIMELINE");
+  const char* tl_path = h->timeline_path.empty() ? nullptr : h->timeline_path.c_str();
   unsigned long long* tl_dev = nullptr;
   if (tl_path) {  // debug: per-problem start / end stamps of this launch, appended to the file as text
     HIP_TRY(hipMalloc(&tl_dev, size_t(prm.P) * 16));
@@ -2563,14 +2561,14 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   const int iters = fp.opt.max_iters + 1 + (fp.opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
   // Direct launches by default: an A/B on MI355X (tests/tools/latency_probe.py) shows graph replay and eager launches
   // of this 23..103-kernel sequence within 1 % of each other (C2 71 us, C5 93-99 us device time per solve), as
-  // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  TOA_USE_GRAPH=1 selects the graph path.
+  // MI355X_MICROARCH.md's "boundary" row predicts (eager == hipGraph).  toa_tuning::wide_graph selects the graph path.
   // Persistent form (one launch for the whole solve) whenever every workgroup is certainly co-resident: one
-  // 64-thread workgroup per chunk, at most one per CU.  TOA_WIDE_MULTILAUNCH=1 forces the launch-per-iteration form.
+  // 64-thread workgroup per chunk, at most one per CU.  toa_tuning::wide_multilaunch forces the launch-per-iteration form.
   // Instantiated for the small systems only (n <= 15: BASELINE configs C2 / C5 are n = 6): the kernel carries a whole
   // lm_iteration with the NPAD-unrolled register LDL^T per residual-model layout, and 40 copies of it tripled the build.
-  static const bool multilaunch_env = std::getenv("TOA_WIDE_MULTILAUNCH") != nullptr;
+  const bool multilaunch_env = h->tune.wide_multilaunch != 0;
   const bool multilaunch = multilaunch_env || robust;
-  static const bool noteam = std::getenv("TOA_WIDE_NOTEAM") != nullptr;
+  const bool noteam = h->tune.wide_no_team != 0;
   if constexpr (NPAD <= 16) {
     // Team form: a small problem (<= 4096 rows) is cheaper on ONE compute unit with barrier hand-overs than on 16-64
     // of them with HBM hand-overs.  Up to 8 waves (512 threads: two waves per SIMD keep the whole register file usable).
@@ -2600,7 +2598,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
       return TOA_OK;
     }
   }
-  static const bool use_graph = std::getenv("TOA_USE_GRAPH") != nullptr;
+  const bool use_graph = h->tune.wide_graph != 0;
   if (!use_graph) {
     hipLaunchKernelGGL(k_init, dim3(g_p), dim3(256), pwg, h->stream, dp);
     for (int it = 0; it < iters; ++it) {

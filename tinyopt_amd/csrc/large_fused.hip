@@ -801,9 +801,9 @@ int launch_large_fused(toa_handle h, int n, int m, int64_t P, const T* data, T* 
   }
   if constexpr (sizeof(T) == 4 && NB == 8) {   // (NB = 4: ten tiles do not divide by four waves, and hipcc copies accumulators between the
                                                //  waves' unequal tile lists right behind an MFMA — tools/isa_lint.py rejects that code)
-    // the tile-split data pass (two workgroups per CU): rows of whole 16-byte column groups, 16-byte aligned.  TOA_LF_TS=0: the
+    // the tile-split data pass (two workgroups per CU): rows of whole 16-byte column groups, 16-byte aligned.  toa_tuning::large_row_split: the
     // row-split pass (A/B; it also serves every other shape)
-    const bool ts_off = [] { const char* e = std::getenv("TOA_LF_TS"); return e && e[0] == '0'; }();   // (read per call: tests toggle it)
+    const bool ts_off = h->tune.large_row_split != 0;
     if (!ts_off && n % 4 == 0 && (size_t(m) * (size_t(n) + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0)
       return launch_large_fused_r<T, NB, false, true>(h, n, m, P, data, x, opt, res, counters);
   }
@@ -829,8 +829,7 @@ int large_fused_dispatch(toa_handle h, int n, int m, int64_t P, const T* data, T
 // 64 <= n <= 128 (fp64 beyond 96: two half-tile passes, see the kernel), and the LDL^T
 // image n (n + 1) sizeof(T) must fit the LDS.
 bool toa_large_fused_eligible(toa_handle h, int dtype, int n, int m) {
-  static const bool off = [] { const char* e = std::getenv("TOA_LARGE_PIPELINE"); return e && e[0] == '1'; }();
-  if (off) return false;
+  if (h->tune.large_pipeline) return false;
   const size_t esz = dtype == TOA_F32 ? 4 : 8;
   if (n < 64 || n > 128) return false;
   if (size_t(n) * (n + 1) * esz + 16384 > size_t(h->max_lds)) return false;

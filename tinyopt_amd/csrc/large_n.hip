@@ -94,10 +94,9 @@ RocApi& roc_api() {
 
 // Grow the context's scratch block (shared with the row-split path; contents are per-call) to at least `need` bytes.
 int ensure_scratch(toa_handle h, size_t need, const char* what) {
-  // TOA_TEST_SCRATCH_LIMIT_MB: a test hook — requests above the limit fail as an exhausted device would (read per call)
-  if (const char* e = std::getenv("TOA_TEST_SCRATCH_LIMIT_MB"))
-    if (need > size_t(std::atoll(e)) << 20)
-      return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace (TOA_TEST_SCRATCH_LIMIT_MB)");
+  // toa_tuning::fail_workspace_alloc: a test hook — the request fails as on an exhausted device
+  if (h->tune.fail_workspace_alloc)
+    return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace (toa_tuning::fail_workspace_alloc)");
   if (need <= h->scratch_bytes) return TOA_OK;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->scratch) (void)hipFree(h->scratch);
@@ -1227,11 +1226,11 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
   const size_t b_ptr = al(size_t(P) * sizeof(void*));
   // H = J^T J: the hand-written LDS-staged Gram (large_gram_kernel) for fp32 rows that are 16-byte aligned; the library GEMM
-  // otherwise (fp64, odd shapes) or with TOA_LARGE_OWN_GRAM=0.  Same box, 128 problems x n = 256 x m = 8192 fp32
+  // otherwise (fp64, odd shapes) or with toa_tuning::large_library_gram.  Same box, 128 problems x n = 256 x m = 8192 fp32
   // (profiles/r03_ab_log.md): rocblas_sgemm_batched 1.22 ms per pass with every problem rebuilding (the full square,
   // 113 TFLOP/s) plus the J = diag(s) A round trip through HBM in the rows kernel (0.43 -> 0.23 ms without it); this kernel
   // 0.74 ms (the lower tile triangle only: 56 % of the flops, at 104 TFLOP/s issued).
-  const bool force_gemm = [] { const char* e = std::getenv("TOA_LARGE_OWN_GRAM"); return e && e[0] == '0'; }();   // (read per call: tests toggle it)
+  const bool force_gemm = h->tune.large_library_gram != 0;
   const bool own_gram = sizeof(T) == 4 && vec_ok && !force_gemm && n % 4 == 0;
   int gram_R = 1, gram_rows = (m + 3) & ~3;
   const SyrkGeom geo = syrk_geom(n);
@@ -1275,15 +1274,15 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   int* ipiv = reinterpret_cast<int*>(take(b_piv));
   if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
-  // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with TOA_FORCE_ROCSOLVER=1) rocSOLVER
-  static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+  // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with toa_tuning::large_library_solver) rocSOLVER
+  const bool force_lib = h->tune.large_library_solver != 0;
   const size_t chol_lds = ldlt_image_bytes<T>(n);
   const bool own_chol = !lu && !force_lib && n <= 128 && chol_lds + 4096 <= size_t(h->max_lds);  // measured crossover (tools/k3_crossover.py)
   if (own_chol) {
     if (int rc = ensure_lds_attr(h, ldlt_solve_fn<T>(n), chol_lds)) return rc;
   }
   // beyond 128 unknowns: the one-workgroup blocked Cholesky + substitutions (large_chol_solve_kernel) while its panel fits the
-  // LDS (fp32: n <= 1024, fp64: n <= 512); the library beyond, for use_ldlt = false, and with TOA_FORCE_ROCSOLVER=1
+  // LDS (fp32: n <= 1024, fp64: n <= 512); the library beyond, for use_ldlt = false, and with toa_tuning::large_library_solver
   const size_t chol2_lds = chol_solve_lds_bytes<T>(n);
   const bool own_chol2 = !own_chol && !lu && !force_lib && n > 128 && chol2_lds + 2048 <= size_t(h->max_lds);
   if (own_chol2) {
@@ -1417,7 +1416,7 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
 
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
                     int32_t* ok) {
-  static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+  const bool force_lib = h->tune.large_library_solver != 0;
   const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
   const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
   const bool own2 = n > 128 && P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds);   // the one-workgroup blocked Cholesky (fp32: n <= 1024, fp64: n <= 512)
@@ -1437,7 +1436,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
   {  // our own kernels are batch-independent by construction (one workgroup per matrix, fixed-order sums): one launch for all
-    static const bool force_lib = [] { const char* e = std::getenv("TOA_FORCE_ROCSOLVER"); return e && e[0] == '1'; }();
+    const bool force_lib = h->tune.large_library_solver != 0;
     const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
     if (!force_lib && (n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds)))) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   }

@@ -16,7 +16,7 @@ rows.append(f"| c4 | **{c4['value']/1e6:.2f} M LM it/s** (`value_at_oracle_iters
             f"{r['builds_from_memo_per_launch']:.0f} Builds come from the memo): {r['achieved']/1e3:.2f} TB/s = {100*r['frac']:.1f} % of peak, {100*r['frac_of_measured_ceiling']:.0f} % of the "
             f"{r['measured_read_ceiling_GBps']/1e3:.2f} TB/s read ceiling; PMC traffic {pm['hbm_bytes_per_launch']/1e9:.2f} GB vs {pm['algorithmic_bytes_per_launch']/1e9:.2f} GB streamed-algorithmic "
             f"({pm['traffic_over_algorithmic']:.3f}: the memo slots and x) | {c4['cpu_baseline']['value']:.0f} it/s (× {c4['value']/c4['cpu_baseline']['value']:.0f}) |")
-rows.append(f"| c4, `TOA_COOP=0` / `TOA_MEMO=0 TOA_COOP=0` (same call) | {c40['value']/1e6:.2f} M / {c400['value']/1e6:.2f} M | {c40['ms_per_step']:.2f} / {c400['ms_per_step']:.2f} ms | "
+rows.append(f"| c4, `coop_off` / `memo_off + coop_off` (same call) | {c40['value']/1e6:.2f} M / {c400['value']/1e6:.2f} M | {c40['ms_per_step']:.2f} / {c400['ms_per_step']:.2f} ms | "
             f"{100*c40['roofline']['per_iteration']['frac']:.1f} % / {100*c400['roofline']['per_iteration']['frac']:.1f} % per iteration | — |")
 r3 = c3["roofline"]
 rows.append(f"| c3 | **{c3['value']/1e6:.1f} M LM it/s** | {c3['ms_per_step']:.3f} ms (kernel {r3['kernel_ms_avg']:.3f}) | {r3['achieved']/1e3:.2f} TB/s = **{100*r3['frac']:.1f} %**; PMC "
@@ -27,7 +27,7 @@ rl = l128["roofline"]
 rows.append(f"| large128 | **{l128['value']/1e6:.2f} M it/s** (round 2: 0.90) | {l128['ms_per_step']:.2f} ms | MFMA {100*rl['frac']:.1f} % (algorithmic), {100*rl['frac_issued']:.1f} % issued; PMC reads "
             f"{pml['traffic_over_algorithmic']:.3f}× (round 2: 1.067×) | {l128['cpu_baseline']['value']:.0f} it/s |")
 r2 = l256["roofline"]
-rows.append(f"| large256 (128 × n = 256 × m = 8192 fp32) | **{l256['value']/1e3:.1f} k it/s** (round 2: 39.3 k; `TOA_FORCE_ROCSOLVER=1`, same call: {l256r['value']/1e3:.1f} k) | {l256['ms_per_step']:.1f} ms | "
+rows.append(f"| large256 (128 × n = 256 × m = 8192 fp32) | **{l256['value']/1e3:.1f} k it/s** (round 2: 39.3 k; `large_library_solver`, same call: {l256r['value']/1e3:.1f} k) | {l256['ms_per_step']:.1f} ms | "
             f"MFMA {100*r2['frac']:.1f} % of peak over the WHOLE batched solve in algorithmic flops (the Gram kernel alone: 104 TFLOP/s issued) | {l256['cpu_baseline']['value']:.0f} it/s |")
 rows.append(f"| ba | {ba['value']/1e6:.2f} M it/s | {ba['ms_per_step']:.2f} ms | as round 2 | {ba['cpu_baseline']['value']:.0f} it/s |")
 rows.append(f"| balists (4 scenes × 64 cameras × 5000 points × 6 observations per point, fp64) | **{bl['value']:.0f} it/s** (library solver on side streams, same call: {blr['value']:.0f}) | {bl['ms_per_step']:.2f} ms | "

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K3 crossover: the one-wavefront register LDL^T against rocSOLVER's batched Cholesky
 (potrf + potrs, strided batched) on the same damped systems, n = 8 .. 63, and the library path alone beyond.
-Each implementation runs in its own process (TOA_FORCE_ROCSOLVER is read once per process).
+Each implementation runs in its own process (toa_tuning::large_library_solver selects the library).
 
 usage: python tools/k3_crossover.py            (prints a markdown table)"""
 import json
@@ -35,8 +35,8 @@ print(json.dumps(res))
 
 
 def run(force, ns):
-    env = dict(os.environ, TOA_FORCE_ROCSOLVER=force)
-    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, ns)], env=env, capture_output=True, text=True)
+    child = (CHILD % (ROOT, ns)).replace("import tinyopt_amd as ta", "import tinyopt_amd as ta\nta.api.default_context().set_tuning(large_library_solver=%s)" % force, 1)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-3000:])
         raise SystemExit(1)

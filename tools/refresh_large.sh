@@ -3,8 +3,8 @@
 # tools/refresh_profiles.sh leaves under gpurun_out/refresh, so that tools/digest_profiles.py picks them up
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/refresh; mkdir -p $O; cd $R
 for wl in large256 balists; do python bench.py --workload $wl $( [ $wl = large256 ] && echo "--steps 5 --warmup 2" ) > $O/bench_$wl.json 2> $O/bench_$wl.err; done
-TOA_FORCE_ROCSOLVER=1 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu > $O/bench_large256_rocsolver.json 2>/dev/null
-TOA_FORCE_ROCSOLVER=1 python bench.py --workload balists --no-cpu > $O/bench_balists_rocsolver.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_library_solver=1 > $O/bench_large256_rocsolver.json 2>/dev/null
+python bench.py --workload balists --no-cpu --tuning large_library_solver=1 > $O/bench_balists_rocsolver.json 2>/dev/null
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in large256 balists; do

@@ -10,11 +10,11 @@ python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 
 for wl in c4 c3 c2 c5 c1 ba balists; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
 python bench.py --workload large256 --steps 5 --warmup 2 > $O/bench_large256.json 2> $O/bench_large256.err
-TOA_FORCE_ROCSOLVER=1 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu > $O/bench_large256_rocsolver.json 2>/dev/null
-TOA_FORCE_ROCSOLVER=1 python bench.py --workload balists --no-cpu > $O/bench_balists_rocsolver.json 2>/dev/null
-TOA_LF_TS=0 python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu > $O/bench_large128_rowsplit.json 2>/dev/null
-TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
-TOA_MEMO=0 TOA_COOP=0 python bench.py --workload c4 --no-cpu > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_library_solver=1 > $O/bench_large256_rocsolver.json 2>/dev/null
+python bench.py --workload balists --no-cpu --tuning large_library_solver=1 > $O/bench_balists_rocsolver.json 2>/dev/null
+python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu --tuning large_row_split=1 > $O/bench_large128_rowsplit.json 2>/dev/null
+python bench.py --workload c4 --no-cpu --tuning coop_off=1 > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
+python bench.py --workload c4 --no-cpu --tuning memo_off=1,coop_off=1 > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1

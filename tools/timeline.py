@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reads a TOA_TIMELINE file (per-problem start / end stamps of fused launches, 100 MHz ticks) and prints how many
+"""Reads a toa_debug_timeline file (ctx.debug_timeline(path)) (per-problem start / end stamps of fused launches, 100 MHz ticks) and prints how many
 problems were in flight over the last launch's duration — where a launch loses time (ramp, steady state, drain)."""
 import sys
 import numpy as np
