@@ -84,6 +84,48 @@ def cpu_baseline(n, m, np_dtype, pod, budget_problems):
     }, r1
 
 
+class _DryEvent:
+    """torch.cuda.Event's interface on the host clock (bench.py --dry-run)."""
+
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return max((other.t - self.t) * 1e3, 1e-3)
+
+
+class _DryModel:
+    def __init__(self, P, n, m, tdt, xstar):
+        self.P, self.n, self.m, self.dtype, self.xstar = P, n, m, tdt, xstar
+        self.algorithmic_bytes_per_pass = m * (n + 1) * torch.empty(0, dtype=tdt).element_size()
+        self.packed = torch.zeros(1, dtype=tdt)
+
+
+def _dry_optimize(rank):
+    """Stand-in for ta.Optimize in a --dry-run: writes the planted solution into x and an Output-shaped object with
+    rank-dependent counts (so that the MIN / MAX / SUM reductions over ranks have something to tell apart)."""
+    from types import SimpleNamespace
+
+    def optimize(x, model, opts, out=None):
+        P = x.shape[0]
+        if out is None:
+            out = SimpleNamespace(stop_reason=torch.zeros(P, dtype=torch.int32), num_iters=torch.zeros(P, dtype=torch.int32),
+                                  final_cost=torch.zeros(P, dtype=torch.float64), counters=torch.zeros(8, dtype=torch.int64))
+        x.copy_(model.xstar)
+        out.stop_reason.fill_(3)
+        out.num_iters.fill_(7 + rank % 2)
+        out.final_cost.copy_(torch.arange(P, dtype=torch.float64) + 1000.0 * rank)
+        out.counters.zero_()
+        out.counters[0] = 6 * P
+        out.counters[1] = P
+        out.counters[4] = P
+        return out
+    return optimize
+
+
 def run_single(args, ta, rank, world, local_rank):
     """BASELINE configs C1 / C2 / C5: ONE problem (C1: three scalar starts) per GPU — latency-bound, "replicas only" at
     N > 1.  A step = one whole solve from x0 (`toa_lm_run`, benchmarks/options.h options); the line reports
@@ -461,6 +503,10 @@ def main():
     ap.add_argument("--problems", type=int, default=0, help="override problems per GPU (debug; invalidates the metric)")
     ap.add_argument("--cpu-problems", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1 plumbing check WITHOUT a GPU: gloo + CPU tensors and a stand-in for the solve go through the very same barriers, "
+                         "reductions, result gather, watchdog and JSON assembly as a real run (tests/test_cpu_dist.py runs it at N = 2 and 8, "
+                         "launched exactly as the driver launches the scaling bench); the line says data = dry-run and is not a measurement")
     ap.add_argument("--tuning", default="", help="A/B arms of the library as toa_tuning fields, e.g. coop_off=1,memo_off=1 (recorded in the line; "
                                                  "the default line is measured with none)")
     args = ap.parse_args()
@@ -470,15 +516,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
+    gpu = not args.dry_run
+    if gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl" if gpu else "gloo", rank=rank, world_size=world)
 
     import tinyopt_amd as ta
 
-    if args.tuning:   # typed per-handle state (include/tinyopt_amd.h toa_tuning): the library reads no environment variable
+    if not gpu:
+        if args.workload not in WORKLOADS or WORKLOADS[args.workload][1] > 63:
+            raise SystemExit("--dry-run covers the sharded dense workloads (c4, c3)")
+        args.no_cpu = True
+    if args.tuning and gpu:   # typed per-handle state (include/tinyopt_amd.h toa_tuning): the library reads no environment variable
         ta.api.default_context(local_rank).set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
     if args.workload in SINGLE:
         return run_single(args, ta, rank, world, local_rank)
@@ -489,14 +541,28 @@ def main():
     P, n, m, tdt, tag, desc = WORKLOADS[args.workload]
     if args.problems:
         P = args.problems
-    ctx = ta.api.default_context(local_rank)
-    info = ctx.info()
     opts = ta.Options.benchmark()  # benchmarks/options.h:10-27
     pod = opts.to_pod()
+    dev = "cuda" if gpu else "cpu"
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
+    barrier = (lambda: dist.barrier(device_ids=[local_rank])) if gpu else dist.barrier
+    Event = torch.cuda.Event if gpu else _DryEvent
+    if gpu:
+        ctx = ta.api.default_context(local_rank)
+        info = ctx.info()
+        optimize = ta.Optimize
+    else:   # stand-ins with the shapes, dtypes and fields of the real objects (everything AFTER the solve is the real code path)
+        P = args.problems or 13
+        ctx, info = None, {"name": "dry-run (no device)", "num_cus": 0}
+        optimize = _dry_optimize(rank)
 
     # ---- inputs resident in HBM before the timed region (weak scaling: rank r owns problems [r*P, (r+1)*P))
     large = n > 63
-    if not large:
+    if not gpu:
+        xstar = torch.arange(rank * P, (rank + 1) * P, dtype=tdt)[:, None] * 0.001 + torch.arange(n, dtype=tdt)[None, :]
+        x0 = torch.zeros(P, n, dtype=tdt)
+        model = _DryModel(P, n, m, tdt, xstar)
+    elif not large:
         model, x0, xstar = ta.DenseRow.synthetic(P, n, m, tdt, problem0=rank * P)
     else:  # natural layout (A then b), generated on the device with the same distributions
         gen = torch.Generator(device="cuda").manual_seed(0x7194 + rank)
@@ -508,18 +574,18 @@ def main():
         model = ta.DenseRowNatural(A, bvec)
         del A, bvec, t
     x = x0.clone()
-    out = ta.Optimize(x, model, opts)  # allocates result buffers once
-    torch.cuda.synchronize()
+    out = optimize(x, model, opts)  # allocates result buffers once
+    sync()
 
     def step(acc):
         """One timed unit: restart from x0, run the batched solve, accumulate the step's units on the
         device (no host sync).  Used identically for warmup and timing so that every lazily loaded
         torch kernel (copy, sum, add) is resident before the clock starts."""
         x.copy_(x0)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0 = Event(enable_timing=True)
+        e1 = Event(enable_timing=True)
         e0.record()
-        ta.Optimize(x, model, opts, out=out)  # one kernel launch on torch's current stream
+        optimize(x, model, opts, out=out)  # one kernel launch on torch's current stream
         e1.record()
         it = out.num_iters.sum(dtype=torch.int64)
         ps = out.counters[0] + out.counters[1]   # passes that STREAMED the rows (accumulate + evaluate-only)
@@ -534,19 +600,19 @@ def main():
         wacc = step(wacc)
     if wacc is not None:
         _ = int(wacc[0].item())
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
+        barrier()
+    sync()
 
     acc = None
     t0 = time.perf_counter()
     for k in range(args.steps):
         acc = step(acc)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
+        barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     iters_total = int(acc[0].item())
     passes_total = int(acc[1].item())
@@ -561,14 +627,14 @@ def main():
 
     # ---- max over ranks, totals over ranks
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([iters_total, passes_total], dtype=torch.int64, device="cuda")
+        s = torch.tensor([iters_total, passes_total], dtype=torch.int64, device=dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         iters_all, passes_all = int(s[0].item()), int(s[1].item())
         # per-GPU imbalance of the data-dependent work (no inter-GPU rebalancing, report the spread)
-        lo = torch.tensor([iters_total], dtype=torch.int64, device="cuda")
+        lo = torch.tensor([iters_total], dtype=torch.int64, device=dev)
         hi = lo.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -606,17 +672,17 @@ def main():
         watchdog.daemon = True
         watchdog.start()
     try:
-        if world > 1 and not large and not os.environ.get("TOA_BENCH_TORCH_GATHER"):
+        if world > 1 and not large and gpu and not os.environ.get("TOA_BENCH_TORCH_GATHER"):
             tc = time.perf_counter()
             comm = ta.Communicator.from_torch(ctx)
-            torch.cuda.synchronize()
+            sync()
             comm_init_ms = (time.perf_counter() - tc) * 1e3
             ta.gather_native(comm, x, out, P_total=P * world)      # warm (buffers, RCCL channel set-up)
-            torch.cuda.synchronize()
-            dist.barrier(device_ids=[local_rank])
+            sync()
+            barrier()
             tg = time.perf_counter()
             gathered = ta.gather_native(comm, x, out, P_total=P * world)
-            torch.cuda.synchronize()
+            sync()
             gather_ms = (time.perf_counter() - tg) * 1e3
             gather_impl = "toa_gather (C-ABI): one ncclGather, native dtypes"
             if rank == 0:
@@ -630,10 +696,13 @@ def main():
         tg = time.perf_counter()
         gathered = ta.gather_output(x, {"stop_reason": out.stop_reason, "num_iters": out.num_iters,
                                         "final_cost": out.final_cost}, P_total=P * world)
-        torch.cuda.synchronize()
+        sync()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if world > 1:
             gather_impl = "torch.distributed.gather (float64 payload)"
+            if rank == 0:   # the root holds every rank's shard in problem-id order
+                assert gathered["x"].shape == (P * world, n) and torch.equal(gathered["x"][:P].to(x.dtype), x)
+                assert gathered["num_iters"].shape[0] == P * world and torch.equal(gathered["num_iters"][:P].to(out.num_iters.dtype), out.num_iters)
     if watchdog is not None:
         watchdog.cancel()
 
@@ -654,6 +723,8 @@ def main():
 
     # measured STREAM-like read ceiling over the same packed buffer, next to the nominal peak
     try:
+        if not gpu:
+            raise RuntimeError("dry run")
         stream_read = ctx.hbm_read_GBps(model.packed[: min(model.packed.shape[0], 64)].contiguous() if large else model.packed, reps=5)
     except Exception as e:  # noqa: BLE001
         log(f"[bench] hbm read probe failed: {e}")
@@ -693,7 +764,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": tag, "data": "synthetic",
+        "dtype": tag, "data": "synthetic" if gpu else "dry-run (no GPU work: N > 1 plumbing check, NOT a measurement)",
         "config": {"workload": desc, "problems_per_gpu": P, "n": n, "m": m,
                    "options": "benchmarks/options.h (max_iters 10, min_error 0, min_rerr_dec 1e-12, min_step_norm2 1e-16, max_consec_failures 3)",
                    "parallelism": f"problem-sharded x{world}, no data-path collective, one result gather",

@@ -196,6 +196,8 @@ int toa_get_tuning(toa_handle h, toa_tuning* out);
 int toa_debug_timeline(toa_handle h, const char* path);
 int toa_destroy(toa_handle h);
 const char* toa_last_error(void);
+/* GPUs visible to the process (a sharded host program creates one handle per device; tests use it to skip N > 1 cases). */
+int toa_device_count(int* count);
 /* Device properties the measurement needs (CU count, clock, name). */
 int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size_t name_len);
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "tinyopt_amd/tinyopt.hpp"
@@ -385,8 +386,53 @@ static void sharded() {
   REQUIRE(toa_shard_range(11, 1, 2, &lo, &hi) == 0 && lo == 6 && hi == 11);
 }
 
+// Two ranks, two GPUs, ONE process with a host thread per rank (a handle is per thread and per device): the native collective
+// with more than one participant — what the 2 / 4 / 8-GPU legs of the scaling bench run.  Skipped where fewer than two
+// devices are visible (the gather had only ever run with one rank).  Uneven shards (6 + 5 problems).
+static void sharded_two_ranks() {
+  int ndev = 0;
+  REQUIRE(toa_device_count(&ndev) == 0);
+  if (ndev < 2) { std::printf("sharded_two_ranks: skipped (%d device%s visible)\n", ndev, ndev == 1 ? "" : "s"); return; }
+  const int P_total = 11;
+  std::vector<float> x0(P_total);
+  for (int p = 0; p < P_total; ++p) x0[p] = 0.4f + 0.37f * p;
+  Options options;
+  options.max_iters = 20;
+  options.max_consec_failures = 0;
+  std::vector<float> xref = x0;
+  BatchOutput ref;
+  { Context c0(0); Sqrt2<float> cost(c0, P_total); ref = Optimize(xref, cost, options); }
+  const Communicator::Id id = Communicator::UniqueId();
+  std::vector<float> all_x;
+  BatchOutput root_out;
+  std::string err[2];
+  auto rank_main = [&](int rank) {
+    try {
+      Context ctx(rank);
+      Communicator comm(ctx, id, 2, rank);                         // collective over both threads
+      const auto range = comm.shard(P_total);
+      std::vector<float> x(x0.begin() + range.first, x0.begin() + range.second);
+      Sqrt2<float> cost(ctx, range.second - range.first);
+      std::vector<float> gathered;
+      const auto out = ShardedOptimize(x, cost, options, comm, P_total, &gathered);
+      if (rank == 0) { all_x = gathered; root_out = out; }
+    } catch (const std::exception& e) { err[rank] = e.what(); }
+  };
+  std::thread t1(rank_main, 1);
+  rank_main(0);
+  t1.join();
+  REQUIRE(err[0].empty() && err[1].empty());
+  if (!err[0].empty() || !err[1].empty()) { std::printf("  rank 0: %s\n  rank 1: %s\n", err[0].c_str(), err[1].c_str()); return; }
+  REQUIRE(int(all_x.size()) == P_total && int(root_out.stop_reason.size()) == P_total);
+  for (int p = 0; p < P_total && p < int(all_x.size()); ++p) {
+    REQUIRE(all_x[p] == xref[p]);
+    REQUIRE(root_out.stop_reason[p] == ref.stop_reason[p] && root_out.num_iters[p] == ref.num_iters[p] && root_out.final_cost[p] == ref.final_cost[p]);
+  }
+  std::printf("sharded_two_ranks: ok (2 devices)\n");
+}
+
 int main() {
-  if (const char* e = std::getenv("TOA_TEST_SHARDED"); !e || e[0] != '0') sharded();
+  if (const char* e = std::getenv("TOA_TEST_SHARDED"); !e || e[0] != '0') { sharded(); sharded_two_ranks(); }
   stepping();
   single_problem_overload();
   stop_controls();

@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "_test_header_adaptor")
 def _compile():
     libdir = os.path.join(ROOT, "tinyopt_amd")
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE,
-                    "-L", libdir, "-ltinyopt_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    "-L", libdir, "-ltinyopt_amd", "-pthread", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
 
 
 def test_header_adaptor_compiles_with_plain_gxx(built):

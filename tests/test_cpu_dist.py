@@ -114,3 +114,42 @@ def test_c_abi_shard_range_matches_python(built):
                 assert lib.toa_shard_range(P, r, world, C.byref(lo), C.byref(hi)) == 0
                 assert (lo.value, hi.value) == shard_range(P, r, world)
     assert lib.toa_shard_range(5, 2, 2, C.byref(lo), C.byref(hi)) != 0
+
+
+def _dry_run(world):
+    """`bench.py --gpus N` launched EXACTLY as the driver launches the scaling bench (python -m torch.distributed.run ...), with
+    --dry-run: gloo + CPU tensors and a stand-in for the solve through the real barriers, MAX / SUM / MIN reductions, result
+    gather, watchdog and JSON assembly.  (no multi-GPU box has ever run this code; a shape bug in the N > 1
+    plumbing must not be what the first 8-GPU run finds.)"""
+    import json
+    import subprocess
+    port = 29950 + (os.getpid() % 40) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["scaling"] == "weak" and "dry-run" in d["data"]
+    P = d["config"]["problems_per_gpu"]
+    # the stand-in solves take 7 iterations per problem on even ranks and 8 on odd ones: SUM and MIN / MAX over ranks
+    per_rank = [P * (7 + r % 2) for r in range(world)]
+    assert d["config"]["lm_iterations_per_step_all_gpus"] == sum(per_rank)
+    assert d["config"]["lm_iterations_per_step_per_gpu_min_max"] == [min(per_rank), max(per_rank)]
+    assert abs(d["config"]["iters_per_problem"] - sum(per_rank) / (P * world)) < 1e-12
+    assert d["value"] > 0 and abs(d["value"] - sum(per_rank) * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
+    assert "torch.distributed.gather" in d["config"]["gather_impl"] and d["config"]["gather_ms"] > 0
+    assert d["roofline"]["unit"] == "GB/s" and d["roofline"]["passes_per_launch"] == 7 * P
+    return d
+
+
+def test_bench_dry_run_two_ranks():
+    _dry_run(2)
+
+
+def test_bench_dry_run_eight_ranks():
+    _dry_run(8)

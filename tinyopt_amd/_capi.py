@@ -114,6 +114,7 @@ PROTOTYPES = {
                                    C.POINTER(ToaResults), _P, C.c_double]),
     "toa_model_compile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "toa_abi_version": (C.c_int, []),
+    "toa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "toa_set_tuning": (C.c_int, [_P, C.POINTER(ToaTuning)]),
     "toa_get_tuning": (C.c_int, [_P, C.POINTER(ToaTuning)]),
     "toa_debug_timeline": (C.c_int, [_P, C.c_char_p]),

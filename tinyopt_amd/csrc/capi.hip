@@ -334,6 +334,14 @@ int toa_destroy(toa_handle h) {
   return TOA_OK;
 }
 
+int toa_device_count(int* count) {
+  if (!count) return fail(TOA_E_ARG, "toa_device_count: null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;   // (no device, no driver: zero GPUs, not an error)
+  *count = n;
+  return TOA_OK;
+}
+
 int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size_t name_len) {
   if (!h) return fail(TOA_E_ARG, "null handle");
   if (num_cus) *num_cus = h->num_cus;
