@@ -1417,7 +1417,8 @@ __global__ void __launch_bounds__(256) bl_back_kernel(const BlParams* __restrict
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict__ prm, const int32_t* __restrict__ solve_ok, int timed_out) {
+__global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict__ prm, const int32_t* __restrict__ solve_ok, int timed_out,
+                                                      int* __restrict__ any_active) {
   __shared__ T red[8];
   const long long p = blockIdx.x;
   const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
@@ -1484,7 +1485,7 @@ __global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict
     fl[1] = (!is_lm || S.rebuild) ? 1 : 0;
     fl[2] = action;
     fl[0] = cont;
-    if (cont) atomicAdd(prm->any_active, 1);
+    if (cont) atomicAdd(any_active, 1);   // this pass's slot of the host's ring
     if (!cont) {   // optimizer.h:313-327
       const toa_results& res = prm->res;
       if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;
@@ -1541,6 +1542,34 @@ __global__ void bl_clear_action_kernel(const BlParams* __restrict__ prm) {
   if (p < prm->P) prm->iwork[size_t(p) * ix.total + ix.flags + 2] = 0;
 }
 
+// a scene that is still running when the host's pass budget is exhausted: finalised as kMaxIters (optimizer.h:320-321)
+template <typename T>
+__global__ void __launch_bounds__(64) bl_force_stop_kernel(const BlParams* __restrict__ prm) {
+  const long long p = blockIdx.x;
+  const BlWork<T> wk(prm->C, prm->N, prm->M);
+  const BlIdx ix(prm->C, prm->N, prm->M);
+  int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
+  if (threadIdx.x != 0 || !fl[0]) return;
+  LmState<T>& S = *bl_state<T>(prm, wk, p);
+  const toa_results& res = prm->res;
+  fl[0] = 0;
+  if (S.stop == TOA_STOP_NONE) S.stop = TOA_STOP_MAX_ITERS;
+  res.stop_reason[p] = S.stop;
+  res.num_iters[p] = S.num_iters;
+  res.final_cost[p] = S.final_cost;
+  if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+  if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+  if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+  if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+  if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
+  if (prm->counters) {
+    atomicAdd(&prm->counters[0], S.acc_passes);
+    atomicAdd(&prm->counters[1], S.eval_passes);
+    atomicAdd(&prm->counters[2], S.solves);
+    atomicAdd(&prm->counters[3], 1ull);
+  }
+}
+
 template <typename T>
 int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms) {
   const int C = prm.C, N = prm.N, M = prm.M, n = 6 * C;
@@ -1581,23 +1610,55 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   HIP_TRY(hipGetLastError());
   // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
   const long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  if (max_duration_ms > 0) {
-    HIP_TRY(hipEventCreate(&t0));
-    HIP_TRY(hipEventCreate(&t1));
-    HIP_TRY(hipEventRecord(t0, st));
+  // Round 4: the host no longer waits for a pass before it enqueues the next one.  Every pass leaves "is any scene still
+  // running" in its own slot of a small ring; the slot is copied to pinned host memory behind the pass and the host looks at
+  // pass k's answer only before it enqueues pass k + kAhead — the GPU always has the next pass queued (round 3: a
+  // hipStreamSynchronize + 4-byte read-back per pass, ~40 us of idle GPU each).  The at most kAhead surplus passes that are
+  // enqueued after the last scene has finished find fl[0] == 0 everywhere and return at once (every kernel of the pipeline
+  // checks it first).  max_duration_ms needs the elapsed device time BEFORE each pass is enqueued (optimizer.h:302-305):
+  // that form keeps the pass-by-pass hand-shake.
+  constexpr int kAhead = 2, kRing = 4;
+  struct Events {   // (RAII: every early return below used to leak the timing events — ADVICE r03)
+    hipEvent_t t0 = nullptr, t1 = nullptr, done[kRing] = {};
+    int* host_flags = nullptr;
+    ~Events() {
+      if (t0) (void)hipEventDestroy(t0);
+      if (t1) (void)hipEventDestroy(t1);
+      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+      if (host_flags) (void)hipHostFree(host_flags);
+    }
+  } ev;
+  const bool timed = max_duration_ms > 0;
+  if (timed) {
+    HIP_TRY(hipEventCreate(&ev.t0));
+    HIP_TRY(hipEventCreate(&ev.t1));
+    HIP_TRY(hipEventRecord(ev.t0, st));
   }
+  for (int i = 0; i < kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ev.host_flags), kRing * sizeof(int), hipHostMallocDefault));
+  int* any_ring = prm.any_active;   // kRing ints (the block reserves 256 bytes)
   int rc_all = TOA_OK;
-  for (long long pass = 0; pass < max_passes; ++pass) {
+  bool finished = false;
+  long long pass = 0;
+  for (; pass < max_passes; ++pass) {
+    const int slot = int(pass % kRing);
+    if (pass >= kAhead || timed) {   // the answer of pass - kAhead (timed form: of the previous pass)
+      const long long look = timed ? pass - 1 : pass - kAhead;
+      if (look >= 0) {
+        HIP_TRY(hipEventSynchronize(ev.done[look % kRing]));
+        if (ev.host_flags[look % kRing] == 0) { finished = true; break; }
+      }
+    }
     int timed_out = 0;
-    if (max_duration_ms > 0) {   // the reference adds up the iterations' wall time (optimizer.h:302-305): device time here
-      HIP_TRY(hipEventRecord(t1, st));
-      HIP_TRY(hipEventSynchronize(t1));
+    if (timed) {   // the reference adds up the iterations' wall time (optimizer.h:302-305): device time here
+      HIP_TRY(hipEventRecord(ev.t1, st));
+      HIP_TRY(hipEventSynchronize(ev.t1));
       float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+      HIP_TRY(hipEventElapsedTime(&ms, ev.t0, ev.t1));
       timed_out = double(ms) > max_duration_ms ? 1 : 0;
     }
-    HIP_TRY(hipMemsetAsync(prm.any_active, 0, sizeof(int), st));
+    int* const any_slot = any_ring + slot;
+    HIP_TRY(hipMemsetAsync(any_slot, 0, sizeof(int), st));
     hipLaunchKernelGGL(bl_obs_kernel<T>, dim3(gM, unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_point_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_cam_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
@@ -1617,18 +1678,27 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
       if (rc_all != TOA_OK) break;
     }
     hipLaunchKernelGGL(bl_back_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok);
-    hipLaunchKernelGGL(bl_step_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok, timed_out);
+    hipLaunchKernelGGL(bl_step_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok, timed_out, any_slot);
     hipLaunchKernelGGL(bl_update_kernel<T>, dim3(gX, unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_clear_action_kernel, dim3(unsigned((P + 63) / 64)), dim3(64), 0, st, dev);
     HIP_TRY(hipGetLastError());
-    int active = 0;
-    HIP_TRY(hipMemcpyAsync(&active, prm.any_active, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (active == 0) break;
+    HIP_TRY(hipMemcpyAsync(&ev.host_flags[slot], any_slot, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ev.done[slot], st));
   }
-  if (t0) (void)hipEventDestroy(t0);
-  if (t1) (void)hipEventDestroy(t1);
-  return rc_all;
+  if (rc_all != TOA_OK) return rc_all;
+  if (!finished) {
+    // the passes enqueued last have not been looked at yet; and a loop that ran out of passes must not hand back scenes that
+    // are still running with whatever the caller's result arrays held: they end with kMaxIters, like
+    // optimizer.h:320-321 ends a loop whose iteration count is exhausted
+    HIP_TRY(hipStreamSynchronize(st));
+    bool any = false;
+    for (long long k = std::max(0ll, pass - kAhead); k < pass; ++k) any = ev.host_flags[k % kRing] != 0;   // (the LAST pass decides)
+    if (any) {
+      hipLaunchKernelGGL(bl_force_stop_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  return TOA_OK;
 }
 
 }  // namespace toa

@@ -1297,7 +1297,36 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // row slices of the n x n staging copies: ~8 workgroups per CU over the batch, at least 8 rows each
   const int stage_rows = int(std::max<long long>(8, (long long)n * P / std::max<long long>(1, (long long)h->num_cus * 8)));
   int active = int(P), want_j = int(P);
-  for (long long pass = 0; pass < max_passes && active > 0; ++pass) {
+  // Round 4: where every stage of a pass is a kernel of ours (hand-written Gram + own Cholesky: fp32, aligned rows, n <= 1024)
+  // nothing in a pass needs a host-side count, every kernel skips the problems that have finished, and each pass leaves its
+  // (active, want-Jacobian) pair in its own slot of `summary` — so the host enqueues kAhead passes ahead and looks at pass
+  // k's pair (copied to pinned memory behind the pass) only before it enqueues pass k + kAhead: no hipStreamSynchronize in the
+  // loop, the GPU always has the next pass queued (round 3: a blocking 8-byte read-back per pass, ~35 us of idle GPU each).
+  // The at most kAhead surplus passes after the last problem has finished are launches of kernels that return at once.
+  // With a LIBRARY stage in the pass (rocBLAS GEMM sized by want_j, rocSOLVER over all P matrices) the pass-by-pass
+  // hand-shake stays: a surplus library pass would cost more than the read-back.
+  constexpr int kAhead = 2, kRing = 4;
+  const bool ahead = own_gram && (own_chol || own_chol2);
+  struct Ring {
+    hipEvent_t done[kRing] = {};
+    int* host = nullptr;   // [kRing][2], pinned
+    ~Ring() {
+      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+      if (host) (void)hipHostFree(host);
+    }
+  } ring;
+  if (ahead) {
+    for (int i = 0; i < kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&ring.done[i], hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ring.host), kRing * 2 * sizeof(int), hipHostMallocDefault));
+  }
+  long long pass = 0;
+  for (; pass < max_passes && active > 0; ++pass) {
+    if (ahead && pass >= kAhead) {
+      const int slot = int((pass - kAhead) % kRing);
+      HIP_TRY(hipEventSynchronize(ring.done[slot]));
+      active = ring.host[2 * slot];
+      if (active == 0) break;
+    }
     const dim3 rgrid(row_blocks, unsigned(P));
     const size_t xs_bytes = size_t(n) * sizeof(T);
     if (!vec_ok) {
@@ -1365,11 +1394,21 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     int* sum_dev = a.summary + 2 * pass;
     hipLaunchKernelGGL(large_post_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a, sum_dev);
     HIP_TRY(hipGetLastError());
-    int sum_host[2];
-    HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, sizeof(sum_host), hipMemcpyDeviceToHost, st));
+    if (ahead) {
+      const int slot = int(pass % kRing);
+      HIP_TRY(hipMemcpyAsync(ring.host + 2 * slot, sum_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(ring.done[slot], st));
+    } else {
+      int sum_host[2];
+      HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, sizeof(sum_host), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      active = sum_host[0];
+      want_j = sum_host[1];
+    }
+  }
+  if (ahead && active > 0 && pass > 0) {   // the pass budget ran out before a zero was seen: the LAST pass decides
     HIP_TRY(hipStreamSynchronize(st));
-    active = sum_host[0];
-    want_j = sum_host[1];
+    active = ring.host[2 * int((pass - 1) % kRing)];
   }
   if (active > 0) return toa_fail(TOA_E_HIP, "large-n LM: pass budget exhausted with active problems (internal error)");
   return TOA_OK;
