@@ -1617,15 +1617,14 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   // enqueued after the last scene has finished find fl[0] == 0 everywhere and return at once (every kernel of the pipeline
   // checks it first).  max_duration_ms needs the elapsed device time BEFORE each pass is enqueued (optimizer.h:302-305):
   // that form keeps the pass-by-pass hand-shake.
-  constexpr int kAhead = 2, kRing = 4;
+  constexpr int kAhead = 2, kRing = toa_context::kPassRing;
   struct Events {   // (RAII: every early return below used to leak the timing events — ADVICE r03)
-    hipEvent_t t0 = nullptr, t1 = nullptr, done[kRing] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t* done = nullptr;     // the handle's ring (kept across calls)
     int* host_flags = nullptr;
     ~Events() {
       if (t0) (void)hipEventDestroy(t0);
       if (t1) (void)hipEventDestroy(t1);
-      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-      if (host_flags) (void)hipHostFree(host_flags);
     }
   } ev;
   const bool timed = max_duration_ms > 0;
@@ -1634,8 +1633,9 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     HIP_TRY(hipEventCreate(&ev.t1));
     HIP_TRY(hipEventRecord(ev.t0, st));
   }
-  for (int i = 0; i < kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ev.host_flags), kRing * sizeof(int), hipHostMallocDefault));
+  if (int rc = ensure_pass_ring(h)) return rc;
+  ev.done = h->pass_done;
+  ev.host_flags = h->pass_flags;
   int* any_ring = prm.any_active;   // kRing ints (the block reserves 256 bytes)
   int rc_all = TOA_OK;
   bool finished = false;
@@ -1668,6 +1668,13 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     HIP_TRY(hipGetLastError());
     // reduced camera system: S dc = -red  (toa_large_solve: dx = -H^-1 g; scale 1: S is already damped).  A scene that is not
     // running (or whose Build failed) still goes through the solver on whatever its S holds: its verdict is ignored.
+    // (the solver's own kernels skip the scenes that have stopped: flags [0]; with passes enqueued ahead of the stop flag the
+    // surplus passes then cost launches, not factorisations)
+    struct MaskScope {
+      toa_handle h;
+      MaskScope(toa_handle hh, const int32_t* m, int64_t s) : h(hh) { h->solve_mask = m; h->solve_mask_stride = s; }
+      ~MaskScope() { h->solve_mask = nullptr; h->solve_mask_stride = 0; }
+    } mask_scope(h, prm.iwork + ix.flags, int64_t(ix.total));
     if (n <= 128) {   // the workgroup LDL^T: one workgroup per matrix, the same arithmetic whatever the batch
       if (int rc = toa_large_solve(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok)) { rc_all = rc; break; }
     } else {

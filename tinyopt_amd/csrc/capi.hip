@@ -322,6 +322,8 @@ int toa_destroy(toa_handle h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->memo) (void)hipFree(h->memo);
   if (h->aux) (void)hipFree(h->aux);
+  if (h->pass_flags) (void)hipHostFree(h->pass_flags);
+  for (hipEvent_t e : h->pass_done) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < h->nside; ++i) {
     if (h->side_blas[i] && h->blas_destroy) (void)h->blas_destroy(h->side_blas[i]);
     if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);

@@ -2136,6 +2136,16 @@ struct toa_context {
   size_t memo_bytes = 0;
   void* aux = nullptr;         // bundle adjustment with visibility lists: its work arrays (`scratch` belongs to the solver it calls)
   size_t aux_bytes = 0;
+  // launch-per-stage pipelines (BA lists, n > 128): the ring through which the host reads "is anything still running" a few
+  // passes late — pinned flags + one event per slot, created on first use and kept (hipHostMalloc costs ~1 ms per call)
+  // set by a pipeline around its toa_large_solve call (bundle adjustment with lists): matrix p is factorised only where
+  // solve_mask[p * solve_mask_stride] != 0 — the workgroups of finished scenes leave at once (own kernels only; the library
+  // path solves everything, as before).  Device pointer; NULL = solve all.
+  const int32_t* solve_mask = nullptr;
+  int64_t solve_mask_stride = 0;
+  static constexpr int kPassRing = 4;
+  int* pass_flags = nullptr;   // [kPassRing][2], pinned host memory
+  hipEvent_t pass_done[kPassRing] = {};
   // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (toa_tuning::wide_graph)
   struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
   WideGraph wgraphs[16];
@@ -2230,6 +2240,13 @@ inline int upload_params(toa_handle h, const void* blk, size_t bytes) {
   HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
   std::memcpy(h->params_shadow, blk, bytes);
   h->params_shadow_bytes = bytes;
+  return TOA_OK;
+}
+
+inline int ensure_pass_ring(toa_handle h) {
+  if (h->pass_flags) return TOA_OK;
+  for (int i = 0; i < toa_context::kPassRing; ++i) HIP_TRY(hipEventCreateWithFlags(&h->pass_done[i], hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pass_flags), toa_context::kPassRing * 2 * sizeof(int), hipHostMallocDefault));
   return TOA_OK;
 }
 

@@ -140,8 +140,14 @@ __global__ void __launch_bounds__(256) large_damp_kernel(const T* __restrict__ H
 // dx = -solution where the factorisation succeeded and the solution is finite; ok flags as on the small-n path
 template <typename T>
 __global__ void __launch_bounds__(256) large_finish_kernel(const T* __restrict__ sol, const int* __restrict__ info,
-                                                           T* __restrict__ dx, int32_t* __restrict__ ok, const int n) {
+                                                           T* __restrict__ dx, int32_t* __restrict__ ok, const int n,
+                                                           const int* __restrict__ active = nullptr) {
   const size_t p = blockIdx.x;
+  if (active && !active[p]) {   // a masked-out matrix was not factorised: no step, no verdict
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dx[p * n + i] = T(0);
+    if (threadIdx.x == 0) ok[p] = 0;
+    return;
+  }
   __shared__ int bad;
   if (threadIdx.x == 0) bad = info[p] != 0;
   __syncthreads();
@@ -1305,19 +1311,13 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // The at most kAhead surplus passes after the last problem has finished are launches of kernels that return at once.
   // With a LIBRARY stage in the pass (rocBLAS GEMM sized by want_j, rocSOLVER over all P matrices) the pass-by-pass
   // hand-shake stays: a surplus library pass would cost more than the read-back.
-  constexpr int kAhead = 2, kRing = 4;
+  constexpr int kAhead = 2, kRing = toa_context::kPassRing;
   const bool ahead = own_gram && (own_chol || own_chol2);
-  struct Ring {
-    hipEvent_t done[kRing] = {};
-    int* host = nullptr;   // [kRing][2], pinned
-    ~Ring() {
-      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-      if (host) (void)hipHostFree(host);
-    }
-  } ring;
+  struct Ring { hipEvent_t* done = nullptr; int* host = nullptr; } ring;   // the handle's pinned ring + events (kept across calls)
   if (ahead) {
-    for (int i = 0; i < kRing; ++i) HIP_TRY(hipEventCreateWithFlags(&ring.done[i], hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ring.host), kRing * 2 * sizeof(int), hipHostMallocDefault));
+    if (int rc = ensure_pass_ring(h)) return rc;
+    ring.done = h->pass_done;
+    ring.host = h->pass_flags;
   }
   long long pass = 0;
   for (; pass < max_passes && active > 0; ++pass) {
@@ -1417,9 +1417,10 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
 
 // The K3 seam (toa_solve_damped) for 64 <= n <= 128 on the workgroup LDL^T above instead of the library.
 template <typename T>
-__global__ void __launch_bounds__(256) large_fill_ones_kernel(int* __restrict__ v, const long long count) {
+__global__ void __launch_bounds__(256) large_fill_ones_kernel(int* __restrict__ v, const long long count,
+                                                              const int32_t* __restrict__ mask, const long long mask_stride) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i < count) v[i] = 1;
+  if (i < count) v[i] = mask ? (mask[i * mask_stride] != 0) : 1;
 }
 
 template <typename T>
@@ -1436,16 +1437,18 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
   a.work = reinterpret_cast<T*>(base);
   a.rhs = reinterpret_cast<T*>(base + b_work);
   a.info = reinterpret_cast<int*>(base + b_work + b_rhs);
-  a.active = reinterpret_cast<int*>(base + b_work + b_rhs + b_i);  // every matrix is solved
+  a.active = reinterpret_cast<int*>(base + b_work + b_rhs + b_i);  // every matrix is solved, unless the caller masks some out
   a.built = a.active;
   const size_t chol_lds = n <= 128 ? ldlt_image_bytes<T>(n) : chol_solve_lds_bytes<T>(n);
   if (int rc = ensure_lds_attr(h, n <= 128 ? ldlt_solve_fn<T>(n) : (const void*)large_chol_solve_kernel<T>, chol_lds)) return rc;
-  hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P);
+  hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P,
+                     h->solve_mask, (long long)h->solve_mask_stride);
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
   if (n <= 128) launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
   else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(kCholThreads), chol_lds, h->stream, a);
-  hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n);
+  hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n,
+                     (const int*)a.active);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
