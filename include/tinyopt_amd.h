@@ -317,9 +317,12 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      kernel of the DenseRow families parks the Gram registers of every accepted point (one slot per resident wave) and,
  *      when the roll-back restored x BIT FOR BIT, reads them back instead of streaming the rows again; g, H and the cost
  *      are the bits a second pass would have produced (tests/test_gpu_memo.py; toa_tuning::memo_off switches the memo off).
- *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128: that
- *      regime reads two integers back per pass (it blocks the host and cannot be captured in a hipGraph); 64 <= n <= 128
- *      is one persistent kernel like the rest. */
+ *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128 (a launch per stage): the
+ *      host enqueues two passes ahead and waits for the (active, want-Jacobian) pair of pass k only before it enqueues pass
+ *      k + 2 where every stage is a kernel of this library (fp32, 16-byte aligned rows, n <= 1024) — the call returns when
+ *      the solve is done and cannot be captured in a hipGraph; with a library stage in the pass (fp64 / odd shapes: rocBLAS
+ *      GEMM, rocSOLVER beyond the LDS) the pair is read back after every pass.  64 <= n <= 128 is one persistent kernel
+ *      like the rest. */
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                const void* data_dev, void* x_dev, const toa_options* options,
                const toa_results* results, uint64_t* counters_dev);
@@ -335,6 +338,11 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
  *                      problems get their full results exactly as in toa_lm_run and are skipped by later calls,
  *                      running ones report num_iters / final_cost so far with stop_reason == kNone;
  *                      active_dev (optional, int32, zeroed by the caller) += 1 per problem still running.
+ *      Every family steps.  TOA_MODEL_DENSE_ROW_NATURAL (64 <= n <= 1024) steps on the launch-per-stage kernels of
+ *      csrc/large_n.hip whatever n is (bit for bit what toa_lm_run gives through that pipeline —
+ *      toa_tuning::large_pipeline; the one-kernel form of 64 <= n <= 128 sums in another order): at most 65 535 problems per
+ *      call, no handle loss, and toa_lm_step reads three integers back (a solve that failed and is retried with a larger
+ *      damping stays inside its iteration, optimizer.h:370-390: the retry passes need a count), so it blocks the host.
  */
 size_t toa_lm_state_bytes(int dtype, int n, int64_t P);
 int toa_lm_begin(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,

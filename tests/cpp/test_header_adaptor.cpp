@@ -72,10 +72,30 @@ static void large_block() {
   }
   Context ctx(0);
   DenseRowNatural<double> cost(ctx, P, n, m, data.data());
+  const std::vector<double> x_start = x;
   const auto out = Optimize(x, cost, Options());
   for (int p = 0; p < P; ++p) {
     REQUIRE(out.Succeeded(p));
     for (int j = 0; j < n; ++j) REQUIRE(std::abs(x[p * n + j] - xs[p * n + j]) < 1e-7);
+  }
+  // the stepping form and the host-side stop controls at this size (optimizer.h:302-305,529-534): a callback that stops
+  // everything after the second iteration
+  std::vector<double> x2 = x_start;
+  Options o2;
+  int calls = 0;
+  o2.stop_callback = [&](double err, double dx2, double g2) { ++calls; return err >= 0 && dx2 >= 0 && g2 > 0 && calls > P; };
+  const auto out2 = Optimize(x2, cost, o2);
+  for (int p = 0; p < P; ++p) {
+    REQUIRE(out2.stop_reason[p] == kUserStopped);
+    REQUIRE(out2.num_iters[p] == 2);
+  }
+  REQUIRE(calls == 2 * P);
+  std::vector<double> x3 = x_start;
+  Optimizer<double, DenseRowNatural<double>> optimizer(x3, cost, Options());
+  const auto out3 = optimizer();
+  for (int p = 0; p < P; ++p) {
+    REQUIRE(out3.stop_reason[p] == out.stop_reason[p]);
+    for (int j = 0; j < n; ++j) REQUIRE(std::abs(x3[p * n + j] - x[p * n + j]) < 1e-9);
   }
 }
 

@@ -241,6 +241,12 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
 int toa_large_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H, void* C, int32_t* ok);
 int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                      const toa_results* results, uint64_t* counters);
+size_t toa_large_state_bytes(int dtype, int n, int64_t P);
+int toa_large_lm_step(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                      const toa_results* results, uint64_t* counters, int mode, void* state, int32_t* active_dev,
+                      const int32_t* stop_request);
+int toa_large_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state, double* err, double* dx2, double* g2,
+                        void* dx_out, void* g_out);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
                    void* dx, int32_t* ok) {
   return dtag == 0 ? toa_inst_solve_0_0(npad, h, n, P, H, g, scale, dx, ok)
@@ -679,7 +685,8 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
     if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
     if (P < 0) return fail(TOA_E_ARG, "P must be >= 0");   // (no upper limit: the launch-per-stage pipeline takes 65 535 problems per slice)
     if (!data) return fail(TOA_E_ARG, "null data pointer");
-    if (mode != 0 || splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: toa_lm_run only");
+    if (splits >= 0) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: no row-split form");
+    if (mode != 0 && n < 64) return fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_NATURAL: the stepping form starts at n = 64 (use TOA_MODEL_DENSE_ROW below)");
   } else {
     if (int rc = check_shape(dtype, n, m, P)) return rc;
     if (int rc = check_model(model, n, m, data)) return rc;
@@ -698,6 +705,11 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (natural) {
     if (h->loss != TOA_LOSS_L2 && !(options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)))   // never silently: not wired into the launch-per-stage pipeline
       return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is available for TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 only");
+    if (mode != 0) {   // the stepping form runs on the launch-per-stage pipeline for every n >= 64 (large_n.hip)
+      if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
+      if (h->loss != TOA_LOSS_L2) return fail(TOA_E_UNSUPPORTED, "toa_lm_step: toa_set_loss is not available in the stepping form at n >= 64");
+      return toa_large_lm_step(h, dtype, n, m, P, data, x, options, results, counters, mode, state, active, stop_request);
+    }
     return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   }
   FusedParams prm;
@@ -773,6 +785,7 @@ int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P, cons
 
 size_t toa_lm_state_bytes(int dtype, int n, int64_t P) {
   if (P < 0 || n < 1) return 0;
+  if (n >= 64) return toa_large_state_bytes(dtype, n, P);   // TOA_MODEL_DENSE_ROW_NATURAL (the only family that wide)
   return dtype == TOA_F32 ? toa::stepping_state_bytes<float>(n, P) : toa::stepping_state_bytes<double>(n, P);
 }
 
@@ -797,6 +810,12 @@ int toa_lm_stop(toa_handle h, int model, int dtype, int n, int m, int64_t P, con
 int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state_dev, double* err_dev, double* dx_norm2_dev,
                      double* grad_norm2_dev, void* dx_dev, void* g_dev) {
   if (!h || !state_dev) return fail(TOA_E_ARG, "toa_lm_step_info: null argument");
+  if (n >= 64) {
+    if ((dtype != TOA_F32 && dtype != TOA_F64) || n > 1024 || P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_lm_step_info: bad shape");
+    if (P == 0) return TOA_OK;
+    TOA_ON_DEVICE(h->device);
+    return toa_large_step_info(h, dtype, n, P, state_dev, err_dev, dx_norm2_dev, grad_norm2_dev, dx_dev, g_dev);
+  }
   if (int rc = check_shape(dtype, n, 1, P)) return rc;
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);

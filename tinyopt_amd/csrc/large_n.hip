@@ -327,6 +327,13 @@ struct LargeArgs {
   T* sc;        // [P][m]
   T* gram_part; // [P][gram_R][tiles of the lower triangle][32 * 32]
   int own_gram, gram_R, gram_rows;   // row chunks per problem, rows per chunk (a multiple of 4)
+  // stepping form (toa_lm_begin / toa_lm_step / toa_lm_stop): one ITERATION per call.  A solver failure that is retried with a
+  // larger damping stays inside its iteration (optimizer.h:370-390), so a step is one pass plus, rarely, retry passes that
+  // only the problems still owing their iteration take part in: stepped [p] = 1 once problem p has had its iteration.
+  int* stepped;                   // [P], NULL outside the stepping form
+  int32_t* active_out;            // optional: += 1 per problem still running after its iteration
+  const int32_t* stop_request;    // toa_lm_stop: [P] StopReason to impose (0 = none)
+  __device__ __forceinline__ bool on(const long long p) const { return active[p] != 0 && !(stepped && stepped[p] != 0); }
 };
 
 template <typename T>
@@ -366,7 +373,7 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
   extern __shared__ char lds_raw[];
   T* xs = reinterpret_cast<T*>(lds_raw);
   const long long p = blockIdx.y;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   const LmState<T>& S = a.st[p];
   const bool want_j = a.opt.solver_type != 0 || S.rebuild;
   const int n = a.n, m = a.m;
@@ -417,7 +424,7 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
   extern __shared__ char lds_raw[];
   T* xs = reinterpret_cast<T*>(lds_raw);
   const long long p = blockIdx.y;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   const LmState<T>& S = a.st[p];
   const bool want_j = a.opt.solver_type != 0 || S.rebuild;
   const int n = a.n, m = a.m, nv = n / VEC;
@@ -574,7 +581,7 @@ __global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, 
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char syrk_lds[];
   const long long p = blockIdx.y;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
   const int n = a.n, m = a.m, ns = geo.ns, K = geo.K;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -661,7 +668,7 @@ __global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, 
 template <typename T>
 __global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
   const long long p = blockIdx.y;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
   const int n = a.n;
   const int t = blockIdx.x;
@@ -682,11 +689,11 @@ __global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<
 // Pointer lists for the batched GEMM: only the problems that are still running AND rebuild their Hessian this pass
 // (index order: deterministic).  The host knows their count from the previous pass's read-back.
 template <typename T>
-__global__ void __launch_bounds__(256) large_compact_kernel(const LargeArgs<T> a) {
+__global__ void __launch_bounds__(256) large_compact_kernel(const LargeArgs<T> a, int* __restrict__ count_out = nullptr) {
   __shared__ int cnt[256];
   const int tid = threadIdx.x;
   const long long per = (a.P + 255) / 256, lo = tid * per, hi = lo + per < a.P ? lo + per : a.P;
-  auto want = [&](long long p) { return a.active[p] && (a.opt.solver_type != 0 || a.st[p].rebuild); };
+  auto want = [&](long long p) { return a.on(p) && (a.opt.solver_type != 0 || a.st[p].rebuild); };
   int c = 0;
   for (long long p = lo; p < hi; ++p) c += want(p) ? 1 : 0;
   cnt[tid] = c;
@@ -694,6 +701,7 @@ __global__ void __launch_bounds__(256) large_compact_kernel(const LargeArgs<T> a
   if (tid == 0) {
     int run = 0;
     for (int t = 0; t < 256; ++t) { const int v = cnt[t]; cnt[t] = run; run += v; }
+    if (count_out) *count_out = run;
   }
   __syncthreads();
   int off = cnt[tid];
@@ -708,7 +716,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   __shared__ double red[256];
   __shared__ int sh_built;
   const long long p = blockIdx.x;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   LmState<T>& S = a.st[p];
   const toa_options& opt = a.opt;
   const int n = a.n, m = a.m, tid = threadIdx.x;
@@ -765,7 +773,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
 template <typename T>
 __global__ void __launch_bounds__(256) large_stage_kernel(const LargeArgs<T> a, const int rows_per_slice) {
   const long long p = blockIdx.y;
-  if (!a.active[p] || !a.built[p]) return;
+  if (!a.on(p) || !a.built[p]) return;
   const int n = a.n, tid = threadIdx.x;
   const bool do_acc = (a.built[p] & 2) != 0, built = (a.built[p] & 1) != 0;
   T* H = a.H + size_t(p) * n * n;
@@ -805,7 +813,7 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
   T* M = reinterpret_cast<T*>(lds_raw);  // n x (n | 1) image, factored in place
   __shared__ T dinv[16 * NB], sol[16 * NB];
   const size_t p = blockIdx.x;
-  if (!a.active[p] || !(a.built[p] & 1)) return;
+  if (!a.on(p) || !(a.built[p] & 1)) return;
   const int n = a.n, LD = n | 1, tid = threadIdx.x;
   const T* Wp = a.work + p * size_t(n) * n;
   for (int e = tid; e < n * n; e += 256) {
@@ -856,7 +864,7 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   T* ys = Lp + size_t(a.n) * LSP;                  // [n]       right-hand side / solution (+ 64 scratch entries, + 32 reciprocals of the block's diagonal)
   __shared__ int fail;
   const size_t p = blockIdx.x;
-  if (!a.active[p] || !(a.built[p] & 1)) return;
+  if (!a.on(p) || !(a.built[p] & 1)) return;
   const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* A = a.work + p * size_t(n) * n;
   for (int i = tid; i < n; i += NT) ys[i] = a.rhs[p * n + i];
@@ -1087,13 +1095,51 @@ void launch_ldlt_solve(int n, unsigned P, size_t lds, hipStream_t st, const Larg
   }
 }
 
+// optimizer.h:313-327: problem p is done — the undamped Hessian, the results row, the counters (a whole 256-thread workgroup)
+template <typename T>
+__device__ void large_finish_problem(const LargeArgs<T>& a, const long long p) {
+  LmState<T>& S = a.st[p];
+  const toa_options& opt = a.opt;
+  const toa_results& res = a.res;
+  const int n = a.n, tid = threadIdx.x;
+  if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
+    double* Hout = res.final_hessian + size_t(p) * n * n;
+    const T* H = a.H + size_t(p) * n * n;
+    const T* hd = a.hd + p * n;
+    for (size_t e = tid; e < size_t(n) * n; e += 256) {
+      const int i = int(e / n), j = int(e % n);
+      T v = H[e];
+      if (i == j) { v = hd[i]; if (opt.solver_type == 0 && S.prev_lambda > T(0)) v = v / (T(1.0f) + S.prev_lambda); }
+      Hout[e] = double(v);
+    }
+  }
+  if (tid == 0) {
+    if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
+    res.stop_reason[p] = S.stop;
+    res.num_iters[p] = S.num_iters;
+    res.final_cost[p] = S.final_cost;
+    if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+    if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+    if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
+    if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+    a.active[p] = 0;
+    if (a.counters) {
+      atomicAdd(&a.counters[0], S.acc_passes);
+      atomicAdd(&a.counters[1], S.eval_passes);
+      atomicAdd(&a.counters[2], S.solves);
+      atomicAdd(&a.counters[3], 1ull);
+    }
+  }
+}
+
 // the rest of Step and of the loop body; finalisation of problems that stop
 template <typename T>
 __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, int* __restrict__ summary) {
   __shared__ double red[256];
-  __shared__ int sh_action, sh_cont;
+  __shared__ int sh_action, sh_cont, sh_retry;
   const long long p = blockIdx.x;
-  if (!a.active[p]) return;
+  if (!a.on(p)) return;
   LmState<T>& S = a.st[p];
   const toa_options& opt = a.opt;
   const toa_results& res = a.res;
@@ -1163,53 +1209,100 @@ __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, i
     }
     sh_action = action;
     sh_cont = cont;
+    sh_retry = rc < 0 ? 1 : 0;
   }
   __syncthreads();
   const int action = sh_action;
   if (action == 1) for (int i = tid; i < n; i += 256) { const T d = dx[i]; x[i] += d; ldx[i] = d; }  // traits.h:184-190
   if (action == 2) for (int i = tid; i < n; i += 256) x[i] -= ldx[i];
+  const bool retry = sh_retry != 0;
   if (sh_cont) {
     if (tid == 0) {
       atomicAdd(&summary[0], 1);
       if (opt.solver_type != 0 || S.rebuild) atomicAdd(&summary[1], 1);
+      if (a.stepped) {   // stepping form: the iteration is over unless the solve is being retried
+        if (retry) atomicAdd(&summary[2], 1);
+        else {
+          a.stepped[p] = 1;   // (every thread read on(p) before the barrier above)
+          res.stop_reason[p] = TOA_STOP_NONE;   // running: the results so far (toa_lm_step's contract)
+          res.num_iters[p] = S.num_iters;
+          res.final_cost[p] = S.final_cost;
+          if (res.num_failures) res.num_failures[p] = int(S.num_failures);
+          if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
+          if (a.active_out) atomicAdd(a.active_out, 1);
+        }
+      }
     }
     return;
   }
-  // ---- optimizer.h:313-327: the problem is done
-  if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
-    double* Hout = res.final_hessian + size_t(p) * n * n;
-    const T* H = a.H + size_t(p) * n * n;
-    const T* hd = a.hd + p * n;
-    for (size_t e = tid; e < size_t(n) * n; e += 256) {
-      const int i = int(e / n), j = int(e % n);
-      T v = H[e];
-      if (i == j) { v = hd[i]; if (opt.solver_type == 0 && S.prev_lambda > T(0)) v = v / (T(1.0f) + S.prev_lambda); }
-      Hout[e] = double(v);
-    }
+  large_finish_problem<T>(a, p);
+}
+
+
+// toa_lm_stop for this pipeline: end the running problems p with stop_request [p] != 0 with that StopReason
+// (optimizer.h:302-305,529-534); their rows are finalised exactly as for a problem that stops by itself.
+template <typename T>
+__global__ void __launch_bounds__(256) large_stop_kernel(const LargeArgs<T> a) {
+  const long long p = blockIdx.x;
+  if (!a.active[p]) return;
+  const int req = a.stop_request[p];
+  if (req == TOA_STOP_NONE) return;
+  if (threadIdx.x == 0) a.st[p].stop = req;
+  __syncthreads();
+  large_finish_problem<T>(a, p);
+}
+
+// What the stepping form keeps between calls (toa_lm_state_bytes at n >= 64): the scalar state, the running flags, and the
+// linearisation an eval-only iteration keeps solving with (g, diag H, H — lm.h:96-117) plus the last steps (roll-back).
+template <typename T>
+struct LargeStateLayout {
+  size_t st, active, built, g, hd, dx, ldx, H, total;
+  __host__ __device__ LargeStateLayout(int n, long long P) {
+    auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_vec = al(size_t(P) * n * sizeof(T));
+    size_t o = 0;
+    st = o; o += al(size_t(P) * sizeof(LmState<T>));
+    active = o; o += al(size_t(P) * sizeof(int));
+    built = o; o += al(size_t(P) * sizeof(int));
+    g = o; o += b_vec; hd = o; o += b_vec; dx = o; o += b_vec; ldx = o; o += b_vec;
+    H = o; o += al(size_t(P) * n * n * sizeof(T));
+    total = o;
   }
-  if (tid == 0) {
-    if (S.stop == TOA_STOP_NONE && S.num_iters >= S.max_iters) S.stop = TOA_STOP_MAX_ITERS;  // :320-321
-    res.stop_reason[p] = S.stop;
-    res.num_iters[p] = S.num_iters;
-    res.final_cost[p] = S.final_cost;
-    if (res.num_failures) res.num_failures[p] = int(S.num_failures);
-    if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
-    if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
-    if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
-    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
-    a.active[p] = 0;
-    if (a.counters) {
-      atomicAdd(&a.counters[0], S.acc_passes);
-      atomicAdd(&a.counters[1], S.eval_passes);
-      atomicAdd(&a.counters[2], S.solves);
-      atomicAdd(&a.counters[3], 1ull);
-    }
+};
+
+// toa_lm_step_info for that state block: cost, |dx|^2, |g|^2 (the arithmetic of large_post_kernel) and the two vectors
+template <typename T>
+__global__ void __launch_bounds__(256) large_step_info_kernel(const char* __restrict__ state, const long long P, const int n,
+                                                              double* __restrict__ err, double* __restrict__ dx2,
+                                                              double* __restrict__ g2, T* __restrict__ dx_out, T* __restrict__ g_out) {
+  __shared__ double red[256];
+  const long long p = blockIdx.x;
+  const LargeStateLayout<T> lay(n, P);
+  const LmState<T>& S = reinterpret_cast<const LmState<T>*>(state + lay.st)[p];
+  const T* dx = reinterpret_cast<const T*>(state + lay.dx) + p * n;
+  const T* g = reinterpret_cast<const T*>(state + lay.g) + p * n;
+  double sd = 0, sg = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const T d = dx[i], gi = g[i];
+    sd += double(d * d);
+    sg += double(gi * gi);
+    if (dx_out) dx_out[p * n + i] = d;
+    if (g_out) g_out[p * n + i] = gi;
+  }
+  sd = double(T(block_sum<T>(sd, red)));
+  sg = double(T(block_sum<T>(sg, red)));
+  if (threadIdx.x == 0) {
+    if (err) err[p] = S.cost_val;
+    if (dx2) dx2[p] = sd;
+    if (g2) g2[p] = sg;
   }
 }
 
+// mode 0: the whole solve.  1 / 2 / 3: toa_lm_begin / toa_lm_step / toa_lm_stop on `state` (LargeStateLayout).
 template <typename T>
 int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
-                   const toa_results& res, uint64_t* counters) {
+                   const toa_results& res, uint64_t* counters, int mode = 0, void* state = nullptr,
+                   int32_t* active_dev = nullptr, const int32_t* stop_request = nullptr) {
   const size_t nn = size_t(n) * n;
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
@@ -1217,7 +1310,10 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const size_t b_st = al(size_t(P) * sizeof(LmState<T>)), b_i = al(size_t(P) * sizeof(int));
   const size_t b_vec = al(size_t(P) * n * sizeof(T)), b_mat = al(size_t(P) * nn * sizeof(T));
   const size_t b_J = al(size_t(P) * m * n * sizeof(T)), b_r = al(size_t(P) * m * sizeof(T));
-  const size_t b_sum = al(size_t(2) * sizeof(int) * size_t(max_passes + 1));
+  const bool stepping = mode != 0;
+  const LargeStateLayout<T> lay(n, P);
+  const long long step_passes = (long long)max_tries + 2;   // one iteration: a pass + its retries (optimizer.h:370-390)
+  const size_t b_sum = stepping ? al(size_t(4) * sizeof(int) * size_t(step_passes + 1)) : al(size_t(2) * sizeof(int) * size_t(max_passes + 1));
   // vectorised rows kernel (see large_rows_vec_kernel): geometry and the per-wave J^T r partials
   constexpr int VEC = 16 / int(sizeof(T));
   const bool vec_ok = n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
@@ -1255,20 +1351,25 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // not finite, as everywhere else in this path
   const bool lu = !opt.use_ldlt;
   const size_t b_piv = lu ? al(size_t(P) * n * sizeof(int)) : 0;
-  const size_t need = b_st + 3 * b_i + 6 * b_vec + 3 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv;
+  // what outlives a pass (LargeStateLayout) sits in the caller's state block in the stepping form, in the scratch otherwise
+  const size_t need = (stepping ? 0 : lay.total) + 2 * b_i + 2 * b_vec + 2 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
+  char* keep = stepping ? static_cast<char*>(state) : take(lay.total);
   LargeArgs<T> a;
   a.data = data; a.x = x; a.n = n; a.m = m; a.P = P; a.opt = opt; a.res = res;
   a.counters = reinterpret_cast<unsigned long long*>(counters);
-  a.st = reinterpret_cast<LmState<T>*>(take(b_st));
-  a.active = reinterpret_cast<int*>(take(b_i));
-  a.built = reinterpret_cast<int*>(take(b_i));
+  a.st = reinterpret_cast<LmState<T>*>(keep + lay.st);
+  a.active = reinterpret_cast<int*>(keep + lay.active);
+  a.built = reinterpret_cast<int*>(keep + lay.built);
+  a.g = reinterpret_cast<T*>(keep + lay.g); a.hd = reinterpret_cast<T*>(keep + lay.hd); a.dx = reinterpret_cast<T*>(keep + lay.dx);
+  a.ldx = reinterpret_cast<T*>(keep + lay.ldx); a.H = reinterpret_cast<T*>(keep + lay.H);
   a.info = reinterpret_cast<int*>(take(b_i));
-  a.g = reinterpret_cast<T*>(take(b_vec)); a.hd = reinterpret_cast<T*>(take(b_vec)); a.dx = reinterpret_cast<T*>(take(b_vec));
-  a.ldx = reinterpret_cast<T*>(take(b_vec)); a.gnew = reinterpret_cast<T*>(take(b_vec)); a.rhs = reinterpret_cast<T*>(take(b_vec));
-  a.H = reinterpret_cast<T*>(take(b_mat)); a.Hnew = reinterpret_cast<T*>(take(b_mat)); a.work = reinterpret_cast<T*>(take(b_mat));
+  a.stepped = stepping ? reinterpret_cast<int*>(take(b_i)) : (take(b_i), nullptr);
+  a.active_out = active_dev; a.stop_request = stop_request;
+  a.gnew = reinterpret_cast<T*>(take(b_vec)); a.rhs = reinterpret_cast<T*>(take(b_vec));
+  a.Hnew = reinterpret_cast<T*>(take(b_mat)); a.work = reinterpret_cast<T*>(take(b_mat));
   a.J = reinterpret_cast<T*>(take(b_Juse)); a.r = reinterpret_cast<T*>(take(b_r));
   a.sc = reinterpret_cast<T*>(take(b_sc)); a.gram_part = reinterpret_cast<T*>(take(b_gp));
   a.own_gram = own_gram ? 1 : 0; a.gram_R = gram_R; a.gram_rows = gram_rows;
@@ -1294,11 +1395,22 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   if (own_chol2) {
     if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T>, chol2_lds)) return rc;
   }
-  HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
-  HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
+  if (mode == 3) {   // toa_lm_stop
+    hipLaunchKernelGGL(large_stop_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  }
+  if (mode <= 1) {   // the whole solve, or toa_lm_begin: construct the state (no data pass)
+    HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
+    HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
+    HIP_TRY(hipMemsetAsync(a.g, 0, b_vec, st));
+    // counters ACCUMULATE on every path (fused, row-split, stepping, here): the caller zeroes them (include/tinyopt_amd.h)
+    hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    if (mode == 1) return TOA_OK;
+  }
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
-  // counters ACCUMULATE on every path (fused, row-split, stepping, here): the caller zeroes them (include/tinyopt_amd.h)
-  hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
+  if (stepping) HIP_TRY(hipMemsetAsync(a.stepped, 0, b_i, st));
   const T one = 1, zero = 0;
   // row slices of the n x n staging copies: ~8 workgroups per CU over the batch, at least 8 rows each
   const int stage_rows = int(std::max<long long>(8, (long long)n * P / std::max<long long>(1, (long long)h->num_cus * 8)));
@@ -1312,7 +1424,9 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   // With a LIBRARY stage in the pass (rocBLAS GEMM sized by want_j, rocSOLVER over all P matrices) the pass-by-pass
   // hand-shake stays: a surplus library pass would cost more than the read-back.
   constexpr int kAhead = 2, kRing = toa_context::kPassRing;
-  const bool ahead = own_gram && (own_chol || own_chol2);
+  const bool ahead = !stepping && own_gram && (own_chol || own_chol2);
+  const int sum_stride = stepping ? 4 : 2;   // the stepping form also counts the retries still owed (slot 2)
+  const long long pass_limit = stepping ? step_passes : max_passes;
   struct Ring { hipEvent_t* done = nullptr; int* host = nullptr; } ring;   // the handle's pinned ring + events (kept across calls)
   if (ahead) {
     if (int rc = ensure_pass_ring(h)) return rc;
@@ -1320,7 +1434,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
     ring.host = h->pass_flags;
   }
   long long pass = 0;
-  for (; pass < max_passes && active > 0; ++pass) {
+  for (; pass < pass_limit && active > 0; ++pass) {
     if (ahead && pass >= kAhead) {
       const int slot = int((pass - kAhead) % kRing);
       HIP_TRY(hipEventSynchronize(ring.done[slot]));
@@ -1356,7 +1470,16 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
         hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(geo.T), unsigned(P)), dim3(256), 0, st, a, geo);
       }
     } else if (want_j > 0) {
-      hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
+      if (stepping) {   // the host has no count from a previous pass here: the list's length comes back with it
+        int* cnt_dev = a.summary + sum_stride * pass + 3;
+        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a, cnt_dev);
+        HIP_TRY(hipMemcpyAsync(&want_j, cnt_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+      } else {
+        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
+      }
+    }
+    if (!own_gram && want_j > 0) {
       int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
       if constexpr (sizeof(T) == 4) {
         rc = api.sgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, a.jptr, n, a.jptr, n, &zero, a.hptr, n, want_j);
@@ -1391,7 +1514,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
       if (rc == 0) rc = api.dpotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
     }
     if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER potrf/potrs returned status " + std::to_string(rc));
-    int* sum_dev = a.summary + 2 * pass;
+    int* sum_dev = a.summary + sum_stride * pass;
     hipLaunchKernelGGL(large_post_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a, sum_dev);
     HIP_TRY(hipGetLastError());
     if (ahead) {
@@ -1399,13 +1522,19 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
       HIP_TRY(hipMemcpyAsync(ring.host + 2 * slot, sum_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(ring.done[slot], st));
     } else {
-      int sum_host[2];
-      HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, sizeof(sum_host), hipMemcpyDeviceToHost, st));
+      int sum_host[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, size_t(stepping ? 3 : 2) * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       active = sum_host[0];
       want_j = sum_host[1];
+      if (stepping) {   // another pass only for the problems whose solve is being retried
+        if (sum_host[2] == 0) return TOA_OK;
+        active = sum_host[2];
+        want_j = int(P);
+      }
     }
   }
+  if (stepping) return TOA_OK;   // (retries are bounded by max_tries inside the state machine)
   if (ahead && active > 0 && pass > 0) {   // the pass budget ran out before a zero was seen: the LAST pass decides
     HIP_TRY(hipStreamSynchronize(st));
     active = ring.host[2 * int((pass - 1) % kRing)];
@@ -1518,6 +1647,37 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
     if (rc != TOA_OK) return rc;
     if (P <= 0) break;
   }
+  return TOA_OK;
+}
+
+// The stepping form at n >= 64 (toa_lm_begin / toa_lm_step / toa_lm_stop, capi.hip): mode 1 / 2 / 3 on the launch-per-stage
+// pipeline — every n >= 64, either solver flavour — with what outlives a pass kept in the caller's state block.
+size_t toa_large_state_bytes(int dtype, int n, int64_t P) {
+  return dtype == TOA_F32 ? toa::LargeStateLayout<float>(n, P).total : toa::LargeStateLayout<double>(n, P).total;
+}
+
+int toa_large_lm_step(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
+                      const toa_results* results, uint64_t* counters, int mode, void* state, int32_t* active_dev,
+                      const int32_t* stop_request) {
+  if (P > 65535) return toa_fail(TOA_E_UNSUPPORTED, "stepping form at n >= 64: at most 65 535 problems per call");
+  toa::RocApi& api = toa::roc_api();
+  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
+  if (dtype == TOA_F32)
+    return toa::large_lm_run_t<float>(h, api, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options, *results,
+                                      counters, mode, state, active_dev, stop_request);
+  return toa::large_lm_run_t<double>(h, api, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results,
+                                     counters, mode, state, active_dev, stop_request);
+}
+
+int toa_large_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state, double* err, double* dx2, double* g2,
+                        void* dx_out, void* g_out) {
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::large_step_info_kernel<float>, dim3(unsigned(P)), dim3(256), 0, h->stream, static_cast<const char*>(state),
+                       (long long)P, n, err, dx2, g2, static_cast<float*>(dx_out), static_cast<float*>(g_out));
+  else
+    hipLaunchKernelGGL(toa::large_step_info_kernel<double>, dim3(unsigned(P)), dim3(256), 0, h->stream, static_cast<const char*>(state),
+                       (long long)P, n, err, dx2, g2, static_cast<double*>(dx_out), static_cast<double*>(g_out));
+  HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
 
