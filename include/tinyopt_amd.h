@@ -188,7 +188,8 @@ typedef struct toa_tuning {
   int32_t large_library_gram;    /* n > 128: rocBLAS batched GEMM instead of the hand-written MFMA Gram */
   int32_t large_library_solver;  /* rocSOLVER potrf / potrs wherever a solver of our own would run (also toa_solve_damped for n <= 63) */
   int32_t fail_workspace_alloc;  /* TEST HOOK: the n > 128 workspace request fails as on a full device (kOutOfMemory path) */
-  int32_t reserved[18];
+  int32_t large_one_lane;        /* n > 128, own kernels: the whole batch on one stream instead of two half-batch lanes (same bits) */
+  int32_t reserved[17];
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
 int toa_get_tuning(toa_handle h, toa_tuning* out);

@@ -443,3 +443,27 @@ def test_blocked_cholesky_failure_and_batch_independence(ta):
         dq, okq = ta.solve_damped(Hd[q:q + 1].contiguous(), gd[q:q + 1].contiguous(), 1.0)
         torch.cuda.synchronize()
         assert int(okq[0]) == 1 and torch.equal(dq[0], dx[q])
+
+
+@pytest.mark.parametrize("P,n,m", [(17, 160, 480), (32, 256, 1024)])
+def test_two_lanes_give_the_bits_of_one_lane(ta, oracle, P, n, m):
+    """n > 128 with every stage a kernel of ours: the batch runs as two half-batch lanes on two streams (one lane's
+    factorisations beside the other lane's Gram).  The geometry is that of the whole batch, so nothing a problem computes
+    depends on the split — same x, same trajectories, bit for bit, as toa_tuning::large_one_lane."""
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, np.float32, seed=n + P)
+    A[3, :, 5] = 0.0   # one problem that fails its solves (retries, an early end): the lanes finish at different passes
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    ctx = ta.api.default_context()
+    outs = []
+    for one_lane in (1, 0, 0):
+        x = torch.from_numpy(x0.copy()).cuda()
+        with ctx.tuning(large_one_lane=one_lane):
+            out = ta.Optimize(x, model, ta.Options(), history=True)
+        torch.cuda.synchronize()
+        outs.append((x, out))
+    for x, out in outs[1:]:
+        assert torch.equal(x, outs[0][0])
+        for f in ("stop_reason", "num_iters", "final_cost", "num_failures", "errs", "deltas2", "successes", "final_hessian"):
+            assert torch.equal(getattr(out, f), getattr(outs[0][1], f)), f
+        assert torch.equal(out.counters[:4], outs[0][1].counters[:4])
+    assert int(outs[0][1].num_iters.max()) > int(outs[0][1].num_iters.min())

@@ -330,6 +330,10 @@ int toa_destroy(toa_handle h) {
   if (h->aux) (void)hipFree(h->aux);
   if (h->pass_flags) (void)hipHostFree(h->pass_flags);
   for (hipEvent_t e : h->pass_done) if (e) (void)hipEventDestroy(e);
+  if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
+  for (hipEvent_t e : h->lane_gram) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->lane_join) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t s : h->lane_stream) if (s) (void)hipStreamDestroy(s);
   for (int i = 0; i < h->nside; ++i) {
     if (h->side_blas[i] && h->blas_destroy) (void)h->blas_destroy(h->side_blas[i]);
     if (h->side_done[i]) (void)hipEventDestroy(h->side_done[i]);

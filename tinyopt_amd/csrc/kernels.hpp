@@ -2143,9 +2143,11 @@ struct toa_context {
   // path solves everything, as before).  Device pointer; NULL = solve all.
   const int32_t* solve_mask = nullptr;
   int64_t solve_mask_stride = 0;
-  static constexpr int kPassRing = 4;
-  int* pass_flags = nullptr;   // [kPassRing][2], pinned host memory
-  hipEvent_t pass_done[kPassRing] = {};
+  static constexpr int kPassRing = 4, kLanes = 4;   // (lanes: the n > 128 pipeline runs the batch as up to four lanes on as many streams)
+  int* pass_flags = nullptr;   // [kLanes][kPassRing][2], pinned host memory
+  hipEvent_t pass_done[kLanes * kPassRing] = {};
+  hipStream_t lane_stream[kLanes - 1] = {};
+  hipEvent_t lane_fork = nullptr, lane_join[kLanes - 1] = {}, lane_gram[kLanes * kPassRing] = {};
   // row-split path: optional hipGraph of the (init, [partial, step] x iters) launch sequence (toa_tuning::wide_graph)
   struct WideGraph { const void* k_init; const void* k_part; const void* k_step; unsigned g_p, g_u; size_t lds; int iters; hipGraphExec_t exec; };
   WideGraph wgraphs[16];
@@ -2245,8 +2247,13 @@ inline int upload_params(toa_handle h, const void* blk, size_t bytes) {
 
 inline int ensure_pass_ring(toa_handle h) {
   if (h->pass_flags) return TOA_OK;
-  for (int i = 0; i < toa_context::kPassRing; ++i) HIP_TRY(hipEventCreateWithFlags(&h->pass_done[i], hipEventDisableTiming));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pass_flags), toa_context::kPassRing * 2 * sizeof(int), hipHostMallocDefault));
+  constexpr int kSlots = toa_context::kPassRing * toa_context::kLanes;
+  for (int i = 0; i < kSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&h->pass_done[i], hipEventDisableTiming));
+  for (hipStream_t& s : h->lane_stream) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+  for (hipEvent_t& e : h->lane_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t& e : h->lane_gram) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pass_flags), kSlots * 2 * sizeof(int), hipHostMallocDefault));
   return TOA_OK;
 }
 

@@ -1313,7 +1313,7 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const bool stepping = mode != 0;
   const LargeStateLayout<T> lay(n, P);
   const long long step_passes = (long long)max_tries + 2;   // one iteration: a pass + its retries (optimizer.h:370-390)
-  const size_t b_sum = stepping ? al(size_t(4) * sizeof(int) * size_t(step_passes + 1)) : al(size_t(2) * sizeof(int) * size_t(max_passes + 1));
+  const size_t b_sum = stepping ? al(size_t(4) * sizeof(int) * size_t(step_passes + 1)) : al(size_t(2) * sizeof(int) * size_t(max_passes + 1) * toa_context::kLanes);
   // vectorised rows kernel (see large_rows_vec_kernel): geometry and the per-wave J^T r partials
   constexpr int VEC = 16 / int(sizeof(T));
   const bool vec_ok = n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
@@ -1414,7 +1414,6 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const T one = 1, zero = 0;
   // row slices of the n x n staging copies: ~8 workgroups per CU over the batch, at least 8 rows each
   const int stage_rows = int(std::max<long long>(8, (long long)n * P / std::max<long long>(1, (long long)h->num_cus * 8)));
-  int active = int(P), want_j = int(P);
   // Round 4: where every stage of a pass is a kernel of ours (hand-written Gram + own Cholesky: fp32, aligned rows, n <= 1024)
   // nothing in a pass needs a host-side count, every kernel skips the problems that have finished, and each pass leaves its
   // (active, want-Jacobian) pair in its own slot of `summary` — so the host enqueues kAhead passes ahead and looks at pass
@@ -1427,101 +1426,96 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const bool ahead = !stepping && own_gram && (own_chol || own_chol2);
   const int sum_stride = stepping ? 4 : 2;   // the stepping form also counts the retries still owed (slot 2)
   const long long pass_limit = stepping ? step_passes : max_passes;
-  struct Ring { hipEvent_t* done = nullptr; int* host = nullptr; } ring;   // the handle's pinned ring + events (kept across calls)
-  if (ahead) {
-    if (int rc = ensure_pass_ring(h)) return rc;
-    ring.done = h->pass_done;
-    ring.host = h->pass_flags;
-  }
-  long long pass = 0;
-  for (; pass < pass_limit && active > 0; ++pass) {
-    if (ahead && pass >= kAhead) {
-      const int slot = int((pass - kAhead) % kRing);
-      HIP_TRY(hipEventSynchronize(ring.done[slot]));
-      active = ring.host[2 * slot];
-      if (active == 0) break;
-    }
-    const dim3 rgrid(row_blocks, unsigned(P));
+
+  // One pass of the loop body for the problems of `la` (the whole batch, or one lane's share of it) on stream ls
+  auto enqueue_pass = [&](const LargeArgs<T>& la, hipStream_t ls, const long long Pl, int* sum_dev, int& want_j,
+                          hipEvent_t wait_first = nullptr, hipEvent_t record_after_gram = nullptr) -> int {
+    if (wait_first) HIP_TRY(hipStreamWaitEvent(ls, wait_first, 0));
+    const dim3 rgrid(row_blocks, unsigned(Pl));
     const size_t xs_bytes = size_t(n) * sizeof(T);
     if (!vec_ok) {
-      hipLaunchKernelGGL(large_rows_kernel<T>, rgrid, dim3(256), xs_bytes, st, a);
+      hipLaunchKernelGGL(large_rows_kernel<T>, rgrid, dim3(256), xs_bytes, ls, la);
     } else {
       switch (KV) {
-        case 1: hipLaunchKernelGGL((large_rows_vec_kernel<T, 1>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 2: hipLaunchKernelGGL((large_rows_vec_kernel<T, 2>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 3: hipLaunchKernelGGL((large_rows_vec_kernel<T, 3>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 4: hipLaunchKernelGGL((large_rows_vec_kernel<T, 4>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 5: hipLaunchKernelGGL((large_rows_vec_kernel<T, 5>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 6: hipLaunchKernelGGL((large_rows_vec_kernel<T, 6>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        case 7: hipLaunchKernelGGL((large_rows_vec_kernel<T, 7>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
-        default: hipLaunchKernelGGL((large_rows_vec_kernel<T, 8>), rgrid, dim3(256), xs_bytes, st, a, LPR); break;
+        case 1: hipLaunchKernelGGL((large_rows_vec_kernel<T, 1>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 2: hipLaunchKernelGGL((large_rows_vec_kernel<T, 2>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 3: hipLaunchKernelGGL((large_rows_vec_kernel<T, 3>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 4: hipLaunchKernelGGL((large_rows_vec_kernel<T, 4>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 5: hipLaunchKernelGGL((large_rows_vec_kernel<T, 5>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 6: hipLaunchKernelGGL((large_rows_vec_kernel<T, 6>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        case 7: hipLaunchKernelGGL((large_rows_vec_kernel<T, 7>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
+        default: hipLaunchKernelGGL((large_rows_vec_kernel<T, 8>), rgrid, dim3(256), xs_bytes, ls, la, LPR); break;
       }
     }
     if (own_gram) {
       if constexpr (sizeof(T) == 4) {
-        const dim3 ggrid(unsigned(geo.groups * gram_R), unsigned(P)), gblock(unsigned(geo.waves * 64));
+        const dim3 ggrid(unsigned(geo.groups * gram_R), unsigned(Pl)), gblock(unsigned(geo.waves * 64));
         const size_t glds = size_t(2) * geo.K * geo.ns * sizeof(T) + 256;   // (+ the one-step over-read of the operand prefetch)
         switch (geo.tpw) {
-          case 1: hipLaunchKernelGGL((large_gram_kernel<T, 1>), ggrid, gblock, glds, st, a, geo); break;
-          case 2: hipLaunchKernelGGL((large_gram_kernel<T, 2>), ggrid, gblock, glds, st, a, geo); break;
-          case 3: hipLaunchKernelGGL((large_gram_kernel<T, 3>), ggrid, gblock, glds, st, a, geo); break;
-          default: hipLaunchKernelGGL((large_gram_kernel<T, 4>), ggrid, gblock, glds, st, a, geo); break;
+          case 1: hipLaunchKernelGGL((large_gram_kernel<T, 1>), ggrid, gblock, glds, ls, la, geo); break;
+          case 2: hipLaunchKernelGGL((large_gram_kernel<T, 2>), ggrid, gblock, glds, ls, la, geo); break;
+          case 3: hipLaunchKernelGGL((large_gram_kernel<T, 3>), ggrid, gblock, glds, ls, la, geo); break;
+          default: hipLaunchKernelGGL((large_gram_kernel<T, 4>), ggrid, gblock, glds, ls, la, geo); break;
         }
-        hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(geo.T), unsigned(P)), dim3(256), 0, st, a, geo);
+        hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(geo.T), unsigned(Pl)), dim3(256), 0, ls, la, geo);
+        if (record_after_gram) HIP_TRY(hipEventRecord(record_after_gram, ls));
       }
     } else if (want_j > 0) {
       if (stepping) {   // the host has no count from a previous pass here: the list's length comes back with it
-        int* cnt_dev = a.summary + sum_stride * pass + 3;
-        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a, cnt_dev);
-        HIP_TRY(hipMemcpyAsync(&want_j, cnt_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        int* cnt_dev = sum_dev + 3;
+        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, ls, la, cnt_dev);
+        HIP_TRY(hipMemcpyAsync(&want_j, cnt_dev, sizeof(int), hipMemcpyDeviceToHost, ls));
+        HIP_TRY(hipStreamSynchronize(ls));
       } else {
-        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(large_compact_kernel<T>, dim3(1), dim3(256), 0, ls, la);
       }
     }
     if (!own_gram && want_j > 0) {
       int rc;  // J row-major [m][n] == column-major n x m (ld n):  H = Jc Jc^T,  g = Jc r
       if constexpr (sizeof(T) == 4) {
-        rc = api.sgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, a.jptr, n, a.jptr, n, &zero, a.hptr, n, want_j);
-        if (rc == 0 && !vec_ok) rc = api.sgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+        rc = api.sgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, la.jptr, n, la.jptr, n, &zero, la.hptr, n, want_j);
+        if (rc == 0 && !vec_ok) rc = api.sgemv(h->blas, kOpN, n, m, &one, la.J, n, int64_t(m) * n, la.r, 1, m, &zero, la.gnew, 1, n, int(Pl));
       } else {
-        rc = api.dgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, a.jptr, n, a.jptr, n, &zero, a.hptr, n, want_j);
-        if (rc == 0 && !vec_ok) rc = api.dgemv(h->blas, kOpN, n, m, &one, a.J, n, int64_t(m) * n, a.r, 1, m, &zero, a.gnew, 1, n, int(P));
+        rc = api.dgemm_b(h->blas, kOpN, kOpT, n, n, m, &one, la.jptr, n, la.jptr, n, &zero, la.hptr, n, want_j);
+        if (rc == 0 && !vec_ok) rc = api.dgemv(h->blas, kOpN, n, m, &one, la.J, n, int64_t(m) * n, la.r, 1, m, &zero, la.gnew, 1, n, int(Pl));
       }
       if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
     }
-    hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(large_stage_kernel<T>, dim3(unsigned((n + stage_rows - 1) / stage_rows), unsigned(P)), dim3(256), 0, st, a, stage_rows);
+    hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(Pl)), dim3(256), 0, ls, la);
+    hipLaunchKernelGGL(large_stage_kernel<T>, dim3(unsigned((n + stage_rows - 1) / stage_rows), unsigned(Pl)), dim3(256), 0, ls, la, stage_rows);
     int rc = 0;
     if (own_chol) {
-      launch_ldlt_solve<T>(n, unsigned(P), chol_lds, st, a);
+      launch_ldlt_solve<T>(n, unsigned(Pl), chol_lds, ls, la);
     } else if (own_chol2) {
-      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(kCholThreads), chol2_lds, st, a);
+      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(Pl)), dim3(kCholThreads), chol2_lds, ls, la);
     } else if (lu) {
       if constexpr (sizeof(T) == 4) {
-        rc = api.sgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
-        if (rc == 0) rc = api.sgetrs(h->blas, kOpN, n, 1, a.work, n, int64_t(nn), ipiv, int64_t(n), a.rhs, n, int64_t(n), int(P));
+        rc = api.sgetrf(h->blas, n, n, la.work, n, int64_t(nn), ipiv, int64_t(n), la.info, int(Pl));
+        if (rc == 0) rc = api.sgetrs(h->blas, kOpN, n, 1, la.work, n, int64_t(nn), ipiv, int64_t(n), la.rhs, n, int64_t(n), int(Pl));
       } else {
-        rc = api.dgetrf(h->blas, n, n, a.work, n, int64_t(nn), ipiv, int64_t(n), a.info, int(P));
-        if (rc == 0) rc = api.dgetrs(h->blas, kOpN, n, 1, a.work, n, int64_t(nn), ipiv, int64_t(n), a.rhs, n, int64_t(n), int(P));
+        rc = api.dgetrf(h->blas, n, n, la.work, n, int64_t(nn), ipiv, int64_t(n), la.info, int(Pl));
+        if (rc == 0) rc = api.dgetrs(h->blas, kOpN, n, 1, la.work, n, int64_t(nn), ipiv, int64_t(n), la.rhs, n, int64_t(n), int(Pl));
       }
-      HIP_TRY(hipMemsetAsync(a.info, 0, size_t(P) * sizeof(int), st));   // unchecked: a singular pivot is not a failure by itself
+      HIP_TRY(hipMemsetAsync(la.info, 0, size_t(Pl) * sizeof(int), ls));   // unchecked: a singular pivot is not a failure by itself
     } else if constexpr (sizeof(T) == 4) {
-      rc = api.spotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
-      if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
+      rc = api.spotrf(h->blas, kFillUpper, n, la.work, n, int64_t(nn), la.info, int(Pl));
+      if (rc == 0) rc = api.spotrs(h->blas, kFillUpper, n, 1, la.work, n, int64_t(nn), la.rhs, n, int64_t(n), int(Pl));
     } else {
-      rc = api.dpotrf(h->blas, kFillUpper, n, a.work, n, int64_t(nn), a.info, int(P));
-      if (rc == 0) rc = api.dpotrs(h->blas, kFillUpper, n, 1, a.work, n, int64_t(nn), a.rhs, n, int64_t(n), int(P));
+      rc = api.dpotrf(h->blas, kFillUpper, n, la.work, n, int64_t(nn), la.info, int(Pl));
+      if (rc == 0) rc = api.dpotrs(h->blas, kFillUpper, n, 1, la.work, n, int64_t(nn), la.rhs, n, int64_t(n), int(Pl));
     }
     if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER potrf/potrs returned status " + std::to_string(rc));
-    int* sum_dev = a.summary + sum_stride * pass;
-    hipLaunchKernelGGL(large_post_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a, sum_dev);
+    hipLaunchKernelGGL(large_post_kernel<T>, dim3(unsigned(Pl)), dim3(256), 0, ls, la, sum_dev);
     HIP_TRY(hipGetLastError());
-    if (ahead) {
-      const int slot = int(pass % kRing);
-      HIP_TRY(hipMemcpyAsync(ring.host + 2 * slot, sum_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipEventRecord(ring.done[slot], st));
-    } else {
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  };
+
+  if (!ahead) {   // a library stage in the pass, or the stepping form: pass by pass, the counts read back behind each
+    int active = int(P), want_j = int(P);
+    for (long long pass = 0; pass < pass_limit && active > 0; ++pass) {
+      int* sum_dev = a.summary + sum_stride * pass;
+      if (int rc = enqueue_pass(a, st, P, sum_dev, want_j)) return rc;
       int sum_host[3] = {0, 0, 0};
       HIP_TRY(hipMemcpyAsync(sum_host, sum_dev, size_t(stepping ? 3 : 2) * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1533,13 +1527,102 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
         want_j = int(P);
       }
     }
+    if (stepping) return TOA_OK;   // (retries are bounded by max_tries inside the state machine)
+    if (active > 0) return toa_fail(TOA_E_HIP, "large-n LM: pass budget exhausted with active problems (internal error)");
+    return TOA_OK;
   }
-  if (stepping) return TOA_OK;   // (retries are bounded by max_tries inside the state machine)
-  if (ahead && active > 0 && pass > 0) {   // the pass budget ran out before a zero was seen: the LAST pass decides
-    HIP_TRY(hipStreamSynchronize(st));
-    active = ring.host[2 * int((pass - 1) % kRing)];
+
+  // ---- own kernels only: enqueue-ahead, and the batch in LANES on separate streams.  The one-workgroup Cholesky is a latency
+  // chain (0.33 ms per n = 256 matrix whatever the batch, on a fraction of the compute units) that the Gram of the SAME
+  // problems has to wait for; with the batch split, one lane's factorisations run beside another lane's rows + Gram kernels
+  // (lane l's pass starts behind lane l - 1's Gram: the stagger).  The geometry (row chunks per problem, row blocks, stage
+  // slices) stays that of the whole batch, so every problem sees the arithmetic of the one-lane run: the bits do not depend
+  // on the split (toa_tuning::large_one_lane: 1 = one lane, k > 1 = k lanes, for the A/B).  What it buys is modest — +6 % at
+  // 128 x n = 256 — because a Gram that runs beside ANY factorisation kernel takes 1.8x as long (kernel trace,
+  // profiles/r04_ab_log.md section 3; not compute-unit sharing: a factorisation that claims the whole LDS of its unit changes
+  // nothing), so the overlap returns about half of what it hides.
+  if (int rc = ensure_pass_ring(h)) return rc;
+  int nlanes = h->tune.large_one_lane ? 1 : (P >= 16 ? 2 : 1);   // (measured, 128 x n = 256: 1 lane 80.5 k, 2: 85.5 k, 3: 85 k, 4: 85 k it/s)
+  if (h->tune.large_one_lane > 1) nlanes = std::min<int>(h->tune.large_one_lane, toa_context::kLanes);   // (A/B: an explicit lane count)
+  nlanes = int(std::min<long long>(nlanes, std::max<long long>(1, P)));
+  struct Lane { LargeArgs<T> a; hipStream_t st; long long P, pass; int active; bool done; int* host; hipEvent_t* ev; int* sums; };
+  Lane lane[toa_context::kLanes];
+  for (int l = 0; l < nlanes; ++l) {
+    const long long p0 = P * l / nlanes, p1 = P * (l + 1) / nlanes;
+    Lane& L = lane[l];
+    L.a = a;
+    L.P = p1 - p0; L.pass = 0; L.active = int(L.P); L.done = false;
+    L.st = l == 0 ? st : h->lane_stream[l - 1];
+    L.host = h->pass_flags + l * 2 * kRing;
+    L.ev = h->pass_done + l * kRing;
+    L.sums = a.summary + size_t(l) * 2 * size_t(max_passes + 1);
+    LargeArgs<T>& b = L.a;
+    b.P = L.P;
+    b.data += size_t(p0) * m * (size_t(n) + 1); b.x += p0 * n;
+    b.st += p0; b.active += p0; b.built += p0; b.info += p0;
+    b.g += p0 * n; b.hd += p0 * n; b.dx += p0 * n; b.ldx += p0 * n; b.gnew += p0 * n; b.rhs += p0 * n;
+    b.H += size_t(p0) * nn; b.Hnew += size_t(p0) * nn; b.work += size_t(p0) * nn;
+    b.r += size_t(p0) * m; b.sc += size_t(p0) * m;
+    b.gram_part += size_t(p0) * gram_R * geo.T * 1024;
+    b.gpart += size_t(p0) * size_t(std::max(gslots, 0)) * n;
+    toa_results& r = b.res;
+    auto adv = [&](auto*& ptr, size_t per) { if (ptr) ptr += size_t(p0) * per; };
+    adv(r.stop_reason, 1); adv(r.num_iters, 1); adv(r.num_failures, 1); adv(r.num_consec_failures, 1);
+    adv(r.final_cost, 1); adv(r.final_num_residuals, 1); adv(r.final_rerr_dec, 1); adv(r.final_hessian, nn);
+    adv(r.errs, size_t(r.hist_stride)); adv(r.deltas2, size_t(r.hist_stride)); adv(r.successes, size_t(r.hist_stride));
+    adv(r.final_inlier_ratio, 1);
   }
-  if (active > 0) return toa_fail(TOA_E_HIP, "large-n LM: pass budget exhausted with active problems (internal error)");
+  struct Join {   // whatever happens below, nothing of ours is still running on the lane stream when the call returns
+    toa_handle h; bool forked = false, joined = false;
+    ~Join() { if (forked && !joined) for (hipStream_t s : h->lane_stream) if (s) (void)hipStreamSynchronize(s); }
+  } join{h};
+  if (nlanes > 1) {
+    HIP_TRY(hipEventRecord(h->lane_fork, st));
+    for (int l = 1; l < nlanes; ++l) HIP_TRY(hipStreamWaitEvent(lane[l].st, h->lane_fork, 0));
+    join.forked = true;
+  }
+  bool all_done = false;
+  while (!all_done) {
+    all_done = true;
+    for (int l = 0; l < nlanes; ++l) {
+      Lane& L = lane[l];
+      if (L.done) continue;
+      if (L.pass >= max_passes) { L.done = true; continue; }
+      if (L.pass >= kAhead) {
+        const int slot = int((L.pass - kAhead) % kRing);
+        HIP_TRY(hipEventSynchronize(L.ev[slot]));
+        L.active = L.host[2 * slot];
+        if (L.active == 0) { L.done = true; continue; }
+      }
+      int* sum_dev = L.sums + 2 * L.pass;
+      int want_all = int(L.P);
+      // the stagger: lane l's pass k starts when lane l - 1's Gram of pass k is done, so that from then on one lane's solve
+      // runs beside another's data pass instead of all the Grams (and then all the solves) sharing the chip in lockstep
+      hipEvent_t wait_ev = (l > 0 && !lane[l - 1].done) ? h->lane_gram[(l - 1) * kRing + L.pass % kRing] : nullptr;
+      hipEvent_t rec_ev = (l + 1 < nlanes) ? h->lane_gram[l * kRing + L.pass % kRing] : nullptr;
+      if (int rc = enqueue_pass(L.a, L.st, L.P, sum_dev, want_all, wait_ev, rec_ev)) return rc;
+      const int slot = int(L.pass % kRing);
+      HIP_TRY(hipMemcpyAsync(L.host + 2 * slot, sum_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, L.st));
+      HIP_TRY(hipEventRecord(L.ev[slot], L.st));
+      ++L.pass;
+      all_done = false;
+    }
+  }
+  if (nlanes > 1) {
+    for (int l = 1; l < nlanes; ++l) {
+      HIP_TRY(hipEventRecord(h->lane_join[l - 1], lane[l].st));
+      HIP_TRY(hipStreamWaitEvent(st, h->lane_join[l - 1], 0));
+    }
+    join.joined = true;
+  }
+  for (int l = 0; l < nlanes; ++l) {
+    Lane& L = lane[l];
+    if (L.active > 0 && L.pass > 0) {   // the pass budget ran out before a zero was seen: the LAST pass decides
+      HIP_TRY(hipStreamSynchronize(L.st));
+      L.active = L.host[2 * int((L.pass - 1) % kRing)];
+    }
+    if (L.active > 0) return toa_fail(TOA_E_HIP, "large-n LM: pass budget exhausted with active problems (internal error)");
+  }
   return TOA_OK;
 }
 
