@@ -32,7 +32,7 @@ WORKLOADS = {
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
     # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
     "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, workgroup-per-problem kernel (64 <= n <= 128)"),
-    "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written tile-split MFMA Gram + rocSOLVER potrf/potrs"),
+    "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written tile-split MFMA Gram + one-workgroup blocked Cholesky, two staggered lanes, passes enqueued ahead"),
 }
 # single-problem configs of BASELINE.json (latency-bound: SURVEY §8d "report us/iter and GB/s"); replicas only at N > 1
 SINGLE = {
@@ -468,7 +468,7 @@ def run_balists(args, ta, rank, world, local_rank):
                    "parallelism": f"scene-sharded x{world}, no data-path collective",
                    "iters_per_problem": iters_all / args.steps / (P * world), "ms_per_lm_iteration": elapsed / max(iters_all / (P * world), 1) * 1e3,
                    "final_reprojection_rms_px_max": rms, "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "latency", "kernel": "bl_* pipeline (10 launches + one host read-back per Build + Solve attempt; rocSOLVER potrf / potrs of the 384 x 384 reduced camera system)",
+        "roofline": {"bound": "latency", "kernel": "bl_* pipeline (13 launches per Build + Solve attempt, enqueued two passes ahead of the stop flag; one-workgroup blocked Cholesky of the 384 x 384 reduced camera system per scene)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bl,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
                      "note": "launch / latency-bound at this size (a few scenes, ~1 MB of observations each): the figure of merit is ms per LM "
@@ -773,7 +773,7 @@ def main():
                    "iters_per_problem": iters_all / args.steps / (P * world),
                    "lm_iterations_per_step_per_gpu_min_max": rank_iters,
                    "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else ("large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)" if n <= 128 else "large_gram_kernel + the rest of the n > 128 pipeline (rows, reduce, pre, rocSOLVER potrf / potrs, post: the whole batched solve)"),
+        "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else ("large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)" if n <= 128 else "large_gram_kernel + the rest of the n > 128 pipeline (rows, reduce, pre, stage, one-workgroup blocked Cholesky, post: the whole batched solve, two staggered lanes)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of the same workload and binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,

@@ -71,7 +71,7 @@ def main():
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
                  "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba",
                  "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0",
-                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit"):
+                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
@@ -162,6 +162,27 @@ def main():
         for name in (f"{tag}_pmc_balists.json", "pmc_latest_balists.json"):
             with open(os.path.join(DST, name), "w") as f:
                 json.dump(outp, f, indent=1)
+    # ---- HBM traffic of the whole n > 128 pipeline (tools/pmc_sum.sh): every large_* kernel, per batched solve
+    ps = os.path.join(SRC, "pmcsum_large256.json")
+    if os.path.exists(ps) and os.path.exists(os.path.join(DST, f"{tag}_bench_large256.json")):
+        d = json.load(open(ps))
+        bb = json.loads(open(os.path.join(DST, f"{tag}_bench_large256.json")).read())
+        rb = bb["roofline"]
+        alg = rb["algorithmic_bytes_per_pass"] * rb["passes_per_launch"]
+        raw = (d["FETCH_SIZE_KB_per_solve"] + d["WRITE_SIZE_KB_per_solve"]) * 1024.0
+        calb = d["FETCH_SIZE_KB_per_solve"] * 1024.0 * cal + d["WRITE_SIZE_KB_per_solve"] * 1024.0
+        outp = {"round": tag, "workload": "large256", "problems": bb["config"]["problems_per_gpu"],
+                "kernels": "every kernel of the pipeline (large_rows_vec / gram / gram_reduce / pre / stage / chol_solve / post), summed per batched solve: tools/pmc_sum.sh",
+                "FETCH_SIZE_KB_per_launch": d["FETCH_SIZE_KB_per_solve"], "WRITE_SIZE_KB_per_launch": d["WRITE_SIZE_KB_per_solve"],
+                "FETCH_SIZE_KB_top_kernels": d["FETCH_SIZE_KB_per_solve_top"], "WRITE_SIZE_KB_top_kernels": d["WRITE_SIZE_KB_per_solve_top"],
+                "fetch_calibration_bytes_per_reported_byte": cal,
+                "hbm_bytes_per_launch_raw": raw, "hbm_bytes_per_launch": calb, "algorithmic_bytes_per_launch": alg,
+                "algorithmic_note": "m (n + 1) sizeof(T) per pass that streamed the rows; an accumulate pass reads A TWICE by design (rows kernel: r and the row scales; Gram kernel: J^T J) and the solve works on n x n matrices in L2 / HBM",
+                "traffic_over_algorithmic": calb / alg}
+        for name in (f"{tag}_pmcsum_large256.json", "pmc_latest_large256.json"):
+            with open(os.path.join(DST, name), "w") as f:
+                json.dump(outp, f, indent=1)
+        print("large256 pipeline", {k: outp[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
     # ---- HBM traffic of the bundle-adjustment kernel (work arrays included: they do not fit the L2s)
     if os.path.isdir(os.path.join(SRC, "pmc_ba")) and os.path.exists(os.path.join(DST, f"{tag}_bench_ba.json")):
         bb = json.loads(open(os.path.join(DST, f"{tag}_bench_ba.json")).read())

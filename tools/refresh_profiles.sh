@@ -13,6 +13,7 @@ python bench.py --workload large256 --steps 5 --warmup 2 > $O/bench_large256.jso
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_library_solver=1 > $O/bench_large256_rocsolver.json 2>/dev/null
 python bench.py --workload balists --no-cpu --tuning large_library_solver=1 > $O/bench_balists_rocsolver.json 2>/dev/null
 python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu --tuning large_row_split=1 > $O/bench_large128_rowsplit.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_one_lane=1 > $O/bench_large256_one_lane.json 2>/dev/null
 python bench.py --workload c4 --no-cpu --tuning coop_off=1 > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
 python bench.py --workload c4 --no-cpu --tuning memo_off=1,coop_off=1 > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
@@ -57,5 +58,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 # HBM traffic of the whole BA-lists pipeline (every kernel, per batched solve)
 cd $R; bash tools/pmc_sum.sh balists "bl_|rocsolver|rocblas|Cijk|large_" 6 --workload balists --steps 3 --warmup 2 > $O/pmcsum_balists.txt 2>&1; cp gpurun_out/pmcsum_balists.json $O/
+# ... and of the whole n > 128 pipeline (rows, Gram, reduce, pre, stage, factorisation, post), per batched solve
+bash tools/pmc_sum.sh large256 "large_" 4 --workload large256 --steps 2 --warmup 1 > $O/pmcsum_large256.txt 2>&1; cp gpurun_out/pmcsum_large256.json $O/
 find $O -name "*.csv" | wc -l
 du -sh $O
