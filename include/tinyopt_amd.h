@@ -318,7 +318,10 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      kernel of the DenseRow families parks the Gram registers of every accepted point (one slot per resident wave) and,
  *      when the roll-back restored x BIT FOR BIT, reads them back instead of streaming the rows again; g, H and the cost
  *      are the bits a second pass would have produced (tests/test_gpu_memo.py; toa_tuning::memo_off switches the memo off).
- *      Asynchronous on the handle's stream, except TOA_MODEL_DENSE_ROW_NATURAL beyond n = 128 (a launch per stage): the
+ *      One asynchronous launch on the handle's stream, capturable into a hipGraph once a first un-captured call of the
+ *      shape has made the handle's workspaces (they grow on demand, which a capture cannot do: such a call is refused with
+ *      TOA_E_UNSUPPORTED, the capture left valid; tests/test_gpu_graph_capture.py) — except TOA_MODEL_DENSE_ROW_NATURAL beyond
+ *      n = 128 (a launch per stage): the
  *      host enqueues two passes ahead and waits for the (active, want-Jacobian) pair of pass k only before it enqueues pass
  *      k + 2 where every stage is a kernel of this library (fp32, 16-byte aligned rows, n <= 1024) — the call returns when
  *      the solve is done and cannot be captured in a hipGraph; with a library stage in the pass (fp64 / odd shapes: rocBLAS

@@ -791,7 +791,7 @@ int launch_ba(toa_handle h, BaParams& prm) {
   const BaWork<T> wk(prm.C, prm.N, ROBUST);
   const size_t need = size_t(prm.P) * wk.total * sizeof(T);
   if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = grow_sync(h, "device workspace")) return rc;
     if (h->scratch) (void)hipFree(h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
@@ -1581,7 +1581,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
   const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = grow_sync(h, "bundle adjustment workspace")) return rc;
     if (h->aux) (void)hipFree(h->aux);
     h->aux = nullptr;
     h->aux_bytes = 0;

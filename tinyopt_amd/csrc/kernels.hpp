@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 #endif
@@ -2132,6 +2133,8 @@ struct toa_context {
   size_t params_shadow_bytes = 0;
   void* scratch = nullptr;     // row-split path: state + partials + folded H (grown on demand)
   size_t scratch_bytes = 0;
+  std::vector<std::unique_ptr<char[]>> captured_blocks;   // parameter blocks of launches captured into hipGraphs (upload_params)
+  bool shadow_retired = false;
   void* memo = nullptr;        // fused kernel: one parked linearisation per resident wave (lm_device.hpp; grown on demand)
   size_t memo_bytes = 0;
   void* aux = nullptr;         // bundle adjustment with visibility lists: its work arrays (`scratch` belongs to the solver it calls)
@@ -2187,6 +2190,19 @@ int toa_fail(int code, const std::string& msg);
                       std::string(#expr) + ": " + hipGetErrorString(e_));                       \
   } while (0)
 
+// Before a device workspace is re-allocated: everything queued on the stream may still use the old block, so the stream is
+// drained first — which, like the hipMalloc that follows, cannot happen while the stream is being CAPTURED into a hipGraph.
+// Workspaces only ever grow and are kept, so one un-captured call of the same shape beforehand is all a capturing caller
+// needs; without it the call is refused here instead of failing inside the runtime with the capture invalidated.
+inline int grow_sync(toa_context* h, const char* what) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return toa_fail(TOA_E_UNSUPPORTED, std::string(what) + ": a device workspace has to grow, which cannot happen while the stream is being captured; "
+                                       "run this shape once before hipStreamBeginCapture (workspaces only grow and are kept by the handle)");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return TOA_OK;
+}
+
 namespace toa {
 // Every C entry point runs on its handle's GPU and leaves the CALLER's current device as it found it: torch (and any
 // other HIP user of the process) reads its "current device" through hipGetDevice, so a library that switched it as a
@@ -2229,13 +2245,21 @@ inline int ensure_lds_attr(toa_handle h, const void* fn, size_t bytes) {
 // buffers (an outer loop re-solving, the stepping form, the benchmark) present byte-identical blocks: the upload — a
 // staged ~10 us stream operation in front of every launch — is skipped when the block already there is the same.
 inline int upload_params(toa_handle h, const void* blk, size_t bytes) {
-  // Under stream capture the copy below is only RECORDED: the device block changes when the graph is launched, not now, so
-  // the shadow would claim contents the device does not hold yet.  While capturing: always record the upload and forget
-  // the shadow (the next eager call uploads again).
+  // Under stream capture the copy below is only RECORDED, host POINTER included: the graph reads the block when it is
+  // launched, long after the caller's stack copy is gone — so the block is parked in host memory the handle keeps for its
+  // lifetime (1 KB per captured launch).  And once a graph of ours exists, a replay can rewrite the device block behind the
+  // shadow's back at any time: from then on every eager call uploads (~10 us), the shadow is retired for this handle.
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-    HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
+    h->captured_blocks.emplace_back(new char[bytes]);
+    std::memcpy(h->captured_blocks.back().get(), blk, bytes);
+    HIP_TRY(hipMemcpyAsync(h->params_dev, h->captured_blocks.back().get(), bytes, hipMemcpyHostToDevice, h->stream));
     h->params_shadow_bytes = 0;
+    h->shadow_retired = true;
+    return TOA_OK;
+  }
+  if (h->shadow_retired) {
+    HIP_TRY(hipMemcpyAsync(h->params_dev, blk, bytes, hipMemcpyHostToDevice, h->stream));
     return TOA_OK;
   }
   if (bytes == h->params_shadow_bytes && std::memcmp(h->params_shadow, blk, bytes) == 0) return TOA_OK;
@@ -2414,7 +2438,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
       const size_t stride = (Model::kMemoBytes + 255) & ~size_t(255);
       const size_t need_b = stride * size_t(grid) * 4;
       if (need_b > h->memo_bytes) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (int rc = grow_sync(h, "memo of the last accepted linearisation")) return rc;
         if (h->memo) (void)hipFree(h->memo);
         h->memo = nullptr;
         h->memo_bytes = 0;
@@ -2550,7 +2574,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   const size_t b_sync = (size_t(2 * P + 1) * sizeof(unsigned) + 255) & ~size_t(255);
   const size_t need = b_state + b_part + b_hsum + b_sync;
   if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = grow_sync(h, "device workspace")) return rc;
     if (h->scratch) (void)hipFree(h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;

@@ -713,7 +713,7 @@ int launch_large_accumulate(toa_handle h, int n, int m, int64_t P, const T* data
   const size_t per_wg = (size_t(4) * NT * 64 * sizeof(Acc) + 255) & ~size_t(255);
   const size_t need = per_wg * size_t(grid);
   if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = grow_sync(h, "device workspace")) return rc;
     if (h->scratch) (void)hipFree(h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
@@ -763,7 +763,7 @@ int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T
   const size_t per_wg = ((size_t(4) * NT * 64 * sizeof(Acc) + size_t(n) * n * sizeof(T)) + 255) & ~size_t(255);
   const size_t need = per_wg * size_t(grid);
   if (need > h->scratch_bytes) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = grow_sync(h, "device workspace")) return rc;
     if (h->scratch) (void)hipFree(h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;

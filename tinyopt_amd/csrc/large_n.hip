@@ -98,7 +98,7 @@ int ensure_scratch(toa_handle h, size_t need, const char* what) {
   if (h->tune.fail_workspace_alloc)
     return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace (toa_tuning::fail_workspace_alloc)");
   if (need <= h->scratch_bytes) return TOA_OK;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rc = grow_sync(h, what)) return rc;
   if (h->scratch) (void)hipFree(h->scratch);
   h->scratch = nullptr;
   h->scratch_bytes = 0;
