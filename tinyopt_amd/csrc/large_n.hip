@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(256) large_step_info_kernel(const char* __rest
 
 // mode 0: the whole solve.  1 / 2 / 3: toa_lm_begin / toa_lm_step / toa_lm_stop on `state` (LargeStateLayout).
 template <typename T>
-int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
+int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
                    const toa_results& res, uint64_t* counters, int mode = 0, void* state = nullptr,
                    int32_t* active_dev = nullptr, const int32_t* stop_request = nullptr) {
   const size_t nn = size_t(n) * n;
@@ -1379,7 +1379,6 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   a.jptr = reinterpret_cast<const T**>(take(b_ptr));
   a.hptr = reinterpret_cast<T**>(take(b_ptr));
   int* ipiv = reinterpret_cast<int*>(take(b_piv));
-  if (int rc = ensure_blas(h, api)) return rc;
   hipStream_t st = h->stream;
   // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with toa_tuning::large_library_solver) rocSOLVER
   const bool force_lib = h->tune.large_library_solver != 0;
@@ -1394,6 +1393,15 @@ int large_lm_run_t(toa_handle h, RocApi& api, int n, int m, int64_t P, const T* 
   const bool own_chol2 = !own_chol && !lu && !force_lib && n > 128 && chol2_lds + 2048 <= size_t(h->max_lds);
   if (own_chol2) {
     if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T>, chol2_lds)) return rc;
+  }
+  // rocBLAS / rocSOLVER are opened (dlopen, a handle: a cold load of their code objects, minutes in a bare process) only
+  // when a stage of THIS solve is theirs — fp32 with aligned rows up to n = 1024 never touches them
+  const bool needs_lib = !(own_gram && (own_chol || own_chol2));
+  static RocApi no_api;
+  RocApi& api = needs_lib ? roc_api() : no_api;
+  if (needs_lib) {
+    if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER for this shape: " + api.err);
+    if (int rc = ensure_blas(h, api)) return rc;
   }
   if (mode == 3) {   // toa_lm_stop
     hipLaunchKernelGGL(large_stop_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, a);
@@ -1706,8 +1714,6 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
   // 64 <= n <= 128: the whole loop in one persistent kernel, Gram on the matrix cores (large_fused.hip)
   // (use_ldlt = false needs the library's general LU: the launch-per-stage pipeline below, for every n >= 64)
   if (options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
-  toa::RocApi& api = toa::roc_api();
-  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
   // The pipeline's kernels index problems through grid.y (65 535): a larger batch goes through it slice by slice — the
   // problems are independent, so the slices are just shorter batches (same bits), and the workspace is sized for one slice.
   constexpr int64_t kSlice = 65535;
@@ -1724,9 +1730,9 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
     char* xs = static_cast<char*>(x) + size_t(p0) * size_t(n) * es;
     int rc;
     if (dtype == TOA_F32)
-      rc = toa::large_lm_run_t<float>(h, api, n, m, Ps, reinterpret_cast<const float*>(d), reinterpret_cast<float*>(xs), *options, r, counters);
+      rc = toa::large_lm_run_t<float>(h, n, m, Ps, reinterpret_cast<const float*>(d), reinterpret_cast<float*>(xs), *options, r, counters);
     else
-      rc = toa::large_lm_run_t<double>(h, api, n, m, Ps, reinterpret_cast<const double*>(d), reinterpret_cast<double*>(xs), *options, r, counters);
+      rc = toa::large_lm_run_t<double>(h, n, m, Ps, reinterpret_cast<const double*>(d), reinterpret_cast<double*>(xs), *options, r, counters);
     if (rc != TOA_OK) return rc;
     if (P <= 0) break;
   }
@@ -1743,12 +1749,10 @@ int toa_large_lm_step(toa_handle h, int dtype, int n, int m, int64_t P, const vo
                       const toa_results* results, uint64_t* counters, int mode, void* state, int32_t* active_dev,
                       const int32_t* stop_request) {
   if (P > 65535) return toa_fail(TOA_E_UNSUPPORTED, "stepping form at n >= 64: at most 65 535 problems per call");
-  toa::RocApi& api = toa::roc_api();
-  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "large-n LM needs rocBLAS + rocSOLVER: " + api.err);
   if (dtype == TOA_F32)
-    return toa::large_lm_run_t<float>(h, api, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options, *results,
+    return toa::large_lm_run_t<float>(h, n, m, P, static_cast<const float*>(data), static_cast<float*>(x), *options, *results,
                                       counters, mode, state, active_dev, stop_request);
-  return toa::large_lm_run_t<double>(h, api, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results,
+  return toa::large_lm_run_t<double>(h, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results,
                                      counters, mode, state, active_dev, stop_request);
 }
 
