@@ -462,6 +462,14 @@ int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, 
                    const toa_options* options, const toa_results* results, uint64_t* counters_dev);
 int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, const void* x_dev,
                        int want_grad, void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);
+/*      Row-split execution of a run-time model (num_params <= 12) for FEW, HUGE problems — the reference's one `Optimize(x, cost)`
+ *      over tens of thousands of residuals (BASELINE C2 / C5 shapes) with the residual supplied as text: the contract of
+ *      toa_lm_run_split.  The items of each problem are cut into `splits` chunks (0 = chosen automatically), a wavefront per
+ *      chunk, partials folded in fixed order; ONE persistent launch when P * splits <= the device's compute units, one launch
+ *      pair per iteration otherwise.  Its kernels are a second code object, compiled (or loaded from the cache) at the first
+ *      such call.  toa_jit_lm_run takes this route by itself when P * 4 <= #CUs and m >= 512 (toa_tuning::wide_no_autosplit). */
+int toa_jit_lm_run_split(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
+                         const toa_options* options, const toa_results* results, uint64_t* counters_dev, int splits);
 
 /* ---- C1: the result gather of a sharded batch (SURVEY §8(b) export list `gather(handle_group...)`, §8(e)).
  *      Problems are independent (the reference optimises exactly one x per call, docs/API.md:12), so a batch of P_total

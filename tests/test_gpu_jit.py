@@ -281,3 +281,60 @@ def test_code_objects_are_cached_on_disk(ta, tmp_path):
         assert not d.from_cache                                                      # "" = no cache
     finally:
         ta.JitResidual.set_cache_dir(None)
+
+
+REPROJ = """
+const S X = x[0] * p[0] + x[1] * p[1] + x[2] * p[2] + x[9];
+const S Y = x[3] * p[0] + x[4] * p[1] + x[5] * p[2] + x[10];
+const S Z = x[6] * p[0] + x[7] * p[1] + x[8] * p[2] + x[11];
+r[0] = h[0] * X / Z + h[1] - p[3];
+r[1] = h[0] * Y / Z + h[2] - p[4];
+"""
+
+
+@pytest.mark.parametrize("dtype,tdt,npts,P", [(np.float64, torch.float64, 25000, 1), (np.float64, torch.float64, 4096, 3),
+                                               (np.float32, torch.float32, 3000, 2)])
+def test_single_problem_wide_m_reprojection_supplied_as_source(ta, oracle, dtype, tdt, npts, P):
+    """BASELINE config 5 — ONE pose, 25 000 points = 50 000 residuals (benchmarks/…; tests/sophus.cpp's `Optimize(pose, lambda)`
+    shape) — with the reprojection residual handed over as TEXT on the SE3 manifold: the run-time model takes the row-split form
+    (a wavefront per chunk of items, one persistent launch) by itself, and lands on the oracle's trajectory like the compiled-in
+    SE3Reproj model does; every execution form (automatic, explicit chunk counts, launch-per-iteration, one wavefront) agrees."""
+    data, p0, pstar = oracle.synth_se3_reproj(P, npts, dtype, seed=4)
+    o = ta.Options()
+    ref = oracle.se3_reproj_lm(data, p0, npts, o.to_pod())
+    fit = ta.JitResidual(REPROJ, n=6, item_scalars=5, residuals_per_item=2, header_scalars=8, dtype=tdt, manifold="se3")
+    d = torch.from_numpy(data).cuda()
+    model = fit.bind(d[:, 8:].reshape(P, npts, 5).contiguous(), header=d[:, :8].contiguous())
+    ctx = ta.api.default_context()
+    tol_x = 1e-9 if dtype == np.float64 else 5e-4
+    results = []
+    for splits, tune in ((None, {}), (0, {}), (7, {}), (16, dict(wide_multilaunch=1)), (None, dict(wide_no_autosplit=1))):
+        x = torch.from_numpy(p0.copy()).cuda()
+        with ctx.tuning(**tune):
+            out = ta.Optimize(x, model, o, splits=splits)
+        torch.cuda.synchronize()
+        xg, stop = x.cpu().numpy(), out.stop_reason.cpu().numpy()
+        assert np.abs(xg - ref["x"]).max() < tol_x, (splits, tune)
+        if dtype == np.float64:
+            assert np.array_equal(stop, ref["stop"]) and np.array_equal(out.num_iters.cpu().numpy(), ref["iters"]), (splits, tune)
+            assert np.allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-10)
+            assert np.allclose(out.final_hessian.cpu().numpy(), ref["H"], rtol=1e-9, atol=1e-6 * np.abs(ref["H"]).max())
+        else:
+            assert (stop >= 0).all()
+        results.append(xg)
+    # the compiled-in model on the same bytes
+    x = torch.from_numpy(p0.copy()).cuda()
+    ta.Optimize(x, ta.SE3Reproj(d, npts), o)
+    assert np.abs(x.cpu().numpy() - results[0]).max() < tol_x
+    # run to run: the row-split form folds its partials in fixed order
+    x = torch.from_numpy(p0.copy()).cuda()
+    ta.Optimize(x, model, o)
+    assert np.array_equal(x.cpu().numpy(), results[0])
+
+
+def test_row_split_refusals(ta):
+    fit = ta.JitResidual("r[0] = x[0] - p[0];", n=20, item_scalars=1)
+    x = torch.zeros(1, 20, dtype=torch.float64, device="cuda")
+    data = torch.zeros(1, 1024, 1, dtype=torch.float64, device="cuda")
+    with pytest.raises(Exception, match="at most 12 parameters"):
+        ta.Optimize(x, fit.bind(data), ta.Options(), splits=4)

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "toa_model_destroy": (C.c_int, [_P]),
     "toa_jit_lm_run": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
     "toa_jit_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "toa_jit_lm_run_split": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P, C.c_int]),
     "toa_lm_run_split": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
                                    C.POINTER(ToaResults), _P, C.c_int]),
 }

@@ -796,8 +796,8 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
                                        C.byref(pod), C.byref(res), out.counters.data_ptr(), float(options.max_duration_ms or 0.0)))
         return out
     if isinstance(cost, JitModel):
-        if options.has_host_controls() or splits is not None:
-            raise ValueError("a run-time compiled model runs as one launch per solve: no stop callbacks / splits")
+        if options.has_host_controls():
+            raise ValueError("a run-time compiled model has no stepping form: no stop callbacks / max_duration_ms")
         pod = options.to_pod()
         if out is None:
             out = _alloc_output(P, n, options, history, x.device)
@@ -805,8 +805,12 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
             out.counters.zero_()
         res = _results_pod(out)
         _apply_loss(ctx, cost)
-        check(ctx.lib.toa_jit_lm_run(ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(), C.byref(pod),
-                                     C.byref(res), out.counters.data_ptr()))
+        if splits is None:   # the library decides (row-split for few, huge problems: P * 4 <= #CUs and m >= 512)
+            check(ctx.lib.toa_jit_lm_run(ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(), C.byref(pod),
+                                         C.byref(res), out.counters.data_ptr()))
+        else:                # explicit row-split execution with `splits` chunks per problem (0 = automatic count)
+            check(ctx.lib.toa_jit_lm_run_split(ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(), C.byref(pod),
+                                               C.byref(res), out.counters.data_ptr(), int(splits)))
         return out
     if options.has_host_controls():
         if splits is not None or out is not None:

@@ -977,7 +977,12 @@ struct JetModel {
     d = data + size_t(p) * (F::kH + size_t(items) * F::kD);
     it0 = 0; it1 = items;
   }
-  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }  // one chunk (stepping form)
+  // rows [row0, row0 + rows) of the problem = whole items (the launchers cut chunks at multiples of kR rows): the row-split form
+  __device__ __forceinline__ void bind_chunk(long long p, int row0, int rows, int) {
+    bind(p);
+    it0 = row0 / F::kR;
+    it1 = min(items, (row0 + rows) / F::kR);
+  }
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
     if constexpr (MANIFOLD == 1) Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
     else euclid_plus_eq(L, dv, sign, lane);
