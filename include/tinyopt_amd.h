@@ -324,7 +324,8 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      n = 128 (a launch per stage): the
  *      host enqueues two passes ahead and waits for the (active, want-Jacobian) pair of pass k only before it enqueues pass
  *      k + 2 where every stage is a kernel of this library (fp32, 16-byte aligned rows, n <= 1024) — the call returns when
- *      the solve is done and cannot be captured in a hipGraph; with a library stage in the pass (fp64 / odd shapes: rocBLAS
+ *      the solve is done; under stream capture that form records its whole pass budget instead (every kernel skips finished
+ *      problems) and the graph replays the solve with no host in the loop; with a library stage in the pass (no capture) (fp64 / odd shapes: rocBLAS
  *      GEMM, rocSOLVER beyond the LDS) the pair is read back after every pass.  64 <= n <= 128 is one persistent kernel
  *      like the rest. */
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _problem(ta, P, n, m, dtype):
+def _problem(ta, P, n, m, dtype):  # noqa: D103
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     return ta.DenseRow.synthetic(P, n, m, tdt)
 
@@ -58,3 +58,42 @@ def test_capture_that_would_grow_a_workspace_is_refused(ta):
         o2 = ta.Optimize(x, big, opts)
         s.synchronize()
         assert bool((o2.stop_reason > 0).all())
+
+
+def test_the_n_256_pipeline_is_capturable_where_every_stage_is_ours(ta, oracle):
+    """fp32, aligned rows, n = 256: rows kernel, Gram, factorisation and the state machine are all kernels of this library
+    that skip finished problems, so under capture the whole pass budget is recorded and the graph replays the solve with no
+    host in the loop — the bits of the eager call.  fp64 (library Gram) says it cannot."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        P, n, m = 6, 256, 768
+        A, b, x0h, _ = oracle.synth_dense_row(P, n, m, np.float32, seed=3)
+        model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        x0 = torch.from_numpy(x0h).cuda()
+        opts = ta.Options.benchmark()
+        x_ref = x0.clone()
+        ref = ta.Optimize(x_ref, model, opts)            # eager (and the warm call)
+        x = x0.clone()
+        out = ta.Optimize(x, model, opts)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ta.Optimize(x, model, opts, out=out)
+        for _ in range(2):
+            x.copy_(x0)
+            out.num_iters.zero_()
+            g.replay()
+            s.synchronize()
+            assert torch.equal(x, x_ref)
+            assert torch.equal(out.num_iters, ref.num_iters) and torch.equal(out.stop_reason, ref.stop_reason)
+            assert torch.equal(out.final_cost, ref.final_cost)
+        A64, b64, x064, _ = oracle.synth_dense_row(2, 160, 480, np.float64, seed=4)
+        m64 = ta.DenseRowNatural(torch.from_numpy(A64).cuda(), torch.from_numpy(b64).cuda())
+        x64 = torch.from_numpy(x064).cuda()
+        o64 = ta.Optimize(x64.clone(), m64, opts)
+        s.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(Exception, match="can be captured"):
+            with torch.cuda.graph(g2, stream=s):
+                ta.Optimize(x64, m64, opts, out=o64)
+    torch.cuda.synchronize()

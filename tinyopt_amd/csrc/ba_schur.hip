@@ -1572,6 +1572,11 @@ __global__ void __launch_bounds__(64) bl_force_stop_kernel(const BlParams* __res
 
 template <typename T>
 int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms) {
+  {   // a host loop over passes (stop flags come back through a pinned ring): refused under stream capture, never half-recorded
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run cannot be captured into a hipGraph (its pass loop runs on the host)");
+  }
   const int C = prm.C, N = prm.N, M = prm.M, n = 6 * C;
   const long long P = prm.P;
   const BlWork<T> wk(C, N, M);

@@ -1519,6 +1519,23 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     return TOA_OK;
   };
 
+  // Under stream capture (hipGraph) the host can look at nothing: where every stage is ours the whole pass budget is recorded —
+  // max_passes passes, each kernel of which returns at once for the problems that have finished — and the graph replays the
+  // solve with no host in the loop (one lane: a captured fork / join would only add edges).  A typical solve needs a fifth of
+  // the budget; the rest costs ~40 us of empty launches per pass.  With a library stage in the pass there is no such form.
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      if (!ahead)
+        return toa_fail(TOA_E_UNSUPPORTED, "large-n LM under stream capture: only the solves whose every stage is a kernel of this library "
+                                           "(fp32, 16-byte aligned rows, use_ldlt, n <= 1024, not the stepping form) can be captured");
+      for (long long pass = 0; pass < max_passes; ++pass) {
+        int want_all = int(P);
+        if (int rc = enqueue_pass(a, st, P, a.summary + 2 * pass, want_all)) return rc;
+      }
+      return TOA_OK;
+    }
+  }
   if (!ahead) {   // a library stage in the pass, or the stepping form: pass by pass, the counts read back behind each
     int active = int(P), want_j = int(P);
     for (long long pass = 0; pass < pass_limit && active > 0; ++pass) {
