@@ -338,3 +338,33 @@ def test_row_split_refusals(ta):
     data = torch.zeros(1, 1024, 1, dtype=torch.float64, device="cuda")
     with pytest.raises(Exception, match="at most 12 parameters"):
         ta.Optimize(x, fit.bind(data), ta.Options(), splits=4)
+
+
+def test_row_split_chunks_fall_on_item_boundaries(ta, oracle):
+    """Three residuals per item: chunks are multiples of lcm(16, 3) = 48 rows, so no item straddles two chunks.  Every chunk
+    count — more chunks than the rows allow included — gives the one-wavefront result up to the fold order; m = 0 (mod 48) or not."""
+    body = "r[0] = x[0] * p[0] + x[1] - p[1];\nr[1] = x[2] * p[0] * p[0] - p[2] + x[1];\nr[2] = sin(x[0]) * p[0] + x[3] - p[3];"
+    fit = ta.JitResidual(body, n=4, item_scalars=4, residuals_per_item=3)
+    rng = np.random.default_rng(5)
+    for items in (700, 768, 17):
+        P = 2
+        xs = rng.uniform(-1, 1, (P, 4))
+        t = rng.uniform(-2, 2, (P, items))
+        d = np.stack([t, xs[:, :1] * t + xs[:, 1:2], xs[:, 2:3] * t * t + xs[:, 1:2], np.sin(xs[:, :1]) * t + xs[:, 3:4]], -1)
+        d[..., 1:] += 1e-3 * rng.standard_normal(d[..., 1:].shape)
+        model = fit.bind(torch.from_numpy(d).cuda())
+        x0 = xs + 0.2 * rng.uniform(-1, 1, xs.shape)
+        ctx = ta.api.default_context()
+        with ctx.tuning(wide_no_autosplit=1):
+            xr = torch.from_numpy(x0.copy()).cuda()
+            ref = ta.Optimize(xr, model, ta.Options())
+        for splits in (0, 1, 3, 5, 64, 1000):
+            x = torch.from_numpy(x0.copy()).cuda()
+            out = ta.Optimize(x, model, ta.Options(), splits=splits)
+            torch.cuda.synchronize()
+            assert float((x - xr).abs().max()) < 1e-9, (items, splits)
+            assert torch.equal(out.stop_reason, ref.stop_reason) and torch.equal(out.num_iters, ref.num_iters), (items, splits)
+            assert np.allclose(out.final_cost.cpu().numpy(), ref.final_cost.cpu().numpy(), rtol=1e-10)
+    # an empty batch is a no-op
+    x = torch.zeros(0, 4, dtype=torch.float64, device="cuda")
+    ta.Optimize(x, fit.bind(torch.zeros(0, 5, 4, dtype=torch.float64, device="cuda")), ta.Options(), splits=2)

@@ -508,7 +508,7 @@ class JitModel(_LossMixin):
         self.P, self.items, self.n, self.dtype = data.shape[0], data.shape[1], res.n, res.dtype
         self.xdim = res.xdim
         self.m = self.items * res.kR
-        flat = data.reshape(self.P, -1)
+        flat = data.reshape(self.P, self.items * res.kD)   # (explicit: an empty batch has no size to infer)
         if res.kH:
             assert header is not None and header.shape == (self.P, res.kH) and header.dtype == res.dtype
             flat = torch.cat([header, flat], dim=1)
