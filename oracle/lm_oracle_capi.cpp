@@ -65,20 +65,46 @@ struct DenseRowAcc {
   const T* A;  // m×n row-major
   const T* b;  // m
   mutable std::vector<T> Jrow;
+  mutable std::vector<double> gd, Hd;   // (ORACLE_GRAM_DOUBLE builds only)
   DenseRowAcc(int n_, int m_, const T* A_, const T* b_) : n(n_), m(m_), A(A_), b(b_), Jrow(n_) {}
   Cost operator()(const std::vector<T>& x, T* g, T* H) const {
     T c = 0;
     const int kind = g_loss_kind;
     const T th2 = T(g_loss_th2);
     int inliers = 0;
+    // ORACLE_COST_LANES (default 1 = the sequential sum this oracle is pinned with): tools/iter_inflation.py builds copies with
+    // L > 1 partial sums folded by a tree — the shape of Eigen's packet reduction and of the device's blocked sums — or with a
+    // double accumulator (ORACLE_COST_DOUBLE), to show how the iteration count at the float floor depends on the ORDER of
+    // this one sum.  Never defined in the library the tests load.
+#ifndef ORACLE_COST_LANES
+#define ORACLE_COST_LANES 1
+#endif
+    T cl[ORACLE_COST_LANES] = {};
+    double cd = 0;
     for (int i = 0; i < m; ++i) {
       const T* a = A + size_t(i) * n;
       T t = 0;
+#if defined(ORACLE_DOT_DOUBLE)     // (tools/iter_inflation.py only: a_i . x summed in double, rounded once)
+      { double td = 0; for (int j = 0; j < n; ++j) td += double(a[j]) * double(x[j]); t = T(td); }
+#elif defined(ORACLE_DOT_TREE)     // (... or as a 16-lane tree of partial sums, the shape of the device's reduction)
+      { T tl[16] = {}; for (int j = 0; j < n; ++j) tl[j & 15] = std::fma(a[j], x[j], tl[j & 15]);
+        for (int w2 = 8; w2 >= 1; w2 /= 2) for (int k = 0; k < w2; ++k) tl[k] += tl[k + w2];
+        t = tl[0]; }
+#else
       for (int j = 0; j < n; ++j) t += a[j] * x[j];
+#endif
       const T r = t + T(0.1) * std::sin(t) - b[i];
       T w = T(1);
       if (kind == 0) {
+#if defined(ORACLE_COST_DOUBLE)
+        cd += double(r) * double(r);
+#elif defined(ORACLE_COST_BY_PASS_KIND)   // the tree sum on passes that want the gradient, the sequential one on cost-only passes
+        if (g) cl[i % ORACLE_COST_LANES] += r * r; else c += r * r;
+#elif ORACLE_COST_LANES > 1
+        cl[i % ORACLE_COST_LANES] += r * r;
+#else
         c += r * r;
+#endif
       } else {
         const auto ls = robust::Apply<T>(kind, r * r, th2);
         c += ls.l;
@@ -89,6 +115,15 @@ struct DenseRowAcc {
         const T s = T(1) + T(0.1) * std::cos(t);
         T* J = Jrow.data();
         for (int j = 0; j < n; ++j) J[j] = s * a[j];
+#if defined(ORACLE_GRAM_DOUBLE)   // (tools/iter_inflation.py only: g and H summed in double, rounded to T once at the end)
+        if (gd.empty()) { gd.assign(n, 0.0); Hd.assign(size_t(n) * n, 0.0); }
+        for (int j = 0; j < n; ++j) gd[j] += double(w * J[j] * r);
+        if (H)
+          for (int q = 0; q < n; ++q) {
+            const T Jq = w * J[q];
+            for (int p = 0; p < n; ++p) Hd[size_t(q) * n + p] += double(J[p] * Jq);
+          }
+#else
         for (int j = 0; j < n; ++j) g[j] += w * J[j] * r;
         if (H) {
           for (int q = 0; q < n; ++q) {  // column q of col-major H: H[q*n + p] += J[p]*J[q]
@@ -97,8 +132,32 @@ struct DenseRowAcc {
             for (int p = 0; p < n; ++p) Hq[p] += J[p] * Jq;
           }
         }
+#endif
       }
     }
+#if defined(ORACLE_GRAM_DOUBLE)
+    if (g && !gd.empty()) {
+      for (int j = 0; j < n; ++j) g[j] += T(gd[j]);
+      if (H) for (size_t e = 0; e < size_t(n) * n; ++e) H[e] += T(Hd[e]);
+      gd.clear(); Hd.clear();
+    }
+#endif
+    if (kind == 0) {
+#if defined(ORACLE_COST_DOUBLE)
+      c = T(cd);
+#elif defined(ORACLE_COST_BY_PASS_KIND)
+      if (g) {
+        for (int w = ORACLE_COST_LANES / 2; w >= 1; w /= 2)
+          for (int k = 0; k < w; ++k) cl[k] += cl[k + w];
+        c = cl[0];
+      }
+#elif ORACLE_COST_LANES > 1
+      for (int w = ORACLE_COST_LANES / 2; w >= 1; w /= 2)
+        for (int k = 0; k < w; ++k) cl[k] += cl[k + w];
+      c = cl[0];
+#endif
+    }
+    (void)cl; (void)cd;
     return kind == 0 ? Cost(double(c), m) : Cost(double(c), m, m ? float(inliers) / float(m) : 1.0f);
   }
 };
