@@ -1563,8 +1563,8 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   // (lane l's pass starts behind lane l - 1's Gram: the stagger).  The geometry (row chunks per problem, row blocks, stage
   // slices) stays that of the whole batch, so every problem sees the arithmetic of the one-lane run: the bits do not depend
   // on the split (toa_tuning::large_one_lane: 1 = one lane, k > 1 = k lanes, for the A/B).  What it buys is modest — +6 % at
-  // 128 x n = 256 — because a Gram workgroup (16 waves x 114 VGPRs) owns the register file of its compute unit: the
-  // factorisations run on compute units the Gram does not have, the overlap is a partition of the chip and the chip-time of
+  // 128 x n = 256 — because a Gram workgroup (12 waves x 114 VGPRs at n = 256) leaves 152 registers per SIMD and the 8-wave
+  // factorisation needs 224: the factorisations run on compute units the Gram does not have, the overlap is a partition of the chip and the chip-time of
   // a pass is conserved (profiles/r04_ab_log.md section 3).
   if (int rc = ensure_pass_ring(h)) return rc;
   int nlanes = h->tune.large_one_lane ? 1 : (P >= 16 ? 2 : 1);   // (measured, 128 x n = 256: 1 lane 80.5 k, 2: 85.5 k, 3: 85 k, 4: 85 k it/s)
