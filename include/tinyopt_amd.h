@@ -403,8 +403,9 @@ int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t
  *      C x N mask, and the reduced camera system (6 C unknowns, in HBM) is solved by the workgroup LDL^T up to 128 unknowns, by
  *      the one-workgroup blocked Cholesky up to 512 (85 cameras in fp64; 170 in fp32) and by rocSOLVER's potrf + potrs (opened
  *      with dlopen, one scene per call) beyond — up to 682 cameras.  A pipeline of small
- *      kernels per Build + Solve attempt (csrc/ba_schur.hip, "bl_*"); every sum has a fixed order.  The host reads one integer
- *      back per pass (it blocks until the solve is done; not graph-capturable), which is also where max_duration_ms is
+ *      kernels per Build + Solve attempt (csrc/ba_schur.hip, "bl_*"); every sum has a fixed order.  The host enqueues two passes
+ *      ahead and reads each pass's stop flag (a pinned ring) two passes late; the call returns when the solve is done and is
+ *      not graph-capturable (refused with a message under capture).  With max_duration_ms > 0 the flag is read after every pass, which is where it is
  *      honoured: > 0 ends every scene still running with kTimedOut once the launches' device time exceeds it
  *      (Options::max_duration_ms, optimizer.h:302-305).
  *        intr_dev:    [P][4] of T = f cx cy 0

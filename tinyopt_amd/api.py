@@ -751,8 +751,8 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
 
     x: [P, n] GPU tensor, updated IN PLACE (the reference takes x by non-const reference).
     cost: a device model (``DenseRow``, ...).  Returns the per-problem Output.  One kernel launch,
-    asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128, whose host loop reads
-    two integers back per pass and therefore blocks until the solve is done.  ``out.counters`` is zeroed here and added to by the
+    asynchronous on torch's current stream — except ``DenseRowNatural`` beyond n = 128, a host loop over passes that returns
+    when the solve is done (it enqueues two passes ahead of the stop counts where every stage is a kernel of this library).  ``out.counters`` is zeroed here and added to by the
     library (every path accumulates); ``zero_counters=False`` skips that fill launch for a caller whose ``out`` is fresh or who
     wants running totals (it is ~8 us of a 50 us single-problem solve; the C-ABI takes the counters as they are).
     """
