@@ -472,6 +472,18 @@ int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t
  *      such call.  toa_jit_lm_run takes this route by itself when P * 4 <= #CUs and m >= 512 (toa_tuning::wide_no_autosplit). */
 int toa_jit_lm_run_split(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
                          const toa_options* options, const toa_results* results, uint64_t* counters_dev, int splits);
+/*      The stepping form of a run-time model (num_params <= 12): the contracts of toa_lm_begin / toa_lm_step / toa_lm_stop with
+ *      state_dev = toa_lm_state_bytes(dtype, num_params, P) bytes; toa_lm_step_info reads that block as for the built-in
+ *      families.  This is what lets Options::stop_callback / stop_callback2 / max_duration_ms (options.h:96-106) work for a
+ *      residual that arrived as text: both host mirrors run their callback loop over it. */
+int toa_jit_lm_begin(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
+                     const toa_options* options, const toa_results* results, void* state_dev);
+int toa_jit_lm_step(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
+                    const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
+                    int32_t* active_dev);
+int toa_jit_lm_stop(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
+                    const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
+                    const int32_t* stop_request_dev);
 
 /* ---- C1: the result gather of a sharded batch (SURVEY §8(b) export list `gather(handle_group...)`, §8(e)).
  *      Problems are independent (the reference optimises exactly one x per call, docs/API.md:12), so a batch of P_total

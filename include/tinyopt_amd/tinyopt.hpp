@@ -407,8 +407,7 @@ BatchOutput Optimize(std::vector<Scalar>& x, const Cost& cost, const Options& op
   if (int64_t(x.size()) != P * cost.xdim())
     throw std::invalid_argument("tinyopt_amd::Optimize: x must hold P * (parameters per problem) scalars");
   if (options.has_host_controls()) {
-    if constexpr (detail::is_jit<Cost>::value) throw std::invalid_argument("a run-time compiled model runs as one launch per solve: no stop callbacks / time limit");
-    else return OptimizeWithHostControls(x, cost, options, history);
+    return OptimizeWithHostControls(x, cost, options, history);   // (run-time models too: toa_jit_lm_begin / step / stop)
   }
   const Context& ctx = cost.ctx();
   DeviceBuffer<Scalar> dx(ctx, x.size());
@@ -477,16 +476,23 @@ class Optimizer {
       r_.errs = errs_.data(); r_.deltas2 = d2_.data(); r_.successes = succ_.data(); r_.hist_stride = hist_stride_;
     }
     apply_loss(cost);
-    check(toa_lm_begin(cost.ctx().get(), Cost::model_id, dtype_of<Scalar>(), n_, cost.m(), P_, cost.data(), dx_.data(), &pod_, &r_,
-                       state_.data()));
+    if constexpr (detail::is_jit<Cost>::value)
+      check(toa_jit_lm_begin(cost.ctx().get(), cost.jit_handle(), cost.items(), P_, cost.data(), dx_.data(), &pod_, &r_, state_.data()));
+    else
+      check(toa_lm_begin(cost.ctx().get(), Cost::model_id, dtype_of<Scalar>(), n_, cost.m(), P_, cost.data(), dx_.data(), &pod_, &r_,
+                         state_.data()));
   }
   // One pass of the loop body for every running problem; returns how many are still running.
   int64_t Step() {
     const Context& ctx = cost_->ctx();
     active_.zero();
     apply_loss(*cost_);
-    check(toa_lm_step(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
-                      nullptr, state_.data(), active_.data()));
+    if constexpr (detail::is_jit<Cost>::value)
+      check(toa_jit_lm_step(ctx.get(), cost_->jit_handle(), cost_->items(), P_, cost_->data(), dx_.data(), &pod_, &r_, nullptr,
+                            state_.data(), active_.data()));
+    else
+      check(toa_lm_step(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
+                        nullptr, state_.data(), active_.data()));
     check(toa_synchronize(ctx.get()));
     int32_t a = 0;
     active_.download(&a);
@@ -533,8 +539,12 @@ class Optimizer {
     const Context& ctx = cost_->ctx();
     DeviceBuffer<int32_t> dr(ctx, P_);
     dr.upload(request.data());
-    check(toa_lm_stop(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
-                      nullptr, state_.data(), dr.data()));
+    if constexpr (detail::is_jit<Cost>::value)
+      check(toa_jit_lm_stop(ctx.get(), cost_->jit_handle(), cost_->items(), P_, cost_->data(), dx_.data(), &pod_, &r_, nullptr,
+                            state_.data(), dr.data()));
+    else
+      check(toa_lm_stop(ctx.get(), Cost::model_id, dtype_of<Scalar>(), n_, cost_->m(), P_, cost_->data(), dx_.data(), &pod_, &r_,
+                        nullptr, state_.data(), dr.data()));
     check(toa_synchronize(ctx.get()));
   }
   void SetStopReason(const std::vector<int32_t>& stop) { stop_.upload(stop.data()); }

@@ -165,6 +165,13 @@ static void circle_jit() {
   CircleFit<double> builtin(ctx, 1, n, obs.data());
   const auto outb = Optimize(xb, builtin, options);
   REQUIRE(out.num_iters[0] == outb.num_iters[0] && x[0] == xb[0] && x[1] == xb[1] && x[2] == xb[2]);
+  // Options::stop_callback on a residual that arrived as text (the stepping form of the run-time model): stop after 3 iterations
+  std::vector<double> xc{0, 0, 1};
+  Options oc = options;
+  int calls = 0;
+  oc.stop_callback = [&](double, double, double) { return ++calls >= 3; };
+  const auto outc = Optimize(xc, fit.bind(1, n, obs.data()), oc);
+  REQUIRE(outc.stop_reason[0] == kUserStopped && outc.num_iters[0] == 3 && calls == 3);
   bool threw = false;
   try {
     JitResidual<double> bad(ctx, "r[0] = no_such_function(x[0]);", 1, 1);

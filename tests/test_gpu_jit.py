@@ -368,3 +368,67 @@ def test_row_split_chunks_fall_on_item_boundaries(ta, oracle):
     # an empty batch is a no-op
     x = torch.zeros(0, 4, dtype=torch.float64, device="cuda")
     ta.Optimize(x, fit.bind(torch.zeros(0, 5, 4, dtype=torch.float64, device="cuda")), ta.Options(), splits=2)
+
+
+def test_stepping_form_and_stop_controls_for_a_residual_supplied_as_text(ta, oracle):
+    """`optimizer.Step(x, acc, out)` and Options::stop_callback / stop_callback2 / max_duration_ms (optimizer.h:302-305,331-539,
+    options.h:96-106) for a run-time model: stepping to the end reproduces Optimize; a callback stops the named problems after
+    that iteration with kUserStopped and a finalised Output row; a time limit gives kTimedOut."""
+    P, npts = 9, 40
+    obs = _circle_obs(P, npts, np.float64, seed=3)
+    x0 = np.tile(np.array([0, 0, 1], np.float64), (P, 1)) + 0.1 * np.random.default_rng(1).uniform(-1, 1, (P, 3))
+    o = ta.Options(); o.lm.damping_init = 1e1
+    fit = ta.JitResidual(CIRCLE, n=3, item_scalars=2)
+    model = fit.bind(torch.from_numpy(obs).cuda())
+    xr = torch.from_numpy(x0.copy()).cuda()
+    ref = ta.Optimize(xr, model, o, history=True)
+    x = torch.from_numpy(x0.copy()).cuda()
+    opt = ta.Optimizer(x, model, o, history=True)
+    steps = 0
+    while opt.Step() > 0:
+        steps += 1
+        assert steps < o.max_iters + 3
+    torch.cuda.synchronize()
+    assert torch.equal(opt.out.stop_reason, ref.stop_reason) and torch.equal(opt.out.num_iters, ref.num_iters)
+    assert float((x - xr).abs().max()) < 1e-10 and np.allclose(opt.out.final_cost.cpu().numpy(), ref.final_cost.cpu().numpy(), rtol=1e-9)
+    # callbacks: from the second pass on, stop the problems whose cost is above the median
+    seen = []
+    e1 = ref.errs.cpu().numpy()[:, 1]
+    thr = float(np.median(e1))
+
+    def cb(err, dx2, g2):
+        seen.append((err, dx2, g2))
+        return len(seen) > P and err > thr
+
+    o2 = ta.Options(); o2.lm.damping_init = 1e1; o2.stop_callback = cb
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o2, history=True)
+    torch.cuda.synchronize()
+    stop, iters = out.stop_reason.cpu().numpy(), out.num_iters.cpu().numpy()
+    user = e1 > thr
+    assert user.sum() == P // 2
+    assert (stop[user] == int(ta.StopReason.kUserStopped)).all() and (iters[user] == 2).all()
+    assert np.array_equal(stop[~user], ref.stop_reason.cpu().numpy()[~user]) and np.array_equal(iters[~user], ref.num_iters.cpu().numpy()[~user])
+    assert np.allclose(sorted(c[0] for c in seen[:P]), sorted(ref.errs.cpu().numpy()[:, 0]), rtol=1e-9)
+    assert (out.final_cost.cpu().numpy()[user] > 0).all() and float(out.final_hessian[torch.from_numpy(user).cuda()].abs().sum()) > 0
+    got = []
+    o3 = ta.Options(); o3.stop_callback2 = lambda err, dx, g: (got.append((dx.shape, g.shape)) or True)
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o3)
+    assert (out.stop_reason.cpu().numpy() == int(ta.StopReason.kUserStopped)).all() and got == [((3,), (3,))] * P
+    o4 = ta.Options(); o4.max_duration_ms = 1e-6
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o4)
+    assert (out.stop_reason.cpu().numpy() == int(ta.StopReason.kTimedOut)).all() and (out.num_iters.cpu().numpy() == 1).all()
+    # the SE3 pose prior as text, stepped: lands where the one-launch solve lands
+    rng = np.random.default_rng(7)
+    ident = np.tile(np.concatenate([np.eye(3).reshape(-1), np.zeros(3)]), (4, 1))
+    hdr = torch.from_numpy(oracle.se3_plus(ident, 0.6 * rng.uniform(-1, 1, (4, 6)))).cuda()
+    prior = ta.JitResidual(SE3_PRIOR, n=6, item_scalars=0, residuals_per_item=6, header_scalars=12, manifold="se3").bind(None, header=hdr)
+    xa = torch.from_numpy(ident.copy()).cuda(); xb = torch.from_numpy(ident.copy()).cuda()
+    ra = ta.Optimize(xa, prior, ta.Options())
+    rb = ta.Optimizer(xb, prior, ta.Options())()
+    assert torch.equal(ra.stop_reason, rb.stop_reason) and torch.equal(ra.num_iters, rb.num_iters) and float((xa - xb).abs().max()) < 1e-10
+    with pytest.raises(Exception, match="at most 12 parameters"):
+        wide = ta.JitResidual("r[0] = x[0] - p[0];", n=20, item_scalars=1)
+        ta.Optimizer(torch.zeros(1, 20, dtype=torch.float64, device="cuda"), wide.bind(torch.zeros(1, 8, 1, dtype=torch.float64, device="cuda")))

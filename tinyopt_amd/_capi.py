@@ -125,6 +125,9 @@ PROTOTYPES = {
     "toa_jit_lm_run": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
     "toa_jit_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),
     "toa_jit_lm_run_split": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P, C.c_int]),
+    "toa_jit_lm_begin": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
+    "toa_jit_lm_step": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P, _P, _P]),
+    "toa_jit_lm_stop": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P, _P, _P]),
     "toa_lm_run_split": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions),
                                    C.POINTER(ToaResults), _P, C.c_int]),
 }

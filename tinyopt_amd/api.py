@@ -796,8 +796,10 @@ def Optimize(x: torch.Tensor, cost, options: Optional[Options] = None, *, histor
                                        C.byref(pod), C.byref(res), out.counters.data_ptr(), float(options.max_duration_ms or 0.0)))
         return out
     if isinstance(cost, JitModel):
-        if options.has_host_controls():
-            raise ValueError("a run-time compiled model has no stepping form: no stop callbacks / max_duration_ms")
+        if options.has_host_controls():   # the stepping form of the run-time model (toa_jit_lm_begin / step / stop)
+            if splits is not None or out is not None:
+                raise ValueError("stop callbacks / max_duration_ms run through the stepping form: splits / out are not taken")
+            return _optimize_with_host_controls(x, cost, options, history, ctx)
         pod = options.to_pod()
         if out is None:
             out = _alloc_output(P, n, options, history, x.device)
@@ -852,8 +854,13 @@ class Optimizer:
         self._state = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=x.device)
         self._active = torch.zeros(1, dtype=torch.int32, device=x.device)
         _apply_loss(self.ctx, cost)
-        check(self.ctx.lib.toa_lm_begin(self.ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
-                                        x.data_ptr(), C.byref(self.pod), C.byref(self._res), self._state.data_ptr()))
+        self._jit = isinstance(cost, JitModel)
+        if self._jit:
+            check(self.ctx.lib.toa_jit_lm_begin(self.ctx.h, cost.res._h, cost.items, P, cost.packed.data_ptr(), x.data_ptr(),
+                                                C.byref(self.pod), C.byref(self._res), self._state.data_ptr()))
+        else:
+            check(self.ctx.lib.toa_lm_begin(self.ctx.h, cost.model_id, _dtype_code(x.dtype), n, cost.m, P, cost.packed.data_ptr(),
+                                            x.data_ptr(), C.byref(self.pod), C.byref(self._res), self._state.data_ptr()))
 
     def Step(self, sync: bool = True) -> Optional[int]:
         """One pass of the loop body for every running problem.  Returns how many are still running (host sync), or
@@ -861,9 +868,14 @@ class Optimizer:
         x, cost = self.x, self.cost
         self._active.zero_()
         _apply_loss(self.ctx, cost)
-        check(self.ctx.lib.toa_lm_step(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
-                                       cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
-                                       self.out.counters.data_ptr(), self._state.data_ptr(), self._active.data_ptr()))
+        if self._jit:
+            check(self.ctx.lib.toa_jit_lm_step(self.ctx.h, cost.res._h, cost.items, x.shape[0], cost.packed.data_ptr(), x.data_ptr(),
+                                               C.byref(self.pod), C.byref(self._res), self.out.counters.data_ptr(),
+                                               self._state.data_ptr(), self._active.data_ptr()))
+        else:
+            check(self.ctx.lib.toa_lm_step(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
+                                           cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
+                                           self.out.counters.data_ptr(), self._state.data_ptr(), self._active.data_ptr()))
         return int(self._active.item()) if sync else None
 
     def __call__(self, max_iters: Optional[int] = None) -> Output:
@@ -893,6 +905,11 @@ class Optimizer:
         their Output rows are finalised exactly as for a problem that stops by itself."""
         x, cost = self.x, self.cost
         request = request.to(device=x.device, dtype=torch.int32).contiguous()
+        if self._jit:
+            check(self.ctx.lib.toa_jit_lm_stop(self.ctx.h, cost.res._h, cost.items, x.shape[0], cost.packed.data_ptr(), x.data_ptr(),
+                                               C.byref(self.pod), C.byref(self._res), self.out.counters.data_ptr(),
+                                               self._state.data_ptr(), request.data_ptr()))
+            return
         check(self.ctx.lib.toa_lm_stop(self.ctx.h, cost.model_id, _dtype_code(x.dtype), cost.n, cost.m, x.shape[0],
                                        cost.packed.data_ptr(), x.data_ptr(), C.byref(self.pod), C.byref(self._res),
                                        self.out.counters.data_ptr(), self._state.data_ptr(), request.data_ptr()))
