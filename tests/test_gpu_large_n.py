@@ -467,3 +467,30 @@ def test_two_lanes_give_the_bits_of_one_lane(ta, oracle, P, n, m):
             assert torch.equal(getattr(out, f), getattr(outs[0][1], f)), f
         assert torch.equal(out.counters[:4], outs[0][1].counters[:4])
     assert int(outs[0][1].num_iters.max()) > int(outs[0][1].num_iters.min())
+
+
+def test_a_few_huge_problems_take_the_row_split_pipeline(ta, oracle):
+    """64 <= n <= 128 with ONE (or a handful of) problems of tens of thousands of rows: a workgroup per problem would use one
+    compute unit, so toa_lm_run routes such a batch to the launch-per-stage pipeline, whose rows kernel and Gram split every
+    problem's rows over the chip; toa_tuning::wide_no_autosplit keeps the one-kernel form.  The two forms agree to summation
+    order, and both with the float64 oracle (a float32 oracle's SEQUENTIAL sum over 30 000 rows is itself off by 5e-4)."""
+    P, n, m = 2, 96, 30000
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=9)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    o = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A.astype(np.float64), b.astype(np.float64), x0.astype(np.float64), o.to_pod(), history=True)
+    ctx = ta.api.default_context()
+    res = []
+    for tune in ({}, dict(wide_no_autosplit=1)):
+        x = torch.from_numpy(x0.copy()).cuda()
+        with ctx.tuning(**tune):
+            out = ta.Optimize(x, model, o, history=True)
+        torch.cuda.synchronize()
+        assert bool((out.stop_reason > 0).all())
+        assert float((x - torch.from_numpy(xs).cuda()).abs().max()) < 1e-3
+        assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-4
+        e = out.errs.cpu().numpy()
+        assert np.allclose(e[:, :3], ref["errs"][:, :3], rtol=2e-4)          # the descent before the float floor
+        res.append((x.clone(), out))
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5
+    assert np.allclose(res[0][1].errs.cpu().numpy()[:, :3], res[1][1].errs.cpu().numpy()[:, :3], rtol=2e-4)

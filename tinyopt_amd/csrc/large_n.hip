@@ -1322,7 +1322,9 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   while (LPR * 2 <= std::min(64, nv)) LPR *= 2;
   const int KV = vec_ok ? (nv + LPR - 1) / LPR : 0;
   const int RPW = 64 / LPR;
-  const long long wg_target = (long long)h->num_cus * 16 / std::max<long long>(1, P) + 1;
+  // (capped at one workgroup per compute unit and problem: every workgroup leaves four partial J^T r vectors that
+  //  large_pre_kernel sums one after the other — 16 000 of them for ONE problem of 65 536 rows took longer than the data pass)
+  const long long wg_target = std::min<long long>((long long)h->num_cus * 16 / std::max<long long>(1, P) + 1, h->num_cus);
   const unsigned row_blocks = unsigned(std::max<long long>(1, std::min<long long>((m + 4 * (vec_ok ? RPW : 4) - 1) / (4 * (vec_ok ? RPW : 4)), wg_target)));
   const int gslots = vec_ok ? int(row_blocks) * 4 : 0;
   const size_t b_gpart = al(size_t(P) * size_t(std::max(gslots, 1)) * n * sizeof(T));
@@ -1339,7 +1341,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   if (own_gram) {   // about four workgroups per CU when every problem rebuilds (a late pass with few of them left is bound by ONE
                     // workgroup's run time, which shrinks with the chunk); the rows of a chunk a multiple of the LDS stage
     const long long want_wgs = (long long)h->num_cus * 4, per_chunk = P * geo.groups;
-    gram_R = int(std::max<long long>(1, std::min<long long>(32, (want_wgs + per_chunk - 1) / per_chunk)));
+    gram_R = int(std::max<long long>(1, std::min<long long>(256, (want_wgs + per_chunk - 1) / per_chunk)));   // (a FEW huge problems: up to 256 row chunks each)
     gram_rows = (((m + gram_R - 1) / gram_R) + geo.K - 1) / geo.K * geo.K;
     gram_R = (m + gram_rows - 1) / gram_rows;
   }
@@ -1730,7 +1732,14 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
                      const toa_results* results, uint64_t* counters) {
   // 64 <= n <= 128: the whole loop in one persistent kernel, Gram on the matrix cores (large_fused.hip)
   // (use_ldlt = false needs the library's general LU: the launch-per-stage pipeline below, for every n >= 64)
-  if (options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
+  // ... unless the batch is a FEW huge problems: one workgroup per problem would leave the chip idle, while the pipeline below
+  // splits the rows of every problem over the compute units (rows kernel: one workgroup per CU; Gram: up to 256 row chunks).
+  // Measured, n = 128 fp32: 1 x 65 536 rows 19.2 -> 5.2 ms, 4 x 16 384: 7.5 -> 4.4, 16 x 8 192: 4.0 -> 3.7 (1 x 20 000 at n = 96:
+  // 3.3 against 3.5 — hence the row threshold).  The M-estimator lives in the one-kernel form only.
+  // (fp32 with 16-byte rows: every stage of the pipeline is then a kernel of this library — no rocBLAS / rocSOLVER load, no per-pass read-back)
+  const bool few_huge = P * 16 <= (int64_t)h->num_cus && P * (int64_t)m >= 49152 && h->loss == TOA_LOSS_L2 && !h->tune.wide_no_autosplit &&
+                        dtype == TOA_F32 && n % 4 == 0 && (int64_t(m) * (n + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
+  if (options->use_ldlt && !few_huge && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   // The pipeline's kernels index problems through grid.y (65 535): a larger batch goes through it slice by slice — the
   // problems are independent, so the slices are just shorter batches (same bits), and the workspace is sized for one slice.
   constexpr int64_t kSlice = 65535;
