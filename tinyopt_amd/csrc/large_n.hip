@@ -680,7 +680,19 @@ __global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<
     const int li = e >> 5, lj = e & 31, gi = 32 * ti + li, gj = 32 * tj + lj;
     if (gi >= n || gj >= n) continue;
     T s = 0;
-    for (int r = 0; r < a.gram_R; ++r) s += a.gram_part[((size_t(p) * a.gram_R + r) * geo.T + t) * 1024 + e];   // fixed order
+    // fixed order; eight loads in flight per trip (a dependent load per partial was 0.7 us each: 181 us for the 256 row chunks
+    // of a single huge problem, nine times the Gram itself)
+    const T* gp = a.gram_part + (size_t(p) * a.gram_R * geo.T + t) * 1024 + e;
+    const size_t gstride = size_t(geo.T) * 1024;
+    int r = 0;
+    for (; r + 8 <= a.gram_R; r += 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = gp[size_t(r + u) * gstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < a.gram_R; ++r) s += gp[size_t(r) * gstride];
     H[size_t(gi) * n + gj] = s;
     if (ti != tj) H[size_t(gj) * n + gi] = s;
   }
@@ -723,7 +735,17 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   const bool is_lm = opt.solver_type == 0;
   const bool do_acc = !is_lm || S.rebuild;
   double c = 0;
-  for (int i = tid; i < m; i += 256) { const T r = a.r[p * m + i]; c += double(r * r); }
+  {
+    int i = tid;
+    for (; i + 7 * 256 < m; i += 8 * 256) {   // (eight loads in flight per trip, the same order of additions)
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.r[p * m + i + u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += double(v[u] * v[u]);
+    }
+    for (; i < m; i += 256) { const T r = a.r[p * m + i]; c += double(r * r); }
+  }
   c = block_sum<T>(c, red);
   const double cost_val = normalize_cost(double(T(c)), m, opt);
   bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
@@ -738,7 +760,16 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
       T gi;
       if (a.gslots > 0) {  // fixed-order sum of the per-wave partials of the vectorised rows kernel
         gi = 0;
-        for (int sl = 0; sl < a.gslots; ++sl) gi += a.gpart[(size_t(p) * a.gslots + sl) * n + i];
+        const T* gq = a.gpart + size_t(p) * a.gslots * n + i;   // (eight loads in flight per trip, added in slot order)
+        int sl = 0;
+        for (; sl + 8 <= a.gslots; sl += 8) {
+          T v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = gq[size_t(sl + u) * n];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gi += v[u];
+        }
+        for (; sl < a.gslots; ++sl) gi += gq[size_t(sl) * n];
       } else {
         gi = a.gnew[p * n + i];
       }
@@ -1732,12 +1763,15 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
                      const toa_results* results, uint64_t* counters) {
   // 64 <= n <= 128: the whole loop in one persistent kernel, Gram on the matrix cores (large_fused.hip)
   // (use_ldlt = false needs the library's general LU: the launch-per-stage pipeline below, for every n >= 64)
-  // ... unless the batch is a FEW huge problems: one workgroup per problem would leave the chip idle, while the pipeline below
-  // splits the rows of every problem over the compute units (rows kernel: one workgroup per CU; Gram: up to 256 row chunks).
-  // Measured, n = 128 fp32: 1 x 65 536 rows 19.2 -> 5.2 ms, 4 x 16 384: 7.5 -> 4.4, 16 x 8 192: 4.0 -> 3.7 (1 x 20 000 at n = 96:
-  // 3.3 against 3.5 — hence the row threshold).  The M-estimator lives in the one-kernel form only.
+  // ... unless the batch is a FEW huge problems: a workgroup per problem leaves the chip idle and lasts as long as ONE problem
+  // (~0.35 us per row at n = 128), while the pipeline below splits the rows of every problem over the compute units (rows
+  // kernel: one workgroup per CU and problem; Gram: up to 256 row chunks) at a latency floor of ~1.2 ms per solve.  Measured
+  // crossover, fp32 (ms per solve, pipeline / one kernel): 1 x 65 536 x n = 128: 2.0 / 19.1; 1 x 20 000 x 96: 1.2 / 3.3;
+  // 4 x 16 384 x 128: 1.6 / 7.5; 32 x 8 192 x 128: 2.0 / 4.0; 64 x 4 096 x 128: 1.9 / 2.7; but 24 x 2 048 x 128: 1.5 / 1.25,
+  // 64 x 3 000 x 96: 1.45 / 1.14, 128 x 4 096 x 128: 2.8 / 2.5 — so: enough rows per problem to outlast the floor, and a batch
+  // small enough that the pipeline's own data passes stay under it.  The M-estimator lives in the one-kernel form only.
   // (fp32 with 16-byte rows: every stage of the pipeline is then a kernel of this library — no rocBLAS / rocSOLVER load, no per-pass read-back)
-  const bool few_huge = P * 16 <= (int64_t)h->num_cus && P * (int64_t)m >= 49152 && h->loss == TOA_LOSS_L2 && !h->tune.wide_no_autosplit &&
+  const bool few_huge = int64_t(m) * n >= 393216 && P * int64_t(m) * n <= (int64_t(1) << 25) && h->loss == TOA_LOSS_L2 && !h->tune.wide_no_autosplit &&
                         dtype == TOA_F32 && n % 4 == 0 && (int64_t(m) * (n + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
   if (options->use_ldlt && !few_huge && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   // The pipeline's kernels index problems through grid.y (65 535): a larger batch goes through it slice by slice — the
