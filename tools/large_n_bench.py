@@ -32,6 +32,7 @@ def main():
     for dt, n, m, P in ((torch.float32, 63, 2000, 2048), (torch.float32, 64, 2000, 2048), (torch.float32, 96, 3000, 1024),
                         (torch.float32, 128, 4096, 512), (torch.float32, 128, 4096, 2048),
                         (torch.float32, 256, 8192, 128), (torch.float32, 512, 8192, 64), (torch.float32, 768, 8192, 32), (torch.float32, 1024, 8192, 16),
+                        (torch.float32, 128, 65536, 1), (torch.float32, 128, 16384, 4), (torch.float32, 96, 20000, 1),   # a few huge problems: the row-split pipeline
                         (torch.float64, 256, 4096, 64), (torch.float64, 64, 2000, 1024),
                         (torch.float64, 96, 3000, 512), (torch.float64, 128, 4096, 256)):
         A, b, x0, xs = synth(P, n, m, dt)
