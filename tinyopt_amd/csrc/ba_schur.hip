@@ -960,12 +960,19 @@ __global__ void __launch_bounds__(64) bl_index_c_kernel(const BlParams* __restri
   const int* oc = prm->obs_cam + size_t(p) * M;
   int* co = iw + ix.cam_order;
   int pos = iw[ix.cam_start + c];
-  for (int i0 = 0; i0 < M; i0 += 64) {
-    const int i = i0 + lane;
-    const bool mine = i < M && oc[i] == c;
-    const unsigned long long mask = __ballot(mine);
-    if (mine) co[pos + __popcll(mask & ((1ull << lane) - 1ull))] = i;
-    pos += __popcll(mask);
+  // eight trips' worth of camera ids in flight at a time (a dependent load per trip was 0.28 us x 469 trips = 130 us per call
+  // at 30 000 observations — 2 % of a four-scene solve spent building an index); the list order is unchanged
+  for (int i0 = 0; i0 < M; i0 += 64 * 8) {
+    int cam[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u + lane; cam[u] = i < M ? oc[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool mine = cam[u] == c;
+      const unsigned long long mask = __ballot(mine);
+      if (mine) co[pos + __popcll(mask & ((1ull << lane) - 1ull))] = i0 + 64 * u + lane;
+      pos += __popcll(mask);
+    }
   }
 }
 
