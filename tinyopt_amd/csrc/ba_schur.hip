@@ -1262,7 +1262,13 @@ __global__ void __launch_bounds__(256) bl_psolve_kernel(const BlParams* __restri
 // in LDS by the first 64 threads.  For observation i of point j, camera c' contributes iff it sees j: a binary search of
 // the point's (camera-sorted) list.  S(c, c') -= T_i (J_p,i'^T J_c,i'),   red_c -= T_i g_pj  [red = g_c - W V^-1 g_p].
 template <typename T>
-__global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restrict__ prm) {
+__global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restrict__ prm, const int split, T* __restrict__ spart,
+                                                       T* __restrict__ rpart) {
+  // Round 4: with split > 1 (scenes whose cameras see >= 256 observations each, C <= 128 — a property of the scene, never of the
+  // batch, so that a scene solved alone still gives the bits of its row in a batch) the observations of camera c are dealt to
+  // `split` workgroups in contiguous runs; each leaves its partial block row (and partial right-hand side) in spart / rpart
+  // and bl_schur_reduce_kernel sums them in run order and finishes the row.  Four scenes x 64 cameras are 256 workgroups of
+  // ~470 observations each — one per compute unit, 0.255 ms per pass; dealt four ways the chip is full.
   // One workgroup per camera c forms block row c of S (lower block triangle, mirrored) and of the reduced right-hand side.
   // Per staged chunk of 32 of the camera's observations (point j each):
   //   T_s  = J_c,s^T (J_p,s V_j^-1)                 6 x 3   thread s
@@ -1281,7 +1287,7 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
   __shared__ short cl[kS][kListCap];
   __shared__ int jl[kS], l0[kS], ln[kS];
   const long long p = blockIdx.y;
-  const int c = blockIdx.x;
+  const int c = blockIdx.x / split, part = blockIdx.x % split;
   const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
   const BlWork<T> wk(C, N, M);
   const BlIdx ix(C, N, M);
@@ -1292,7 +1298,13 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
   T* rg = static_cast<T*>(prm->rhsall) + size_t(p) * n;
   const int* oc = prm->obs_cam + size_t(p) * M;
   const int tid = threadIdx.x;
-  const int k0 = iw[ix.cam_start + c], k1 = iw[ix.cam_start + c + 1];
+  int k0 = iw[ix.cam_start + c], k1 = iw[ix.cam_start + c + 1];
+  if (split > 1) {   // this workgroup's run of the camera's observations: whole staged chunks
+    const int per = (((k1 - k0 + split - 1) / split) + 31) / 32 * 32;
+    k0 = min(k1, k0 + part * per);
+    k1 = min(k1, k0 + per);
+  }
+  T* sp = split > 1 ? spart + ((size_t(p) * C + c) * split + part) * size_t(C) * 36 : nullptr;
   const int lane = tid & 63, ent = lane % kFast;
   const bool live = lane < 54;
   const int ad = live ? 9 * (tid >> 6) + lane / kFast : 0, a = ad / 6, d = ad % 6;   // component (a, d), list entries ent, ent + 6, ...
@@ -1371,6 +1383,14 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
       }
     }
     __syncthreads();
+    if (split > 1) {   // the partial block row of this run, tile by tile
+      for (int e = tid; e < kTile * 36; e += 256) {
+        const int c2 = cbase + e / 36;
+        if (c2 <= c && c2 < C) sp[size_t(c2) * 36 + e % 36] = Srow[c2 - cbase][e % 36];
+      }
+      __syncthreads();
+      continue;
+    }
     for (int e = tid; e < kTile * 36; e += 256) {
       const int c2 = cbase + e / 36, q = e % 36, qa = q / 6, qd = q % 6;
       if (c2 > c || c2 >= C) continue;
@@ -1384,7 +1404,56 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
     }
     __syncthreads();
   }
-  if (live && ent == 0 && d == 0) rg[6 * c + a] = w[wk.gc + 6 * c + a] + rva;
+  if (live && ent == 0 && d == 0) {
+    if (split > 1) rpart[((size_t(p) * C + c) * split + part) * 6 + a] = rva;
+    else rg[6 * c + a] = w[wk.gc + 6 * c + a] + rva;
+  }
+}
+
+// split > 1: block row c of S and of the reduced right-hand side from the `split` partial rows, summed in run order
+template <typename T>
+__global__ void __launch_bounds__(256) bl_schur_reduce_kernel(const BlParams* __restrict__ prm, const int split, const T* __restrict__ spart,
+                                                              const T* __restrict__ rpart) {
+  constexpr int kTile = 64;
+  __shared__ T Srow[kTile][36];
+  const long long p = blockIdx.y;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int C = prm->C, N = prm->N, M = prm->M, n = 6 * C;
+  const BlWork<T> wk(C, N, M);
+  const BlIdx ix(C, N, M);
+  const int* iw = prm->iwork + size_t(p) * ix.total;
+  if (!iw[ix.flags + 0] || !iw[ix.flags + 3]) return;
+  const T* w = static_cast<const T*>(prm->work) + size_t(p) * wk.total;
+  T* Sg = static_cast<T*>(prm->Sall) + size_t(p) * n * n;
+  T* rg = static_cast<T*>(prm->rhsall) + size_t(p) * n;
+  const T* sp = spart + (size_t(p) * C + c) * split * size_t(C) * 36;
+  for (int cbase = 0; cbase <= c; cbase += kTile) {
+    for (int e = tid; e < kTile * 36; e += 256) {
+      const int c2 = cbase + e / 36;
+      T v = T(0);
+      if (c2 <= c && c2 < C)
+        for (int k = 0; k < split; ++k) v += sp[(size_t(k) * C + c2) * 36 + e % 36];
+      Srow[e / 36][e % 36] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < kTile * 36; e += 256) {
+      const int c2 = cbase + e / 36, q = e % 36, qa = q / 6, qd = q % 6;
+      if (c2 > c || c2 >= C) continue;
+      T v = Srow[c2 - cbase][q];
+      if (c2 == c) {   // the diagonal block: symmetrise + U_c with its damped diagonal (as bl_schur_kernel does for split = 1)
+        v = (qd <= qa) ? Srow[c2 - cbase][qa * 6 + qd] : Srow[c2 - cbase][qd * 6 + qa];
+        v += (qa == qd) ? w[wk.Ud + 6 * c + qa] : w[wk.U + 36 * c + 6 * qa + qd];
+      }
+      Sg[size_t(6 * c + qa) * n + 6 * c2 + qd] = v;
+      if (c2 != c) Sg[size_t(6 * c2 + qd) * n + 6 * c + qa] = v;
+    }
+    __syncthreads();
+  }
+  if (tid < 6) {
+    T v = T(0);
+    for (int k = 0; k < split; ++k) v += rpart[((size_t(p) * C + c) * split + k) * 6 + tid];
+    rg[6 * c + tid] = w[wk.gc + 6 * c + tid] + v;
+  }
 }
 
 template <typename T>
@@ -1591,7 +1660,10 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t b_work = al(size_t(P) * wk.total * sizeof(T)), b_iwork = al(size_t(P) * ix.total * sizeof(int)), b_ok = al(size_t(P) * sizeof(int32_t));
   const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
-  const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v;
+  // bl_schur split (see the kernel): a property of the scene's shape only
+  const int split = (C <= 128 && M / std::max(C, 1) >= 256) ? 4 : 1;   // (8: 5.02 ms at four scenes against 5.10, 10.43 against 10.28 at 32)
+  const size_t b_sp = split > 1 ? al(size_t(P) * C * split * C * 36 * sizeof(T)) : 0, b_rp = split > 1 ? al(size_t(P) * C * split * 6 * sizeof(T)) : 0;
+  const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v + b_sp + b_rp;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
     if (int rc = grow_sync(h, "bundle adjustment workspace")) return rc;
     if (h->aux) (void)hipFree(h->aux);
@@ -1608,6 +1680,8 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   prm.Sall = base + b_work + b_iwork + b_ok + 256;
   prm.rhsall = static_cast<char*>(prm.Sall) + b_S;
   prm.dcall = static_cast<char*>(prm.rhsall) + b_v;
+  T* spart = reinterpret_cast<T*>(static_cast<char*>(prm.dcall) + b_v);
+  T* rpart = reinterpret_cast<T*>(static_cast<char*>(prm.dcall) + b_v + b_sp);
   HIP_TRY(hipMemsetAsync(prm.dcall, 0, b_v, h->stream));
   static_assert(sizeof(BlParams) <= 1024, "parameter block too large");
   if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
@@ -1676,7 +1750,8 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     hipLaunchKernelGGL(bl_cam_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_build_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_psolve_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
-    hipLaunchKernelGGL(bl_schur_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_schur_kernel<T>, dim3(unsigned(C * split), unsigned(P)), dim3(256), 0, st, dev, split, spart, rpart);
+    if (split > 1) hipLaunchKernelGGL(bl_schur_reduce_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev, split, (const T*)spart, (const T*)rpart);
     HIP_TRY(hipGetLastError());
     // reduced camera system: S dc = -red  (toa_large_solve: dx = -H^-1 g; scale 1: S is already damped).  A scene that is not
     // running (or whose Build failed) still goes through the solver on whatever its S holds: its verdict is ignored.
