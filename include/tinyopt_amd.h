@@ -189,7 +189,8 @@ typedef struct toa_tuning {
   int32_t large_library_solver;  /* rocSOLVER potrf / potrs wherever a solver of our own would run (also toa_solve_damped for n <= 63) */
   int32_t fail_workspace_alloc;  /* TEST HOOK: the n > 128 workspace request fails as on a full device (kOutOfMemory path) */
   int32_t large_one_lane;        /* n > 128, own kernels: the whole batch on one stream instead of two half-batch lanes (same bits) */
-  int32_t reserved[17];
+  int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
+  int32_t reserved[16];
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
 int toa_get_tuning(toa_handle h, toa_tuning* out);

@@ -494,3 +494,25 @@ def test_a_few_huge_problems_take_the_row_split_pipeline(ta, oracle):
         res.append((x.clone(), out))
     assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5
     assert np.allclose(res[0][1].errs.cpu().numpy()[:, :3], res[1][1].errs.cpu().numpy()[:, :3], rtol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [130, 160, 200, 256, 384, 500])
+def test_cholesky_lookahead_gives_the_bits_of_the_plain_schedule(ta, dtype, n):
+    """Round 4: in block step k wave 0 updates the tiles of the NEXT diagonal block first and factors it while the other waves
+    finish the trailing update.  Which wave computes a tile never mattered and every pivot sees the same values: the solution
+    and the verdicts are bit for bit those of the schedule without look-ahead — also for an indefinite matrix."""
+    if dtype == np.float64 and n > 512:
+        pytest.skip("fp64 panel beyond the LDS range")
+    P = 5
+    H, g = _spd_batch(P, n, dtype, seed=n)
+    H[3, n // 2 + 7, n // 2 + 7] = -1.0          # a pivot that fails deep inside (info != 0 for that matrix only)
+    ctx = ta.api.default_context()
+    outs = []
+    for flag in (0, 1):
+        with ctx.tuning(large_chol_no_lookahead=flag):
+            dx, ok = ta.solve_damped(torch.from_numpy(H).cuda(), torch.from_numpy(g).cuda(), 1.0 + 1e-4)
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), ok.clone()))
+    assert outs[0][1].cpu().numpy().tolist() == [1, 1, 1, 0, 1]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

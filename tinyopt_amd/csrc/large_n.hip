@@ -885,7 +885,11 @@ __device__ __forceinline__ T chol_bcast(const T v, const int src) {
   }
 }
 constexpr int kCholThreads = 512;
-template <typename T>
+// LOOK (round 4): look-ahead — in the trailing-update phase of block k, wave 0 updates the four tiles that hold the NEXT diagonal
+// block first and factors it at once, while the other seven waves update the rest; the next step then starts at its panel.  The
+// diagonal blocks were 0.17 of an n = 384 fp64 solve's 0.68 ms with seven of eight waves waiting; every tile and every pivot
+// sees the arithmetic it saw before (which wave computes a tile never mattered): the same bits, checked against LOOK = false.
+template <typename T, bool LOOK = true>
 __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const LargeArgs<T> a) {
   constexpr int B = 32, LS = B + 1, LSP = B + 4, NT = kCholThreads, NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char chol_lds[];
@@ -907,49 +911,53 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
 #else
 #define CH_TICK(i)
 #endif
+  // the diagonal block at k0: wave 0, lane r holds row r of the block (columns past the diagonal are never read)
+  auto diag_block = [&](const int k0, const int bs) __attribute__((always_inline)) {
+    T r[B];
+#pragma unroll
+    for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? A[size_t(k0 + lane) * n + k0 + c] : T(0);
+    bool bad = false;
+    T* colj = ys + n;                                  // 64 scratch entries behind the right-hand side: column j of the block, lane by lane
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      colj[lane] = r[j];                               // column j before its scaling, lane by lane (through LDS, not lane broadcasts:
+      __builtin_amdgcn_wave_barrier();                 //  500 readlanes into scalar registers made hipcc spill hundreds of them)
+      const T d = colj[j];                             // the pivot: entry (j, j) after the updates of columns < j
+      const bool live = j < bs;
+      const bool pos = d > T(0) && d <= NumLimits<T>::max();
+      if (live && !pos) bad = true;
+      const T dd = (live && pos) ? d : T(1);
+      const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj (ONE LDS round trip per column)
+#pragma unroll
+      for (int c = j + 1; c < B; ++c) r[c] = fma(-t, colj[c], r[c]);   // (lanes < c hold zeros there and are not stored)
+      __builtin_amdgcn_wave_barrier();
+    }
+    // the scaling by 1 / sqrt(d_j), once for all columns: lane j takes the root of ITS pivot (one sqrt and one division per lane,
+    // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors go round through LDS
+    T dj = T(1);
+#pragma unroll
+    for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
+    const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
+    colj[lane] = rs;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < B; ++c) r[c] *= colj[c];       // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
+    __builtin_amdgcn_wave_barrier();
+    if (lane < bs) {
+#pragma unroll
+      for (int c = 0; c < B; ++c)
+        if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
+      ys[n + 64 + lane] = rs;                          // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
+    }
+    if (bad && lane == 0) fail = 1;
+  };
+  bool have_diag = false;   // LOOK: the block was factored during the previous step's trailing update
   for (int k0 = 0; k0 < n; k0 += B) {
     const int bs = min(B, n - k0), k1 = k0 + bs;
-    // ---- diagonal block: wave 0, lane r holds row r of the block (columns past the diagonal are never read)
-    if (wave == 0) {
-      T r[B];
-#pragma unroll
-      for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? A[size_t(k0 + lane) * n + k0 + c] : T(0);
-      bool bad = false;
-      T* colj = ys + n;                                  // 64 scratch entries behind the right-hand side: column j of the block, lane by lane
-#pragma unroll
-      for (int j = 0; j < B; ++j) {
-        colj[lane] = r[j];                               // column j before its scaling, lane by lane (through LDS, not lane broadcasts:
-        __builtin_amdgcn_wave_barrier();                 //  500 readlanes into scalar registers made hipcc spill hundreds of them)
-        const T d = colj[j];                             // the pivot: entry (j, j) after the updates of columns < j
-        const bool live = j < bs;
-        const bool pos = d > T(0) && d <= NumLimits<T>::max();
-        if (live && !pos) bad = true;
-        const T dd = (live && pos) ? d : T(1);
-        const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj (ONE LDS round trip per column)
-#pragma unroll
-        for (int c = j + 1; c < B; ++c) r[c] = fma(-t, colj[c], r[c]);   // (lanes < c hold zeros there and are not stored)
-        __builtin_amdgcn_wave_barrier();
-      }
-      // the scaling by 1 / sqrt(d_j), once for all columns: lane j takes the root of ITS pivot (one sqrt and one division per lane,
-      // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors go round through LDS
-      T dj = T(1);
-#pragma unroll
-      for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
-      const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
-      colj[lane] = rs;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < B; ++c) r[c] *= colj[c];       // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
-      __builtin_amdgcn_wave_barrier();
-      if (lane < bs) {
-#pragma unroll
-        for (int c = 0; c < B; ++c)
-          if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
-        ys[n + 64 + lane] = rs;                          // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
-      }
-      if (bad && lane == 0) fail = 1;
+    if (!have_diag) {
+      if (wave == 0) diag_block(k0, bs);
+      __syncthreads();
     }
-    __syncthreads();
     CH_TICK(0)
     if (fail) break;
     // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update)
@@ -984,11 +992,12 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
       const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
       const int l15 = lane & 15, kq = lane >> 4;
       constexpr int U = sizeof(T) == 8 ? 2 : 4;
-      for (int t = wave; t < ntile; t += U * NW) {       // U tiles per trip: their old values are in flight under the MFMAs
+      // U tiles per trip (t, t + step, ...): their old values are in flight under the MFMAs
+      auto trip = [&](const int t, const int step) __attribute__((always_inline)) {
         int ti[U], tj[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {                    // t -> (ti, tj), ti >= tj, row-major over the lower triangle
-          int row = 0, rem = t + u * NW;
+          int row = 0, rem = t + u * step;
           while (rem > row) { rem -= row + 1; ++row; }
           ti[u] = row; tj[u] = rem;
         }
@@ -998,7 +1007,7 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            old[u][reg] = (t + u * NW < ntile && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
+            old[u][reg] = (t + u * step < ntile && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
           }
         Acc acc[U];
 #pragma unroll
@@ -1017,9 +1026,22 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            if (t + u * NW < ntile && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
+            if (t + u * step < ntile && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
           }
+      };
+      const bool look = LOOK && k1 < n;   // there is a next diagonal block: tiles 0 .. 2 of the trailing triangle (3 rides along)
+      if (!look) {
+        for (int t = wave; t < ntile; t += U * NW) trip(t, NW);
+      } else if (wave == 0) {
+        for (int t = 0; t < 4; t += U) trip(t, 1);
+        // wave 0's own stores of those tiles, then its loads of the block: ordered through the workgroup's memory scope
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        diag_block(k1, min(B, n - k1));
+      } else {
+        for (int t = 4 + (wave - 1); t < ntile; t += U * (NW - 1)) trip(t, NW - 1);
       }
+      have_diag = look;
     }
     __syncthreads();
     CH_TICK(2)
@@ -1426,6 +1448,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const bool own_chol2 = !own_chol && !lu && !force_lib && n > 128 && chol2_lds + 2048 <= size_t(h->max_lds);
   if (own_chol2) {
     if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T>, chol2_lds)) return rc;
+    if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T, false>, chol2_lds)) return rc;
   }
   // rocBLAS / rocSOLVER are opened (dlopen, a handle: a cold load of their code objects, minutes in a bare process) only
   // when a stage of THIS solve is theirs — fp32 with aligned rows up to n = 1024 never touches them
@@ -1528,7 +1551,8 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     if (own_chol) {
       launch_ldlt_solve<T>(n, unsigned(Pl), chol_lds, ls, la);
     } else if (own_chol2) {
-      hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(Pl)), dim3(kCholThreads), chol2_lds, ls, la);
+      if (h->tune.large_chol_no_lookahead) hipLaunchKernelGGL((large_chol_solve_kernel<T, false>), dim3(unsigned(Pl)), dim3(kCholThreads), chol2_lds, ls, la);
+      else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(Pl)), dim3(kCholThreads), chol2_lds, ls, la);
     } else if (lu) {
       if constexpr (sizeof(T) == 4) {
         rc = api.sgetrf(h->blas, n, n, la.work, n, int64_t(nn), ipiv, int64_t(n), la.info, int(Pl));
@@ -1711,11 +1735,13 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
   a.built = a.active;
   const size_t chol_lds = n <= 128 ? ldlt_image_bytes<T>(n) : chol_solve_lds_bytes<T>(n);
   if (int rc = ensure_lds_attr(h, n <= 128 ? ldlt_solve_fn<T>(n) : (const void*)large_chol_solve_kernel<T>, chol_lds)) return rc;
+  if (n > 128) { if (int rc = ensure_lds_attr(h, (const void*)large_chol_solve_kernel<T, false>, chol_lds)) return rc; }
   hipLaunchKernelGGL(large_fill_ones_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, h->stream, a.active, (long long)P,
                      h->solve_mask, (long long)h->solve_mask_stride);
   const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
   hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, a.work, a.rhs, n, scale);
   if (n <= 128) launch_ldlt_solve<T>(n, unsigned(P), chol_lds, h->stream, a);
+  else if (h->tune.large_chol_no_lookahead) hipLaunchKernelGGL((large_chol_solve_kernel<T, false>), dim3(unsigned(P)), dim3(kCholThreads), chol_lds, h->stream, a);
   else hipLaunchKernelGGL(large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(kCholThreads), chol_lds, h->stream, a);
   hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, a.rhs, a.info, dx, ok, n,
                      (const int*)a.active);
