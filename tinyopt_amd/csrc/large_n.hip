@@ -960,6 +960,27 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     }
     CH_TICK(0)
     if (fail) break;
+    // LOOK: the forward substitution L y = b rides along — block k's unknowns by the LAST wave here (the arithmetic of the
+    // separate pass below, with the block read from LDS instead of the matrix), the rows below at the start of the update
+    // phase from the panel in LDS: the pass over L in the L2-resident matrix (0.09 of an n = 384 fp64 solve's 0.68 ms) is gone
+    if constexpr (LOOK) {
+      if (wave == NW - 1) {
+        T y = lane < bs ? ys[k0 + lane] : T(0);
+        T lr[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) lr[c] = (lane < bs && c <= lane) ? Ld[lane * LS + c] : T(1);
+        T rinv = T(1);
+#pragma unroll
+        for (int c = 0; c < B; ++c) rinv = (c == lane && lane < bs) ? T(1) / lr[c] : rinv;
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+          const T yc = chol_bcast(y * rinv, c);
+          if (lane == c) y = yc;
+          else if (lane > c) y = fma(-lr[c], yc, y);
+        }
+        if (lane < bs) ys[k0 + lane] = y;
+      }
+    }
     // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update)
     for (int i = k1 + tid; i < n; i += NT) {
       T x[B];
@@ -988,6 +1009,15 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     // read-modify-write of the tile in the L2-resident matrix.  (A lane per column with the rows in batches of eight — VALU, one
     // dependent global round trip per batch — took 122 us of a 376 us n = 256 solve.)
     {
+      if constexpr (LOOK) {   // y_i -= L_i,k . y_k for the rows below, from the panel in LDS (same order of FMAs as the separate pass)
+        for (int i = k1 + tid; i < n; i += NT) {
+          T sy = ys[i];
+          const T* Li = Lp + size_t(i - k1) * LSP;
+#pragma unroll
+          for (int c = 0; c < B; ++c) sy = fma(-Li[c], ys[k0 + (c < bs ? c : 0)], sy);
+          ys[i] = sy;
+        }
+      }
       using Acc = typename Mfma<T>::Acc;
       const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
       const int l15 = lane & 15, kq = lane >> 4;
@@ -1050,7 +1080,8 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     if (tid == 0) a.info[p] = 1;
     return;
   }
-  // ---- L y = b
+  // ---- L y = b (LOOK: done inside the factorisation loop)
+  if constexpr (!LOOK)
   for (int k0 = 0; k0 < n; k0 += B) {
     const int bs = min(B, n - k0), k1 = k0 + bs;
     if (wave == 0) {
