@@ -1115,36 +1115,58 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   }
   CH_TICK(3)
   // ---- L^T x = y
-  for (int k0 = ((n - 1) / B) * B; k0 >= 0; k0 -= B) {
-    const int bs = min(B, n - k0);
-    if (wave == 0) {
-      T xv = lane < bs ? ys[k0 + lane] : T(0);
-      T lcol[B];                                         // column `lane` of L_kk: entries (c, lane), c >= lane (all loads in flight,
-#pragma unroll                                           //  coalesced across lanes; inside the loop below they were 64 dependent round trips)
-      for (int c = 0; c < B; ++c) lcol[c] = (lane < bs && c < bs && c >= lane) ? A[size_t(k0 + c) * n + k0 + lane] : T(0);
-      T ldiag = T(1);
+  auto back_block = [&](const int k0, const int bs) __attribute__((always_inline)) {   // wave 0: the 32 unknowns of block k0
+    T xv = lane < bs ? ys[k0 + lane] : T(0);
+    T lcol[B];                                         // column `lane` of L_kk: entries (c, lane), c >= lane (all loads in flight,
+#pragma unroll                                         //  coalesced across lanes; inside the loop below they were 64 dependent round trips)
+    for (int c = 0; c < B; ++c) lcol[c] = (lane < bs && c < bs && c >= lane) ? A[size_t(k0 + c) * n + k0 + lane] : T(0);
+    T ldiag = T(1);
 #pragma unroll
-      for (int c = 0; c < B; ++c) ldiag = (c == lane && c < bs) ? lcol[c] : ldiag;
-      ldiag = T(1) / ldiag;
+    for (int c = 0; c < B; ++c) ldiag = (c == lane && c < bs) ? lcol[c] : ldiag;
+    ldiag = T(1) / ldiag;
 #pragma unroll
-      for (int c = B - 1; c >= 0; --c) {
-        const T xc = chol_bcast(xv * ldiag, c);          // lane c: its unknown (for c >= bs: 0)
-        if (lane == c) xv = xc;
-        else if (lane < c) xv = fma(-lcol[c], xc, xv);   // L_c,lane: the entry of L^T this lane's equation holds for unknown c
+    for (int c = B - 1; c >= 0; --c) {
+      const T xc = chol_bcast(xv * ldiag, c);          // lane c: its unknown (for c >= bs: 0)
+      if (lane == c) xv = xc;
+      else if (lane < c) xv = fma(-lcol[c], xc, xv);   // L_c,lane: the entry of L^T this lane's equation holds for unknown c
+    }
+    if (lane < bs) ys[k0 + lane] = xv;
+  };
+  auto back_update = [&](const int j, const int k0, const int bs) __attribute__((always_inline)) {   // x_j -= sum_c L_(k0+c),j x_(k0+c)
+    T sx = ys[j];
+    T lv[B];
+#pragma unroll
+    for (int c = 0; c < B; ++c) lv[c] = c < bs ? A[size_t(k0 + c) * n + j] : T(0);   // (coalesced across lanes)
+#pragma unroll
+    for (int c = 0; c < B; ++c) sx = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], sx);
+    ys[j] = sx;
+  };
+  if constexpr (LOOK) {
+    // look-ahead again: once block k is solved, wave 0 updates the 32 unknowns of the block ABOVE it and solves that block at
+    // once, while the other waves update the unknowns further up — one barrier per block instead of two, and the serial
+    // 32-step chain of a block runs beside the updates of the previous one.  Every unknown sees the same FMAs in the same order.
+    const int klast = ((n - 1) / B) * B;
+    if (wave == 0) back_block(klast, min(B, n - klast));
+    __syncthreads();
+    for (int k0 = klast; k0 > 0; k0 -= B) {
+      const int bs = min(B, n - k0), kn = k0 - B;      // (every block above the last one is full)
+      if (wave == 0) {
+        if (lane < B) back_update(kn + lane, k0, bs);
+        __builtin_amdgcn_wave_barrier();
+        back_block(kn, B);
+      } else {
+        for (int j = tid - 64; j < kn; j += NT - 64) back_update(j, k0, bs);
       }
-      if (lane < bs) ys[k0 + lane] = xv;
+      __syncthreads();
     }
-    __syncthreads();
-    for (int j = tid; j < k0; j += NT) {                // the unknowns above: x_j -= sum_c L_(k0+c),j x_(k0+c)  (coalesced across lanes)
-      T s = ys[j];
-      T lv[B];
-#pragma unroll
-      for (int c = 0; c < B; ++c) lv[c] = c < bs ? A[size_t(k0 + c) * n + j] : T(0);
-#pragma unroll
-      for (int c = 0; c < B; ++c) s = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], s);
-      ys[j] = s;
+  } else {
+    for (int k0 = ((n - 1) / B) * B; k0 >= 0; k0 -= B) {
+      const int bs = min(B, n - k0);
+      if (wave == 0) back_block(k0, bs);
+      __syncthreads();
+      for (int j = tid; j < k0; j += NT) back_update(j, k0, bs);   // the unknowns above
+      __syncthreads();
     }
-    __syncthreads();
   }
   CH_TICK(4)
 #ifdef TOA_CHOL_TIMING
