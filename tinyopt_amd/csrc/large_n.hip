@@ -874,16 +874,10 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
 //   substitutions    the same panels: the block by wave 0 (lane r owns unknown r), the rest by a thread per row / column
 // Cholesky without pivoting, as the library path: a pivot that is not positive (or not finite) fails the solve (info != 0).
 // Every sum has a fixed order: a matrix solved alone gives the bits of its row in a batch.
+// (round 4, late: v_readlane into scalar registers instead of ds_bpermute — the lane index is a compile-time constant at every call site
+//  after unrolling, and a dependent 32-step chain pays the LDS crossbar's latency per step with the shuffle)
 template <typename T>
-__device__ __forceinline__ T chol_bcast(const T v, const int src) {
-  if constexpr (sizeof(T) == 4) {
-    return __shfl(v, src, 64);
-  } else {
-    const long long b = __double_as_longlong(v);
-    const int lo = __shfl(int(unsigned(b)), src, 64), hi = __shfl(int(b >> 32), src, 64);
-    return __longlong_as_double((long long)(((unsigned long long)unsigned(hi) << 32) | unsigned(lo)));
-  }
-}
+__device__ __forceinline__ T chol_bcast(const T v, const int src) { return wave_bcast(v, src); }
 constexpr int kCholThreads = 512;
 // LOOK (round 4): look-ahead — in the trailing-update phase of block k, wave 0 updates the four tiles that hold the NEXT diagonal
 // block first and factors it at once, while the other seven waves update the rest; the next step then starts at its panel.  The
@@ -917,32 +911,28 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
 #pragma unroll
     for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? A[size_t(k0 + lane) * n + k0 + c] : T(0);
     bool bad = false;
-    T* colj = ys + n;                                  // 64 scratch entries behind the right-hand side: column j of the block, lane by lane
 #pragma unroll
     for (int j = 0; j < B; ++j) {
-      colj[lane] = r[j];                               // column j before its scaling, lane by lane (through LDS, not lane broadcasts:
-      __builtin_amdgcn_wave_barrier();                 //  500 readlanes into scalar registers made hipcc spill hundreds of them)
-      const T d = colj[j];                             // the pivot: entry (j, j) after the updates of columns < j
+      // column j before its scaling, lane by lane, comes out of the register by v_readlane (lane index = compile-time constant) instead of
+      // an LDS round trip per column (write, wave barrier, 32 - j broadcast reads).  One column's broadcasts at a time (sched_barrier).
+      const T d = chol_bcast(r[j], j);                 // the pivot: entry (j, j) after the updates of columns < j
       const bool live = j < bs;
       const bool pos = d > T(0) && d <= NumLimits<T>::max();
       if (live && !pos) bad = true;
       const T dd = (live && pos) ? d : T(1);
-      const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj (ONE LDS round trip per column)
+      const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj
 #pragma unroll
-      for (int c = j + 1; c < B; ++c) r[c] = fma(-t, colj[c], r[c]);   // (lanes < c hold zeros there and are not stored)
-      __builtin_amdgcn_wave_barrier();
+      for (int c = j + 1; c < B; ++c) r[c] = fma(-t, chol_bcast(r[j], c), r[c]);   // (lanes < c hold zeros there and are not stored)
+      __builtin_amdgcn_sched_barrier(0);
     }
     // the scaling by 1 / sqrt(d_j), once for all columns: lane j takes the root of ITS pivot (one sqrt and one division per lane,
-    // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors go round through LDS
+    // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors come back as lane broadcasts
     T dj = T(1);
 #pragma unroll
     for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
     const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
-    colj[lane] = rs;
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < B; ++c) r[c] *= colj[c];       // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
-    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < B; ++c) r[c] *= chol_bcast(rs, c);   // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
     if (lane < bs) {
 #pragma unroll
       for (int c = 0; c < B; ++c)
