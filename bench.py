@@ -32,7 +32,7 @@ WORKLOADS = {
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
     # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
     "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, workgroup-per-problem kernel (64 <= n <= 128)"),
-    "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written tile-split MFMA Gram + one-workgroup blocked Cholesky, two staggered lanes, passes enqueued ahead"),
+    "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written MFMA Gram (operand-sharing deal of the 36 tiles) + one-workgroup blocked Cholesky, passes enqueued ahead"),
 }
 # single-problem configs of BASELINE.json (latency-bound: SURVEY §8d "report us/iter and GB/s"); replicas only at N > 1
 SINGLE = {

@@ -190,7 +190,9 @@ typedef struct toa_tuning {
   int32_t fail_workspace_alloc;  /* TEST HOOK: the n > 128 workspace request fails as on a full device (kOutOfMemory path) */
   int32_t large_one_lane;        /* n > 128, own kernels: the whole batch on one stream instead of two half-batch lanes (same bits) */
   int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
-  int32_t reserved[16];
+  int32_t large_gram_plain_deal; /* 224 < n <= 256, own Gram: the tiles dealt round-robin to the waves instead of the operand-sharing deal (triangles of
+                                    blocks; A/B and the bit-identity test: which wave computes a tile does not change its bits) */
+  int32_t reserved[15];
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
 int toa_get_tuning(toa_handle h, toa_tuning* out);

@@ -455,7 +455,7 @@ def test_two_lanes_give_the_bits_of_one_lane(ta, oracle, P, n, m):
     model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
     ctx = ta.api.default_context()
     outs = []
-    for one_lane in (1, 0, 0):
+    for one_lane in (1, 2, 2):   # (2 = two lanes asked for by name: at 224 < n <= 256 the default is one lane since the operand-sharing Gram)
         x = torch.from_numpy(x0.copy()).cuda()
         with ctx.tuning(large_one_lane=one_lane):
             out = ta.Optimize(x, model, ta.Options(), history=True)
@@ -516,3 +516,28 @@ def test_cholesky_lookahead_gives_the_bits_of_the_plain_schedule(ta, dtype, n):
         outs.append((dx.clone(), ok.clone()))
     assert outs[0][1].cpu().numpy().tolist() == [1, 1, 1, 0, 1]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("P,n,m", [(5, 256, 1100), (3, 228, 777), (18, 240, 2048)])
+def test_operand_sharing_deal_of_the_gram_tiles_gives_the_bits_of_the_plain_deal(ta, oracle, P, n, m):
+    """224 < n <= 256 (an 8 x 8 block triangle, 36 tiles, 12 waves): by default a wave's three tiles share their operands — eight
+    triangles of blocks (x,y), (x,z), (y,z) and four matched pairs (a,a), (b,b), (a,b): three / two LDS operand reads per three MFMAs
+    instead of six (large_gram_kernel<T, 3, true>, syrk_stage_tri).  Every tile still sums its rows in the same order, so H — and with
+    it the whole solve — has the bits of the round-robin deal (toa_tuning::large_gram_plain_deal), with one lane or two."""
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, np.float32, seed=n + 7 * P)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    ctx = ta.api.default_context()
+    opts = ta.Options.benchmark()
+    opts.hessian.save_last = True
+    outs = []
+    for plain, lanes in ((1, 1), (0, 1), (0, 2), (0, 0)):
+        x = torch.from_numpy(x0.copy()).cuda()
+        with ctx.tuning(large_gram_plain_deal=plain, large_one_lane=lanes):
+            out = ta.Optimize(x, model, opts, history=True)
+        torch.cuda.synchronize()
+        outs.append((x, out))
+    for x, out in outs[1:]:
+        assert torch.equal(x, outs[0][0])
+        for f in ("stop_reason", "num_iters", "final_cost", "num_failures", "errs", "deltas2", "successes", "final_hessian"):
+            assert torch.equal(getattr(out, f), getattr(outs[0][1], f)), f
+    assert bool(outs[0][1].Succeeded().all())

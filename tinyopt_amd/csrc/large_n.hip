@@ -9,6 +9,7 @@
 // rocSOLVER / rocBLAS are opened with dlopen on first use: the 900 MB library is not a link-time dependency of the
 // n <= 63 product path and costs nothing until a large-n solve is requested.  No CPU fallback: if the libraries
 // are missing the call fails with TOA_E_UNSUPPORTED.
+#include <type_traits>
 #include <dlfcn.h>
 
 #include <mutex>
@@ -574,8 +575,48 @@ __device__ __forceinline__ void syrk_stage(float __attribute__((ext_vector_type(
     }
   }
 }
-template <typename T, int TPW>
-__global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
+// The 36 tiles of an 8 x 8 block triangle (224 < n <= 256) dealt to 12 waves so that a wave's three tiles SHARE their operands (round 4,
+// late): the kernel above reads two operands from LDS per MFMA — 96 of the LDS' 128 bytes per cycle at three waves per SIMD, which is
+// what holds it at 77 % of its MFMA bound.  K8 minus the perfect matching (0,1)(2,3)(4,5)(6,7) splits into eight triangles: a wave
+// with blocks x > y > z owns tiles (x,y), (x,z), (y,z) — three operands for three MFMAs; the four matched pairs a > b take (a,a), (b,b),
+// (a,b) — two operands.  Still three MFMAs per wave and step on every SIMD.  Which wave computes a tile never mattered to its bits.
+__device__ static constexpr unsigned kTriBlocks[12] = {0x420, 0x630, 0x750, 0x721, 0x531, 0x641, 0x652, 0x743, 0x010, 0x032, 0x054, 0x076};
+template <typename T, bool PAIR>
+__device__ __forceinline__ void syrk_stage_tri(float __attribute__((ext_vector_type(16))) (&acc)[3], const unsigned char* lds, const int base,
+                                               const int o0, const int o1, const int o2, const int K) {
+  int p0 = base + o0, p1 = base + o1, p2 = base + o2;
+  if constexpr (!PAIR) {
+    T r0 = *reinterpret_cast<const T*>(lds + p0), r1 = *reinterpret_cast<const T*>(lds + p1), r2 = *reinterpret_cast<const T*>(lds + p2);
+    for (int k8 = 0; k8 < K; k8 += 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {             // the next step's operands are in flight during this step's MFMAs (q == 3: see syrk_stage)
+        const T n0 = *reinterpret_cast<const T*>(lds + p0 + (q + 1) * 256), n1 = *reinterpret_cast<const T*>(lds + p1 + (q + 1) * 256),
+                n2 = *reinterpret_cast<const T*>(lds + p2 + (q + 1) * 256);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, r1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, r2, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, r2, acc[2], 0, 0, 0);
+        r0 = n0; r1 = n1; r2 = n2;
+      }
+      p0 += 1024; p1 += 1024; p2 += 1024;
+    }
+  } else {
+    T r0 = *reinterpret_cast<const T*>(lds + p0), r1 = *reinterpret_cast<const T*>(lds + p1);
+    for (int k8 = 0; k8 < K; k8 += 8) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const T n0 = *reinterpret_cast<const T*>(lds + p0 + (q + 1) * 256), n1 = *reinterpret_cast<const T*>(lds + p1 + (q + 1) * 256);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, r0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, r1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, r1, acc[2], 0, 0, 0);
+        r0 = n0; r1 = n1;
+      }
+      p0 += 1024; p1 += 1024;
+    }
+  }
+}
+template <typename T, int TPW, bool TRI = false>
+__global__ void __launch_bounds__(TRI ? 768 : 1024) large_gram_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
+  static_assert(!TRI || TPW == 3, "the operand-sharing deal: three tiles per wave");
   static_assert(sizeof(T) == 4, "fp32 only");
   typedef float f32x16 __attribute__((ext_vector_type(16)));
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -594,6 +635,22 @@ __global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, 
   // and a second code path costs accumulator copies and registers.
   int tile[TPW], offA[TPW], offB[TPW];
   int cnt = 0;
+  bool tri_pair = false;
+  if constexpr (TRI) {                          // blocks x > y > z of this wave: tiles (x,y), (x,z), (y,z); a matched pair x > y: (x,x), (y,y), (x,y)
+    const unsigned code = kTriBlocks[wave];
+    const int bx = int(code >> 8), by = int((code >> 4) & 15), bz = int(code & 15);
+    tri_pair = wave >= 8;
+    const int lo = l5 * 128 + l31 * 4;
+    if (!tri_pair) {
+      tile[0] = bx * (bx + 1) / 2 + by; tile[1] = bx * (bx + 1) / 2 + bz; tile[2] = by * (by + 1) / 2 + bz;
+      offA[0] = bx * K * 128 + lo; offA[1] = by * K * 128 + lo; offA[2] = bz * K * 128 + lo;
+    } else {
+      tile[0] = by * (by + 1) / 2 + by; tile[1] = bz * (bz + 1) / 2 + bz; tile[2] = by * (by + 1) / 2 + bz;
+      offA[0] = by * K * 128 + lo; offA[1] = bz * K * 128 + lo; offA[2] = offA[1];
+    }
+    offB[0] = offB[1] = offB[2] = 0;
+    cnt = 3;
+  } else {
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     int t = t_lo + wave + s * geo.waves;
@@ -603,6 +660,7 @@ __global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, 
     while (rem > ti) { rem -= ti + 1; ++ti; }
     offA[s] = ti * K * 128 + l5 * 128 + l31 * 4;
     offB[s] = rem * K * 128 + l5 * 128 + l31 * 4;
+  }
   }
   const T* A = a.data + size_t(p) * m * (n + 1);
   const T* scp = a.sc + size_t(p) * m;
@@ -646,24 +704,33 @@ __global__ void __launch_bounds__(1024) large_gram_kernel(const LargeArgs<T> a, 
   put(0);
   fetch(row0 + K);                              // (rows past the chunk fetch nothing and stage zeros)
   __syncthreads();
-  int cur = 0;
-  for (int r0 = row0; r0 < row1; r0 += K) {
-    if (r0 + K < row1) {
-      put(cur ? 0 : buf_bytes);
-      fetch(r0 + 2 * K);
+  // the stage loop and the stores of the tiles; STAGE: 0 the plain deal, 1 a triangle of blocks, 2 a matched pair.  (The two operand-sharing
+  // forms are two INSTANCES of the whole loop, chosen once per wave: as two arms inside one loop hipcc keeps an accumulator set per arm.)
+  auto run = [&](auto stage_c) __attribute__((always_inline)) {
+    constexpr int STAGE = decltype(stage_c)::value;
+    int cur = 0;
+    for (int r0 = row0; r0 < row1; r0 += K) {
+      if (r0 + K < row1) {
+        put(cur ? 0 : buf_bytes);
+        fetch(r0 + 2 * K);
+      }
+      if constexpr (STAGE == 0) syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K);
+      else if constexpr (TRI) syrk_stage_tri<T, STAGE == 2>(acc, syrk_lds, cur ? buf_bytes : 0, offA[0], offA[1], offA[2], K);
+      __syncthreads();
+      cur ^= 1;
     }
-    syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K);
-    __syncthreads();
-    cur ^= 1;
-  }
-  // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int s = 0; s < TPW; ++s) {
-    if (s >= cnt) continue;
-    T* blk = a.gram_part + ((size_t(p) * a.gram_R + chunk) * geo.T + tile[s]) * 1024;
+    for (int s = 0; s < TPW; ++s) {
+      if (s >= cnt) continue;
+      T* blk = a.gram_part + ((size_t(p) * a.gram_R + chunk) * geo.T + tile[s]) * 1024;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) blk[((reg & 3) + 8 * (reg >> 2) + 4 * l5) * 32 + l31] = acc[s][reg];
-  }
+      for (int reg = 0; reg < 16; ++reg) blk[((reg & 3) + 8 * (reg >> 2) + 4 * l5) * 32 + l31] = acc[s][reg];
+    }
+  };
+  if constexpr (!TRI) run(std::integral_constant<int, 0>{});
+  else if (tri_pair) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 1>{});
 }
 template <typename T>
 __global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
@@ -1434,6 +1501,8 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const bool own_gram = sizeof(T) == 4 && vec_ok && !force_gemm && n % 4 == 0;
   int gram_R = 1, gram_rows = (m + 3) & ~3;
   const SyrkGeom geo = syrk_geom(n);
+  // 224 < n <= 256: the operand-sharing deal of the tiles (syrk_stage_tri; toa_tuning::large_gram_plain_deal: the round-robin deal, same bits)
+  const bool gram_tri = !h->tune.large_gram_plain_deal && geo.nt == 8 && geo.groups == 1 && geo.waves == 12 && geo.tpw == 3;
   if (own_gram) {   // about four workgroups per CU when every problem rebuilds (a late pass with few of them left is bound by ONE
                     // workgroup's run time, which shrinks with the chunk); the rows of a chunk a multiple of the LDS stage
     const long long want_wgs = (long long)h->num_cus * 4, per_chunk = P * geo.groups;
@@ -1561,7 +1630,10 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
         switch (geo.tpw) {
           case 1: hipLaunchKernelGGL((large_gram_kernel<T, 1>), ggrid, gblock, glds, ls, la, geo); break;
           case 2: hipLaunchKernelGGL((large_gram_kernel<T, 2>), ggrid, gblock, glds, ls, la, geo); break;
-          case 3: hipLaunchKernelGGL((large_gram_kernel<T, 3>), ggrid, gblock, glds, ls, la, geo); break;
+          case 3:
+            if (gram_tri) hipLaunchKernelGGL((large_gram_kernel<T, 3, true>), ggrid, gblock, glds, ls, la, geo);
+            else hipLaunchKernelGGL((large_gram_kernel<T, 3>), ggrid, gblock, glds, ls, la, geo);
+            break;
           default: hipLaunchKernelGGL((large_gram_kernel<T, 4>), ggrid, gblock, glds, ls, la, geo); break;
         }
         hipLaunchKernelGGL(large_gram_reduce_kernel<T>, dim3(unsigned(geo.T), unsigned(Pl)), dim3(256), 0, ls, la, geo);
@@ -1668,6 +1740,9 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   // a pass is conserved (profiles/r04_ab_log.md section 3).
   if (int rc = ensure_pass_ring(h)) return rc;
   int nlanes = h->tune.large_one_lane ? 1 : (P >= 16 ? 2 : 1);   // (measured, 128 x n = 256: 1 lane 80.5 k, 2: 85.5 k, 3: 85 k, 4: 85 k it/s)
+  // ... with the operand-sharing Gram (one lane's Gram 451 -> 420 us) ONE lane is the faster schedule: 9.59 ms per 128-problem solve
+  // against 9.93 with two lanes (plain deal, same call: 9.92 / 9.79) — profiles/r04_ab_log.md section 8d
+  if (gram_tri && h->tune.large_one_lane == 0) nlanes = 1;
   if (h->tune.large_one_lane > 1) nlanes = std::min<int>(h->tune.large_one_lane, toa_context::kLanes);   // (A/B: an explicit lane count)
   nlanes = int(std::min<long long>(nlanes, std::max<long long>(1, P)));
   struct Lane { LargeArgs<T> a; hipStream_t st; long long P, pass; int active; bool done; int* host; hipEvent_t* ev; int* sums; };
