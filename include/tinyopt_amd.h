@@ -188,7 +188,8 @@ typedef struct toa_tuning {
   int32_t large_library_gram;    /* n > 128: rocBLAS batched GEMM instead of the hand-written MFMA Gram */
   int32_t large_library_solver;  /* rocSOLVER potrf / potrs wherever a solver of our own would run (also toa_solve_damped for n <= 63) */
   int32_t fail_workspace_alloc;  /* TEST HOOK: the n > 128 workspace request fails as on a full device (kOutOfMemory path) */
-  int32_t large_one_lane;        /* n > 128, own kernels: the whole batch on one stream instead of two half-batch lanes (same bits) */
+  int32_t large_one_lane;        /* n > 128, own kernels: 1 = the whole batch on one stream instead of two half-batch lanes (same bits); k > 1 = k lanes by name
+                                    (0: two lanes from 16 problems on, one at 224 < n <= 256 where the operand-sharing Gram runs) */
   int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
   int32_t large_gram_plain_deal; /* 224 < n <= 256, own Gram: the tiles dealt round-robin to the waves instead of the operand-sharing deal (triangles of
                                     blocks; A/B and the bit-identity test: which wave computes a tile does not change its bits) */
