@@ -71,7 +71,7 @@ def main():
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
                  "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba",
                  "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0",
-                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane"):
+                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane", "bench_large256_two_lanes", "bench_large256_plain_deal"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:

@@ -6,6 +6,8 @@ for wl in large256 balists; do python bench.py --workload $wl $( [ $wl = large25
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_library_solver=1 > $O/bench_large256_rocsolver.json 2>/dev/null
 python bench.py --workload balists --no-cpu --tuning large_library_solver=1 > $O/bench_balists_rocsolver.json 2>/dev/null
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_one_lane=1 > $O/bench_large256_one_lane.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_one_lane=2 > $O/bench_large256_two_lanes.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_gram_plain_deal=1 > $O/bench_large256_plain_deal.json 2>/dev/null
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in large256 balists; do

@@ -14,6 +14,8 @@ python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large
 python bench.py --workload balists --no-cpu --tuning large_library_solver=1 > $O/bench_balists_rocsolver.json 2>/dev/null
 python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu --tuning large_row_split=1 > $O/bench_large128_rowsplit.json 2>/dev/null
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_one_lane=1 > $O/bench_large256_one_lane.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_one_lane=2 > $O/bench_large256_two_lanes.json 2>/dev/null
+python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_gram_plain_deal=1 > $O/bench_large256_plain_deal.json 2>/dev/null
 python bench.py --workload c4 --no-cpu --tuning coop_off=1 > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
 python bench.py --workload c4 --no-cpu --tuning memo_off=1,coop_off=1 > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
