@@ -21,6 +21,15 @@
 // DPP rows); s = 1 + 0.1 cos t scales the lane's a-values into J in registers; the lane holding
 // b_i replaces it by r_i = t + 0.1 sin t - b_i.
 #pragma once
+// Register class of the Gram accumulators in the inline-asm MFMAs: AGPRs ("+a") — or VGPRs ("+v") in the translation units
+// of the TEAM form (-DTOA_ACC_VGPR): under a launch bound that leaves fewer than 256 registers per lane hipcc splits the
+// budget of a kernel whose inline asm names AGPRs HALF AND HALF between the two files (768 threads: 84 + 84) and parks the
+// destination registers of in-flight loads in the accumulator file (tools/isa_lint.py); with "+v" the whole budget is VGPRs.
+#ifdef TOA_ACC_VGPR
+#define TOA_ACC "+v"
+#else
+#define TOA_ACC "+a"
+#endif
 #include <type_traits>
 #include "robust.hpp"
 #include "wave_utils.hpp"
@@ -68,9 +77,9 @@ struct GramStep {
   static __device__ __forceinline__ void from(Acc* acc, const T* w) {
     if constexpr (I < NB) {
       if constexpr (sizeof(T) == 4)
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : TOA_ACC(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
       else
-        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : TOA_ACC(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
       if constexpr (J + 1 < NB) from<I, J + 1>(acc, w);
       else from<I + 1, I + 1>(acc, w);
     }
@@ -98,9 +107,9 @@ struct GramStep {
     if constexpr (I < NB) {
       if constexpr (tile(I, J) >= T0 && tile(I, J) < T1) {
         if constexpr (sizeof(T) == 4)
-          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : TOA_ACC(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
         else
-          asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
+          asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : TOA_ACC(acc[tile(I, J)]) : "v"(w[I]), "v"(w[J]));
       }
       if constexpr (J + 1 < NB) from_range<T0, T1, I, J + 1>(acc, w);
       else from_range<T0, T1, I + 1, I + 1>(acc, w);
@@ -135,31 +144,31 @@ struct GramStep {
     }                                                                                                   \
   };
 // tile order matches DenseRowGram::tile(i, j): (0,0),(0,1)..(0,NB-1),(1,1)...
-TOA_GRAM_STEP(float, F32, 1, TOA_MF32(0, 1, 1), "+a"(acc[0]), "v"(w[0]))
+TOA_GRAM_STEP(float, F32, 1, TOA_MF32(0, 1, 1), TOA_ACC(acc[0]), "v"(w[0]))
 TOA_GRAM_STEP(float, F32, 2, TOA_MF32(0, 3, 3) TOA_MF32(1, 3, 4) TOA_MF32(2, 4, 4),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
 TOA_GRAM_STEP(float, F32, 3,
               TOA_MF32(0, 6, 6) TOA_MF32(1, 6, 7) TOA_MF32(2, 6, 8) TOA_MF32(3, 7, 7) TOA_MF32(4, 7, 8) TOA_MF32(5, 8, 8),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]),
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]) TOA_C TOA_ACC(acc[3]) TOA_C TOA_ACC(acc[4]) TOA_C TOA_ACC(acc[5]),
               "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]))
 TOA_GRAM_STEP(float, F32, 4,
               TOA_MF32(0, 10, 10) TOA_MF32(1, 10, 11) TOA_MF32(2, 10, 12) TOA_MF32(3, 10, 13) TOA_MF32(4, 11, 11)
               TOA_MF32(5, 11, 12) TOA_MF32(6, 11, 13) TOA_MF32(7, 12, 12) TOA_MF32(8, 12, 13) TOA_MF32(9, 13, 13),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]) TOA_C
-              "+a"(acc[6]) TOA_C "+a"(acc[7]) TOA_C "+a"(acc[8]) TOA_C "+a"(acc[9]),
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]) TOA_C TOA_ACC(acc[3]) TOA_C TOA_ACC(acc[4]) TOA_C TOA_ACC(acc[5]) TOA_C
+              TOA_ACC(acc[6]) TOA_C TOA_ACC(acc[7]) TOA_C TOA_ACC(acc[8]) TOA_C TOA_ACC(acc[9]),
               "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]) TOA_C "v"(w[3]))
-TOA_GRAM_STEP(double, F64, 1, TOA_MF64(0, 1, 1), "+a"(acc[0]), "v"(w[0]))
+TOA_GRAM_STEP(double, F64, 1, TOA_MF64(0, 1, 1), TOA_ACC(acc[0]), "v"(w[0]))
 TOA_GRAM_STEP(double, F64, 2, TOA_MF64(0, 3, 3) TOA_MF64(1, 3, 4) TOA_MF64(2, 4, 4),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]), "v"(w[0]) TOA_C "v"(w[1]))
 TOA_GRAM_STEP(double, F64, 3,
               TOA_MF64(0, 6, 6) TOA_MF64(1, 6, 7) TOA_MF64(2, 6, 8) TOA_MF64(3, 7, 7) TOA_MF64(4, 7, 8) TOA_MF64(5, 8, 8),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]),
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]) TOA_C TOA_ACC(acc[3]) TOA_C TOA_ACC(acc[4]) TOA_C TOA_ACC(acc[5]),
               "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]))
 TOA_GRAM_STEP(double, F64, 4,
               TOA_MF64(0, 10, 10) TOA_MF64(1, 10, 11) TOA_MF64(2, 10, 12) TOA_MF64(3, 10, 13) TOA_MF64(4, 11, 11)
               TOA_MF64(5, 11, 12) TOA_MF64(6, 11, 13) TOA_MF64(7, 12, 12) TOA_MF64(8, 12, 13) TOA_MF64(9, 13, 13),
-              "+a"(acc[0]) TOA_C "+a"(acc[1]) TOA_C "+a"(acc[2]) TOA_C "+a"(acc[3]) TOA_C "+a"(acc[4]) TOA_C "+a"(acc[5]) TOA_C
-              "+a"(acc[6]) TOA_C "+a"(acc[7]) TOA_C "+a"(acc[8]) TOA_C "+a"(acc[9]),
+              TOA_ACC(acc[0]) TOA_C TOA_ACC(acc[1]) TOA_C TOA_ACC(acc[2]) TOA_C TOA_ACC(acc[3]) TOA_C TOA_ACC(acc[4]) TOA_C TOA_ACC(acc[5]) TOA_C
+              TOA_ACC(acc[6]) TOA_C TOA_ACC(acc[7]) TOA_C TOA_ACC(acc[8]) TOA_C TOA_ACC(acc[9]),
               "v"(w[0]) TOA_C "v"(w[1]) TOA_C "v"(w[2]) TOA_C "v"(w[3]))
 #undef TOA_GRAM_STEP
 
@@ -712,9 +721,9 @@ struct DenseRowGram {
 #pragma unroll
         for (int j = i; j < NBM; ++j) {
           if constexpr (sizeof(T) == 4)
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : TOA_ACC(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
           else
-            asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
+            asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : TOA_ACC(acc[tile(i, j)]) : "v"(w[i]), "v"(w[j]));
         }
 #elif !defined(TOA_ABL_NOMFMA)
       if constexpr (T0 != 0 || T1 != NT) GramStep<T, NBM>::template run_range<T0, T1>(acc, w, TAIL_STEP ? last : 0);
@@ -849,7 +858,7 @@ struct DenseRowGram {
   __device__ __forceinline__ void mfma_retire() {
     asm volatile("s_nop 7" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+    for (int t = 0; t < NT; ++t) asm volatile("" : TOA_ACC(acc[t]));
   }
 
   // One pass over the problem's rows.  WANT_H: full Gram (K1).  !WANT_H: cost only (K2) — returns
@@ -1297,7 +1306,7 @@ struct DenseRowGram {
 #pragma unroll
         for (int q = 0; q < 16; ++q) op[q] = *reinterpret_cast<const T*>(stage + ((q & 1) ? wr1 : wr0) + q * 512);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : "+a"(acc[0]) : "v"(op[q]));
+        for (int q = 0; q < 16; ++q) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : TOA_ACC(acc[0]) : "v"(op[q]));
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -1433,7 +1442,7 @@ struct DenseRowGram {
     if (WANT_H) {
       asm volatile("s_nop 7" ::: "memory");   // mfma_retire() over the tiles of this pass
 #pragma unroll
-      for (int t = T0; t < T1; ++t) asm volatile("" : "+a"(acc[t]));
+      for (int t = T0; t < T1; ++t) asm volatile("" : TOA_ACC(acc[t]));
       if (THINP) {
 #pragma unroll
         for (int t = 0; t < NTM; ++t) accT[t] = kgroup_allreduce_sum(accT[t]);
@@ -1505,11 +1514,11 @@ struct DenseRowGram {
   template <int t>
   __device__ __forceinline__ void lds_read_tile(unsigned a0) {
     if constexpr (sizeof(T) == 4) {
-      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(acc[t]) : "v"(a0), "n"(t * 64 * 16) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : TOA_ACC(acc[t]) : "v"(a0), "n"(t * 64 * 16) : "memory");
     } else {
       // fp64: a tile is 8 dwords, read as two halves through a cast of the register variable
-      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[0]) : "v"(a0), "n"(t * 64 * 32) : "memory");
-      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "+a"(reinterpret_cast<u32x4*>(&acc[t])[1]) : "v"(a0), "n"(t * 64 * 32 + 16) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : TOA_ACC(reinterpret_cast<u32x4*>(&acc[t])[0]) : "v"(a0), "n"(t * 64 * 32) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : TOA_ACC(reinterpret_cast<u32x4*>(&acc[t])[1]) : "v"(a0), "n"(t * 64 * 32 + 16) : "memory");
     }
     if constexpr (t + 1 < NT) lds_read_tile<t + 1>(a0);
   }
@@ -1538,7 +1547,7 @@ struct DenseRowGram {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+    for (int t = 0; t < NT; ++t) asm volatile("" : TOA_ACC(acc[t]));
     if (THIN) {
 #pragma unroll
       for (int t = 0; t < NTM; ++t) asm volatile("" : "+v"(accT[t]));

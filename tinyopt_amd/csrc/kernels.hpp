@@ -54,19 +54,30 @@ __device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign
 // K chunks itself (steady state: nobody is idle) or its three siblings took some: results do not depend on timing, on the
 // batch size or on the position of a problem in the batch.  All of it lives in LDS at workgroup scope; no barrier (the
 // four waves run different problems at their own pace), no HBM traffic.
-struct CoopSlot {          // one per wave, written by the OWNER except ticket (everybody) and turn (whoever folds)
+struct CoopSlot {          // one per wave, written by the OWNER except ticket / eticket (everybody), turn (whoever folds), edone
   int p;                   // problem of the open pass
   int ticket;              // next chunk of the open ACCUMULATE pass to hand out; >= K: no open pass.  Evaluate-only passes never
-                           // touch it (the owner walks their chunks itself), so whatever ticket a helper draws — however long
-                           // ago it looked at the counter — belongs to an accumulate pass of this slot, and the acquire half of
-                           // the fetch-add shows it that pass's problem and x
+                           // touch it, so whatever ticket a helper draws — however long ago it looked at the counter — belongs
+                           // to an accumulate pass of this slot, and the acquire half of the fetch-add shows it that pass's
+                           // problem and x
   int turn;                // next chunk whose partial may be folded; == K: the pass is complete
-  int pad_[5];
+  int eticket;             // TEAM form only: the same counter for the open EVALUATE-only pass (its own word for the reason above:
+                           // a ticket drawn from it names a chunk of an evaluate-only pass, whenever it is drawn); classic form:
+                           // stays closed, the owner walks the chunks of an evaluate-only pass alone
+  int edone;               // TEAM form: chunks of the open evaluate-only pass whose partial cost sits in the owner's L.tmp[chunk]
+  int pad_[3];
 };
+constexpr int kCoopMaxWaves = 12;
+#ifndef TOA_TEAM_WAVES
+#define TOA_TEAM_WAVES 12
+#endif
+constexpr int kTeamWaves = TOA_TEAM_WAVES;   // waves per workgroup of the team form
 struct CoopCtl {
-  CoopSlot slot[4];
-  int active[4];           // wave w still has (or may still get) problems of its own
+  CoopSlot slot[kCoopMaxWaves];
+  int active[kCoopMaxWaves];   // wave w still has (or may still get) problems of its own
 };
+constexpr int kCoopCtlBytes = 512;
+static_assert(sizeof(CoopCtl) <= kCoopCtlBytes, "control block");
 
 // ROBUST = true: the variant whose passes apply the handle's M-estimator (toa_set_loss) to every residual.  It exists only in
 // the small kernels of the launch-per-iteration forms (accumulate_kernel, wide_partial_kernel): compiled into the fused
@@ -74,9 +85,21 @@ struct CoopCtl {
 // COOP = true: the variant whose passes are ALWAYS the ticketed chunk form (coop_K >= 1; one chunk = the classic pass, bit
 // for bit) — instantiated by the fused kernel only.  A compile-time property, not a run-time branch: two MFMA loops over
 // the same accumulators in one kernel made hipcc keep two AGPR sets (156 -> 196 registers at n = 50: 3 -> 2 waves / SIMD).
-template <typename T, int NBM, int THIN, bool ROBUST = false, bool COOP = false>
+// TEAMW != 4 (12): the TEAM form of the fused kernel (toa_tuning::team_on) — a workgroup of TEAMW waves of which
+// only the first `coop_NO` pull problems (owners); the others are helpers from the first cycle on (ghost problems, as in the
+// tail of the classic form) and evaluate-only passes are ticketed as well.  With 2 owners on each of 256 compute units 512
+// problems are in flight instead of 3 072: their rows (209 MB at C4) stay in the 256 MiB Infinity Cache between two passes.
+// Which wave computes a chunk never changes its bits: the team form and the classic form of a shape give the same bits
+// (tests/test_gpu_team.py).  Built, measured, and NOT the default: the part of an LM iteration that only the owner can do
+// (fold, LDL^T, step test) bounds a problem's chain at ~45 us per iteration, two chains per compute unit leave the SIMDs
+// short of work, and with enough chains to fill them the rows no longer fit the cache (profiles/r05_ab_log.md §1).
+template <typename T, int NBM, int THIN, bool ROBUST = false, bool COOP = false, int TEAMW = 4>
 struct DenseRowModel {
   using Scalar = T;
+  static constexpr int kWaves = TEAMW;            // waves per workgroup of the fused kernel
+  static constexpr bool kTeam = TEAMW != 4;
+  static_assert(TEAMW == 4 || (COOP && !ROBUST), "the team form is a cooperative form");
+  static_assert(TEAMW <= kCoopMaxWaves, "control block");
   static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   // register-LDL^T width: the largest n this (NBM, THIN) layout serves, rounded to the 8-column chunk (n = 50: 56, not 64)
@@ -102,20 +125,30 @@ struct DenseRowModel {
   static constexpr int kCoopPeriod = DenseRowGram<T, NBM, THIN>::kSuper16 ? 16 : 8;   // steps per super-batch / per turn of the load ring (kDepth * U)
   static_assert(!(COOP && ROBUST), "no cooperative form of the robust passes");
   int coop_K, coop_cs, coop_lds_per_wave, coop_tot_off, cur_p, helping, help_o, help_c;
+  int coop_NO;     // owners per workgroup (classic form: every wave, 4)
+  int help_kind;   // team form: the ticket coop_find drew names a chunk of an accumulate (0) / evaluate-only (1) pass
   __device__ __forceinline__ void init(int n, int m_, const void* d) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
     loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
     coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; coop_tot_off = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
+    coop_NO = 4; help_kind = 0;
     stage = nullptr;
+  }
+  // the workgroup's control block sits behind the kWaves carves
+  __device__ __forceinline__ CoopCtl* coop_ctl() const {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    return reinterpret_cast<CoopCtl*>(smem + size_t(kWaves) * coop_lds_per_wave);
   }
   // tot_off: where in a wave's carve the chunk partials of ITS passes are summed — 0 = its LDL^T workspace M (free during a
   // pass; the carve starts with it), or an area of its own when M is smaller than the Gram registers (n = 12 fp64)
   __device__ __forceinline__ void coop_init(int K, int chunk_steps, int lds_per_wave, int tot_off) { coop_K = K; coop_cs = chunk_steps; coop_lds_per_wave = lds_per_wave; coop_tot_off = tot_off; }
   __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
-#ifdef TOA_ABL_REUSE  // ablation: every wave streams one of 64 problems (cache-resident data, same instruction stream)
-  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p & 63) * lay.elems_per_problem(); rows_real = m; }
+#ifdef TOA_ABL_REUSE  // ablation: every wave streams one of TOA_ABL_REUSE problems (cache-resident data, same instruction stream).
+  // 64 (26 MB): concurrent readers of a problem share an XCD's L2; 518 = 4 * 129 + 2 (211 MB): the co-readers p, p + 518, ...
+  // sit on consecutive XCDs (workgroup -> XCD is round-robin), so every re-read is served by the Infinity Cache, none by an L2
+  __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p % (TOA_ABL_REUSE)) * lay.elems_per_problem(); rows_real = m; }
 #else
   __device__ __forceinline__ void bind(long long p) { prob = data + size_t(p) * lay.elems_per_problem(); rows_real = m; cur_p = int(p); }
 #endif
@@ -139,16 +172,63 @@ struct DenseRowModel {
   // The shape of the loop is what hipcc's register allocation tolerated (A/B log, profiles/r03_ab_log.md): do-while, the
   // scalars that cross the pass re-derived behind optimisation barriers, the total read back through in-out asm operands.
   __device__ __forceinline__ T coop_eval(WaveLds<T>& L, const int n, const int lane) {
-    // Evaluate-only pass: the same chunks, summed in the same order, by the owner alone — no ticket, no slot.  (A helper
-    // that looked at this slot's counter during the previous accumulate pass and draws its ticket only now must never land
-    // in a pass of a different kind — ADVICE r03: the counter therefore stays closed across evaluate-only passes.)
+    // Evaluate-only pass: the same chunks, summed in the same order.  Classic form: by the owner alone — no ticket, no slot.
+    // (A helper that looked at this slot's counter during the previous accumulate pass and draws its ticket only now must
+    // never land in a pass of a different kind — ADVICE r03: the accumulate counter stays closed across evaluate-only passes.)
+    // Team form: ticketed through the slot's SECOND counter (eticket), owner and helpers in this one loop; every chunk's
+    // partial cost goes to the owner's L.tmp[chunk] and the owner adds them up in chunk order — the classic form's sum.
     const int st = lay.m4 >> 2;
     T tot = T(0);
-    for (int c = 0; c < coop_K; ++c) {
-      reg_fence();
-      const T part = gram.template pass_chunk<false>(prob, lay, n, L.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
-      reg_fence();
-      tot = c == 0 ? part : tot + part;
+    if constexpr (!kTeam) {
+      for (int c = 0; c < coop_K; ++c) {
+        reg_fence();
+        const T part = gram.template pass_chunk<false>(prob, lay, n, L.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
+        reg_fence();
+        tot = c == 0 ? part : tot + part;
+      }
+    } else {
+      extern __shared__ __attribute__((aligned(16))) char smem[];
+      const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+      const bool help = helping != 0;
+      int c, o;
+      if (!help) {
+        o = w;
+        CoopSlot& S = coop_ctl()->slot[w];
+        if (lane == 0) {
+          S.p = cur_p;
+          S.edone = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&S.eticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // chunk 0 is the owner's
+        c = 0;
+      } else {
+        o = __builtin_amdgcn_readfirstlane(help_o);
+        c = __builtin_amdgcn_readfirstlane(help_c);
+      }
+      do {
+        const WaveLds<T> Lo = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n);
+        CoopSlot& S = coop_ctl()->slot[o];
+        const T* pr = help ? data + size_t(__builtin_amdgcn_readfirstlane(S.p)) * lay.elems_per_problem() : prob;
+        reg_fence();
+        const T part = gram.template pass_chunk<false>(pr, lay, n, Lo.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
+        reg_fence();
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (lane == 0) Lo.tmp[c] = part;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {
+          __hip_atomic_fetch_add(&S.edone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          c = __hip_atomic_fetch_add(&S.eticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+      } while (c < coop_K);
+      if (!help) {
+        CoopSlot& S = coop_ctl()->slot[w];
+        for (int spin = 0; __hip_atomic_load(&S.edone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K; ++spin) {
+          __builtin_amdgcn_s_sleep(2);
+          if (spin > (1 << 24)) asm volatile("s_trap 2");
+        }
+        for (int q = 0; q < coop_K; ++q) tot = q == 0 ? L.tmp[0] : tot + L.tmp[q];
+      }
     }
     return tot;
   }
@@ -161,7 +241,7 @@ struct DenseRowModel {
     int c, o;
     if (!help) {
       o = w;
-      CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[w];
+      CoopSlot& S = coop_ctl()->slot[w];
       if (lane == 0) {
         S.p = cur_p;
         S.turn = 0;
@@ -176,7 +256,7 @@ struct DenseRowModel {
     }
     do {   // (both sides arrive with a valid ticket: no guard — a guard costs the kernel its third wave per SIMD)
       const T* xs_o = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n).xs;
-      const T* pr = help ? data + size_t(__builtin_amdgcn_readfirstlane(reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[o].p)) * lay.elems_per_problem()
+      const T* pr = help ? data + size_t(__builtin_amdgcn_readfirstlane(coop_ctl()->slot[o].p)) * lay.elems_per_problem()
                          : prob;
       reg_fence();
       const T part = gram.template pass_chunk<WANT_H>(pr, lay, n, xs_o, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
@@ -185,7 +265,7 @@ struct DenseRowModel {
       c = __builtin_amdgcn_readfirstlane(c);
       o = __builtin_amdgcn_readfirstlane(o);
       asm volatile("" : "+s"(c), "+s"(o));
-      CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[o];
+      CoopSlot& S = coop_ctl()->slot[o];
       T* totp = reinterpret_cast<T*>(smem + size_t(o) * coop_lds_per_wave + coop_tot_off);
       // fold in ticket order
       // (bounded: a protocol bug must end in a trapped launch, not in a GPU that never comes back — ~1 s of polling)
@@ -207,7 +287,7 @@ struct DenseRowModel {
     // (A helper falls through the owner's epilogue as well — its own slot's turn has been K since its last pass, and what
     //  the read-back puts into its dead Gram registers does not matter: an early return for it here, i.e. a path on which
     //  the accumulators die, made hipcc allocate 16 more registers for the whole kernel.)
-    CoopSlot& S = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave)->slot[w];
+    CoopSlot& S = coop_ctl()->slot[w];
     for (int spin = 0; __hip_atomic_load(&S.turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K; ++spin) {
       __builtin_amdgcn_s_sleep(2);
       if (spin > (1 << 24)) asm volatile("s_trap 2");
@@ -217,34 +297,52 @@ struct DenseRowModel {
   }
   // A wave whose queue is dry looks for a sibling's open ACCUMULATE pass and takes a ticket of it (only accumulate passes
   // ever open the counter: a ticket drawn late still names a chunk of an accumulate pass).  false: no sibling is active any more.
+  // Team form: the helpers (and owners whose queue is dry) look at the OWNERS' slots only, and at both counters.
   __device__ __forceinline__ bool coop_find(const int lane) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(4) * coop_lds_per_wave);
+    CoopCtl* ctl = coop_ctl();
     if (!helping) {
       helping = 1;
       help_o = w;
       if (lane == 0) __hip_atomic_store(&ctl->active[w], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    const int no = kTeam ? coop_NO : 4;
     for (int spins = 0;;) {
       bool any = false;
-      for (int t = 1; t < 4; ++t) {
-        const int q = (help_o + t) & 3;
+      for (int t = 1; t <= (kTeam ? no : 3); ++t) {
+        int q;
+        if constexpr (kTeam) { q = help_o + t; while (q >= no) q -= no; }
+        else q = (help_o + t) & 3;
         if (q == w) continue;
         if (__hip_atomic_load(&ctl->active[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
         any = true;
-        if (__hip_atomic_load(&ctl->slot[q].ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= coop_K) continue;
-        int cc = 0;
-        if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        cc = __builtin_amdgcn_readfirstlane(cc);
-        if (cc < coop_K) {
-          help_o = __builtin_amdgcn_readfirstlane(q);
-          help_c = cc;
-          return true;
+        if (__hip_atomic_load(&ctl->slot[q].ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K) {
+          int cc = 0;
+          if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+          cc = __builtin_amdgcn_readfirstlane(cc);
+          if (cc < coop_K) {
+            help_o = __builtin_amdgcn_readfirstlane(q);
+            help_c = cc;
+            help_kind = 0;
+            return true;
+          }
+        }
+        if constexpr (kTeam) {
+          if (__hip_atomic_load(&ctl->slot[q].eticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K) {
+            int cc = 0;
+            if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].eticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cc = __builtin_amdgcn_readfirstlane(cc);
+            if (cc < coop_K) {
+              help_o = __builtin_amdgcn_readfirstlane(q);
+              help_c = cc;
+              help_kind = 1;
+              return true;
+            }
+          }
         }
       }
       if (!any) return false;
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(kTeam ? 2 : 8);
       if (++spins > (1 << 24)) asm volatile("s_trap 2");   // (a sibling that never finishes: trap rather than hang)
     }
   }
@@ -296,7 +394,7 @@ struct DenseRowModel {
 // The model whose data passes honour toa_set_loss, for the kernels that only run passes (Model itself where the family
 // has no separate variant: the Jet models branch at run time, the others have no M-estimator).
 template <typename M> struct RobustOf { using type = M; };
-template <typename T, int NBM, int THIN, bool COOP> struct RobustOf<DenseRowModel<T, NBM, THIN, false, COOP>> { using type = DenseRowModel<T, NBM, THIN, true, false>; };
+template <typename T, int NBM, int THIN, bool COOP, int TEAMW> struct RobustOf<DenseRowModel<T, NBM, THIN, false, COOP, TEAMW>> { using type = DenseRowModel<T, NBM, THIN, true, false>; };
 
 // Gaussian prior  r = (x - y) / sigma,  m = n — the residual of the reference's published dense
 // benchmark, with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66, 90-99;
@@ -1281,12 +1379,18 @@ struct FusedParams {
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
   int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
   int coop_cs;                   // steps (of 4 rows) per chunk, a multiple of the load ring's period
+  int team_owners;               // team form (ModelWaves != 4): waves of a workgroup that pull problems (the rest only help)
+  int team_prio;                 // team form: toa_tuning::team_prio
 };
 
 template <typename M, typename = void>
 struct ModelStageBytes { static constexpr size_t value = 0; };
 template <typename M>
 struct ModelStageBytes<M, std::enable_if_t<(M::kStageBytes > 0)>> { static constexpr size_t value = M::kStageBytes; };
+template <typename M, typename = void>
+struct ModelWaves { static constexpr int value = 4; };
+template <typename M>
+struct ModelWaves<M, std::enable_if_t<(M::kWaves > 0)>> { static constexpr int value = M::kWaves; };
 template <typename M, typename = void>
 struct ModelCoop { static constexpr bool value = false; };
 template <typename M>
@@ -1296,12 +1400,17 @@ struct ModelCoop<M, std::enable_if_t<M::kCoop>> { static constexpr bool value = 
 // hipcc parks the destination registers of the in-flight asm loads in AGPRs right after issuing them — tools/isa_lint.py
 // caught exactly that when 5 waves/SIMD were requested for the fp64 n <= 15 kernel.)
 template <typename Model>
-__global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
+__global__ void __launch_bounds__(64 * ModelWaves<Model>::value) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kW = ModelWaves<Model>::value;   // waves per workgroup: 4, or 12 in the team form
+  constexpr bool kTeam = kW != 4;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n = prm_g->n;
+  // owners: the waves that pull problems.  Classic form: all four.  Team form: the first team_owners of the workgroup.
+  const int NO = kTeam ? __builtin_amdgcn_readfirstlane(prm_g->team_owners) : 4;
+  const bool owner = !kTeam || __builtin_amdgcn_readfirstlane(wave) < NO;
   WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave, n);
   // private per-wave copies of the option / result PODs (no inter-wave synchronisation anywhere)
   {
@@ -1317,7 +1426,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
       if (prm_g->memo_lds_off)   // (a generic pointer into LDS: the flat stores / loads of memo_save / memo_load reach it too)
         L.st->memo_slot = reinterpret_cast<unsigned long long>(static_cast<void*>(smem + size_t(wave) * prm_g->lds_per_wave + prm_g->memo_lds_off));
       else if (prm_g->memo)
-        L.st->memo_slot = reinterpret_cast<unsigned long long>(prm_g->memo) + (size_t(blockIdx.x) * 4 + wave) * prm_g->memo_stride;
+        L.st->memo_slot = owner ? reinterpret_cast<unsigned long long>(prm_g->memo) + (size_t(blockIdx.x) * NO + wave) * prm_g->memo_stride : 0ull;
     }
   }
   wave_sync();
@@ -1331,11 +1440,14 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   int* queue = prm_g->queue;
   if constexpr (ModelCoop<Model>::value) {   // the workgroup's control block: every wave marks itself as an owner, no pass open
     model.coop_init(prm_g->coop_K, prm_g->coop_cs, prm_g->lds_per_wave, prm_g->coop_tot_off);
-    CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(4) * prm_g->lds_per_wave);
+    model.coop_NO = NO;
+    CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(kW) * prm_g->lds_per_wave);
     if (lane == 0) {
       ctl->slot[wave].ticket = prm_g->coop_K;
       ctl->slot[wave].turn = prm_g->coop_K;
-      ctl->active[wave] = 1;
+      ctl->slot[wave].eticket = prm_g->coop_K;
+      ctl->slot[wave].edone = prm_g->coop_K;
+      ctl->active[wave] = owner ? 1 : 0;
     }
     __syncthreads();   // the only workgroup barrier of the kernel: nobody scans the slots before they exist
   }
@@ -1343,12 +1455,12 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   // The first problem of every wave is assigned statically (wave w of the launch takes problem w); the shared counter hands
   // out the rest.  4 096 waves popping the same address at launch time serialise in the L2 (~5 ns per atomic = 20-30 us
   // before the last wave has its first problem: 4 % of a C3 launch, visible in the launch timeline).
-  const int nwaves = int(gridDim.x) * 4;
-  bool first = true, dry = false;
+  const int nwaves = int(gridDim.x) * NO;   // (owners of the launch)
+  bool first = owner, dry = !owner;           // (a helper of the team form starts where an owner ends up: queue dry, looking for tickets)
   for (;;) {  // one work item = one whole problem
     int p = 0;
     if (first) {
-      p = int(blockIdx.x) * 4 + wave;
+      p = int(blockIdx.x) * NO + wave;
       first = false;
     } else if (dry) {
       p = int(P);
@@ -1382,7 +1494,12 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
     // the issue slots: a wave drops one level per problem it has finished.  (Measured and rejected, profiles/r02_ab_log.md:
     // no priorities; a level that follows the lag behind the average wave; re-queueing unfinished problems iteration by
     // iteration through HBM during the drain.)
-    {
+    if (kTeam && prm_g->team_prio == 0) {
+      // Team form: an owner's LDL^T, step test and bookkeeping are the serial part of its problem's chain — every other wave
+      // of the compute unit can only work on a chunk that some owner has opened — so the owners outrank the helpers.
+      if (owner && !ghost) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(1);
+    } else {
       const int lag = 1 - solved;
       if (lag >= 1) __builtin_amdgcn_s_setprio(3);
       else if (lag == 0) __builtin_amdgcn_s_setprio(2);
@@ -1390,6 +1507,14 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
       else __builtin_amdgcn_s_setprio(0);
     }
     ++solved;
+    if constexpr (kTeam) {
+      // a ticket of an evaluate-only pass: its chunk(s) are worked off right here (DenseRowModel::coop_eval — the helper's
+      // side of the owner's loop), no ghost problem needed
+      if (ghost && model.help_kind) {
+        (void)model.coop_eval(L, n, lane);
+        continue;
+      }
+    }
     if (ghost) p = 0;
     model.bind(p);
     wave_sync();
@@ -1416,7 +1541,7 @@ __global__ void __launch_bounds__(256) lm_fused_kernel(const FusedParams* __rest
   // next launch on the stream needs no memset in front of it (one stream operation, ~5 us, per solve: 1 % of a C3 launch).
   if (lane == 0) {
     const int gone = atomicAdd(&queue[16], 1);
-    if (gone == int(gridDim.x) * 4 - 1) {
+    if (gone == int(gridDim.x) * kW - 1) {
       __hip_atomic_store(&queue[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&queue[16], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2286,16 +2411,40 @@ inline int ensure_pass_ring(toa_handle h) {
   return TOA_OK;
 }
 
-// waves per workgroup is fixed at 4 (256 threads); LDS per wave decides how many WGs fit per CU.
+// waves per workgroup: 4 (256 threads) everywhere but the team form of the fused kernel; LDS per wave decides how many WGs fit per CU.
 template <typename T>
-inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg) {
+inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg, int waves = 4) {
   size_t pw = WaveLds<T>::bytes(n);
   pw = (pw + 15) & ~size_t(15);
   *per_wave = pw;
-  *per_wg = pw * 4;
+  *per_wg = pw * waves;
   if (*per_wg > 160 * 1024) return toa_fail(TOA_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB per workgroup");
   (void)h;
   return TOA_OK;
+}
+
+// Chunks per pass of a cooperative model — a property of the SHAPE, never of the batch, the position in it, or of which
+// form of the kernel runs (classic / team), so that a problem's bits depend on none of them: ~1024 rows per chunk
+// (256 for the 64-row super-batch layouts); toa_tuning::coop_chunks overrides (experiments, and the team form's tests).
+template <typename Model>
+inline void coop_chunking(toa_handle h, int n, int m, int* K_out, int* cs_out) {
+  (void)n;
+  const int steps_total = (m + 3) / 4;
+  constexpr bool super16 = Model::kCoopPeriod == 16;
+  int K = super16 ? std::max(2, std::min(16, (m + 128) / 256)) : std::max(2, std::min(16, (m + 512) / 1024));
+  if (h->tune.coop_chunks >= 2 && h->tune.coop_chunks <= 64) K = h->tune.coop_chunks;
+  const int period = Model::kCoopPeriod;   // steps per ring turn / super-batch: chunk boundaries fall on it
+  int cs = (steps_total + K - 1) / K;
+  cs = (cs + period - 1) / period * period;
+  *cs_out = cs;
+  *K_out = (steps_total + cs - 1) / cs;
+}
+// Can this shape run in the team form (kTeamWaves carves + the control block in one workgroup, cooperative passes on)?
+template <typename T>
+inline bool team_fits(toa_handle h, int n, int m) {
+  if (h->tune.coop_off || m < 1024) return false;
+  const size_t pw = (WaveLds<T>::bytes(n) + 15) & ~size_t(15);
+  return pw * kTeamWaves + kCoopCtlBytes <= 160 * 1024;
 }
 
 template <typename Model>
@@ -2324,9 +2473,15 @@ inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* 
 template <typename Model>
 inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   using T = typename Model::Scalar;
+  constexpr int kW = ModelWaves<Model>::value;
+  constexpr bool kTeam = kW != 4;
   FusedParams prm = prm_in;
   size_t pw, pwg;
-  if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg)) return rc;
+  if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg, kW)) return rc;
+  // team form: owners per workgroup = problems in flight per compute unit (one workgroup of twelve waves per CU)
+  const int NO = kTeam ? std::max(1, std::min(kW, h->tune.team_owners > 0 ? h->tune.team_owners : (kW >= 12 ? 2 : 1))) : 4;
+  prm.team_owners = NO;
+  prm.team_prio = h->tune.team_prio;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
   // [0] pop counter, [16] waves that have left: zeroed when the handle is created and by the last wave of every launch
@@ -2348,7 +2503,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     if (w == 0) {
       if (lds_bytes > max_set)   // the limit only ever grows: a smaller request must not lower it under a cached larger one
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, kern, 256, lds_bytes));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, kern, 64 * kW, lds_bytes));
       if (w < 1) w = 1;
       if (h->ncfg < 256) h->cfg[h->ncfg++] = {(const void*)kern, lds_bytes, w};
     }
@@ -2359,7 +2514,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if constexpr (ModelStageBytes<Model>::value > 0) {   // the LDS stage of the row-per-lane pass, part of every wave's carve
     prm.stage_off = (int)pw;
     pw += ModelStageBytes<Model>::value;
-    pwg = pw * 4;
+    pwg = pw * kW;
     prm.lds_per_wave = (int)pw;
   }
   int wg_per_cu = 0;
@@ -2377,7 +2532,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
       // a small Gram is parked in LDS when that costs no resident workgroup (C3: parking in HBM after every accepted step
       // measured 1.5 % of the launch for a workload that never rejects a step)
       const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
-      if (mb <= 4096 && (pw + mb) * 4 <= 160 * 1024) {
+      if (!kTeam && mb <= 4096 && (pw + mb) * 4 <= 160 * 1024) {
         int w2 = 0;
         if (int rc = occupancy((pw + mb) * 4, &w2)) return rc;
         if (w2 == wg_per_cu) {
@@ -2395,44 +2550,38 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if constexpr (ModelCoop<Model>::value) {
     prm.coop_K = 1;                       // one chunk = the classic pass, bit for bit
     prm.coop_cs = (prm.m + 3) / 4;
-    pwg += 256;                           // the control block (the waves' carves are far below the LDS limit of a smaller grid)
+    pwg += kCoopCtlBytes;                 // the control block (the waves' carves are far below the LDS limit of a smaller grid)
     // Cooperative passes (CoopCtl): on for a SHAPE (never for a batch size or a position in the batch, so that a problem's
     // bits do not depend on them), when a pass has enough rows to be worth sharing.  The chunk total of a pass is summed in
     // the owner's LDL^T workspace when the Gram registers fit it, in an area of its own otherwise (if that costs no
     // resident workgroup).  toa_tuning::coop_off switches it off (A/B).
     const bool coop_on = !h->tune.coop_off;
-    const int steps_total = ((prm.m + 3) / 4);
     constexpr bool super16 = Model::kCoopPeriod == 16;   // fp64 n <= 15: 64-row super-batches, 52 KB problems — share from 256 rows
     bool room = Model::kMemoBytes <= WaveLds<T>::m_elems(prm.n) * sizeof(T);
     if (coop_on && prm.m >= (super16 ? 256 : 1024) && !room) {
       const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
       int w2 = 0;
-      if ((pw + mb) * 4 + 256 <= 160 * 1024) {
-        if (int rc = occupancy((pw + mb) * 4 + 256, &w2)) return rc;
+      if ((pw + mb) * kW + kCoopCtlBytes <= 160 * 1024) {
+        if (int rc = occupancy((pw + mb) * kW + kCoopCtlBytes, &w2)) return rc;
         if (w2 == wg_per_cu) {
           prm.coop_tot_off = (int)pw;
           pw += mb;
-          pwg = pw * 4 + 256;
+          pwg = pw * kW + kCoopCtlBytes;
           prm.lds_per_wave = (int)pw;
           room = true;
         }
       }
     }
+    if (kTeam && !(coop_on && room)) return toa_fail(TOA_E_UNSUPPORTED, "team form of the fused kernel: this shape has no cooperative passes");
     if (coop_on && prm.m >= (super16 ? 256 : 1024) && room) {
       // chunks per pass: ~1024 rows each (256 for the super-batch form).  Same box, C4 (m = 2000), three interleaved rounds
       // (profiles/r03_ab_log.md): K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays
       // its own ramp of the load ring, so the coarsest split that still lets a sibling help wins.  (toa_tuning::coop_chunks: experiments)
-      int K = super16 ? std::max(2, std::min(16, (prm.m + 128) / 256)) : std::max(2, std::min(16, (prm.m + 512) / 1024));
-      if (h->tune.coop_chunks >= 2 && h->tune.coop_chunks <= 64) K = h->tune.coop_chunks;
-      const int period = Model::kCoopPeriod;   // steps per ring turn / super-batch: chunk boundaries fall on it
-      int cs = (steps_total + K - 1) / K;
-      cs = (cs + period - 1) / period * period;
-      prm.coop_cs = cs;
-      prm.coop_K = (steps_total + cs - 1) / cs;
+      coop_chunking<Model>(h, prm.n, prm.m, &prm.coop_K, &prm.coop_cs);
     }
   }
   long long grid = (long long)h->num_cus * wg_per_cu;
-  const long long need = (prm.P + 3) / 4;
+  const long long need = (prm.P + NO - 1) / NO;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
   // (Sizing the grid to P / rounds waves so that every round is full was tried: at the BASELINE shard size 625 workgroups
@@ -2441,7 +2590,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   if constexpr (ModelMemo<Model>::value) {
     if (memo_on && prm.memo_lds_off == 0) {
       const size_t stride = (Model::kMemoBytes + 255) & ~size_t(255);
-      const size_t need_b = stride * size_t(grid) * 4;
+      const size_t need_b = stride * size_t(grid) * NO;
       if (need_b > h->memo_bytes) {
         if (int rc = grow_sync(h, "memo of the last accepted linearisation")) return rc;
         if (h->memo) (void)hipFree(h->memo);
@@ -2466,7 +2615,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     prm.timeline = tl_dev;
     if (int rc = upload_params(h, &prm, sizeof(prm))) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pwg, h->stream, (const FusedParams*)h->params_dev);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kW), pwg, h->stream, (const FusedParams*)h->params_dev);
   if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess) {
     h->queue_dirty = true;
     return toa_fail(TOA_E_HIP, std::string("lm_fused_kernel launch: ") + hipGetErrorString(e_));

@@ -2,7 +2,8 @@
 """ISA lint for the inline-asm MFMAs: hipcc's hazard recognizer does not look inside asm statements, so an
 accumulator copy it inserts (v_accvgpr_read / v_accvgpr_mov / any non-MFMA reader of an AGPR) could overtake
 the matrix core.  This scans the gfx950 code objects of the built translation units and fails if such a
-reader follows an MFMA that wrote the same AGPR with fewer than MIN_WAIT wait states in between
+reader follows an MFMA that wrote the same AGPR (or, in the VGPR-accumulator translation units of the team form, any
+instruction that touches a VGPR an MFMA wrote) with fewer than MIN_WAIT wait states in between
 (every instruction = 1, `s_nop N` = N + 1, a later MFMA = its passes - 1; straight-line approximation, conservative).
 
 usage: python tools/isa_lint.py [objects...]    (default: tinyopt_amd/csrc/_obj/*.o)
@@ -182,10 +183,19 @@ def lint_object(obj):
                     # the matrix core runs one MFMA at a time: this one could only issue once the previous one was
                     # (passes - 1) issue slots into its execution (8-pass f32 16x16x4, 16-pass f64 16x16x4)
                     step = 15 if "f64" in op else 7
+                    # VGPR-form accumulators (-DTOA_ACC_VGPR translation units): an MFMA whose A / B operand is a register a
+                    # recent MFMA wrote would need the XDL-write -> XDL-read-SrcA/B wait states (SrcC == vDst accumulation does not)
+                    ab = rest.split(",")[1:3]
+                    for r in vregs(",".join(ab)):
+                        if ("v", r) in last_write and last_write[("v", r)] < MIN_WAIT:
+                            problems.append(f"{os.path.basename(obj)}: {func[:90]}: `{ins}` reads v{r} as an A/B operand {last_write[('v', r)]} wait states after an MFMA wrote it")
                     for r in last_write:
                         last_write[r] += step
                     for r in aregs(dst):
                         last_write[r] = 0
+                    if dst.strip().startswith("v"):
+                        for r in vregs(dst):
+                            last_write[("v", r)] = 0
                     continue
                 # readers: anything that names an AGPR as a source
                 srcs = rest.split(",", 1)[1] if "," in rest else ""
@@ -195,6 +205,14 @@ def lint_object(obj):
                 for r in aregs(srcs):
                     if r in last_write and last_write[r] < need:
                         problems.append(f"{os.path.basename(obj)}: {func[:90]}: `{ins}` reads a{r} {last_write[r]} wait states after an MFMA wrote it")
+                # VGPR-form accumulators: any non-MFMA instruction that reads OR writes (WAW) a VGPR an MFMA wrote too recently
+                if any(isinstance(k, tuple) for k in last_write) and not op.startswith("s_"):
+                    for r in vregs(rest.split("<")[0]):
+                        k = ("v", r)
+                        if k in last_write:
+                            if last_write[k] < need:
+                                problems.append(f"{os.path.basename(obj)}: {func[:90]}: `{ins}` touches v{r} {last_write[k]} wait states after an MFMA wrote it")
+                            last_write.pop(k, None)
                 # any write to an AGPR by a non-MFMA instruction ends the tracking of that register
                 dst = rest.split(",")[0]
                 if op.startswith("v_accvgpr_write") or op.startswith("v_accvgpr_mov"):

@@ -16,7 +16,7 @@ sobj=tinyopt_amd/_variants/solve_${DT}_$tag.o
   -c tinyopt_amd/csrc/inst.hip -o $sobj &
 wait
 others=$(ls tinyopt_amd/csrc/_obj/*.o | grep -v "inst_${DT}_${NBM}.o\|solve_${DT}.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others $obj $sobj -o tinyopt_amd/_variants/lib_$tag.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -ldl $others $obj $sobj -o tinyopt_amd/_variants/lib_$tag.so
 python tools/isa_lint.py $obj | tail -1
 python tools/kernel_regs.py $obj "lm_fused_kernelINS_13DenseRowModelIfLi3ELi3|accumulate_kernelINS_13DenseRowModelIfLi3ELi3"
 echo built tinyopt_amd/_variants/lib_$tag.so
