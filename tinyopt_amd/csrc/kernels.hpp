@@ -1374,7 +1374,9 @@ struct FusedParams {
   double loss_th2;
   void* memo;                    // mode 0, models with kMemo: one slot of memo_stride bytes per resident wave (null = off)
   unsigned long long memo_stride;
-  int stage_off;                 // row-per-lane fp64 pass: byte offset of the wave's LDS stage in its carve
+  int stage_off;                 // row-per-lane fp64 pass: byte offset of the wave's LDS stage in its LDS region
+  int carve_off;                 // byte offset of the wave's carve in its LDS region (> 0: a stage in front of it, overlapping the carve's
+                                 // pass-dead head — WaveLds::pass_dead_bytes)
   int coop_tot_off;              // cooperative passes: byte offset of the chunk-partial total in a wave's carve (0 = its M)
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
   int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
@@ -1411,7 +1413,7 @@ __global__ void __launch_bounds__(64 * ModelWaves<Model>::value) lm_fused_kernel
   // owners: the waves that pull problems.  Classic form: all four.  Team form: the first team_owners of the workgroup.
   const int NO = kTeam ? __builtin_amdgcn_readfirstlane(prm_g->team_owners) : 4;
   const bool owner = !kTeam || __builtin_amdgcn_readfirstlane(wave) < NO;
-  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave, n);
+  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave + prm_g->carve_off, n);
   // private per-wave copies of the option / result PODs (no inter-wave synchronisation anywhere)
   {
     const int* src_o = reinterpret_cast<const int*>(&prm_g->opt);
@@ -2511,9 +2513,15 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     return TOA_OK;
   };
   prm.stage_off = 0;
-  if constexpr (ModelStageBytes<Model>::value > 0) {   // the LDS stage of the row-per-lane pass, part of every wave's carve
-    prm.stage_off = (int)pw;
-    pw += ModelStageBytes<Model>::value;
+  prm.carve_off = 0;
+  if constexpr (ModelStageBytes<Model>::value > 0) {
+    // The LDS stage of the row-per-lane pass: it begins at the wave's region and ends INSIDE the carve, over the part of it
+    // that is dead while a pass runs (WaveLds::pass_dead_bytes: LDL^T workspace, the solve's scratch, the step).  C3 (fp64,
+    // n = 12): 8 192 + 6 464 = 14 656 bytes per wave were two workgroups per compute unit (round 3 / 4 ran this kernel at
+    // two waves per SIMD without noticing); overlaid 11 104, with the memo's 2 048 behind them 13 152 <= 160 KiB / 12: three.
+    const size_t dead = std::min(WaveLds<T>::pass_dead_bytes(prm.n), size_t(ModelStageBytes<Model>::value));
+    prm.carve_off = int(ModelStageBytes<Model>::value - dead);
+    pw += prm.carve_off;
     pwg = pw * kW;
     prm.lds_per_wave = (int)pw;
   }

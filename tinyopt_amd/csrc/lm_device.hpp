@@ -119,21 +119,28 @@ struct WaveLds {
     b += (sizeof(toa_results) + 15) & ~size_t(15);
     return b;
   }
+  // The carve STARTS with everything that is dead while a data pass runs — the factorisation workspace, the solve's scratch
+  // vectors and permutation, the step (written by the solve, consumed before the next pass), the row-split scratch: a model
+  // whose pass stages rows through LDS (DenseRowGram::pass16s) lays its stage over these bytes (lm_fused_kernel: the stage
+  // begins in front of the carve and ends pass_dead_bytes into it).  Alive across a pass and therefore behind them: x, the
+  // gradient and the damped diagonal (an evaluate-only iteration solves with the last build's), the last step, the memo's x.
+  static __host__ __device__ size_t pass_dead_bytes(int n) { return (m_elems(n) + 4 * 64) * sizeof(T) + 64 * sizeof(int); }
   __device__ static WaveLds carve(char* base, int n) {
     WaveLds w;
     w.LD = ld_for(n);
     T* p = reinterpret_cast<T*>(base);
     w.M = p; p += m_elems(n);
-    w.xs = p; p += 64;
-    w.g = p; p += 64;
-    w.hd = p; p += 64;
     w.tmp = p; p += 64;
     w.vec = p; p += 64;
     w.dx = p; p += 64;
-    w.ldx = p; p += 64;
     w.aux = p; p += 64;
-    w.xsv = p; p += 64;
     w.perm = reinterpret_cast<int*>(p);
+    p = reinterpret_cast<T*>(reinterpret_cast<char*>(p) + 64 * sizeof(int));
+    w.xs = p; p += 64;
+    w.g = p; p += 64;
+    w.hd = p; p += 64;
+    w.ldx = p; p += 64;
+    w.xsv = p; p += 64;
     size_t off = (m_elems(n) + 9 * 64) * sizeof(T) + 64 * sizeof(int);
     off = (off + 15) & ~size_t(15);
     w.st = reinterpret_cast<LmState<T>*>(base + off);
