@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0 (stdout); diagnostics go to stderr.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -49,6 +50,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def eigen_probe():
+    """"if find_package(Eigen3) succeeds on the box, additionally build an Eigen-backed variant ...; otherwise state
+    'Eigen unavailable; baseline is restatement'".  The reference itself (header-only over Eigen 3.4) does not travel to the GPU
+    box and no Eigen-backed variant is shipped, so this only REPORTS what the box has."""
+    import glob
+    hits = []
+    for pat in ("/usr/include/eigen3/Eigen/Core", "/usr/local/include/eigen3/Eigen/Core", "/opt/*/include/eigen3/Eigen/Core",
+                "/usr/include/Eigen/Core", "/opt/rocm/include/Eigen/Core"):
+        hits += glob.glob(pat)
+    if not hits:
+        return "unavailable: no Eigen/Core on this box; the baseline is the restatement (oracle/lm_oracle.hpp, kind = port)"
+    return f"present at {os.path.dirname(os.path.dirname(hits[0]))} but unused: the reference's sources do not travel with the repo; baseline is the restatement"
+
+
 def cpu_baseline(n, m, np_dtype, pod, budget_problems):
     """Oracle (CPU restatement of the reference algorithm) timed on this host, single thread, on a
     bounded sample of the same workload.  kind = "port" (the real reference needs Eigen; not buildable)."""
@@ -76,7 +91,7 @@ def cpu_baseline(n, m, np_dtype, pod, budget_problems):
     except OSError:
         pass
     return {
-        "value": it1 / r1["seconds"], "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        "value": it1 / r1["seconds"], "unit": "LM iterations/s", "cores": 1, "kind": "port", "eigen": eigen_probe(),
         "sample": f"{budget_problems} problems of the same workload (n={n}, m={m}), {it1} LM iterations, "
                   f"{r1['seconds']:.1f} s single thread; oracle/lm_oracle.hpp built with {build}",
         "all_cores": {"value": int(rall["iters"].sum()) / rall["seconds"], "cores": ncores, "seconds": rall["seconds"]},
@@ -263,7 +278,7 @@ def run_single(args, ta, rank, world, local_rank):
             it_cpu += solve_once()
             t_cpu += time.perf_counter() - tc
             reps += 1
-        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port", "eigen": eigen_probe(),
                                   "us_per_solve": t_cpu / reps * 1e6, "lm_iterations_per_solve": it_cpu / reps / P,
                                   "sample": f"the same problem solved {reps} times by oracle/lm_oracle.hpp (g++ -O3 -march=native), {t_cpu:.2f} s, one thread"}
         result["config"]["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
@@ -372,7 +387,7 @@ def run_ba(args, ta, rank, world, local_rank):
         r = pyoracle.ba_lm(data[:S], x0h[:S], C, N, pod, history=False, lib=lib)
         t_cpu = time.perf_counter() - tc
         it_cpu = int(r["iters"].sum())
-        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port", "eigen": eigen_probe(),
                                   "sample": f"{S} scenes of the same workload solved the reference's way — dense (6C + 3N)^2 = 816^2 Hessian + "
                                             f"dense LDL^T (oracle/ba.hpp; math.h:232-240) — {it_cpu} LM iterations, {t_cpu:.1f} s, one thread",
                                   "iters_per_problem": it_cpu / S}
@@ -484,7 +499,7 @@ def run_balists(args, ta, rank, world, local_rank):
         r = pyoracle.ba_lm(ds, x0s, Cs, Ns, pod, history=False, lib=lib)
         t_cpu = time.perf_counter() - tc
         it_cpu = int(r["iters"].sum())
-        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        result["cpu_baseline"] = {"value": it_cpu / t_cpu, "unit": "LM iterations/s", "cores": 1, "kind": "port", "eigen": eigen_probe(),
                                   "sample": f"NOT the bench shape (a 15 384^2 dense Hessian is 1.9 GB and ~1e12 flops per LDL^T): the same generator at "
                                             f"{Cs} cameras x {Ns} points, all visible ({6 * Cs + 3 * Ns} unknowns), solved the reference's way — dense "
                                             f"Hessian + dense LDL^T (oracle/ba.hpp; math.h:232-240) — {it_cpu} LM iterations, {t_cpu:.1f} s, one thread",
@@ -614,6 +629,7 @@ def main():
         barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     iters_total = int(acc[0].item())
     passes_total = int(acc[1].item())
     acc_passes_total = int(acc[3].item())
@@ -639,9 +655,15 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         rank_iters = [int(lo.item()) / args.steps, int(hi.item()) / args.steps]
+        # every rank's own kernel time and wall time, so that the first real multi-GPU run shows stragglers (one all_gather of 2 doubles)
+        mine = torch.tensor([kern_avg_s * 1e3, elapsed_local * 1e3 / args.steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms_avg": [float(v[0].item()) for v in allr], "ms_per_step": [float(v[1].item()) for v in allr]}
     else:
         iters_all, passes_all = iters_total, passes_total
         rank_iters = [iters_total / args.steps, iters_total / args.steps]
+        per_rank = None
 
     # ---- the single end-of-job collective: gather results to rank 0 (timed separately)
     # N > 1: `toa_gather` of the C-ABI — one ncclGather of (x, stop_reason, num_iters, final_cost) in native types
@@ -725,10 +747,25 @@ def main():
     try:
         if not gpu:
             raise RuntimeError("dry run")
-        stream_read = ctx.hbm_read_GBps(model.packed[: min(model.packed.shape[0], 64)].contiguous() if large else model.packed, reps=5)
+        probe_src = model.packed
+        if large:   # (a slice of whole problems, at most ~1 GiB; the natural layout's rows are 4 (n + 1)-byte records: cut on a 16-byte boundary)
+            rows = max(1, min(probe_src.shape[0], (1 << 30) // max(1, probe_src.shape[1] * probe_src.element_size())))
+            probe_src = probe_src[:rows]
+        nb = probe_src.numel() * probe_src.element_size() // 16 * 16
+        out_gbs = ctypes.c_double()
+        ta.api.check(ctx.lib.toa_hbm_read_probe(ctx.h, ctypes.c_void_p(probe_src.data_ptr()), nb, 5, ctypes.byref(out_gbs)))
+        stream_read = out_gbs.value
     except Exception as e:  # noqa: BLE001
         log(f"[bench] hbm read probe failed: {e}")
         stream_read = None
+    # the same for a working set that stays on-die (the 256 MiB Infinity Cache): the ceiling of re-reads, next to HBM's
+    try:
+        if not gpu:
+            raise RuntimeError("dry run")
+        llc_read = ctx.llc_read_GBps(model.packed)
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] llc read probe failed: {e}")
+        llc_read = None
     # secondary ceiling ("MFMA ceiling reported additionally"): matrix-core flops ISSUED by the accumulate
     # passes (NBM(NBM+1)/2 tiles of v_mfma_*_16x16x4 = 2048 flop per 4 rows) against the dense fp32 / fp64 MFMA peak
     if large:
@@ -772,12 +809,14 @@ def main():
                    "lm_iterations_per_step_all_gpus": iters_all / args.steps,
                    "iters_per_problem": iters_all / args.steps / (P * world),
                    "lm_iterations_per_step_per_gpu_min_max": rank_iters,
+                   "per_rank": per_rank,
                    "device": info["name"], "num_cus": info["num_cus"]},
         "roofline": {"bound": "hbm", "kernel": "lm_fused_kernel" if not large else ("large_fused_kernel (data pass + fold + blocked LDL^T + step: the whole launch)" if n <= 128 else "large_gram_kernel + the rest of the n > 128 pipeline (rows, reduce, pre, stage, one-workgroup blocked Cholesky, post: the whole batched solve, two staggered lanes)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc passes of the same workload and binary, collected by tools/refresh_profiles.sh; not this run)") if traffic else None,
                      "measured_read_ceiling_GBps": stream_read,
+                     "llc_read_ceiling_GBps": llc_read,
                      "frac_of_measured_ceiling": (achieved / stream_read) if stream_read else None,
                      "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_per_launch,
                      "passes_accounting": "only the passes that streamed the rows count (accumulate + evaluate-only, device counters); "
@@ -812,7 +851,9 @@ def main():
                               "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_all": r["kernel_ms_all"],
                               "hbm_secondary": {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"],
                                                 "algorithmic_bytes_per_pass": r["algorithmic_bytes_per_pass"],
-                                                "passes_per_launch": r["passes_per_launch"]}}
+                                                "passes_per_launch": r["passes_per_launch"],
+                                                "measured_read_ceiling_GBps": r["measured_read_ceiling_GBps"],
+                                                "llc_read_ceiling_GBps": r["llc_read_ceiling_GBps"]}}
     if not args.no_cpu and world == 1:  # the CPU baseline leg runs on rank 0 at N = 1 only
         np_dtype = np.float32 if tdt == torch.float32 else np.float64
         est = 4e-4 * (n * n * m) / (50 * 50 * 2000) * 8  # rough seconds per problem (8 iterations)

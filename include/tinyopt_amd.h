@@ -215,6 +215,11 @@ int toa_device_info(toa_handle h, int* num_cus, int* clock_khz, char* name, size
 /* Measured read ceiling of this GPU's HBM (SURVEY §8d asks for a STREAM-like figure next to the nominal 8 TB/s):
  * streams `bytes` from src_dev `reps` times with 16-byte loads and reports GB/s between two HIP events. */
 int toa_hbm_read_probe(toa_handle h, const void* src_dev, size_t bytes, int reps, double* gb_per_s);
+/* Measured read ceiling of the 256 MiB Infinity Cache for the access pattern of this library's kernels (a problem's rows re-read
+ * by its own waves): `bytes` (<= ~200 MB to stay on-die; larger buffers measure HBM) as two contiguous slices per compute unit,
+ * six waves per slice; the rate of the re-reads, GB/s.  ~7.7 TB/s on MI355X against 6.3 from HBM: the XCD <-> IO-die fabric
+ * bounds it (profiles/r05_ab_log.md §1a). */
+int toa_llc_read_probe(toa_handle h, const void* src_dev, size_t bytes, double* gb_per_s);
 
 /* ---- device memory conveniences for non-torch callers (the C++ header adaptor) ---- */
 int toa_malloc(toa_handle h, void** dev_ptr, size_t bytes);
@@ -337,7 +342,18 @@ int toa_inv_cov(toa_handle h, int dtype, int n, int64_t P, const void* H_dev, vo
  *      the solve is done; under stream capture that form records its whole pass budget instead (every kernel skips finished
  *      problems) and the graph replays the solve with no host in the loop; with a library stage in the pass (no capture) (fp64 / odd shapes: rocBLAS
  *      GEMM, rocSOLVER beyond the LDS) the pair is read back after every pass.  64 <= n <= 128 is one persistent kernel
- *      like the rest. */
+ *      like the rest.  A capture of that form records at most 1024 passes: options whose pass budget is larger
+ *      (max_consec_failures == 0: up to 255 retries per iteration) are refused under capture with the node count.
+ *      BATCH INDEPENDENCE: within one execution form a problem's bits depend neither on the batch size nor on its position
+ *      in the batch (every sum has a fixed order; tests/test_gpu_coop.py, test_gpu_large_n.py).  The FORM, however, is chosen
+ *      from the batch shape — a handful of huge problems is split by rows over the chip (n <= 63: P * 4 <= #CUs and m >= 512;
+ *      64 <= n <= 128: m * n >= 393 216 and P * m * n <= 2^25), everything else is one wavefront / one workgroup per problem
+ *      — and two forms sum in different orders: the same problem solved in a batch on either side of such a crossover agrees
+ *      to rounding, not bit for bit (toa_tuning::wide_no_autosplit pins the per-problem form).
+ *      LIFETIME under graphs: a captured launch bakes the device pointers of the handle's workspaces (scratch, memo, work
+ *      arrays) into the graph.  Once any launch of a handle has been captured, a workspace that a later, larger eager call
+ *      outgrows is no longer freed but kept until toa_destroy (the new block is allocated beside it), so an earlier graph can
+ *      be replayed at any time before toa_destroy — never after it (tests/test_gpu_graph_capture.py). */
 int toa_lm_run(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                const void* data_dev, void* x_dev, const toa_options* options,
                const toa_results* results, uint64_t* counters_dev);

@@ -97,3 +97,83 @@ def test_the_n_256_pipeline_is_capturable_where_every_stage_is_ours(ta, oracle):
             with torch.cuda.graph(g2, stream=s):
                 ta.Optimize(x64, m64, opts, out=o64)
     torch.cuda.synchronize()
+
+
+def test_a_graph_survives_a_later_larger_eager_call(ta):
+    """a captured launch bakes the pointers of the handle's workspaces (memo slots, scratch) into the graph; a later
+    eager call with a larger shape makes them grow.  Once a launch has been captured the outgrown block is kept until toa_destroy
+    (toa_release_workspace), so the earlier graph still replays — and still gives the bits of its eager twin."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        opts = ta.Options.benchmark()
+        # (a) the fused kernel: memo slots for 40 problems' waves, then a batch that needs every resident slot
+        model, x0, _ = _problem(ta, 40, 50, 1100, np.float32)
+        x_ref = x0.clone()
+        ref = ta.Optimize(x_ref, model, opts)
+        x = x0.clone()
+        out = ta.Optimize(x, model, opts)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ta.Optimize(x, model, opts, out=out)
+        big, xb, _ = _problem(ta, 5000, 50, 1100, np.float32)
+        ob = ta.Optimize(xb.clone(), big, opts)            # the memo block grows here
+        s.synchronize()
+        assert bool((ob.stop_reason > 0).all())
+        for _ in range(2):
+            x.copy_(x0)
+            out.num_iters.zero_()
+            g.replay()
+            s.synchronize()
+            assert torch.equal(x, x_ref) and torch.equal(out.num_iters, ref.num_iters) and torch.equal(out.final_cost, ref.final_cost)
+        # (b) the n > 128 pipeline: its scratch block (rows, Gram partials, factor workspace) outgrown by a larger batch
+        rng = np.random.default_rng(7)
+        P, n, m = 4, 160, 640
+        A = rng.uniform(-1, 1, (P, m, n)).astype(np.float32)
+        xs = rng.uniform(-1, 1, (P, n)).astype(np.float32)
+        t = np.einsum("pmn,pn->pm", A, xs)
+        b = (t + 0.1 * np.sin(t)).astype(np.float32)
+        x0n = torch.from_numpy(xs + 0.3 * rng.uniform(-1, 1, (P, n)).astype(np.float32)).cuda()
+        mdl = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        xr = x0n.clone()
+        refn = ta.Optimize(xr, mdl, opts)
+        xn = x0n.clone()
+        outn = ta.Optimize(xn, mdl, opts)
+        s.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=s):
+            ta.Optimize(xn, mdl, opts, out=outn)
+        A2 = rng.uniform(-1, 1, (24, 2 * m, n)).astype(np.float32)
+        b2 = rng.uniform(-1, 1, (24, 2 * m)).astype(np.float32)
+        big2 = ta.DenseRowNatural(torch.from_numpy(A2).cuda(), torch.from_numpy(b2).cuda())
+        ta.Optimize(torch.zeros(24, n, device="cuda"), big2, opts)          # scratch grows
+        s.synchronize()
+        for _ in range(2):
+            xn.copy_(x0n)
+            outn.num_iters.zero_()
+            g2.replay()
+            s.synchronize()
+            assert torch.equal(xn, xr) and torch.equal(outn.num_iters, refn.num_iters) and torch.equal(outn.final_cost, refn.final_cost)
+    torch.cuda.synchronize()
+
+
+def test_capture_of_an_unbounded_retry_budget_is_refused_with_the_numbers(ta):
+    """max_consec_failures == 0 means up to 255 retries per iteration — (max_iters + 2) * 256 passes of ~7 kernels.
+    The n > 128 capture records its whole budget, so such options are refused under capture (the eager call runs them)."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        rng = np.random.default_rng(8)
+        P, n, m = 2, 160, 480
+        A = rng.uniform(-1, 1, (P, m, n)).astype(np.float32)
+        b = rng.uniform(-1, 1, (P, m)).astype(np.float32)
+        mdl = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        opts = ta.Options.benchmark()
+        opts.max_consec_failures = 0
+        x = torch.zeros(P, n, device="cuda")
+        out = ta.Optimize(x, mdl, opts)                   # eager: fine
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(Exception, match="graph nodes"):
+            with torch.cuda.graph(g, stream=s):
+                ta.Optimize(x, mdl, opts, out=out)
+    torch.cuda.synchronize()

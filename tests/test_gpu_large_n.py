@@ -496,6 +496,30 @@ def test_a_few_huge_problems_take_the_row_split_pipeline(ta, oracle):
     assert np.allclose(res[0][1].errs.cpu().numpy()[:, :3], res[1][1].errs.cpu().numpy()[:, :3], rtol=2e-4)
 
 
+def test_both_sides_of_the_batch_size_crossover_follow_the_oracle(ta, oracle):
+    """at 64 <= n <= 128 the execution form is chosen from the BATCH shape (P * m * n <= 2^25: the row-split pipeline,
+    above: a workgroup per problem) — like the row-split form below n = 64 — so a problem's summation order, hence its last bits,
+    depend on the batch it arrives in (include/tinyopt_amd.h says so).  What is guaranteed on both sides of the crossover: the
+    trajectory of the float64 oracle to float32 tolerance, and agreement with each other to summation order."""
+    n, m = 96, 4100                                     # m * n = 393 600 >= 393 216
+    P_big = 90                                          # 90 * m * n > 2^25: the one-kernel form; the first two alone: the pipeline
+    A, b, x0, xs = oracle.synth_dense_row(P_big, n, m, np.float32, seed=21)
+    o = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A.astype(np.float64), b.astype(np.float64), x0.astype(np.float64), o.to_pod(), history=True)
+    got = []
+    for P in (2, P_big):
+        model = ta.DenseRowNatural(torch.from_numpy(A[:P]).cuda(), torch.from_numpy(b[:P]).cuda())
+        x = torch.from_numpy(x0[:P].copy()).cuda()
+        out = ta.Optimize(x, model, o, history=True)
+        torch.cuda.synchronize()
+        assert bool((out.stop_reason > 0).all())
+        assert np.abs(x.cpu().numpy() - ref["x"][:P]).max() < 1e-4
+        assert np.allclose(out.errs.cpu().numpy()[:, :3], ref["errs"][:P, :3], rtol=2e-4)
+        got.append((x.cpu().numpy(), out.errs.cpu().numpy()))
+    assert np.abs(got[0][0] - got[1][0][:2]).max() < 1e-5
+    assert np.allclose(got[0][1][:, :3], got[1][1][:2, :3], rtol=2e-4)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n", [130, 160, 200, 256, 384, 500])
 def test_cholesky_lookahead_gives_the_bits_of_the_plain_schedule(ta, dtype, n):

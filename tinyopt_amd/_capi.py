@@ -95,6 +95,7 @@ PROTOTYPES = {
     "toa_set_loss": (C.c_int, [_P, C.c_int, C.c_double]),
     "toa_robust_norm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, C.c_double, _P, _P]),
     "toa_hbm_read_probe": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "toa_llc_read_probe": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_double)]),
     "toa_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "toa_free": (C.c_int, [_P, _P]),
     "toa_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -163,6 +163,13 @@ class Context:
                                           int(reps), C.byref(out)))
         return out.value
 
+    def llc_read_GBps(self, tensor, max_bytes: int = 192 << 20) -> float:
+        """Measured re-read rate of a working set that fits the Infinity Cache (the first `max_bytes` of `tensor`)."""
+        out = C.c_double()
+        nbytes = min(tensor.numel() * tensor.element_size(), int(max_bytes))
+        check(self.lib.toa_llc_read_probe(self.h, C.c_void_p(tensor.data_ptr()), nbytes, C.byref(out)))
+        return out.value
+
     def set_tuning(self, **kw) -> None:
         """The A/B arms of the library (include/tinyopt_amd.h toa_tuning) as typed per-handle state: ``ctx.set_tuning(memo_off=1)``;
         no arguments = the library's own choices.  The product reads no environment variable."""

@@ -792,7 +792,7 @@ int launch_ba(toa_handle h, BaParams& prm) {
   const size_t need = size_t(prm.P) * wk.total * sizeof(T);
   if (need > h->scratch_bytes) {
     if (int rc = grow_sync(h, "device workspace")) return rc;
-    if (h->scratch) (void)hipFree(h->scratch);
+    toa_release_workspace(h, h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&h->scratch, need));
@@ -1666,7 +1666,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v + b_sp + b_rp;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
     if (int rc = grow_sync(h, "bundle adjustment workspace")) return rc;
-    if (h->aux) (void)hipFree(h->aux);
+    toa_release_workspace(h, h->aux);
     h->aux = nullptr;
     h->aux_bytes = 0;
     HIP_TRY(hipMalloc(&h->aux, need));

@@ -2267,6 +2267,11 @@ struct toa_context {
   size_t scratch_bytes = 0;
   std::vector<std::unique_ptr<char[]>> captured_blocks;   // parameter blocks of launches captured into hipGraphs (upload_params)
   bool shadow_retired = false;
+  // Workspaces a captured hipGraph may still point into.  Once ANY launch of this handle has been captured (shadow_retired),
+  // a workspace that has to grow is not freed but parked here until toa_destroy: a graph bakes the raw device pointers of the
+  // scratch / memo / aux blocks of its capture time into its nodes, and a later eager call with a larger shape must not pull
+  // them from under a replay.  toa_release_workspace() is the only way a handle's workspace is given up.
+  std::vector<void*> retired_blocks;
   void* memo = nullptr;        // fused kernel: one parked linearisation per resident wave (lm_device.hpp; grown on demand)
   size_t memo_bytes = 0;
   void* aux = nullptr;         // bundle adjustment with visibility lists: its work arrays (`scratch` belongs to the solver it calls)
@@ -2321,6 +2326,14 @@ int toa_fail(int code, const std::string& msg);
       return toa_fail(e_ == hipErrorOutOfMemory ? TOA_E_NOMEM : TOA_E_HIP,                      \
                       std::string(#expr) + ": " + hipGetErrorString(e_));                       \
   } while (0)
+
+// Give up a workspace block of the handle that is about to be replaced by a larger one: freed at once — unless a launch of
+// this handle has ever been captured into a hipGraph, whose nodes may hold pointers into it (kept until toa_destroy then).
+inline void toa_release_workspace(toa_context* h, void* block) {
+  if (!block) return;
+  if (h->shadow_retired) h->retired_blocks.push_back(block);
+  else (void)hipFree(block);
+}
 
 // Before a device workspace is re-allocated: everything queued on the stream may still use the old block, so the stream is
 // drained first — which, like the hipMalloc that follows, cannot happen while the stream is being CAPTURED into a hipGraph.
@@ -2601,7 +2614,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
       const size_t need_b = stride * size_t(grid) * NO;
       if (need_b > h->memo_bytes) {
         if (int rc = grow_sync(h, "memo of the last accepted linearisation")) return rc;
-        if (h->memo) (void)hipFree(h->memo);
+        toa_release_workspace(h, h->memo);
         h->memo = nullptr;
         h->memo_bytes = 0;
         HIP_TRY(hipMalloc(&h->memo, need_b));
@@ -2737,7 +2750,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   const size_t need = b_state + b_part + b_hsum + b_sync;
   if (need > h->scratch_bytes) {
     if (int rc = grow_sync(h, "device workspace")) return rc;
-    if (h->scratch) (void)hipFree(h->scratch);
+    toa_release_workspace(h, h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&h->scratch, need));

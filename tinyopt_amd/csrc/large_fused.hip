@@ -714,7 +714,7 @@ int launch_large_accumulate(toa_handle h, int n, int m, int64_t P, const T* data
   const size_t need = per_wg * size_t(grid);
   if (need > h->scratch_bytes) {
     if (int rc = grow_sync(h, "device workspace")) return rc;
-    if (h->scratch) (void)hipFree(h->scratch);
+    toa_release_workspace(h, h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&h->scratch, need));
@@ -764,7 +764,7 @@ int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T
   const size_t need = per_wg * size_t(grid);
   if (need > h->scratch_bytes) {
     if (int rc = grow_sync(h, "device workspace")) return rc;
-    if (h->scratch) (void)hipFree(h->scratch);
+    toa_release_workspace(h, h->scratch);
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&h->scratch, need));

@@ -100,7 +100,7 @@ int ensure_scratch(toa_handle h, size_t need, const char* what) {
     return toa_fail(TOA_E_NOMEM, std::string(what) + ": cannot allocate " + std::to_string(need >> 20) + " MiB of device workspace (toa_tuning::fail_workspace_alloc)");
   if (need <= h->scratch_bytes) return TOA_OK;
   if (int rc = grow_sync(h, what)) return rc;
-  if (h->scratch) (void)hipFree(h->scratch);
+  toa_release_workspace(h, h->scratch);
   h->scratch = nullptr;
   h->scratch_bytes = 0;
   if (hipMalloc(&h->scratch, need) != hipSuccess) {
@@ -1701,6 +1701,16 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
       if (!ahead)
         return toa_fail(TOA_E_UNSUPPORTED, "large-n LM under stream capture: only the solves whose every stage is a kernel of this library "
                                            "(fp32, 16-byte aligned rows, use_ldlt, n <= 1024, not the stepping form) can be captured");
+      // The budget is an internal bound, not something the caller chose: with max_consec_failures == 0 a Build may be retried
+      // 255 times per iteration, i.e. tens of thousands of passes of ~7 kernels each — a graph of 10^5 nodes whose every replay
+      // pays ~40 us per empty pass.  Such a budget is refused here with the numbers; the eager call has no such limit.
+      constexpr long long kMaxCapturedPasses = 1024;
+      if (max_passes > kMaxCapturedPasses)
+        return toa_fail(TOA_E_UNSUPPORTED, "large-n LM under stream capture: the pass budget of these options is " + std::to_string(max_passes) +
+                                           " passes (~" + std::to_string(max_passes * 7) + " graph nodes, ~" + std::to_string(max_passes * 40 / 1000) +
+                                           " ms of empty launches per replay); at most " + std::to_string(kMaxCapturedPasses) +
+                                           " are recorded — set max_consec_failures > 0 (the retry bound per iteration) or lower max_iters");
+      h->shadow_retired = true;   // (a graph of this handle now exists: its workspaces are never freed under it, toa_release_workspace)
       for (long long pass = 0; pass < max_passes; ++pass) {
         int want_all = int(P);
         if (int rc = enqueue_pass(a, st, P, a.summary + 2 * pass, want_all)) return rc;
