@@ -848,6 +848,12 @@ def main():
                               "frac_issued": mfma_issued_per_pass * sec["accumulate_passes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12 / sec["peak"],
                               "achieved_full_square_accounting_r01": 2 * m * n * n * sec["accumulate_passes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12,
                               "accumulate_passes_per_launch": sec["accumulate_passes_per_launch"],
+                              # Builds served from the memo of the last accepted linearisation (round 5) run no data pass: they are in the
+                              # time, not in `achieved`.  Priced per BUILD — every Build of the loop credited with a pass's flops, the
+                              # scale on which the launches of earlier rounds (no memo: every Build streamed) were quoted:
+                              "builds_from_memo_per_launch": r["builds_from_memo_per_launch"],
+                              "per_build": {"builds_per_launch": sec["accumulate_passes_per_launch"] + r["builds_from_memo_per_launch"],
+                                            "frac": sec["frac"] * (sec["accumulate_passes_per_launch"] + r["builds_from_memo_per_launch"]) / max(sec["accumulate_passes_per_launch"], 1e-9)},
                               "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_all": r["kernel_ms_all"],
                               "hbm_secondary": {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"],
                                                 "algorithmic_bytes_per_pass": r["algorithmic_bytes_per_pass"],

@@ -109,3 +109,53 @@ def test_memo_with_device_ad_rows(ta, oracle):
     _assert_identical(x_off, o_off, x_on, o_on)
     c_off, c_on = o_off.counters.cpu().numpy(), o_on.counters.cpu().numpy()
     assert c_on[0] + c_on[4] == c_off[0]
+
+
+# ---- round 5: the same memo beyond one wavefront — a workgroup per problem (64 <= n <= 128, large_fused.hip:
+# two H slots per workgroup, a memo hit makes the parked slot the current one again) and the launch-per-stage pipeline
+# (128 < n <= 1024 and the few-huge-problems form, large_n.hip: a memo slot per problem, the rows / Gram kernels skip the problem)
+LARGE_CASES = [
+    # dtype, n, m, P, option overrides, forced pipeline
+    (np.float32, 128, 700, 12, {}, 0),                                        # tile-split pass (fp32, 112 < n <= 128)
+    (np.float32, 100, 500, 12, dict(max_consec_failures=8, max_iters=25), 0),   # row-split pass + fold
+    (np.float32, 64, 300, 16, dict(max_consec_failures=0, max_iters=20), 0),
+    (np.float64, 72, 300, 8, dict(min_rerr_dec=0.0, min_step_norm2=0.0, max_iters=20, max_consec_failures=6), 0),
+    (np.float64, 128, 520, 4, dict(min_rerr_dec=0.0, min_step_norm2=0.0, max_iters=16, max_consec_failures=5), 0),   # two half-tile passes
+    (np.float32, 160, 700, 20, {}, 0),                                        # n > 128: own Gram + own Cholesky, two lanes
+    (np.float32, 256, 900, 6, dict(max_consec_failures=8, max_iters=25), 0),  # the operand-sharing Gram, one lane
+    (np.float32, 132, 600, 5, dict(max_consec_failures=0, max_iters=18), 0),
+    (np.float32, 96, 500, 9, {}, 1),                                          # the pipeline forced below 128 (toa_tuning::large_pipeline)
+    (np.float64, 160, 500, 4, dict(min_rerr_dec=0.0, min_step_norm2=0.0, max_iters=16, max_consec_failures=5), 0),   # library Gram (fp64)
+    (np.float32, 130, 450, 5, {}, 0),                                         # rows not 16-byte aligned: general rows kernel + library GEMM / GEMV
+]
+
+
+@pytest.mark.parametrize("dtype,n,m,P,over,pipeline", LARGE_CASES)
+def test_results_do_not_depend_on_the_memo_beyond_one_wavefront(ta, oracle, dtype, n, m, P, over, pipeline):
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, dtype, seed=177 + n)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    opts = _opts(ta, **over)
+    ctx = ta.api.default_context()
+    with ctx.tuning(large_pipeline=pipeline):
+        x_off, o_off = _solve_t(ta, model, x0, opts, dict(memo_off=1, large_pipeline=pipeline))
+        x_on, o_on = _solve_t(ta, model, x0, opts, dict(memo_off=0, large_pipeline=pipeline))
+    _assert_identical(x_off, o_off, x_on, o_on)
+    c_off = o_off.counters.cpu().numpy()
+    c_on = o_on.counters.cpu().numpy()
+    assert c_off[4] == 0, "toa_tuning::memo_off must stream every Build"
+    assert c_on[0] + c_on[4] == c_off[0], "a Build is either streamed or served from the memo"
+    assert c_on[1] == c_off[1] and c_on[3] == c_off[3] == P
+    if dtype == np.float32:     # (in fp64 (x + dx) - dx rarely restores x bit for bit: nothing to read back, nothing to assert)
+        assert c_on[4] > 0, "no Build was served from the memo: the case does not exercise it"
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    check_trajectories(gpu_dict(o_on, torch.from_numpy(x_on)), dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"],
+                                                  x=ref["x"], cost=ref["cost"], fails=ref["fails"], deltas2=ref["deltas2"]),
+                       dtype, opts.to_pod())
+
+
+def _solve_t(ta, model, x0, opts, tune):
+    with ta.api.default_context().tuning(**tune):
+        x = torch.from_numpy(x0).cuda()
+        out = ta.Optimize(x, model, opts, history=True)
+        torch.cuda.synchronize()
+    return x.cpu().numpy(), out

@@ -41,6 +41,8 @@ struct LfArgs {
   unsigned long long* counters;  // [4] or null
   int loss;                      // TOA_LOSS_* of the handle (toa_set_loss): the ROBUST instantiation applies it to every residual
   double loss_th2;
+  int memo;                      // != 0: the linearisation of the last accepted point is kept (second H slot) and read back after a
+                                 // bit-exact roll-back; a failed solve re-entering Build re-uses the one at hand (toa_tuning::memo_off)
 };
 
 template <typename T>
@@ -335,7 +337,18 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
   const bool is_lm = opt.solver_type == 0;
   char* my_scratch = a.scratch + size_t(blockIdx.x) * a.scratch_per_wg;
   Acc* part = reinterpret_cast<Acc*>(my_scratch);                                        // [4][NT][64]
-  T* Hs = reinterpret_cast<T*>(my_scratch + size_t(4) * NT * 64 * sizeof(Acc));          // [n][n] undamped, full
+  // Two slots for the undamped H [n][n] — the one the current linearisation lives in (sh_cur) and, while the memo is valid, the
+  // one that holds the linearisation of the last ACCEPTED point (sh_memo_idx): an accumulate pass never writes over the parked
+  // slot, a memo hit just makes it the current one again (no n x n copy either way) — and four vectors behind them.
+  T* const Hs_base = reinterpret_cast<T*>(my_scratch + size_t(4) * NT * 64 * sizeof(Acc));
+  T* const hdu = Hs_base + size_t(2) * n * n;   // undamped diagonal of the current linearisation (hd is damped in place, lm.h:108-117)
+  T* const g_m = hdu + NV;                       // memo: J^T r, undamped diagonal, the x it was taken at
+  T* const hdu_m = g_m + NV;
+  T* const xs_m = hdu_m + NV;
+  __shared__ int sh_cur, sh_memo_idx, sh_park, sh_check;
+  __shared__ double lin_cost, memo_cost;         // normalised cost / inliers of the current and of the parked linearisation
+  __shared__ int lin_ninl, memo_ninl;
+  unsigned long long n_reused = 0;               // Builds served without streaming the rows (thread 0)
   // this wave's rows
   const int rows_per_wave = (((m + 3) / 4 + 3) / 4) * 4;
   const int row0 = wave * rows_per_wave;
@@ -362,6 +375,8 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
       S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);
       S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
       S.acc_passes = S.eval_passes = S.solves = S.problems = 0;
+      S.acc_at_x = 0; S.memo_valid = 0; S.memo_hit = 0;
+      sh_cur = 0; sh_memo_idx = 0; sh_park = 0; sh_check = 0;
     }
     for (int i = tid; i < NV; i += 256) {
       xs[i] = i < n ? a.x[p * n + i] : T(0);
@@ -371,9 +386,25 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
 
     for (;;) {  // one Build + Solve attempt per trip (a failed solve re-damps and retries, optimizer.h:358)
       const bool do_acc = !is_lm || S.rebuild;
+      // The callback is a pure function of x (lm_device.hpp, lm_build_and_solve): when the linearisation at THIS x, bit for bit, is
+      // still at hand (a failed solve re-entering Build, optimizer.h:358-393: skip = 1) or parked (the re-accumulation after a
+      // roll-back that restored the accepted point exactly, optimizer.h:283-287 + :266: skip = 2) the rows are not streamed again.
+      const int skip = (do_acc && a.memo) ? (S.acc_at_x ? 1 : (S.memo_hit ? 2 : 0)) : 0;
+      if (tid == 0) {
+        if (skip == 2) sh_cur = sh_memo_idx;
+        else if (do_acc && !skip && S.memo_valid && sh_cur == sh_memo_idx) sh_cur ^= 1;   // never accumulate over the parked slot
+      }
+      __syncthreads();
+      T* const Hs = Hs_base + size_t(sh_cur) * n * n;
       LF_TICK_START
       // ---------------- data pass: this wave's rows ----------------
-      {
+      if (skip) {
+        for (int i = tid; i < n; i += 256) {
+          if (skip == 2) { g[i] = g_m[i]; hdu[i] = hdu_m[i]; }
+          hd[i] = skip == 2 ? hdu_m[i] : hdu[i];
+        }
+        if (tid == 0 && skip == 2) { lin_cost = memo_cost; lin_ninl = memo_ninl; }
+      } else {
         Gram gram;
         if constexpr (TS) {
           if (do_acc) {
@@ -427,16 +458,16 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
       ck_pass += clock64() - ck0;
 #endif
       // ---------------- fold (fixed order) + Build (lm.h:59-120) ----------------
-      const double cost_val = normalize_cost(double(T((costw[0] + costw[1]) + (costw[2] + costw[3]))), m, opt);
+      const double cost_val = skip ? lin_cost : normalize_cost(double(T((costw[0] + costw[1]) + (costw[2] + costw[3]))), m, opt);
       bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
       const int LD = n | 1;
       if constexpr (TS) {
         // no fold: ts_data_pass has left the finished H in the L2-resident copy AND in the image, the undamped diagonal in hd, the
         // raw J^T r in g.  (A pass whose cost turns out invalid has overwritten them too — like the reference, whose Build
         // accumulates into H_ before it looks at the cost, lm.h:59-80.)
-        if (built && do_acc && opt.grad_clipping != 0)
+        if (built && do_acc && !skip && opt.grad_clipping != 0)
           for (int i = tid; i < n; i += 256) { const T mm = opt.grad_clipping; g[i] = fmin(fmax(g[i], -mm), mm); }  // base.h:29-38
-      } else if (built && do_acc) {
+      } else if (built && do_acc && !skip) {
         // H = sum of the four partial Grams, to the L2-resident copy Hs (kept undamped for eval-only iterations and the
         // final export) AND straight into the LDS image the factorisation works on
 #pragma unroll 3
@@ -468,6 +499,9 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
         }
       }
       __syncthreads();
+      if (do_acc && !skip && a.memo) {   // the undamped diagonal outlives the damping below (hd is damped in place)
+        for (int i = tid; i < n; i += 256) hdu[i] = hd[i];
+      }
       if (built && do_acc && opt.check_min_H_diag > 0) {  // lm.h:82-86 (workgroup-uniform condition)
         double low = 0;
         for (int i = tid; i < n; i += 256) low += fabs(hd[i]) < T(opt.check_min_H_diag) ? 1.0 : 0.0;
@@ -479,10 +513,11 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
         for (int i = tid; i < n; i += 256) hd[i] = T(double(hd[i]) * s);
       }
       if (tid == 0) {
-        if (do_acc) n_acc++; else n_eval++;
+        if (skip) n_reused++; else if (do_acc) n_acc++; else n_eval++;
         S.cost_val = cost_val;
         S.cost_nres = m;
-        S.cost_ninl = ROBUST ? (ninlw[0] + ninlw[1]) + (ninlw[2] + ninlw[3]) : m;
+        S.cost_ninl = skip ? lin_ninl : (ROBUST ? (ninlw[0] + ninlw[1]) + (ninlw[2] + ninlw[3]) : m);
+        if (do_acc) { lin_cost = cost_val; lin_ninl = S.cost_ninl; S.acc_at_x = 1; S.memo_hit = 0; }
       }
       for (int i = tid; i < NV; i += 256) rhs[i] = i < n ? g[i] : T(0);
       __syncthreads();
@@ -490,9 +525,9 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
       // ---------------- Solve (gn.h:150-171): blocked LDL^T of H with the damped diagonal (ldlt_wg.hpp) ----------------
       bool ldlt_ok = false;
       if (built) {
-        if (do_acc) {  // the fold has filled the image; only the damped diagonal is missing
+        if (do_acc && !skip) {  // the fold has filled the image; only the damped diagonal is missing
           for (int i = tid; i < n; i += 256) Aimg[i * LD + i] = hd[i];
-        } else {       // H of the last build (the previous factorisation overwrote the image)
+        } else {       // H of the last build / of the linearisation read back (the previous factorisation overwrote the image)
           for (int e = tid; e < n * n; e += 256) {
             const int i = e / n, j = e - i * n;
             Aimg[i * LD + j] = (i == j) ? hd[i] : Hs[e];
@@ -544,19 +579,29 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
         }
         int action = 0;  // 1: x += dx, last_dx = dx ; 2: x -= last_dx
         int cont = 1;
+        int park = 0, check = 0;
         if (rc >= 0) {
           int status = 0;
           if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399
           if (rc == 0) status = lm_judge_core<T>(S, opt, res, p, dx_norm2, grad_norm2, true);
           bool eval_only = false;  // optimizer.h:269-309
+          S.memo_hit = 0;           // (only the roll-back below may arm it, for the Build that follows directly)
           if (status & 1) {
+            // x is about to leave an ACCEPTED point: if the step that follows is rejected the loop comes back here and accumulates
+            // again — park this point's linearisation (lm_device.hpp, lm_iteration).  An eval-only iteration that succeeds leaves
+            // from a point whose linearisation was never formed: nothing to park.
+            if (a.memo) {
+              if (S.acc_at_x) { park = 1; S.memo_valid = 1; sh_memo_idx = sh_cur; memo_cost = lin_cost; memo_ninl = lin_ninl; }
+              else S.memo_valid = 0;
+            }
             action = 1;
+            S.acc_at_x = 0;
             S.has_last_dx = 1;
             S.last_was_success = 1;
             if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
           } else {
-            if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
-            else if (status & 2) { action = 1; S.has_last_dx = 1; }
+            if (S.has_last_dx) { action = 2; S.has_last_dx = 0; S.acc_at_x = 0; check = (a.memo && S.memo_valid) ? 1 : 0; }
+            else if (status & 2) { action = 1; S.has_last_dx = 1; S.acc_at_x = 0; }
             eval_only = (S.last_was_success == 0);
             S.last_was_success = 0;
           }
@@ -567,12 +612,24 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
         }
         sh_action = action;
         sh_cont = cont;
+        sh_park = park;
+        sh_check = check;
       }
       __syncthreads();
       const int action = sh_action;
+      if (sh_park) for (int i = tid; i < n; i += 256) { g_m[i] = g[i]; hdu_m[i] = hdu[i]; xs_m[i] = xs[i]; }   // (x BEFORE the step)
       if (action == 1) for (int i = tid; i < n; i += 256) { const T d = dx[i]; xs[i] += d; ldx[i] = d; }  // traits.h:184-190
       if (action == 2) for (int i = tid; i < n; i += 256) xs[i] -= ldx[i];
       __syncthreads();
+      if (sh_check) {
+        // (x + dx) - dx is x again only when both roundings cancel: compare the BIT PATTERNS with the parked point's and let the
+        // next Build read the memo back only on a match in every component — never an approximation
+        double diff = 0;
+        for (int i = tid; i < n; i += 256) diff += bits_equal(xs[i], xs_m[i]) ? 0.0 : 1.0;
+        diff = wg_sum<T>(diff, red);
+        if (tid == 0) S.memo_hit = diff == 0 ? 1 : 0;
+        __syncthreads();
+      }
       LF_TICK(5)
       if (!sh_cont) break;
     }
@@ -580,6 +637,7 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
     for (int i = tid; i < n; i += 256) a.x[p * n + i] = xs[i];
     if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
       double* Hout = res.final_hessian + size_t(p) * n * n;
+      const T* const Hs = Hs_base + size_t(sh_cur) * n * n;   // H of the last build
       for (size_t e = tid; e < size_t(n) * n; e += 256) {
         const int i = int(e / n), j = int(e % n);
         T v = Hs[e];
@@ -612,6 +670,7 @@ __device__ __forceinline__ void large_fused_body(const LfArgs<T>& a) {
       atomicAdd(&a.counters[1], n_eval);
       atomicAdd(&a.counters[2], n_solves);
       atomicAdd(&a.counters[3], n_problems);
+      if (n_reused) atomicAdd(&a.counters[4], n_reused);
     }
     const int gone = atomicAdd(&a.queue[16], 1);  // the last workgroup to leave resets the queue for the next launch
     if (gone == int(gridDim.x) - 1) {
@@ -760,7 +819,8 @@ int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T
   long long grid = (long long)h->num_cus * wg_per_cu;
   if (grid > P) grid = P;
   if (grid < 1) return TOA_OK;
-  const size_t per_wg = ((size_t(4) * NT * 64 * sizeof(Acc) + size_t(n) * n * sizeof(T)) + 255) & ~size_t(255);
+  // 4 partial Grams + two H slots (the current linearisation and the parked one) + four vectors (undamped diagonal; memo: g, diagonal, x)
+  const size_t per_wg = ((size_t(4) * NT * 64 * sizeof(Acc) + (size_t(2) * n * n + size_t(4) * 16 * NB) * sizeof(T)) + 255) & ~size_t(255);
   const size_t need = per_wg * size_t(grid);
   if (need > h->scratch_bytes) {
     if (int rc = grow_sync(h, "device workspace")) return rc;
@@ -782,6 +842,7 @@ int launch_large_fused_r(toa_handle h, int n, int m, int64_t P, const T* data, T
   a.counters = reinterpret_cast<unsigned long long*>(counters);
   a.loss = h->loss;
   a.loss_th2 = h->loss_th2;
+  a.memo = h->tune.memo_off ? 0 : 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, h->stream, a);
   if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess) {
     h->queue_dirty = true;

@@ -334,7 +334,21 @@ struct LargeArgs {
   int* stepped;                   // [P], NULL outside the stepping form
   int32_t* active_out;            // optional: += 1 per problem still running after its iteration
   const int32_t* stop_request;    // toa_lm_stop: [P] StopReason to impose (0 = none)
+  // Memo of linearisations (round 5; lm_device.hpp lm_build_and_solve / lm_iteration, here per problem): H has TWO slots per
+  // problem — the current linearisation (cur [p]) and, while S.memo_valid, the one of the last ACCEPTED point (midx [p]); a
+  // fresh accumulation never lands on the parked slot and a memo hit makes it the current one again, so nothing n x n is ever
+  // copied for the memo.  skip [p], set by the post kernel for the NEXT pass: 0 = stream the rows, 1 = the linearisation at
+  // hand is the one of x (a failed solve re-entering Build), 2 = the parked one is (the roll-back restored x bit for bit).
+  // The rows / Gram kernels leave a skipped problem alone.  NULL skip = off (stepping form, toa_tuning::memo_off).
+  int *skip, *cur, *midx;
+  int hslots;                      // H slots per problem (2 with the memo, 1 without)
+  T *hdu, *g_m, *hdu_m, *xs_m;     // [P][n]: undamped diagonal of the current linearisation; memo: J^T r, diagonal, x
+  double *lin_cost, *memo_cost;    // [P]: normalised cost of the current / parked linearisation
   __device__ __forceinline__ bool on(const long long p) const { return active[p] != 0 && !(stepped && stepped[p] != 0); }
+  __device__ __forceinline__ bool streams(const long long p) const { return on(p) && !(skip && skip[p] != 0); }   // takes part in the data pass
+  __device__ __forceinline__ T* Hcur(const long long p) const {
+    return H + (hslots > 1 ? size_t(p) * 2 + size_t(cur[p]) : size_t(p)) * size_t(n) * size_t(n);
+  }
 };
 
 template <typename T>
@@ -363,8 +377,11 @@ __global__ void __launch_bounds__(256) large_init_kernel(const LargeArgs<T> a) {
   S.max_iters = opt.max_iters + 1 + (opt.check_final_cost ? 1 : 0);  // optimizer.h:248-250
   S.has_last_dx = 0; S.last_was_success = 1; S.iter = 0;
   S.acc_passes = S.eval_passes = S.solves = S.problems = 0;
+  S.reused_passes = 0;
+  S.acc_at_x = 0; S.memo_valid = 0; S.memo_hit = 0;
   a.active[p] = 1;
   a.built[p] = 0;
+  if (a.skip) { a.skip[p] = 0; a.cur[p] = 0; a.midx[p] = 0; }
 }
 
 // r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1 + 0.1 cos(a_i.x)) a_i   (SURVEY §8d DenseRow family).
@@ -374,7 +391,7 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
   extern __shared__ char lds_raw[];
   T* xs = reinterpret_cast<T*>(lds_raw);
   const long long p = blockIdx.y;
-  if (!a.on(p)) return;
+  if (!a.streams(p)) return;
   const LmState<T>& S = a.st[p];
   const bool want_j = a.opt.solver_type != 0 || S.rebuild;
   const int n = a.n, m = a.m;
@@ -425,7 +442,7 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
   extern __shared__ char lds_raw[];
   T* xs = reinterpret_cast<T*>(lds_raw);
   const long long p = blockIdx.y;
-  if (!a.on(p)) return;
+  if (!a.streams(p)) return;
   const LmState<T>& S = a.st[p];
   const bool want_j = a.opt.solver_type != 0 || S.rebuild;
   const int n = a.n, m = a.m, nv = n / VEC;
@@ -622,7 +639,7 @@ __global__ void __launch_bounds__(TRI ? 768 : 1024) large_gram_kernel(const Larg
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char syrk_lds[];
   const long long p = blockIdx.y;
-  if (!a.on(p)) return;
+  if (!a.streams(p)) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
   const int n = a.n, m = a.m, ns = geo.ns, K = geo.K;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -735,7 +752,7 @@ __global__ void __launch_bounds__(TRI ? 768 : 1024) large_gram_kernel(const Larg
 template <typename T>
 __global__ void __launch_bounds__(256) large_gram_reduce_kernel(const LargeArgs<T> a, const SyrkGeom geo) {
   const long long p = blockIdx.y;
-  if (!a.on(p)) return;
+  if (!a.streams(p)) return;
   if (!(a.opt.solver_type != 0 || a.st[p].rebuild)) return;
   const int n = a.n;
   const int t = blockIdx.x;
@@ -772,7 +789,7 @@ __global__ void __launch_bounds__(256) large_compact_kernel(const LargeArgs<T> a
   __shared__ int cnt[256];
   const int tid = threadIdx.x;
   const long long per = (a.P + 255) / 256, lo = tid * per, hi = lo + per < a.P ? lo + per : a.P;
-  auto want = [&](long long p) { return a.on(p) && (a.opt.solver_type != 0 || a.st[p].rebuild); };
+  auto want = [&](long long p) { return a.streams(p) && (a.opt.solver_type != 0 || a.st[p].rebuild); };
   int c = 0;
   for (long long p = lo; p < hi; ++p) c += want(p) ? 1 : 0;
   cnt[tid] = c;
@@ -801,8 +818,9 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   const int n = a.n, m = a.m, tid = threadIdx.x;
   const bool is_lm = opt.solver_type == 0;
   const bool do_acc = !is_lm || S.rebuild;
+  const int skip = a.skip ? a.skip[p] : 0;   // != 0: the rows were not streamed this pass, the linearisation is read back (memo)
   double c = 0;
-  {
+  if (!skip) {
     int i = tid;
     for (; i + 7 * 256 < m; i += 8 * 256) {   // (eight loads in flight per trip, the same order of additions)
       T v[8];
@@ -814,13 +832,21 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
     for (; i < m; i += 256) { const T r = a.r[p * m + i]; c += double(r * r); }
   }
   c = block_sum<T>(c, red);
-  const double cost_val = normalize_cost(double(T(c)), m, opt);
+  const double cost_val = skip ? (skip == 2 ? a.memo_cost[p] : a.lin_cost[p]) : normalize_cost(double(T(c)), m, opt);
   bool built = m > 0 && cost_val != kDblMax;  // cost.h:83 isValid
   bool assigned = false;                      // H, g took the fresh accumulation (also when the diagonal check then fails the Build)
   T* g = a.g + p * n;
   T* hd = a.hd + p * n;
-  T* H = a.H + size_t(p) * n * n;
-  if (built && do_acc) {  // H, g assigned from the fresh accumulation (gn.h:77-81,109-113)
+  if (built && do_acc && skip) {   // the linearisation of THIS x, bit for bit, is at hand (1) or parked (2: cur [p] already names its H slot)
+    double low = 0;
+    for (int i = tid; i < n; i += 256) {
+      if (skip == 2) { g[i] = a.g_m[p * n + i]; a.hdu[p * n + i] = a.hdu_m[p * n + i]; }
+      const T d = a.hdu[p * n + i];
+      hd[i] = d;
+      if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
+    }
+    if (block_sum<T>(low, red) > 0) built = false;
+  } else if (built && do_acc) {  // H, g assigned from the fresh accumulation (gn.h:77-81,109-113)
     const T* Hn = a.Hnew + size_t(p) * n * n;   // (H = Hnew itself: large_stage_kernel, all CUs instead of this one workgroup)
     double low = 0;
     for (int i = tid; i < n; i += 256) {
@@ -844,6 +870,7 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
       g[i] = gi;
       const T d = Hn[size_t(i) * n + i];
       hd[i] = d;
+      if (a.skip) a.hdu[p * n + i] = d;   // the undamped diagonal outlives the damping below
       if (opt.check_min_H_diag > 0 && fabs(d) < T(opt.check_min_H_diag)) low = 1;  // lm.h:82-86
     }
     assigned = true;
@@ -858,10 +885,11 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   if (built)
     for (int i = tid; i < n; i += 256) a.rhs[p * n + i] = g[i];
   if (tid == 0) {
-    if (do_acc) S.acc_passes++; else S.eval_passes++;
+    if (skip) S.reused_passes++; else if (do_acc) S.acc_passes++; else S.eval_passes++;
     S.cost_val = cost_val;
     S.cost_nres = m;
     S.cost_ninl = m;
+    if (a.skip && do_acc) { a.lin_cost[p] = cost_val; S.acc_at_x = 1; S.memo_hit = 0; }
     a.built[p] = (built ? 1 : 0) | (assigned ? 2 : 0);   // bit 0: Build succeeded; bit 1: H = Hnew is due (large_stage_kernel)
   }
 }
@@ -874,7 +902,7 @@ __global__ void __launch_bounds__(256) large_stage_kernel(const LargeArgs<T> a, 
   if (!a.on(p) || !a.built[p]) return;
   const int n = a.n, tid = threadIdx.x;
   const bool do_acc = (a.built[p] & 2) != 0, built = (a.built[p] & 1) != 0;
-  T* H = a.H + size_t(p) * n * n;
+  T* H = a.Hcur(p);
   const T* src = do_acc ? a.Hnew + size_t(p) * n * n : H;
   T* W = a.work + size_t(p) * n * n;
   const T* hd = a.hd + p * n;
@@ -1267,7 +1295,7 @@ __device__ void large_finish_problem(const LargeArgs<T>& a, const long long p) {
   const int n = a.n, tid = threadIdx.x;
   if (opt.save_last && res.final_hessian) {  // undamped (lm.h:157-171)
     double* Hout = res.final_hessian + size_t(p) * n * n;
-    const T* H = a.H + size_t(p) * n * n;
+    const T* H = a.Hcur(p);
     const T* hd = a.hd + p * n;
     for (size_t e = tid; e < size_t(n) * n; e += 256) {
       const int i = int(e / n), j = int(e % n);
@@ -1292,6 +1320,7 @@ __device__ void large_finish_problem(const LargeArgs<T>& a, const long long p) {
       atomicAdd(&a.counters[1], S.eval_passes);
       atomicAdd(&a.counters[2], S.solves);
       atomicAdd(&a.counters[3], 1ull);
+      if (S.reused_passes) atomicAdd(&a.counters[4], S.reused_passes);
     }
   }
 }
@@ -1300,10 +1329,11 @@ __device__ void large_finish_problem(const LargeArgs<T>& a, const long long p) {
 template <typename T>
 __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, int* __restrict__ summary) {
   __shared__ double red[256];
-  __shared__ int sh_action, sh_cont, sh_retry;
+  __shared__ int sh_action, sh_cont, sh_retry, sh_park, sh_check;
   const long long p = blockIdx.x;
   if (!a.on(p)) return;
   LmState<T>& S = a.st[p];
+  const bool memo = a.skip != nullptr;
   const toa_options& opt = a.opt;
   const toa_results& res = a.res;
   const int n = a.n, tid = threadIdx.x;
@@ -1349,19 +1379,28 @@ __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, i
     }
     int action = 0;  // 1: x += dx, last_dx = dx ; 2: x -= last_dx
     int cont = 1;
+    int park = 0, check = 0;
     if (rc >= 0) {
       int status = 0;
       if (rc == 1) S.stop = TOA_STOP_SOLVER_FAILED;  // :396-399
       if (rc == 0) status = lm_judge_core<T>(S, opt, res, p, dx_norm2, grad_norm2, true);
       bool eval_only = false;  // optimizer.h:269-309
+      S.memo_hit = 0;           // (only the roll-back below may arm it, for the Build that follows directly)
       if (status & 1) {
+        // x is about to leave an ACCEPTED point: park its linearisation (the slot it lives in simply becomes the memo's) — unless
+        // it was never formed (an eval-only iteration that succeeded): lm_device.hpp, lm_iteration
+        if (memo) {
+          if (S.acc_at_x) { park = 1; S.memo_valid = 1; a.midx[p] = a.cur[p]; a.memo_cost[p] = a.lin_cost[p]; }
+          else S.memo_valid = 0;
+        }
         action = 1;
+        S.acc_at_x = 0;
         S.has_last_dx = 1;
         S.last_was_success = 1;
         if (opt.check_final_cost && S.iter + 1 == S.max_iters) eval_only = true;
       } else {
-        if (S.has_last_dx) { action = 2; S.has_last_dx = 0; }
-        else if (status & 2) { action = 1; S.has_last_dx = 1; }
+        if (S.has_last_dx) { action = 2; S.has_last_dx = 0; S.acc_at_x = 0; check = (memo && S.memo_valid) ? 1 : 0; }
+        else if (status & 2) { action = 1; S.has_last_dx = 1; S.acc_at_x = 0; }
         eval_only = (S.last_was_success == 0);
         S.last_was_success = 0;
       }
@@ -1373,16 +1412,37 @@ __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, i
     sh_action = action;
     sh_cont = cont;
     sh_retry = rc < 0 ? 1 : 0;
+    sh_park = park;
+    sh_check = check;
   }
   __syncthreads();
   const int action = sh_action;
+  if (sh_park) for (int i = tid; i < n; i += 256) { a.g_m[p * n + i] = g[i]; a.hdu_m[p * n + i] = a.hdu[p * n + i]; a.xs_m[p * n + i] = x[i]; }   // (x BEFORE the step)
   if (action == 1) for (int i = tid; i < n; i += 256) { const T d = dx[i]; x[i] += d; ldx[i] = d; }  // traits.h:184-190
   if (action == 2) for (int i = tid; i < n; i += 256) x[i] -= ldx[i];
+  if (sh_check) {
+    // (x + dx) - dx is x again only when both roundings cancel: the BIT PATTERNS are compared with the parked point's, and only a
+    // match in every component lets the next Build read the memo back — never an approximation
+    __syncthreads();
+    double diff = 0;
+    for (int i = tid; i < n; i += 256) diff += bits_equal(x[i], a.xs_m[p * n + i]) ? 0.0 : 1.0;
+    diff = block_sum<T>(diff, red);
+    if (tid == 0) S.memo_hit = diff == 0 ? 1 : 0;
+  }
   const bool retry = sh_retry != 0;
   if (sh_cont) {
     if (tid == 0) {
+      // what the NEXT pass does with this problem (the rows / Gram kernels read skip [p], the stage / pre kernels cur [p])
+      const bool acc_next = opt.solver_type != 0 || S.rebuild;
+      int skip_next = 0;
+      if (memo) {
+        if (acc_next) skip_next = S.acc_at_x ? 1 : (S.memo_hit ? 2 : 0);
+        a.skip[p] = skip_next;
+        if (skip_next == 2) a.cur[p] = a.midx[p];
+        else if (acc_next && !skip_next && S.memo_valid && a.cur[p] == a.midx[p]) a.cur[p] ^= 1;   // never accumulate over the parked slot
+      }
       atomicAdd(&summary[0], 1);
-      if (opt.solver_type != 0 || S.rebuild) atomicAdd(&summary[1], 1);
+      if (acc_next && !skip_next) atomicAdd(&summary[1], 1);
       if (a.stepped) {   // stepping form: the iteration is over unless the solve is being retried
         if (retry) atomicAdd(&summary[2], 1);
         else {
@@ -1519,7 +1579,11 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const bool lu = !opt.use_ldlt;
   const size_t b_piv = lu ? al(size_t(P) * n * sizeof(int)) : 0;
   // what outlives a pass (LargeStateLayout) sits in the caller's state block in the stepping form, in the scratch otherwise
-  const size_t need = (stepping ? 0 : lay.total) + 2 * b_i + 2 * b_vec + 2 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv;
+  // memo of linearisations (LargeArgs::skip ...): the whole-solve form only — the stepping form's state block has one H slot
+  const bool memo_on = !stepping && !h->tune.memo_off;
+  const size_t b_dbl = al(size_t(P) * sizeof(double));
+  const size_t b_memo = memo_on ? 3 * b_i + 4 * b_vec + 2 * b_dbl + 2 * b_mat : 0;
+  const size_t need = (stepping ? 0 : lay.total) + 2 * b_i + 2 * b_vec + 2 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv + b_memo;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
@@ -1546,6 +1610,18 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   a.jptr = reinterpret_cast<const T**>(take(b_ptr));
   a.hptr = reinterpret_cast<T**>(take(b_ptr));
   int* ipiv = reinterpret_cast<int*>(take(b_piv));
+  a.skip = a.cur = a.midx = nullptr;
+  a.hslots = 1;
+  a.hdu = a.g_m = a.hdu_m = a.xs_m = nullptr;
+  a.lin_cost = a.memo_cost = nullptr;
+  if (memo_on) {
+    a.skip = reinterpret_cast<int*>(take(b_i)); a.cur = reinterpret_cast<int*>(take(b_i)); a.midx = reinterpret_cast<int*>(take(b_i));
+    a.hdu = reinterpret_cast<T*>(take(b_vec)); a.g_m = reinterpret_cast<T*>(take(b_vec));
+    a.hdu_m = reinterpret_cast<T*>(take(b_vec)); a.xs_m = reinterpret_cast<T*>(take(b_vec));
+    a.lin_cost = reinterpret_cast<double*>(take(b_dbl)); a.memo_cost = reinterpret_cast<double*>(take(b_dbl));
+    a.H = reinterpret_cast<T*>(take(2 * b_mat));   // two slots per problem (the state block's single one stays unused)
+    a.hslots = 2;
+  }
   hipStream_t st = h->stream;
   // 64 <= n <= 128: the workgroup LDL^T above; beyond (or with toa_tuning::large_library_solver) rocSOLVER
   const bool force_lib = h->tune.large_library_solver != 0;
@@ -1771,7 +1847,11 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     b.data += size_t(p0) * m * (size_t(n) + 1); b.x += p0 * n;
     b.st += p0; b.active += p0; b.built += p0; b.info += p0;
     b.g += p0 * n; b.hd += p0 * n; b.dx += p0 * n; b.ldx += p0 * n; b.gnew += p0 * n; b.rhs += p0 * n;
-    b.H += size_t(p0) * nn; b.Hnew += size_t(p0) * nn; b.work += size_t(p0) * nn;
+    b.H += size_t(p0) * nn * size_t(a.hslots > 1 ? 2 : 1); b.Hnew += size_t(p0) * nn; b.work += size_t(p0) * nn;
+    if (a.skip) {
+      b.skip += p0; b.cur += p0; b.midx += p0; b.lin_cost += p0; b.memo_cost += p0;
+      b.hdu += p0 * n; b.g_m += p0 * n; b.hdu_m += p0 * n; b.xs_m += p0 * n;
+    }
     b.r += size_t(p0) * m; b.sc += size_t(p0) * m;
     b.gram_part += size_t(p0) * gram_R * geo.T * 1024;
     b.gpart += size_t(p0) * size_t(std::max(gslots, 0)) * n;
