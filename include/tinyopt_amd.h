@@ -291,7 +291,8 @@ int toa_robust_norm(toa_handle h, int kind, int dtype, int64_t count, const void
 /* ---- the M-estimator of the handle's cost functor (replaces wrapping a residual in `losses::Huber(n2, th2, true)` & co.
  *      inside the user's cost functor, losses/robust_norms.h:20-26, docs/API.md:396-411): from now on every launch on
  *      this handle passes each residual ITEM's squared norm through rho (TOA_MODEL_DENSE_ROW, and
- *      TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 (fp64: 96) — refused beyond, never ignored: each row's r_i^2;
+ *      TOA_MODEL_DENSE_ROW_NATURAL for every n it takes — the one-kernel form at 64 <= n <= 128, the launch-per-stage
+ *      pipeline beyond it and for fp64 rows above n = 96, the stepping form at n >= 64 (round 5): each row's r_i^2;
  *      TOA_MODEL_CIRCLE_FIT / DENSE_ROW_AD6: each item's ||r||^2): cost += l, the item's J^T J and J^T r scaled by
  *      s = dl/dn2, inliers (n2 <= th2) reported through final_inlier_ratio (cost.h:84-95).  kind = TOA_LOSS_* (TOA_LOSS_L2
  *      = off, the default); th2 = squared threshold.  TOA_MODEL_SE3_REPROJ keeps its loss in its data header.  Both

@@ -174,7 +174,4 @@ def test_refusals(ta, oracle):
     model, x0, _ = _problem(ta, oracle, 2, 32, 128, np.float64, seed=1)
     with pytest.raises(Exception, match="stepping form starts at n = 64"):
         ta.Optimizer(torch.from_numpy(x0.copy()).cuda(), model, ta.Options())
-    model, x0, _ = _problem(ta, oracle, 2, 64, 128, np.float64, seed=1)
-    model = model.with_loss("huber", 1.0)
-    with pytest.raises(Exception, match="toa_set_loss is not available in the stepping form"):
-        ta.Optimizer(torch.from_numpy(x0.copy()).cuda(), model, ta.Options())
+    # (round 5: a loss IS available in the stepping form at n >= 64 — tests/test_gpu_large_n.py::test_stepping_form_with_a_loss_beyond_one_wavefront)

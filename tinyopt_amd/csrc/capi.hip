@@ -769,11 +769,10 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (P == 0) return TOA_OK;
   TOA_ON_DEVICE(h->device);
   if (natural) {
-    if (h->loss != TOA_LOSS_L2 && !(options->use_ldlt && toa_large_fused_eligible(h, dtype, n, m)))   // never silently: not wired into the launch-per-stage pipeline
-      return fail(TOA_E_UNSUPPORTED, "toa_lm_run: toa_set_loss is available for TOA_MODEL_DENSE_ROW_NATURAL at 64 <= n <= 128 only");
+    // (toa_set_loss: every form of this family applies it since round 5 — the one-kernel form at 64 <= n <= 128, the
+    //  launch-per-stage pipeline beyond, for fp64 rows above n = 96, and under the stepping form)
     if (mode != 0) {   // the stepping form runs on the launch-per-stage pipeline for every n >= 64 (large_n.hip)
       if (!state) return fail(TOA_E_ARG, "toa_lm_begin / toa_lm_step: state_dev is null");
-      if (h->loss != TOA_LOSS_L2) return fail(TOA_E_UNSUPPORTED, "toa_lm_step: toa_set_loss is not available in the stepping form at n >= 64");
       return toa_large_lm_step(h, dtype, n, m, P, data, x, options, results, counters, mode, state, active, stop_request);
     }
     return toa_large_lm_run(h, dtype, n, m, P, data, x, options, results, counters);

@@ -341,7 +341,16 @@ struct LargeArgs {
   // hand is the one of x (a failed solve re-entering Build), 2 = the parked one is (the roll-back restored x bit for bit).
   // The rows / Gram kernels leave a skipped problem alone.  NULL skip = off (stepping form, toa_tuning::memo_off).
   int *skip, *cur, *midx;
+  int *lin_ninl, *memo_ninl;       // [P]: inlier residuals of the current / parked linearisation (with a loss)
   int hslots;                      // H slots per problem (2 with the memo, 1 without)
+  // M-estimator of the handle (toa_set_loss; robust_norms.h:20-26, round 5): the rows kernels turn every residual r_i into
+  // sqrt(s_i) r_i and its Jacobian row scale into sqrt(s_i) (1 + 0.1 cos), s_i = dl / dn2 at n2 = r_i^2 — so that the Gram, J^T r
+  // and everything behind them are the weighted ones — and leave the loss l_i per row (the cost is their sum, in the order of the
+  // plain cost's sum) and the inlier count (n2 <= th2; integer atomics: order-free) behind.  loss == TOA_LOSS_L2: nothing of this.
+  int loss;
+  T th2;
+  T* lossv;      // [P][m]
+  int* ninl;     // [P], zeroed by the pre kernel once read
   T *hdu, *g_m, *hdu_m, *xs_m;     // [P][n]: undamped diagonal of the current linearisation; memo: J^T r, diagonal, x
   double *lin_cost, *memo_cost;    // [P]: normalised cost of the current / parked linearisation
   __device__ __forceinline__ bool on(const long long p) const { return active[p] != 0 && !(stepped && stepped[p] != 0); }
@@ -382,6 +391,7 @@ __global__ void __launch_bounds__(256) large_init_kernel(const LargeArgs<T> a) {
   a.active[p] = 1;
   a.built[p] = 0;
   if (a.skip) { a.skip[p] = 0; a.cur[p] = 0; a.midx[p] = 0; }
+  if (a.ninl) a.ninl[p] = 0;
 }
 
 // r_i = a_i.x + 0.1 sin(a_i.x) - b_i ; J_i = (1 + 0.1 cos(a_i.x)) a_i   (SURVEY §8d DenseRow family).
@@ -421,9 +431,22 @@ __global__ void __launch_bounds__(256) large_rows_kernel(const LargeArgs<T> a) {
       const T* row = A + size_t(i0 + k) * n;
       T sn, cs;
       sincos_t(t[k], &sn, &cs);
-      if (lane == 0) rp[i0 + k] = t[k] + T(0.1) * sn - bv[i0 + k];
+      T ri = t[k] + T(0.1) * sn - bv[i0 + k];
+      T sq = T(1);
+      if (a.loss != TOA_LOSS_L2) {   // (wave-uniform)
+        const T n2 = ri * ri;
+        T l, sw;
+        robust_norm(a.loss, n2, a.th2, l, sw);
+        sq = r_sqrt(sw);
+        ri *= sq;
+        if (lane == 0) {
+          a.lossv[p * m + i0 + k] = l;
+          if (n2 <= a.th2) atomicAdd(&a.ninl[p], 1);
+        }
+      }
+      if (lane == 0) rp[i0 + k] = ri;
       if (want_j) {
-        const T sc = T(1) + T(0.1) * cs;
+        const T sc = (T(1) + T(0.1) * cs) * sq;
         if (a.own_gram) { if (lane == 0) a.sc[p * m + i0 + k] = sc; }
         else for (int j = lane; j < n; j += 64) Jp[size_t(i0 + k) * n + j] = sc * row[j];
       }
@@ -479,10 +502,22 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
     for (int off = 1; off < LPR; off <<= 1) t += __shfl_xor(t, off);
     T sn, cs;
     sincos_t(t, &sn, &cs);
-    const T ri = live ? t + T(0.1) * sn - bv[live ? i : 0] : T(0);
+    T ri = live ? t + T(0.1) * sn - bv[live ? i : 0] : T(0);
+    T sq = T(1);
+    if (a.loss != TOA_LOSS_L2) {   // (wave-uniform)
+      const T n2 = ri * ri;
+      T l, sw;
+      robust_norm(a.loss, n2, a.th2, l, sw);
+      sq = r_sqrt(sw);
+      ri *= sq;
+      if (live && rl == 0) {
+        a.lossv[p * m + i] = l;
+        if (n2 <= a.th2) atomicAdd(&a.ninl[p], 1);
+      }
+    }
     if (live && rl == 0) rp[i] = ri;
     if (want_j) {
-      const T sc = T(1) + T(0.1) * cs;
+      const T sc = (T(1) + T(0.1) * cs) * sq;
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
         const int c = rl + k * LPR;
@@ -820,7 +855,8 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
   const bool do_acc = !is_lm || S.rebuild;
   const int skip = a.skip ? a.skip[p] : 0;   // != 0: the rows were not streamed this pass, the linearisation is read back (memo)
   double c = 0;
-  if (!skip) {
+  const bool robust = a.loss != TOA_LOSS_L2;
+  if (!skip && !robust) {
     int i = tid;
     for (; i + 7 * 256 < m; i += 8 * 256) {   // (eight loads in flight per trip, the same order of additions)
       T v[8];
@@ -830,6 +866,16 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
       for (int u = 0; u < 8; ++u) c += double(v[u] * v[u]);
     }
     for (; i < m; i += 256) { const T r = a.r[p * m + i]; c += double(r * r); }
+  } else if (!skip) {   // Cost += l per residual (cost.h:84-95): the rows kernel left the losses
+    int i = tid;
+    for (; i + 7 * 256 < m; i += 8 * 256) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.lossv[p * m + i + u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += double(v[u]);
+    }
+    for (; i < m; i += 256) c += double(a.lossv[p * m + i]);
   }
   c = block_sum<T>(c, red);
   const double cost_val = skip ? (skip == 2 ? a.memo_cost[p] : a.lin_cost[p]) : normalize_cost(double(T(c)), m, opt);
@@ -888,8 +934,13 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
     if (skip) S.reused_passes++; else if (do_acc) S.acc_passes++; else S.eval_passes++;
     S.cost_val = cost_val;
     S.cost_nres = m;
-    S.cost_ninl = m;
-    if (a.skip && do_acc) { a.lin_cost[p] = cost_val; S.acc_at_x = 1; S.memo_hit = 0; }
+    int ninl = m;
+    if (robust) {
+      if (skip) ninl = skip == 2 ? a.memo_ninl[p] : a.lin_ninl[p];
+      else { ninl = a.ninl[p]; a.ninl[p] = 0; }   // (the next pass's rows kernel counts from zero)
+    }
+    S.cost_ninl = ninl;
+    if (a.skip && do_acc) { a.lin_cost[p] = cost_val; a.lin_ninl[p] = ninl; S.acc_at_x = 1; S.memo_hit = 0; }
     a.built[p] = (built ? 1 : 0) | (assigned ? 2 : 0);   // bit 0: Build succeeded; bit 1: H = Hnew is due (large_stage_kernel)
   }
 }
@@ -1313,7 +1364,7 @@ __device__ void large_finish_problem(const LargeArgs<T>& a, const long long p) {
     if (res.num_consec_failures) res.num_consec_failures[p] = int(S.num_consec);
     if (res.final_num_residuals) res.final_num_residuals[p] = S.final_nres;
     if (res.final_rerr_dec) res.final_rerr_dec[p] = S.final_rerr;
-    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = 1.0f;
+    if (res.final_inlier_ratio) res.final_inlier_ratio[p] = S.final_nres > 0 ? float(S.final_ninl) / float(S.final_nres) : 1.0f;
     a.active[p] = 0;
     if (a.counters) {
       atomicAdd(&a.counters[0], S.acc_passes);
@@ -1390,7 +1441,7 @@ __global__ void __launch_bounds__(256) large_post_kernel(const LargeArgs<T> a, i
         // x is about to leave an ACCEPTED point: park its linearisation (the slot it lives in simply becomes the memo's) — unless
         // it was never formed (an eval-only iteration that succeeded): lm_device.hpp, lm_iteration
         if (memo) {
-          if (S.acc_at_x) { park = 1; S.memo_valid = 1; a.midx[p] = a.cur[p]; a.memo_cost[p] = a.lin_cost[p]; }
+          if (S.acc_at_x) { park = 1; S.memo_valid = 1; a.midx[p] = a.cur[p]; a.memo_cost[p] = a.lin_cost[p]; a.memo_ninl[p] = a.lin_ninl[p]; }
           else S.memo_valid = 0;
         }
         action = 1;
@@ -1582,8 +1633,10 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   // memo of linearisations (LargeArgs::skip ...): the whole-solve form only — the stepping form's state block has one H slot
   const bool memo_on = !stepping && !h->tune.memo_off;
   const size_t b_dbl = al(size_t(P) * sizeof(double));
-  const size_t b_memo = memo_on ? 3 * b_i + 4 * b_vec + 2 * b_dbl + 2 * b_mat : 0;
-  const size_t need = (stepping ? 0 : lay.total) + 2 * b_i + 2 * b_vec + 2 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv + b_memo;
+  const size_t b_memo = memo_on ? 5 * b_i + 4 * b_vec + 2 * b_dbl + 2 * b_mat : 0;
+  const bool robust = h->loss != TOA_LOSS_L2;
+  const size_t b_loss = robust ? b_r + b_i : 0;
+  const size_t need = (stepping ? 0 : lay.total) + 2 * b_i + 2 * b_vec + 2 * b_mat + b_Juse + b_r + b_sum + b_gpart + 2 * b_ptr + b_sc + b_gp + b_piv + b_memo + b_loss;
   if (int rc = ensure_scratch(h, need, "large-n LM (the J scratch is P*m*n)")) return rc;
   char* q = static_cast<char*>(h->scratch);
   auto take = [&](size_t b) { char* r = q; q += b; return r; };
@@ -1614,7 +1667,11 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   a.hslots = 1;
   a.hdu = a.g_m = a.hdu_m = a.xs_m = nullptr;
   a.lin_cost = a.memo_cost = nullptr;
+  a.lin_ninl = a.memo_ninl = nullptr;
+  a.loss = h->loss; a.th2 = T(h->loss_th2); a.lossv = nullptr; a.ninl = nullptr;
+  if (robust) { a.lossv = reinterpret_cast<T*>(take(b_r)); a.ninl = reinterpret_cast<int*>(take(b_i)); }
   if (memo_on) {
+    a.lin_ninl = reinterpret_cast<int*>(take(b_i)); a.memo_ninl = reinterpret_cast<int*>(take(b_i));
     a.skip = reinterpret_cast<int*>(take(b_i)); a.cur = reinterpret_cast<int*>(take(b_i)); a.midx = reinterpret_cast<int*>(take(b_i));
     a.hdu = reinterpret_cast<T*>(take(b_vec)); a.g_m = reinterpret_cast<T*>(take(b_vec));
     a.hdu_m = reinterpret_cast<T*>(take(b_vec)); a.xs_m = reinterpret_cast<T*>(take(b_vec));
@@ -1663,6 +1720,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   }
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
   if (stepping) HIP_TRY(hipMemsetAsync(a.stepped, 0, b_i, st));
+  if (robust) HIP_TRY(hipMemsetAsync(a.ninl, 0, b_i, st));   // (the scratch block is shared between calls: the stepping form starts every step from zero)
   const T one = 1, zero = 0;
   // row slices of the n x n staging copies: ~8 workgroups per CU over the batch, at least 8 rows each
   const int stage_rows = int(std::max<long long>(8, (long long)n * P / std::max<long long>(1, (long long)h->num_cus * 8)));
@@ -1849,10 +1907,11 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     b.g += p0 * n; b.hd += p0 * n; b.dx += p0 * n; b.ldx += p0 * n; b.gnew += p0 * n; b.rhs += p0 * n;
     b.H += size_t(p0) * nn * size_t(a.hslots > 1 ? 2 : 1); b.Hnew += size_t(p0) * nn; b.work += size_t(p0) * nn;
     if (a.skip) {
-      b.skip += p0; b.cur += p0; b.midx += p0; b.lin_cost += p0; b.memo_cost += p0;
+      b.skip += p0; b.cur += p0; b.midx += p0; b.lin_cost += p0; b.memo_cost += p0; b.lin_ninl += p0; b.memo_ninl += p0;
       b.hdu += p0 * n; b.g_m += p0 * n; b.hdu_m += p0 * n; b.xs_m += p0 * n;
     }
     b.r += size_t(p0) * m; b.sc += size_t(p0) * m;
+    if (b.lossv) { b.lossv += size_t(p0) * m; b.ninl += p0; }
     b.gram_part += size_t(p0) * gram_R * geo.T * 1024;
     b.gpart += size_t(p0) * size_t(std::max(gslots, 0)) * n;
     toa_results& r = b.res;
@@ -2005,9 +2064,12 @@ int toa_large_lm_run(toa_handle h, int dtype, int n, int m, int64_t P, const voi
   // 64 x 3 000 x 96: 1.45 / 1.14, 128 x 4 096 x 128: 2.8 / 2.5 — so: enough rows per problem to outlast the floor, and a batch
   // small enough that the pipeline's own data passes stay under it.  The M-estimator lives in the one-kernel form only.
   // (fp32 with 16-byte rows: every stage of the pipeline is then a kernel of this library — no rocBLAS / rocSOLVER load, no per-pass read-back)
-  const bool few_huge = int64_t(m) * n >= 393216 && P * int64_t(m) * n <= (int64_t(1) << 25) && h->loss == TOA_LOSS_L2 && !h->tune.wide_no_autosplit &&
+  const bool few_huge = int64_t(m) * n >= 393216 && P * int64_t(m) * n <= (int64_t(1) << 25) && !h->tune.wide_no_autosplit &&
                         dtype == TOA_F32 && n % 4 == 0 && (int64_t(m) * (n + 1)) % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
-  if (options->use_ldlt && !few_huge && toa_large_fused_eligible(h, dtype, n, m)) return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
+  // (a loss on fp64 rows beyond n = 96: the one-kernel form's two half-tile passes have no M-estimator variant — the pipeline does)
+  const bool loss_needs_pipeline = h->loss != TOA_LOSS_L2 && dtype == TOA_F64 && n > 96;
+  if (options->use_ldlt && !few_huge && !loss_needs_pipeline && toa_large_fused_eligible(h, dtype, n, m))
+    return toa_large_fused_lm_run(h, dtype, n, m, P, data, x, options, results, counters);
   // The pipeline's kernels index problems through grid.y (65 535): a larger batch goes through it slice by slice — the
   // problems are independent, so the slices are just shorter batches (same bits), and the workspace is sized for one slice.
   constexpr int64_t kSlice = 65535;
