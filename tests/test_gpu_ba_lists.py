@@ -147,3 +147,31 @@ def test_lists_time_limit_and_malformed_input(ta, oracle):
     with pytest.raises(ta.ToaError):
         ta.Optimize(torch.zeros(1, 12 * 700 + 30, dtype=torch.float64, device="cuda"),
                     ta.BundleAdjustmentLists(model.intr, model.obs_cam, model.obs_pt, model.obs_uv, 700, 10))       # more than 682 cameras
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_use_ldlt_false_in_both_ba_forms(ta, oracle, dtype):
+    """gn.h:157-162 / options.h:59: `use_ldlt = false` = "dx = -H.inverse() * g without any checks".  Round 5: both bundle-
+    adjustment forms take it (the one-workgroup kernel: the pivoted factorisation of the reduced system with its verdict ignored;
+    the lists form: the library's general LU) — for the positive definite systems of a damped bundle adjustment the step is the
+    checked one to rounding, so the oracle's dense trajectory (its own unchecked inverse) must be followed."""
+    P, ncam, npts = 2, 8, 60
+    data, x0, xs = oracle.synth_ba(P, ncam, npts, dtype, seed=41)
+    opts = ta.Options.benchmark()
+    opts.hessian.use_ldlt = False
+    ref = oracle.ba_lm(data, x0, ncam, npts, opts.to_pod())
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    tol = dict(x_tol=1e-5, cost_rtol=1e-8) if dtype == np.float64 else dict(x_tol=5e-2, cost_rtol=5e-3, err_rtol=2e-3, floor_rtol=2e-3)
+    model = ta.BundleAdjustment(torch.from_numpy(data).cuda(), ncam, npts)
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    st = check_trajectories(gpu_dict(out, x), refd, dtype, opts.to_pod(), tol=tol, label="BA use_ldlt=false")
+    assert st["full"] + st["ties"] == P
+    lists = ta.BundleAdjustmentLists.from_dense(torch.from_numpy(data).cuda(), ncam, npts)
+    x2 = torch.from_numpy(x0.copy()).cuda()
+    out2 = ta.Optimize(x2, lists, opts, history=True)
+    torch.cuda.synchronize()
+    st2 = check_trajectories(gpu_dict(out2, x2), refd, dtype, opts.to_pod(), tol=tol, label="BA lists use_ldlt=false")
+    assert st2["full"] + st2["ties"] == P

@@ -446,7 +446,9 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
           const T l21 = (a12 - l20 * l10) / l11;
           const T l22s = a22 - l20 * l20 - l21 * l21;
           const T l22 = sqrt(l22s);
-          if (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0))) bad += T(1);   // not positive definite: the solve fails
+          // not positive definite: the solve fails — unless use_ldlt = false, "dx = -H.inverse() * g without any checks"
+          // (gn.h:157-162, options.h:59): no verdict there; a step that comes out non-finite is refused further down as everywhere
+          if (opt.use_ldlt && (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0)))) bad += T(1);
           r00 = T(1) / l00; r11 = T(1) / l11; r22 = T(1) / l22;
           r10 = -l10 * r00 * r11;
           r21 = -l21 * r11 * r22;
@@ -619,10 +621,18 @@ __global__ void __launch_bounds__(256, TOA_BA_WGS) ba_schur_kernel(const BaParam
       for (int e = tid; e < n * n; e += 256) part[e] = L.M[(e / n) * L.LD + (e % n)];
       __syncthreads();
       constexpr int NBS = NBM + (THIN > 1 ? 1 : 0);   // 16-column panels covering n = 16 NBM + max(THIN - 1, 0) (- 1 without a thin tail)
-      const bool wg_ok = WgLdlt<T, NBS>::factor(L.M, L.LD, n, L.tmp, tid);
+      // use_ldlt = false: the reduced system by the PIVOTED factorisation with its verdict ignored — the solution of every
+      // non-singular system, definite or not, to rounding (the n <= 63 paths do the same, lm_device.hpp)
+      const bool unchecked = !opt.use_ldlt;
+      const bool wg_ok = unchecked ? false : WgLdlt<T, NBS>::factor(L.M, L.LD, n, L.tmp, tid);
       if (wave == 0) {
         bool ok = wg_ok;
-        if (ok) {
+        if (unchecked) {
+          const T rhs = lane < n ? L.vec[lane] : T(0);
+          (void)ldlt_factor_wave<T>(L.M, L.LD, L.perm, L.tmp, n, lane);
+          L.dx[lane] = ldlt_solve_wave<T>(L.M, L.LD, L.perm, L.vec, n, lane, rhs);
+          ok = true;
+        } else if (ok) {
           L.dx[lane] = lane < n ? L.vec[lane] : T(0);
           wave_sync();
           WgLdlt<T, NBS>::solve(L.M, L.LD, n, L.tmp, L.dx, lane);
@@ -863,6 +873,7 @@ int toa_ba_launch_robust(toa_handle h, int dtype, BaParams& prm) {
 }  // namespace toa
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_large_solve_unchecked(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 namespace toa {
 struct BlParams {
   const void* intr;           // [P][4]: f cx cy 0
@@ -1241,7 +1252,7 @@ __global__ void __launch_bounds__(256) bl_psolve_kernel(const BlParams* __restri
     const T l21 = (a12 - l20 * l10) / l11;
     const T l22s = a22 - l20 * l20 - l21 * l21;
     const T l22 = sqrt(l22s);
-    if (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0))) atomicAdd(&fl[4], 1);   // not positive definite: the solve fails
+    if (prm->opt.use_ldlt && (!(l00s > T(0)) || !(l11s > T(0)) || !(l22s > T(0)))) atomicAdd(&fl[4], 1);   // not positive definite: the solve fails (use_ldlt = false: no verdict, gn.h:157-162)
     r00 = T(1) / l00; r11 = T(1) / l11; r22 = T(1) / l22;
     r10 = -l10 * r00 * r11;
     r21 = -l21 * r11 * r22;
@@ -1762,7 +1773,9 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
       MaskScope(toa_handle hh, const int32_t* m, int64_t s) : h(hh) { h->solve_mask = m; h->solve_mask_stride = s; }
       ~MaskScope() { h->solve_mask = nullptr; h->solve_mask_stride = 0; }
     } mask_scope(h, prm.iwork + ix.flags, int64_t(ix.total));
-    if (n <= 128) {   // the workgroup LDL^T: one workgroup per matrix, the same arithmetic whatever the batch
+    if (!prm.opt.use_ldlt) {   // gn.h:157-162: "-H.inverse() * g without any checks": the library's general LU, verdict ignored
+      if (int rc = toa_large_solve_unchecked(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok)) { rc_all = rc; break; }
+    } else if (n <= 128) {   // the workgroup LDL^T: one workgroup per matrix, the same arithmetic whatever the batch
       if (int rc = toa_large_solve(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok)) { rc_all = rc; break; }
     } else {
       // rocSOLVER: ONE matrix per call — its batched Cholesky picks its blocking by batch size, and a scene solved alone must
@@ -1810,7 +1823,6 @@ extern "C" int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_poin
   if (!results->stop_reason || !results->num_iters || !results->final_cost)
     return toa_fail(TOA_E_ARG, "toa_ba_run: stop_reason, num_iters and final_cost outputs are required");
   if (options->solver_type != 0 && options->solver_type != 1) return toa_fail(TOA_E_ARG, "toa_ba_run: solver_type must be 0 (LM) or 1 (GN)");
-  if (!options->use_ldlt) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_run: use_ldlt=false is not available");
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return toa_fail(TOA_E_ARG, "toa_ba_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");
@@ -1840,7 +1852,6 @@ extern "C" int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int nu
   if (!results->stop_reason || !results->num_iters || !results->final_cost)
     return toa_fail(TOA_E_ARG, "toa_ba_lists_run: stop_reason, num_iters and final_cost outputs are required");
   if (options->solver_type != 0 && options->solver_type != 1) return toa_fail(TOA_E_ARG, "toa_ba_lists_run: solver_type must be 0 (LM) or 1 (GN)");
-  if (!options->use_ldlt) return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run: use_ldlt=false is not available");
   if ((results->errs || results->deltas2 || results->successes) && results->hist_stride < options->max_iters + 2)
     return toa_fail(TOA_E_ARG, "toa_ba_lists_run: hist_stride must be >= max_iters + 2");
   if (options->max_iters < 0 || options->max_iters > 65535) return toa_fail(TOA_E_ARG, "max_iters out of range");

@@ -192,6 +192,43 @@ int large_solve_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const
   return TOA_OK;
 }
 
+// dx = -H^-1 g "without any checks on invertibility" (gn.h:157-162, options.h:59: use_ldlt = false): a general LU with partial
+// pivoting from the library, its verdict ignored (a solution that is not finite still ends as ok = 0: the step is refused as
+// everywhere else).  ONE matrix per call: a matrix solved alone gives the bits of its row in a batch.
+template <typename T>
+int large_solve_lu_t(toa_handle h, RocApi& api, int n, int64_t P, const T* H, const T* g, double scale, T* dx, int32_t* ok) {
+  const size_t nn = size_t(n) * n;
+  const size_t b_work = (size_t(P) * nn * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_rhs = (size_t(P) * n * sizeof(T) + 255) & ~size_t(255);
+  const size_t b_info = (size_t(P) * sizeof(int) + 255) & ~size_t(255);
+  const size_t b_piv = (size_t(P) * n * sizeof(int) + 255) & ~size_t(255);
+  if (int rc = ensure_scratch(h, b_work + b_rhs + b_info + b_piv, "large-n solve")) return rc;
+  char* base = static_cast<char*>(h->scratch);
+  T* work = reinterpret_cast<T*>(base);
+  T* rhs = reinterpret_cast<T*>(base + b_work);
+  int* info = reinterpret_cast<int*>(base + b_work + b_rhs);
+  int* ipiv = reinterpret_cast<int*>(base + b_work + b_rhs + b_info);
+  if (int rc = ensure_blas(h, api)) return rc;
+  const unsigned gx = unsigned(std::min<size_t>((nn + 255) / 256, 64));
+  hipLaunchKernelGGL(large_damp_kernel<T>, dim3(gx, unsigned(P)), dim3(256), 0, h->stream, H, g, work, rhs, n, scale);
+  HIP_TRY(hipGetLastError());
+  for (int64_t p = 0; p < P; ++p) {
+    int rc;
+    if constexpr (sizeof(T) == 4) {
+      rc = api.sgetrf(h->blas, n, n, work + p * nn, n, int64_t(nn), ipiv + p * n, int64_t(n), info + p, 1);
+      if (rc == 0) rc = api.sgetrs(h->blas, kOpN, n, 1, work + p * nn, n, int64_t(nn), ipiv + p * n, int64_t(n), rhs + p * n, n, int64_t(n), 1);
+    } else {
+      rc = api.dgetrf(h->blas, n, n, work + p * nn, n, int64_t(nn), ipiv + p * n, int64_t(n), info + p, 1);
+      if (rc == 0) rc = api.dgetrs(h->blas, kOpN, n, 1, work + p * nn, n, int64_t(nn), ipiv + p * n, int64_t(n), rhs + p * n, n, int64_t(n), 1);
+    }
+    if (rc != 0) return toa_fail(TOA_E_HIP, "rocSOLVER getrf/getrs returned status " + std::to_string(rc));
+  }
+  HIP_TRY(hipMemsetAsync(info, 0, size_t(P) * sizeof(int), h->stream));   // unchecked: a singular pivot is not a failure by itself
+  hipLaunchKernelGGL(large_finish_kernel<T>, dim3(unsigned(P)), dim3(256), 0, h->stream, rhs, info, dx, ok, n);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
 // The same solve with ONE matrix per library call — rocSOLVER's batched Cholesky picks its blocking from the batch size, and
 // a caller that promises "a problem solved alone gives the bits of its row in a batch" (bundle adjustment with visibility
 // lists) cannot use it — but the calls spread over up to eight side streams, each with a rocBLAS handle (and so a device
@@ -2037,6 +2074,14 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                                      static_cast<float*>(dx), ok);
   return toa::large_solve_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale,
                                     static_cast<double*>(dx), ok);
+}
+
+int toa_large_solve_unchecked(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
+  toa::RocApi& api = toa::roc_api();
+  if (!api.ok) return toa_fail(TOA_E_UNSUPPORTED, "use_ldlt = false beyond one wavefront needs rocSOLVER (general LU): " + api.err);
+  if (dtype == TOA_F32)
+    return toa::large_solve_lu_t<float>(h, api, n, P, static_cast<const float*>(H), static_cast<const float*>(g), scale, static_cast<float*>(dx), ok);
+  return toa::large_solve_lu_t<double>(h, api, n, P, static_cast<const double*>(H), static_cast<const double*>(g), scale, static_cast<double*>(dx), ok);
 }
 
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
