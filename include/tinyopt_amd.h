@@ -463,7 +463,8 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
                       const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
 /*      Round 4 — the general form.
  *        num_params up to 63: beyond 12 the model is JetRowModel (chunked Jets evaluated in matrix-core operand order, the path
- *          of TOA_MODEL_DENSE_ROW_AD): a Euclidean residual functor with ONE residual per item, no M-estimator.
+ *          of TOA_MODEL_DENSE_ROW_AD): a Euclidean residual functor, no M-estimator; residuals_per_item up to 8 (an item's
+ *          residuals are consecutive rows; round 5), scalars_per_item up to 512; the row-split and the stepping forms take it too.
  *        manifold = TOA_MANIFOLD_SE3: x is ONE pose stored as R (row-major 9) + t (3) = 12 scalars, num_params = 6 (its tangent
  *          in Sophus order upsilon, omega); the body reads the pose through x[0..11] — Jets over the right perturbation
  *          x * exp(delta) at delta = 0 (optimize_autodiff.h:48-77, 3rdparty/traits/sophus.h:13-27) — and may call
@@ -491,7 +492,7 @@ int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, 
                    const toa_options* options, const toa_results* results, uint64_t* counters_dev);
 int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, const void* x_dev,
                        int want_grad, void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);
-/*      Row-split execution of a run-time model (num_params <= 12) for FEW, HUGE problems — the reference's one `Optimize(x, cost)`
+/*      Row-split execution of a run-time model (any num_params; beyond 15 always the launch-per-iteration form) for FEW, HUGE problems — the reference's one `Optimize(x, cost)`
  *      over tens of thousands of residuals (BASELINE C2 / C5 shapes) with the residual supplied as text: the contract of
  *      toa_lm_run_split.  The items of each problem are cut into `splits` chunks (0 = chosen automatically), a wavefront per
  *      chunk, partials folded in fixed order; ONE persistent launch when P * splits <= the device's compute units, one launch

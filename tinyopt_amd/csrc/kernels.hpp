@@ -1249,7 +1249,7 @@ struct JetRowModel {
   static constexpr int kNmax = THIN > 0 ? 16 * NBM + THIN - 1 : 16 * NBM - 1;
   static constexpr int kNpad = (kNmax + 7) & ~7;
   static constexpr int kW = NBM + (THIN ? THIN - 1 : 0);
-  static_assert(F::kR == 1, "one residual per item");
+  static_assert(F::kR >= 1 && F::kR <= 8, "residuals per item");
   static_assert(F::kN <= kNmax, "functor has more parameters than this layout holds");
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   __device__ __forceinline__ void set_loss(int, double) {}
@@ -1257,14 +1257,18 @@ struct JetRowModel {
   const T* data;
   const T* d;
   DenseRowLayout lay;
-  int m;
+  int m;           // residual ROWS of a problem: items x kR (an item's kR residuals are kR consecutive rows — optimize_autodiff.h:123-164
+                   // takes vector residuals of any width; round 5)
+  int row0, mrows; // the rows of the bound problem this model works on: all of them, or one chunk of the row-split form
   __device__ __forceinline__ void init(int n, int m_, const void* dp) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(dp);
+    row0 = 0; mrows = m_;
   }
-  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (F::kH + size_t(m) * F::kD); }
-  __device__ __forceinline__ void bind_chunk(long long p, int, int, int) { bind(p); }   // one chunk (stepping form)
+  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (F::kH + size_t(m / F::kR) * F::kD); row0 = 0; mrows = m; }
+  // row-split execution: rows [r0, r0 + rows) of problem p — r0 on an item boundary (a multiple of lcm(16, kR): jit.hip)
+  __device__ __forceinline__ void bind_chunk(long long p, int r0, int rows, int) { bind(p); row0 = r0; mrows = max(0, min(rows, m - r0)); }
   __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
     const int k = lane >> 4, c = lane & 15;
     SeededX<T, kW> X;
@@ -1279,20 +1283,27 @@ struct JetRowModel {
     const bool isB = (THIN == 0) && ((c + 1) * NBM == lay.rsm);
     gram.clear();
     const T* items = d + F::kH;
-    const int steps = lay.m4 >> 2;
+    const int steps = (mrows + 3) >> 2;
     for (int s = 0; s < steps; ++s) {
       const int row = 4 * s + k;
-      Jet<T, kW> r[1];
-      if (row < m) F::template eval<Jet<T, kW>>(X, d, items + size_t(row) * F::kD, r);   // padding rows stay all-zero
+      Jet<T, kW> rr[F::kR];
+      Jet<T, kW> r0;          // the row's residual: component (row mod kR) of its item's (the item is evaluated once per row)
+      if (row < mrows) {      // padding rows stay all-zero
+        const int grow = row0 + row, item = grow / F::kR, comp = grow - item * F::kR;
+        F::template eval<Jet<T, kW>>(X, d, items + size_t(item) * F::kD, rr);
+        r0 = rr[0];
+#pragma unroll
+        for (int q = 1; q < F::kR; ++q) if (comp == q) r0 = rr[q];
+      }
       T w[NBM], v[THIN ? THIN : 1];
 #pragma unroll
-      for (int cb = 0; cb < NBM; ++cb) w[cb] = r[0].v[cb];                              // J.row(i) = res[i].v (:127-148)
+      for (int cb = 0; cb < NBM; ++cb) w[cb] = r0.v[cb];                              // J.row(i) = res[i].v (:127-148)
       if constexpr (THIN == 0) {
-        if (isB) w[NBM - 1] = r[0].a;
+        if (isB) w[NBM - 1] = r0.a;
       } else {
 #pragma unroll
-        for (int j = 0; j + 1 < THIN; ++j) v[j] = r[0].v[NBM + j];
-        v[THIN - 1] = r[0].a;
+        for (int j = 0; j + 1 < THIN; ++j) v[j] = r0.v[NBM + j];
+        v[THIN - 1] = r0.a;
       }
       gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == steps)));
     }
@@ -1303,10 +1314,12 @@ struct JetRowModel {
   __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
     T csum = 0;
     const T* items = d + F::kH;
-    for (int i = lane; i < m; i += 64) {
-      T r[1];
-      F::template eval<T>(L.xs, d, items + size_t(i) * F::kD, r);   // the same functor on plain scalars (grad == nullptr)
-      csum += r[0] * r[0];
+    const int it0 = row0 / F::kR, nit = mrows / F::kR;
+    for (int i = lane; i < nit; i += 64) {
+      T r[F::kR];
+      F::template eval<T>(L.xs, d, items + size_t(it0 + i) * F::kD, r);   // the same functor on plain scalars (grad == nullptr)
+#pragma unroll
+      for (int q = 0; q < F::kR; ++q) csum += r[q] * r[q];
     }
     cost = wave_allreduce_sum(csum);
     nres = m;
