@@ -166,7 +166,7 @@ int toa_create(toa_handle* out, int device, void* stream);
 /* ---- ABI version.  4 (round 4): counters_dev arrays are [TOA_NUM_COUNTERS = 8] uint64 (they were [4] up to version 2 — a caller
  *      that still allocates 4 entries would be written out of bounds by the memo counter), toa_tuning / toa_jit_spec exist.
  *      The host mirrors (include/tinyopt_amd/tinyopt.hpp, tinyopt_amd/_capi.py) refuse a library whose version differs. */
-#define TOA_ABI_VERSION 4
+#define TOA_ABI_VERSION 5
 int toa_abi_version(void);
 
 /* ---- tuning (per handle).  The arms of the A/B logs (profiles/r0N_ab_log.md) and of the bit-identity tests, as typed state
@@ -469,6 +469,13 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
  *          in Sophus order upsilon, omega); the body reads the pose through x[0..11] — Jets over the right perturbation
  *          x * exp(delta) at delta = 0 (optimize_autodiff.h:48-77, 3rdparty/traits/sophus.h:13-27) — and may call
  *          se3_log<S, T>(R, t, xi); the update is pose <- pose * exp(delta).  tests/sophus.cpp:26-44 `Optimize(pose, lambda)`.
+ *        manifold = TOA_MANIFOLD_USER (round 5): the caller's own parameter container — the reference's extension point
+ *          traits::params_trait<T> (traits.h:103-359; 3rdparty/traits/lieplusplus.h) as text.  x is stored as x_scalars scalars
+ *          per problem, num_params (<= 12) is the dimension of its tangent, and plus_body is the body of
+ *              template <class S> void plus(const T* x, const S* d, S* xp)        xp[0 .. x_scalars) = x (+) d
+ *          written once over the scalar type S like the residual.  The update is x <- plus(x, +-delta) on plain T (PlusEq,
+ *          traits.h:184-190; the roll-back is plus(x, -last_delta), optimizer.h:283-287), the derivative is taken through
+ *          plus(x, Jets seeded on d at d = 0) (optimize_autodiff.h:48-77); the residual body reads x[0 .. x_scalars).
  *        kind = TOA_JIT_ACCUMULATE: a manual Accumulate callback (docs/API.md:37-57, tests/optimize_easy.cpp:35-79) — the body
  *          fills r[q] and, `if (want_grad)`, the Jacobian rows J[q][a] itself (plain T, no AD); x[j], h[k], p[k] as before.
  *        A compiled model is cached on disk (code object keyed by the generated source, the library's headers, the hiprtc
@@ -476,13 +483,16 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
  *          $HOME/.cache/tinyopt_amd; "" = off, NULL = the default again.  The library's headers are embedded in it: no source tree is needed at run time. */
 #define TOA_MANIFOLD_EUCLID 0
 #define TOA_MANIFOLD_SE3 1
+#define TOA_MANIFOLD_USER 2   /* spec.plus_body + spec.x_scalars: a user parameter container (traits::params_trait<T>, traits.h:103-359) */
 #define TOA_JIT_RESIDUAL 0
 #define TOA_JIT_ACCUMULATE 1
 typedef struct toa_jit_spec {
   int32_t dtype, num_params, residuals_per_item, scalars_per_item, header_scalars;
   int32_t manifold;   /* TOA_MANIFOLD_* */
   int32_t kind;       /* TOA_JIT_* */
-  int32_t reserved[9];
+  int32_t x_scalars;  /* TOA_MANIFOLD_USER: scalars of x as STORED ([P][x_scalars]; 1 .. 32); num_params = the tangent's dimension */
+  const char* plus_body;   /* TOA_MANIFOLD_USER: the body of `template <class S> void plus(const T* x, const S* d, S* xp)`: xp = x (+) d */
+  int32_t reserved[6];
 } toa_jit_spec;
 int toa_model_compile_ex(toa_handle h, const toa_jit_spec* spec, const char* body, toa_jit_model* out, char* log_out, size_t log_cap);
 int toa_jit_set_cache_dir(const char* dir);

@@ -58,7 +58,7 @@ class ToaResults(C.Structure):
 
 
 # every symbol include/tinyopt_amd.h declares: name -> (restype, argtypes)
-ABI_VERSION = 4   # include/tinyopt_amd.h TOA_ABI_VERSION
+ABI_VERSION = 5   # include/tinyopt_amd.h TOA_ABI_VERSION
 
 
 class ToaTuning(C.Structure):   # include/tinyopt_amd.h toa_tuning
@@ -69,7 +69,8 @@ class ToaTuning(C.Structure):   # include/tinyopt_amd.h toa_tuning
 
 class ToaJitSpec(C.Structure):   # include/tinyopt_amd.h toa_jit_spec
     _fields_ = [("dtype", C.c_int32), ("num_params", C.c_int32), ("residuals_per_item", C.c_int32), ("scalars_per_item", C.c_int32),
-                ("header_scalars", C.c_int32), ("manifold", C.c_int32), ("kind", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("header_scalars", C.c_int32), ("manifold", C.c_int32), ("kind", C.c_int32), ("x_scalars", C.c_int32),
+                ("plus_body", C.c_char_p), ("reserved", C.c_int32 * 6)]
 
 
 _P = C.c_void_p

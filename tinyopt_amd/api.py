@@ -457,22 +457,31 @@ class JitResidual:
       * ``kind="accumulate"`` — a manual Accumulate callback (docs/API.md:37-57): the body fills ``r[q]`` and, inside
         ``if (want_grad) { ... }``, its own Jacobian rows ``J[q][a]`` (plain T, no AD)."""
 
-    MANIFOLDS = {"euclid": 0, "se3": 1}
+    MANIFOLDS = {"euclid": 0, "se3": 1, "user": 2}
     KINDS = {"residual": 0, "accumulate": 1}
 
     def __init__(self, body: str, n: int, item_scalars: int, residuals_per_item: int = 1, header_scalars: int = 0,
-                 dtype: torch.dtype = torch.float64, ctx: Optional["Context"] = None, manifold: str = "euclid", kind: str = "residual"):
+                 dtype: torch.dtype = torch.float64, ctx: Optional["Context"] = None, manifold: str = "euclid", kind: str = "residual",
+                 plus_body: Optional[str] = None, x_scalars: int = 0):
+        """Round 5 — ``manifold="user"``: the caller's own parameter container (the reference's traits::params_trait<T>, traits.h:103-359).
+        x is stored as ``x_scalars`` scalars per problem ([P, x_scalars]), ``n`` is the dimension of its tangent and ``plus_body``
+        is the body of ``template <class S> void plus(const T* x, const S* d, S* xp)``: xp = x (+) d, written over the scalar type
+        like the residual — the update and the roll-back run it on plain T, the differentiation on Jets seeded on d at d = 0."""
         from ._capi import ToaJitSpec
         self.ctx = ctx or default_context()
         self.n, self.kR, self.kD, self.kH, self.dtype = int(n), int(residuals_per_item), int(item_scalars), int(header_scalars), dtype
         self.manifold, self.kind = manifold, kind
-        self.xdim = 12 if manifold == "se3" else self.n
+        self.xdim = 12 if manifold == "se3" else (int(x_scalars) if manifold == "user" else self.n)
         self._h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
         spec = ToaJitSpec()
         spec.dtype, spec.num_params, spec.residuals_per_item = _dtype_code(dtype), self.n, self.kR
         spec.scalars_per_item, spec.header_scalars = self.kD, self.kH
         spec.manifold, spec.kind = self.MANIFOLDS[manifold], self.KINDS[kind]
+        if manifold == "user":
+            if not plus_body or int(x_scalars) < 1:
+                raise ValueError('manifold="user" needs plus_body (the body of x (+) d) and x_scalars')
+            spec.x_scalars, spec.plus_body = int(x_scalars), plus_body.encode()
         rc = self.ctx.lib.toa_model_compile_ex(self.ctx.h, C.byref(spec), body.encode(), C.byref(self._h), log, len(log))
         self.compile_log = log.value.decode(errors="replace")
         check(rc)

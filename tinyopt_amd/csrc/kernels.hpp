@@ -1048,16 +1048,46 @@ __device__ __forceinline__ void se3_seed_pose(const T* x, Jet<T, 6>* xj) {
   }
 }
 
+// MANIFOLD == 2: a USER manifold (run-time models, TOA_MANIFOLD_USER; the reference's extension point traits::params_trait<T>,
+// traits.h:103-359 — e.g. 3rdparty/traits/lieplusplus.h).  The functor carries the parameter container's size kX (scalars as
+// stored) and ONE function, written over the scalar type like the residual:
+//     template <class S> static void plus(const T* x, const S* d, S* xp)      xp = x (+) d,  d in the kN-dimensional tangent
+// from which both uses follow: the update x <- x (+) (+-delta) on plain T (PlusEq, traits.h:184-190) and the differentiation —
+// the residual is evaluated on xp = plus(x, Jets seeded on d at d = 0), exactly optimize_autodiff.h:48-77.
+template <typename F, typename = void>
+struct FunctorX { static constexpr int value = F::kN; };
+template <typename F>
+struct FunctorX<F, std::enable_if_t<(F::kX > 0)>> { static constexpr int value = F::kX; };
+template <typename T, typename F>
+struct UserManifoldOf {
+  static constexpr int kXdim = FunctorX<F>::value;
+  static __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) {
+    T xo[kXdim], dd[F::kN], xn[kXdim];
+#pragma unroll
+    for (int i = 0; i < kXdim; ++i) xo[i] = L.xs[i];
+#pragma unroll
+    for (int a = 0; a < F::kN; ++a) dd[a] = sign * dv[a];
+    F::template plus<T>(xo, dd, xn);
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < kXdim; ++i) L.xs[i] = xn[i];
+    }
+    wave_sync();
+  }
+};
+
 template <typename T, typename F, int MANIFOLD = 0>
 struct JetModel {
   using Scalar = T;
   static constexpr int kNpad = 16;
-  static constexpr int kXdim = MANIFOLD == 1 ? 12 : 0;
+  static constexpr int kXdim = MANIFOLD == 1 ? 12 : (MANIFOLD == 2 ? FunctorX<F>::value : 0);
   static constexpr int kN = F::kN, kW = F::kN + 1, kG = kW * (kW + 1) / 2;
-  static constexpr int kX = MANIFOLD == 1 ? 12 : F::kN;   // stored scalars of x
+  static constexpr int kX = MANIFOLD == 1 ? 12 : (MANIFOLD == 2 ? FunctorX<F>::value : F::kN);   // stored scalars of x
   static constexpr bool kManual = FunctorManual<F>::value;
   static_assert(F::kN >= 1 && F::kN <= 12, "register Gram: kN <= 12");
-  static_assert(MANIFOLD == 0 || F::kN == 6, "an SE3 pose has a 6-dimensional tangent");
+  static_assert(MANIFOLD != 1 || F::kN == 6, "an SE3 pose has a 6-dimensional tangent");
+  static_assert(kX <= 32, "stored scalars of x");
   const T* data;
   const T* d;
   int items, it0, it1;
@@ -1083,6 +1113,7 @@ struct JetModel {
   }
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
     if constexpr (MANIFOLD == 1) Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
+    else if constexpr (MANIFOLD == 2) UserManifoldOf<T, F>::plus_eq(L, dv, sign, n, lane);
     else euclid_plus_eq(L, dv, sign, lane);
   }
 
@@ -1109,6 +1140,11 @@ struct JetModel {
           Jet<T, kN> xj[kX], r[F::kR];
           if constexpr (MANIFOLD == 1) {
             se3_seed_pose<T>(x, xj);                                  // optimize_autodiff.h:48-55, 73-77
+          } else if constexpr (MANIFOLD == 2) {
+            Jet<T, kN> dj[kN];                                        // x (+) delta over Jets seeded on delta at delta = 0
+#pragma unroll
+            for (int k = 0; k < kN; ++k) dj[k] = Jet<T, kN>(T(0), k);
+            F::template plus<Jet<T, kN>>(x, dj, xj);
           } else {
 #pragma unroll
             for (int k = 0; k < kN; ++k) xj[k] = Jet<T, kN>(x[k], k);   // optimize_autodiff.h:56-69
