@@ -135,13 +135,14 @@ def gpu_dict(out, x):
 
 
 # ---- the second reading of the LM state machine (tests/golden/make_reference_traces.py) -------------------------------------
-def load_reference_traces():
+def load_reference_traces(name="reference_traces.json"):
     """[(case dict, ToaOptions)] of tests/golden/reference_traces.json — per-iteration traces of an independent Python
-    restatement of optimizer.h / lm.h / gn.h (written from the reference, not from oracle/)."""
+    restatement of optimizer.h / lm.h / gn.h (written from the reference, not from oracle/).  name = "reference_traces_robust.json":
+    part 2 (round 5), the M-estimators inside the loop (make_reference_traces_robust.py)."""
     import json
     import os
     from tinyopt_amd._capi import ToaOptions
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_traces.json")) as f:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)) as f:
         cases = json.load(f)["cases"]
     out = []
     for c in cases:

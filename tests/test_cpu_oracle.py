@@ -195,3 +195,26 @@ def test_oracle_follows_the_second_reading(oracle):
     assert {"use_step_quality_approx", "grad_clipping", "check_min_H_diag", "use_ldlt=false", "sqrt cost", "downscale_by_2", "normalize",
             "beale", "himmelblau", "float32"} <= branches, branches
     assert ties <= len(cases) // 8, f"{ties} of {len(cases)} cases parted at a round-off tie"
+
+
+def test_oracle_follows_the_second_reading_of_the_robust_losses(oracle):
+    """tests/golden/reference_traces_robust.json (round 5): the seven M-estimators of robust_norms.h inside the LM loop — cost as a
+    sum of losses, J^T J and J^T r weighted by s, the inlier ratio — restated independently in Python from the reference's header
+    (make_reference_traces_robust.py).  The C++ oracle's DenseRow-with-a-loss path must produce the same numbers."""
+    from parity import check_against_trace, load_reference_traces
+    cases = load_reference_traces("reference_traces_robust.json")
+    assert len(cases) >= 60
+    losses, solvers = set(), set()
+    for c, pod in cases:
+        A = np.array([c["A"]], dtype=np.float64)
+        b = np.array([c["b"]], dtype=np.float64)
+        x0 = np.array([c["x0"]], dtype=np.float64)
+        pod.save_last = 0
+        r = oracle.dense_row_lm(A, b, x0, pod, history=True, loss=c["loss"], th2=c["th2"])
+        got = dict(errs=r["errs"][0], deltas2=r["deltas2"][0], succ=r["succ"][0], stop=r["stop"][0], iters=r["iters"][0],
+                   fails=r["fails"][0], x=r["x"][0], cost=r["cost"][0])
+        assert check_against_trace(c, got, label=c["comment"]) == "full"
+        assert abs(float(r["inlier_ratio"][0]) - c["final_inlier_ratio"]) < 1e-6, (c["comment"], r["inlier_ratio"][0], c["final_inlier_ratio"])
+        losses.add(c["loss"])
+        solvers.add(c["options"]["solver"])
+    assert losses == {"truncated", "huber", "tukey", "arctan", "cauchy", "geman_mcclure", "blake_zisserman"} and solvers == {"lm", "gn"}

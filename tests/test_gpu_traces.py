@@ -69,3 +69,26 @@ def test_device_follows_the_second_reading_stepping_form(ta):
                    stop=int(out.stop_reason[0]), iters=int(out.num_iters[0]), fails=int(out.num_failures[0]),
                    x=x.cpu().numpy()[0], cost=float(out.final_cost[0]))
         check_against_trace(c, got, label=f"stepping {c['function']} {c['x0']}")
+
+
+def test_device_follows_the_second_reading_of_the_robust_losses(ta):
+    """Part 2 of the second reading (tests/golden/reference_traces_robust.json, round 5): the M-estimators inside the loop, on the
+    device — DenseRow + toa_set_loss (the launch-per-iteration form's robust passes) in fp64: same decisions, costs, steps, x and
+    inlier ratio as the independent Python restatement of robust_norms.h; also through the stepping form."""
+    cases = load_reference_traces("reference_traces_robust.json")
+    assert len(cases) >= 60
+    for k, (c, _) in enumerate(cases):
+        o = _options(ta, c)
+        o.hessian.save_last = False
+        A = torch.tensor([c["A"]], dtype=torch.float64, device="cuda")
+        b = torch.tensor([c["b"]], dtype=torch.float64, device="cuda")
+        model = ta.DenseRow.from_arrays(A, b).with_loss(c["loss"], c["th2"] ** 0.5)
+        for form in (("launch",) if k % 4 else ("launch", "step")):
+            x = torch.tensor([c["x0"]], dtype=torch.float64, device="cuda")
+            out = ta.Optimize(x, model, o, history=True) if form == "launch" else ta.Optimizer(x, model, o, history=True)()
+            torch.cuda.synchronize()
+            got = dict(errs=out.errs.cpu().numpy()[0], deltas2=out.deltas2.cpu().numpy()[0], succ=out.successes.cpu().numpy()[0],
+                       stop=int(out.stop_reason[0]), iters=int(out.num_iters[0]), fails=int(out.num_failures[0]),
+                       x=x.cpu().numpy()[0], cost=float(out.final_cost[0]))
+            assert check_against_trace(c, got, label=f"{form}: {c['comment']}") == "full"
+            assert abs(float(out.final_inlier_ratio[0]) - c["final_inlier_ratio"]) < 1e-6, c["comment"]
