@@ -383,10 +383,14 @@ def u8(v):
     return v & 0xFF
 
 
-def optimize(name, x0, opt, max_iters_arg=-1, perturb=lambda c: c):
-    """OptimizeAcc (optimizer.h:242-327) with Step (:331-539) inlined as step()."""
+def optimize(name, x0, opt, max_iters_arg=-1, perturb=lambda c: c, plus=None, ndim=None):
+    """OptimizeAcc (optimizer.h:242-327) with Step (:331-539) inlined as step().
+    plus(x, dx, sign) -> x (+) sign * dx and ndim = the tangent's dimension: a parameter object on a manifold (traits::params_trait<T>::
+    PlusEq, traits.h:149-191; part 3 of the second reading, make_reference_traces_ba.py); default: Euclidean, len(x0)."""
     fn = FUNCS[name]
-    n = len(x0)
+    n = len(x0) if ndim is None else ndim
+    if plus is None:
+        plus = lambda xx, dd, sg: [a + sg * b for a, b in zip(xx, dd)]   # noqa: E731  (x + dx and x + (-dx): the same doubles as before)
     x = list(x0)
     S = Solver(opt, n)
     out = dict(errs=[], deltas2=[], successes=[], final_cost=DBL_MAX, final_nres=0, final_rerr_dec=DBL_MAX, stop=kNone,
@@ -489,17 +493,17 @@ def optimize(name, x0, opt, max_iters_arg=-1, perturb=lambda c: c):
         good, dx = step()
         eval_only = False
         if good:
-            x = [a + b for a, b in zip(x, dx)]
+            x = plus(x, dx, 1.0)
             last_dx = dx
             last_ok = True
             if opt.check_final_cost and it + 1 == max_iters:
                 eval_only = True
         else:
             if last_dx is not None:
-                x = [a + (-b) for a, b in zip(x, last_dx)]
+                x = plus(x, last_dx, -1.0)
                 last_dx = None
             elif dx is not None:
-                x = [a + b for a, b in zip(x, dx)]
+                x = plus(x, dx, 1.0)
                 last_dx = dx
             eval_only = not last_ok
             last_ok = False

@@ -218,3 +218,30 @@ def test_oracle_follows_the_second_reading_of_the_robust_losses(oracle):
         losses.add(c["loss"])
         solvers.add(c["options"]["solver"])
     assert losses == {"truncated", "huber", "tukey", "arctan", "cauchy", "geman_mcclure", "blake_zisserman"} and solvers == {"lm", "gn"}
+
+
+def test_oracle_follows_the_second_reading_of_a_bundle_adjustment(oracle):
+    """tests/golden/reference_traces_ba.json (round 5): small bundle adjustments solved the reference's way by an independent
+    Python restatement — SE3 exp from Sophus' formulas, the Jacobians by dual numbers through x (+) delta (NOT oracle/ba.hpp's
+    closed forms), the M-estimator per observation, the dense (6C + 3N)^2 pivoted LDL^T — make_reference_traces_ba.py.
+    oracle/ba.hpp must take the same decisions and produce the same costs / steps (x: the gauge is free, compared loosely)."""
+    from parity import load_reference_traces
+    cases = load_reference_traces("reference_traces_ba.json")
+    assert len(cases) >= 8
+    losses = set()
+    for c, pod in cases:
+        C_, N_ = c["ncam"], c["npts"]
+        pod.save_last = 0
+        r = oracle.ba_lm(np.array([c["data"]]), np.array([c["x0"]]), C_, N_, pod, loss=c["loss"], th2=c["th2"]) if c["loss"] else \
+            oracle.ba_lm(np.array([c["data"]]), np.array([c["x0"]]), C_, N_, pod)
+        k = c["num_iters"]
+        assert int(r["iters"][0]) == k and int(r["stop"][0]) == c["stop_reason"] and int(r["fails"][0]) == c["num_failures"], c["comment"]
+        assert np.array_equal(r["succ"][0][:k].astype(int), np.asarray(c["successes"])), c["comment"]
+        assert np.allclose(r["errs"][0][:k], c["errs"], rtol=1e-8), (c["comment"], r["errs"][0][:k], c["errs"])
+        assert np.allclose(r["deltas2"][0][:k], c["deltas2"], rtol=1e-5, atol=1e-14), c["comment"]
+        assert abs(r["cost"][0] - c["final_cost"]) <= 1e-8 * abs(c["final_cost"]) and int(r["nres"][0]) == c["final_num_residuals"]
+        assert np.abs(r["x"][0] - np.asarray(c["x"])).max() < 1e-5, c["comment"]
+        if c["loss"]:
+            assert abs(float(r["inlier_ratio"][0]) - c["final_inlier_ratio"]) < 1e-6
+        losses.add(c["loss"])
+    assert None in losses and len(losses) >= 4

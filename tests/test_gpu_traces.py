@@ -92,3 +92,34 @@ def test_device_follows_the_second_reading_of_the_robust_losses(ta):
                        x=x.cpu().numpy()[0], cost=float(out.final_cost[0]))
             assert check_against_trace(c, got, label=f"{form}: {c['comment']}") == "full"
             assert abs(float(out.final_inlier_ratio[0]) - c["final_inlier_ratio"]) < 1e-6, c["comment"]
+
+
+def test_device_follows_the_second_reading_of_a_bundle_adjustment(ta):
+    """Part 3 (tests/golden/reference_traces_ba.json, round 5): both device bundle-adjustment forms — points eliminated, Schur
+    complement on the matrix cores (toa_ba_run) and the visibility-list pipeline (toa_ba_lists_run) — against the independent
+    Python restatement that solves the dense (6C + 3N)^2 system with Jacobians from dual numbers: same decisions, costs, steps,
+    inlier ratio, with and without an M-estimator on each observation."""
+    cases = load_reference_traces("reference_traces_ba.json")
+    assert len(cases) >= 8
+    for c, _ in cases:
+        o = _options(ta, c)
+        o.hessian.save_last = False
+        C_, N_ = c["ncam"], c["npts"]
+        data = torch.tensor([c["data"]], dtype=torch.float64, device="cuda")
+        k = c["num_iters"]
+        for form in ("dense mask", "lists"):
+            model = ta.BundleAdjustment(data, C_, N_) if form == "dense mask" else ta.BundleAdjustmentLists.from_dense(data, C_, N_)
+            if c["loss"]:
+                model = model.with_loss(c["loss"], c["th2"] ** 0.5)
+            x = torch.tensor([c["x0"]], dtype=torch.float64, device="cuda")
+            out = ta.Optimize(x, model, o, history=True)
+            torch.cuda.synchronize()
+            lab = f"{form}: {c['comment']}"
+            assert int(out.num_iters[0]) == k and int(out.stop_reason[0]) == c["stop_reason"] and int(out.num_failures[0]) == c["num_failures"], lab
+            assert np.array_equal(out.successes.cpu().numpy()[0][:k].astype(int), np.asarray(c["successes"])), lab
+            assert np.allclose(out.errs.cpu().numpy()[0][:k], c["errs"], rtol=1e-7), lab
+            assert np.allclose(out.deltas2.cpu().numpy()[0][:k], c["deltas2"], rtol=1e-4, atol=1e-13), lab
+            assert abs(float(out.final_cost[0]) - c["final_cost"]) <= 1e-7 * abs(c["final_cost"]), lab
+            assert int(out.final_num_residuals[0]) == c["final_num_residuals"], lab
+            assert abs(float(out.final_inlier_ratio[0]) - c["final_inlier_ratio"]) < 1e-6, lab
+            assert float((x.cpu() - torch.tensor([c["x"]], dtype=torch.float64)).abs().max()) < 1e-4, lab
