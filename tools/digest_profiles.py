@@ -55,7 +55,7 @@ def main():
                        "bench_line_kernel_ms_avg_hip_events": line["roofline"].get("kernel_ms_avg"),
                        "ratio_rocprof_over_hip_events": (sum(warm) / len(warm)) / line["roofline"]["kernel_ms_avg"] if line["roofline"].get("kernel_ms_avg") else None,
                        "bench_line_value": line["value"], "bench_line_frac": line["roofline"]["frac"]}, f, indent=1)
-    for txt in ("ad_ratio", "large_n_bench", "k3_crossover", "probe_phases", "coop_sweep"):
+    for txt in ("ad_ratio", "large_n_bench", "k3_crossover", "probe_phases", "coop_sweep", "llc_probe", "pytest_gpu"):
         if os.path.exists(os.path.join(SRC, txt + ".txt")):
             shutil.copy(os.path.join(SRC, txt + ".txt"), os.path.join(DST, f"{tag}_{txt}.txt"))
     if os.path.isdir(os.path.join(SRC, "pmc_large128")):   # counters of the n = 128 workgroup-per-problem kernel
@@ -71,7 +71,8 @@ def main():
     for name in ("bench_c4", "bench_c3", "bench_c2", "bench_c5", "bench_c1", "bench_under_rocprof", "bench_under_rocprof_c3",
                  "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba",
                  "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0",
-                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane", "bench_large256_two_lanes", "bench_large256_plain_deal"):
+                 "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane", "bench_large256_two_lanes", "bench_large256_plain_deal",
+                 "bench_large128_memo0", "bench_large256_memo0", "bench_c4_k6", "bench_c4_team2_k6", "bench_c4_team4_k6"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
