@@ -65,7 +65,7 @@ extern "C" {
  * differentiated on the device by dual numbers over the right perturbation; n == m == 6; x: [P][12] poses;
  * data_dev: [P][12] = prior_inv (rotation matrix row-major, translation) */
 #define TOA_MODEL_SE3_PRIOR 9
-/* DenseRow beyond one wavefront (n up to 1024): rows in natural layout.  64 <= n <= 128: one persistent
+/* DenseRow beyond one wavefront (n up to 4096 — beyond 1024 every stage of a pass is the library's): rows in natural layout.  64 <= n <= 128: one persistent
  * workgroup-per-problem kernel (csrc/large_fused.hip).  Beyond: J^T J by a hand-written LDS-staged MFMA Gram (fp32; the
  * library GEMM for fp64), the solve by a one-workgroup blocked Cholesky (fp32 n <= 1024, fp64 n <= 512; rocSOLVER's batched
  * potrf + potrs beyond and for use_ldlt = 0), the LM state machine in small kernels between them (csrc/large_n.hip).
@@ -261,7 +261,7 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  * TOA_MODEL_TESTFN          see the define above.
  * TOA_MODEL_CIRCLE_FIT      n == 3; data_dev: [P][m][2] observed points; x: [P][3].
  * TOA_MODEL_DENSE_ROW_AD6   n == 6; data_dev: [P][m][7] = (a_i, b_i) rows (natural layout); x: [P][6].
- * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 1024 (any P: the n > 128 pipeline takes a large batch 65 535 problems at a time); data_dev: per problem A row-major [m][n] then b [m]
+ * TOA_MODEL_DENSE_ROW_NATURAL  1 <= n <= 4096 (any P: the n > 128 pipeline takes a large batch 65 535 problems at a time); data_dev: per problem A row-major [m][n] then b [m]
  *                           (problem stride m (n + 1) elements); x: [P][n]. */
 
 /* ---- K1/K2: Accumulate callback (replaces `acc(x, grad, H) -> Cost`, docs/API.md:37-57;

@@ -611,3 +611,24 @@ def test_operand_sharing_deal_of_the_gram_tiles_gives_the_bits_of_the_plain_deal
         for f in ("stop_reason", "num_iters", "final_cost", "num_failures", "errs", "deltas2", "successes", "final_hessian"):
             assert torch.equal(getattr(out, f), getattr(outs[0][1], f)), f
     assert bool(outs[0][1].Succeeded().all())
+
+
+@pytest.mark.parametrize("dtype,n,m", [(np.float32, 1056, 1120), (np.float64, 1040, 1100)])
+def test_beyond_1024_unknowns(ta, oracle, dtype, n, m):
+    """Round 5: the reference's Dims == Dynamic is unbounded (optimizer.h:61-92); TOA_MODEL_DENSE_ROW_NATURAL stopped at n = 1024.
+    Beyond it every stage of a pass is the library's (general rows kernel, rocBLAS GEMM / GEMV, rocSOLVER potrf / potrs); the LM
+    state machine around them is the same — the oracle's trajectory, to the tolerance of a sum over ~1100 rows."""
+    P = 1
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype, seed=77)
+    o = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A.astype(np.float64), b.astype(np.float64), x0.astype(np.float64), o.to_pod(), history=True)
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, o, history=True)
+    torch.cuda.synchronize()
+    assert bool((out.stop_reason > 0).all())
+    tol = 1e-8 if dtype == np.float64 else 2e-3
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() < (1e-7 if dtype == np.float64 else 2e-3)
+    assert np.allclose(out.errs.cpu().numpy()[:, :3], ref["errs"][:, :3], rtol=tol)
+    if dtype == np.float64:
+        assert np.array_equal(out.num_iters.cpu().numpy(), ref["iters"]) and np.array_equal(out.stop_reason.cpu().numpy(), ref["stop"])

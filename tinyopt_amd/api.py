@@ -647,7 +647,7 @@ class BundleAdjustment(_LossMixin):
 
 
 class DenseRowNatural(_LossMixin):
-    """The DenseRow family beyond one wavefront (n up to 1024): rows (a_i, b_i) in natural layout.
+    """The DenseRow family beyond one wavefront (n up to 4096): rows (a_i, b_i) in natural layout.
     64 <= n <= 128: the whole loop in one persistent kernel, a workgroup per problem, J^T J on the matrix cores
     without materialising J, blocked LDL^T by the four waves (csrc/large_fused.hip).  Beyond: J^T J through a batched rocBLAS
     GEMM, the damped solve through the workgroup LDL^T / rocSOLVER's batched Cholesky, the LM state machine of

@@ -747,7 +747,9 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   const bool natural = model == TOA_MODEL_DENSE_ROW_NATURAL;  // n beyond one wavefront (large_fused.hip / large_n.hip)
   if (natural) {
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
-    if (n < 1 || n > 1024) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 1024]");
+    // (beyond 1024 unknowns every stage of a pass is the library's — rocBLAS GEMM / GEMV, rocSOLVER potrf / potrs or LU — like
+    //  toa_solve_damped, which takes n up to 4096 the same way; the reference's Dims == Dynamic is unbounded, optimizer.h:61-92)
+    if (n < 1 || n > 4096) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 4096]");
     if (m < 1) return fail(TOA_E_ARG, "m must be >= 1");
     if (P < 0) return fail(TOA_E_ARG, "P must be >= 0");   // (no upper limit: the launch-per-stage pipeline takes 65 535 problems per slice)
     if (!data) return fail(TOA_E_ARG, "null data pointer");
@@ -876,7 +878,7 @@ int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* stat
                      double* grad_norm2_dev, void* dx_dev, void* g_dev) {
   if (!h || !state_dev) return fail(TOA_E_ARG, "toa_lm_step_info: null argument");
   if (n >= 64) {
-    if ((dtype != TOA_F32 && dtype != TOA_F64) || n > 1024 || P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_lm_step_info: bad shape");
+    if ((dtype != TOA_F32 && dtype != TOA_F64) || n > 4096 || P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_lm_step_info: bad shape");
     if (P == 0) return TOA_OK;
     TOA_ON_DEVICE(h->device);
     return toa_large_step_info(h, dtype, n, P, state_dev, err_dev, dx_norm2_dev, grad_norm2_dev, dx_dev, g_dev);

@@ -1627,7 +1627,9 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const size_t b_sum = stepping ? al(size_t(4) * sizeof(int) * size_t(step_passes + 1)) : al(size_t(2) * sizeof(int) * size_t(max_passes + 1) * toa_context::kLanes);
   // vectorised rows kernel (see large_rows_vec_kernel): geometry and the per-wave J^T r partials
   constexpr int VEC = 16 / int(sizeof(T));
-  const bool vec_ok = n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
+  // (n > 1024, round 5: the general rows kernel + the library's GEMM / GEMV / factorisation — the vectorised rows kernel keeps at most
+  //  eight 16-byte vectors of a row per lane, the hand-written Gram's LDS stage ends at 1024 columns)
+  const bool vec_ok = n <= 1024 && n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
   const int nv = n / VEC;
   int LPR = 1;
   while (LPR * 2 <= std::min(64, nv)) LPR *= 2;
