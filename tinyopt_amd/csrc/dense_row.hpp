@@ -1240,18 +1240,71 @@ struct DenseRowGram {
   // stage image: row r at byte r 128, its 16-byte granule g (columns 2 g, 2 g + 1) at position g ^ (r & 7) — for the raw rows
   // and for the scaled rows alike, so [J | r] simply overwrites the row it was made from.  Columns >= RS are zero (the loads
   // of lanes beyond the row's end return 0), which makes the whole pass independent of n: 16 columns, no branches.
+  // Round 5, measured and NOT the default (-DTOA_S16_TWO_SETS; profiles/r05_ab_log.md section 3): TWO sets of load registers, the loads
+  // of super-batch k + 2 issued while k is computed.  The idea: what bounds a launch of 10 000 problems is its tail — a problem
+  // started into an emptying chip takes as long as one started into a full one — and a lone wave with two round trips in flight
+  // should be faster.  It is not by much (3 072 problems, one round: 0.258 -> 0.249 ms), the second set costs the third wave per
+  // SIMD (192 registers), which the steady state does use (40 960 problems: 1.689 -> 1.792 ms), and at the BASELINE's 10 000 the
+  // two cancel (0.541 -> 0.547 ms).  A problem's latency at low occupancy is not its load latency.
+#ifdef TOA_S16_TWO_SETS
+#define TOA_S16_SETS 2
+#else
+#define TOA_S16_SETS 1
+#endif
+  template <bool WANT_H>
+  __device__ __forceinline__ void s16_compute(unsigned char* __restrict__ stage, const int myrow, const int myb, const int wr0, const int wr1,
+                                              const T (&xu)[16], T& csum) {
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    T a[16];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const T2 v = *reinterpret_cast<const T2*>(stage + (myrow ^ (g << 4)));
+      a[2 * g] = v[0];
+      a[2 * g + 1] = v[1];
+    }
+    const T bi = *reinterpret_cast<const T*>(stage + myb);
+    T t = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t = fma(a[j], xu[j], t);
+    T sn, cs;
+    sincos_t_s(t, &sn, &cs);
+    const T sc = T(1) + T(0.1) * cs;
+    const T res = (t + T(0.1) * sn) - bi;
+    if constexpr (!WANT_H) {
+      csum = fma(res, res, csum);
+    } else {
+      // ---- [J | r | 0] over the row it came from
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        *reinterpret_cast<T2*>(stage + (myrow ^ (g << 4))) = T2{sc * a[2 * g], sc * a[2 * g + 1]};
+      }
+      *reinterpret_cast<T*>(stage + myb) = res;   // (after the granule that holds column n: same lane, in order)
+      __builtin_amdgcn_wave_barrier();
+      // ---- sixteen steps on the matrix core
+      T op[16];                          // every operand read is issued before the first MFMA waits for its own
+#pragma unroll
+      for (int q = 0; q < 16; ++q) op[q] = *reinterpret_cast<const T*>(stage + ((q & 1) ? wr1 : wr0) + q * 512);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : TOA_ACC(acc[0]) : "v"(op[q]));
+#if TOA_S16_SETS == 2
+      // two sites of this block in one kernel (one per register set): hipcc moves the accumulator between them, right behind the
+      // last MFMA, where it cannot see the XDL-write -> read hazard of an asm MFMA.  The matrix pipe is waited out inside the
+      // statement instead (18 wait states of a 16-pass DGEMM MFMA: 20 cycles per super-batch of 16 x 64).
+      asm volatile("s_nop 15\n\ts_nop 3" : TOA_ACC(acc[0]));
+#endif
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   template <bool WANT_H>
   __device__ __forceinline__ T pass16s(const T* __restrict__ prob, const DenseRowLayout& lay, const int n, const T* __restrict__ xs,
                                        const int lane, unsigned char* __restrict__ stage) {
     static_assert(sizeof(T) == 8 && NBM == 1 && THIN == 0, "fp64, n <= 15");
-    typedef T T2 __attribute__((ext_vector_type(2)));
     const int RS = lay.rs;                      // n + 1 <= 16: the row [a_i | b_i]
     const int k = lane >> 4, c = lane & 15;
     const int steps = lay.m4 >> 2;
     const unsigned step_bytes_u = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(4 * RS) * 8u)));
     const i32x4 rsrc = make_rsrc(prob, unsigned(steps) * step_bytes_u);
     const unsigned voff = c < RS ? unsigned((k * RS + c) * 8) : 0x80000000u;
-    RawVec<2> st[16];
     if (WANT_H) clear();
     T csum = 0;
     // loop-invariant LDS addresses (bytes from the wave's stage)
@@ -1268,6 +1321,8 @@ struct DenseRowGram {
       const unsigned lo = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b)))), hi = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(b >> 32))));
       xu[j] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
+#if TOA_S16_SETS == 1
+    RawVec<2> st[16];
     s16_issue<0>(st, rsrc, voff, 0u, step_bytes_u);
     for (int s0 = 0; s0 < steps; s0 += 16) {
       // ---- raw rows -> LDS, then the next super-batch's loads into the same registers
@@ -1275,43 +1330,35 @@ struct DenseRowGram {
       s16_to_lds<0>(st, stage + wr0, stage + wr1);
       __builtin_amdgcn_wave_barrier();
       s16_issue<0>(st, rsrc, voff, unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 16) * step_bytes_u))), step_bytes_u);
-      // ---- my row
-      T a[16];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const T2 v = *reinterpret_cast<const T2*>(stage + (myrow ^ (g << 4)));
-        a[2 * g] = v[0];
-        a[2 * g + 1] = v[1];
-      }
-      const T bi = *reinterpret_cast<const T*>(stage + myb);
-      T t = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) t = fma(a[j], xu[j], t);
-      T sn, cs;
-      sincos_t_s(t, &sn, &cs);
-      const T sc = T(1) + T(0.1) * cs;
-      const T res = (t + T(0.1) * sn) - bi;
-      if constexpr (!WANT_H) {
-        csum = fma(res, res, csum);
-      } else {
-        // ---- [J | r | 0] over the row it came from
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-          *reinterpret_cast<T2*>(stage + (myrow ^ (g << 4))) = T2{sc * a[2 * g], sc * a[2 * g + 1]};
-        }
-        *reinterpret_cast<T*>(stage + myb) = res;   // (after the granule that holds column n: same lane, in order)
-        __builtin_amdgcn_wave_barrier();
-        // ---- sixteen steps on the matrix core
-        T op[16];                          // every operand read is issued before the first MFMA waits for its own
-#pragma unroll
-        for (int q = 0; q < 16; ++q) op[q] = *reinterpret_cast<const T*>(stage + ((q & 1) ? wr1 : wr0) + q * 512);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : TOA_ACC(acc[0]) : "v"(op[q]));
-        __builtin_amdgcn_wave_barrier();
-      }
+      s16_compute<WANT_H>(stage, myrow, myb, wr0, wr1, xu, csum);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch past the end (zeros) before its registers die
     s16_touch<0>(st);
+#else
+    // super-batches alternate between the two register sets; the loads of k + 2 go out as soon as k has been copied to LDS, so two
+    // super-batches are in flight while one is computed.  vmcnt(16): the sixteen loads of the YOUNGER set may stay outstanding.
+    RawVec<2> sa[16], sb[16];
+    s16_issue<0>(sa, rsrc, voff, 0u, step_bytes_u);
+    s16_issue<0>(sb, rsrc, voff, unsigned(__builtin_amdgcn_readfirstlane(int(16u * step_bytes_u))), step_bytes_u);
+    for (int s0 = 0; s0 < steps; s0 += 32) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      s16_to_lds<0>(sa, stage + wr0, stage + wr1);
+      __builtin_amdgcn_wave_barrier();
+      s16_issue<0>(sa, rsrc, voff, unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 32) * step_bytes_u))), step_bytes_u);
+      s16_compute<WANT_H>(stage, myrow, myb, wr0, wr1, xu, csum);
+      // the second set: wait / copy / re-issue UNCONDITIONALLY — the load pipeline has one shape on every path (tools/isa_lint.py
+      // follows both sides of every branch) — and only the arithmetic is skipped when an odd super-batch count leaves it no rows
+      // (its loads came back as zeros without touching memory: past the descriptor's end)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      s16_to_lds<0>(sb, stage + wr0, stage + wr1);
+      __builtin_amdgcn_wave_barrier();
+      s16_issue<0>(sb, rsrc, voff, unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(s0 + 48) * step_bytes_u))), step_bytes_u);
+      if (s0 + 16 < steps) s16_compute<WANT_H>(stage, myrow, myb, wr0, wr1, xu, csum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetches past the end (zeros) before their registers die
+    s16_touch<0>(sa);
+    s16_touch<0>(sb);
+#endif
     if (WANT_H) {
       mfma_retire();
       return T(0);
