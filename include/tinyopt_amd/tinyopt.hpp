@@ -309,14 +309,19 @@ class JitResidual {
   //   it through x[0..11] and may call se3_log<S, T>(R, t, xi)  (tests/sophus.cpp:26-44 `Optimize(pose, lambda)`);
   // kind: TOA_JIT_RESIDUAL (differentiated on the device), or TOA_JIT_ACCUMULATE — a manual Accumulate callback: the body fills
   //   r[q] and, inside `if (want_grad)`, its own Jacobian rows J[q][a]  (docs/API.md:37-57);
-  // n up to 63 (beyond 12: one residual per item, Euclidean).  Compiled code objects are cached on disk (toa_jit_set_cache_dir).
+  // n up to 63 (beyond 12: Euclidean residual functors, up to 8 residuals per item).  Compiled code objects are cached on disk (toa_jit_set_cache_dir).
+  // manifold = TOA_MANIFOLD_USER (round 5): the caller's own parameter container — tinyopt's traits::params_trait<T> (traits.h:103-359) as text:
+  //   x_scalars = the container as stored, n = the dimension of its tangent, plus_body = the body of
+  //   `template <class S> void plus(const T* x, const S* d, S* xp)`, xp = x (+) d (PlusEq on plain T; differentiated through Jets seeded on d).
   JitResidual(const Context& ctx, const std::string& body, int n, int item_scalars, int residuals_per_item = 1, int header_scalars = 0,
-              int manifold = TOA_MANIFOLD_EUCLID, int kind = TOA_JIT_RESIDUAL)
-      : ctx_(&ctx), n_(n), kR_(residuals_per_item), kD_(item_scalars), kH_(header_scalars), xdim_(manifold == TOA_MANIFOLD_SE3 ? 12 : n) {
+              int manifold = TOA_MANIFOLD_EUCLID, int kind = TOA_JIT_RESIDUAL, const std::string& plus_body = std::string(), int x_scalars = 0)
+      : ctx_(&ctx), n_(n), kR_(residuals_per_item), kD_(item_scalars), kH_(header_scalars),
+        xdim_(manifold == TOA_MANIFOLD_SE3 ? 12 : (manifold == TOA_MANIFOLD_USER ? x_scalars : n)) {
     std::vector<char> log(1 << 16);
     toa_jit_spec spec{};
     spec.dtype = dtype_of<Scalar>(); spec.num_params = n; spec.residuals_per_item = residuals_per_item;
     spec.scalars_per_item = item_scalars; spec.header_scalars = header_scalars; spec.manifold = manifold; spec.kind = kind;
+    if (manifold == TOA_MANIFOLD_USER) { spec.x_scalars = x_scalars; spec.plus_body = plus_body.c_str(); }
     const int rc = toa_model_compile_ex(ctx.get(), &spec, body.c_str(), &h_, log.data(), log.size());
     log_ = log.data();
     check(rc);

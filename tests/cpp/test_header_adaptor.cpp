@@ -215,6 +215,39 @@ static void jit_manifold_and_manual() {
   REQUIRE(std::abs(v[0] - 1) < 1e-5 && std::abs(v[1] - 1) < 1e-5);
 }
 
+// traits::params_trait<T> (traits.h:103-359) for a parameter type of the caller's own: a planar rotation stored as (cos, sin), one
+// tangent dimension, x (+) d = the rotation of x by d — handed over as text (TOA_MANIFOLD_USER).  Same optimum as the angle form.
+static void jit_user_manifold() {
+  Context ctx(0);
+  const int items = 12;
+  const double truth = 0.9;
+  std::vector<double> data(4 * items);
+  for (int i = 0; i < items; ++i) {
+    const double ax = std::cos(0.7 * i) * (1 + 0.1 * i), ay = std::sin(1.3 * i) - 0.2;
+    data[4 * i] = ax; data[4 * i + 1] = ay;
+    data[4 * i + 2] = std::cos(truth) * ax - std::sin(truth) * ay;
+    data[4 * i + 3] = std::sin(truth) * ax + std::cos(truth) * ay;
+  }
+  JitResidual<double> on_circle(ctx, "r[0] = x[0] * p[0] - x[1] * p[1] - p[2];\nr[1] = x[1] * p[0] + x[0] * p[1] - p[3];", /*n=*/1, /*item_scalars=*/4,
+                                /*residuals_per_item=*/2, /*header_scalars=*/0, TOA_MANIFOLD_USER, TOA_JIT_RESIDUAL,
+                                "const S c = cos(d[0]), s = sin(d[0]);\nxp[0] = x[0] * c - x[1] * s;\nxp[1] = x[1] * c + x[0] * s;", /*x_scalars=*/2);
+  JitResidual<double> by_angle(ctx, "const S c = cos(x[0]), s = sin(x[0]);\nr[0] = c * p[0] - s * p[1] - p[2];\nr[1] = s * p[0] + c * p[1] - p[3];", 1, 4, 2);
+  std::vector<double> xc{std::cos(0.4), std::sin(0.4)}, xa{0.4};
+  const auto oc = Optimize(xc, on_circle.bind(1, items, data.data()), Options());
+  const auto oa = Optimize(xa, by_angle.bind(1, items, data.data()), Options());
+  REQUIRE(oc.Succeeded(0) && oc.Converged(0) && oa.Converged(0));
+  REQUIRE(oc.num_iters[0] == oa.num_iters[0]);
+  REQUIRE(std::abs(std::atan2(xc[1], xc[0]) - truth) < 1e-8 && std::abs(xa[0] - truth) < 1e-8);
+  REQUIRE(std::abs(xc[0] * xc[0] + xc[1] * xc[1] - 1) < 1e-12);          // stays on the manifold
+  bool threw = false;
+  try {
+    JitResidual<double> bad(ctx, "r[0] = x[0];", 1, 0, 1, 0, TOA_MANIFOLD_USER);      // no plus body
+  } catch (const std::exception&) {
+    threw = true;
+  }
+  REQUIRE(threw);
+}
+
 // tests/cov.cpp:20-47 — Gaussian prior with sigma = 4.2: covariance from the final Hessian recovers sigma
 static void prior_cov() {
   Context ctx(0);
@@ -472,6 +505,7 @@ int main() {
   circle();
   circle_jit();
   jit_manifold_and_manual();
+  jit_user_manifold();
   prior_cov();
   run<double>(5, 12, 200, 1e-7);
   run<float>(3, 50, 600, 2e-3);
