@@ -1062,13 +1062,64 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
 template <typename T>
 __device__ __forceinline__ T chol_bcast(const T v, const int src) { return wave_bcast(v, src); }
 constexpr int kCholThreads = 512;
+// The diagonal block of large_chol_solve_kernel: ONE wavefront factors the 32 x 32 block whose lower triangle sits in LDS (row stride
+// LS), lane r = row r in registers, in place; 1 / L_jj to rs_out.  A function of its own (round 5): inlined twice into the kernel,
+// its 500 lane broadcasts and 64 row registers pushed the fp64 kernel to the 256-register limit with hipcc hoisting ~900 scalar and
+// ~70 vector values of the other phases into spill slots (and a scratch reload + s_waitcnt in front of the look-ahead loads).
+//   32 unrolled Cholesky columns: column j before its scaling, lane by lane, comes out of the register by v_readlane (lane index =
+//   compile-time constant; one LDS round trip per column until late round 4); one division per pivot (A_ij / d against the unscaled
+//   column); the scalings 1 / sqrt(d_j) once at the end, lane j takes the root of ITS pivot (one sqrt and one division per lane)
+#ifndef TOA_CHOL_DIAG_CALL
+#define TOA_CHOL_DIAG_CALL __forceinline__
+#endif
+// a uniform base pointer + a 32-bit byte offset per lane: hipcc addresses it as global_load v, v_off, s[base] — one register per
+// address instead of two, no 64-bit index arithmetic (the kernel holds 32 such addresses at a time where it moves a panel row block)
+template <typename T>
+__device__ __forceinline__ T ld_at(const T* base, const unsigned elem) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * unsigned(sizeof(T))); }
+template <typename T>
+__device__ __forceinline__ void st_at(T* base, const unsigned elem, const T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * unsigned(sizeof(T))) = v; }
+template <typename T, int LS>
+__device__ TOA_CHOL_DIAG_CALL void chol_diag_block(__attribute__((address_space(3))) T* Ld, __attribute__((address_space(3))) T* rs_out,
+                                             __attribute__((address_space(3))) int* fail, const int bs) {
+  constexpr int B = 32;
+  const int lane = threadIdx.x & 63;
+  T r[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? Ld[lane * LS + c] : T(0);   // (columns past the diagonal are never read)
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const T d = wave_bcast(r[j], j);                   // the pivot: entry (j, j) after the updates of columns < j
+    const bool live = j < bs;
+    const bool pos = d > T(0) && d <= NumLimits<T>::max();
+    if (live && !pos) bad = true;
+    const T dd = (live && pos) ? d : T(1);
+    const T t = r[j] * (T(1) / dd);                    // A_ij / d: with the unscaled A_cj this is L_ij L_cj
+#pragma unroll
+    for (int c = j + 1; c < B; ++c) r[c] = fma(-t, wave_bcast(r[j], c), r[c]);   // (lanes < c hold zeros there and are not stored)
+    __builtin_amdgcn_sched_barrier(0);                 // one column's broadcasts at a time
+  }
+  T dj = T(1);
+#pragma unroll
+  for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
+  const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
+#pragma unroll
+  for (int c = 0; c < B; ++c) r[c] *= wave_bcast(rs, c);   // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
+  if (lane < bs) {
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      if (c <= lane && c < bs) Ld[lane * LS + c] = r[c];
+    rs_out[lane] = rs;                                 // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
+  }
+  if (bad && lane == 0) *fail = 1;
+}
 // LOOK (round 4): look-ahead — in the trailing-update phase of block k, wave 0 updates the four tiles that hold the NEXT diagonal
 // block first and factors it at once, while the other seven waves update the rest; the next step then starts at its panel.  The
 // diagonal blocks were 0.17 of an n = 384 fp64 solve's 0.68 ms with seven of eight waves waiting; every tile and every pivot
 // sees the arithmetic it saw before (which wave computes a tile never mattered): the same bits, checked against LOOK = false.
 template <typename T, bool LOOK = true>
 __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const LargeArgs<T> a) {
-  constexpr int B = 32, LS = B + 1, LSP = B + 4, NT = kCholThreads, NW = NT / 64;
+  constexpr int B = 32, LS = B + 4, LSP = B + 4, NT = kCholThreads, NW = NT / 64;   // (LS: rows of the block 16-byte aligned — the panel reads them four / two entries per ds_read_b128)
   extern __shared__ __attribute__((aligned(16))) char chol_lds[];
   T* Ld = reinterpret_cast<T*>(chol_lds);          // [B][LS]   the factored diagonal block
   T* Lp = Ld + B * LS;                             // [n][LSP]  the panel's rows below it (row i of the matrix at Lp[i - k1]); row stride 36:
@@ -1077,58 +1128,64 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   __shared__ int fail;
   const size_t p = blockIdx.x;
   if (!a.on(p) || !(a.built[p] & 1)) return;
-  const int n = a.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = a.n, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  int tid = threadIdx.x, lane = tid & 63;   // (not const: see TOA_CHOL_FRESH_LANE)
+  // hipcc hoists every per-lane invariant of the block loop's phases (LDS addresses, masks like c == lane, row offsets: hundreds of
+  // values) in front of the loop and then spills them — scratch reloads with an s_waitcnt in front of loads that should be in flight
+  // together.  The lane index is re-declared opaque at the head of each phase: what depends on it is computed where it is used.
+#define TOA_CHOL_FRESH_LANE asm volatile("" : "+v"(lane), "+v"(tid));   // (uniform for hipcc: tile indices, trip counts and the wave-0 branches live in scalar registers)
   T* A = a.work + p * size_t(n) * n;
   for (int i = tid; i < n; i += NT) ys[i] = a.rhs[p * n + i];
   if (tid == 0) fail = 0;
   __syncthreads();
 #ifdef TOA_CHOL_TIMING
-  unsigned long long tkc[6] = {0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
-#define CH_TICK(i) { const unsigned long long now_ = wall_clock64(); tkc[i] += now_ - tprev; tprev = now_; }
+  __shared__ unsigned long long wt[8], wt0[8];
+  if (tid < 8) wt[tid] = wt0[tid] = 0;
+  const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+  unsigned long long tkc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64(), tsub = tprev;
+#define CH_TICK(i) { const unsigned long long now_ = wall_clock64(); tkc[i] += now_ - tprev; tprev = now_; tsub = now_; }
+#define CH_SUB(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); tkc[i] += now_ - tsub; tsub = now_; }
 #else
 #define CH_TICK(i)
+#define CH_SUB(i)
 #endif
-  // the diagonal block at k0: wave 0, lane r holds row r of the block (columns past the diagonal are never read)
-  auto diag_block = [&](const int k0, const int bs) __attribute__((always_inline)) {
-    T r[B];
+  // the diagonal block at k0 (wave 0): chol_diag_block on the copy in Ld.  `staged`: the look-ahead left the updated entries there —
+  // no store / fence / reload through the matrix (round 5); otherwise they come from the matrix first, lane = column.  The factored
+  // block reaches the matrix from the last wave during the panel phase.
+  auto diag_block = [&](const int k0, const int bs, const bool staged) __attribute__((always_inline)) {
+    if (!staged) {
+      const int col = lane & 31;
+      T in[B / 2];
 #pragma unroll
-    for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? A[size_t(k0 + lane) * n + k0 + c] : T(0);
-    bool bad = false;
+      for (int q = 0; q < B / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        in[q] = (row < bs && col <= row) ? ld_at(A, unsigned((k0 + row) * n + k0 + col)) : T(0);
+      }
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-      // column j before its scaling, lane by lane, comes out of the register by v_readlane (lane index = compile-time constant) instead of
-      // an LDS round trip per column (write, wave barrier, 32 - j broadcast reads).  One column's broadcasts at a time (sched_barrier).
-      const T d = chol_bcast(r[j], j);                 // the pivot: entry (j, j) after the updates of columns < j
-      const bool live = j < bs;
-      const bool pos = d > T(0) && d <= NumLimits<T>::max();
-      if (live && !pos) bad = true;
-      const T dd = (live && pos) ? d : T(1);
-      const T t = r[j] * (T(1) / dd);                  // A_ij / d: with the unscaled A_cj this is L_ij L_cj
-#pragma unroll
-      for (int c = j + 1; c < B; ++c) r[c] = fma(-t, chol_bcast(r[j], c), r[c]);   // (lanes < c hold zeros there and are not stored)
-      __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < B / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        if (row < bs && col <= row) Ld[row * LS + col] = in[q];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    // the scaling by 1 / sqrt(d_j), once for all columns: lane j takes the root of ITS pivot (one sqrt and one division per lane,
-    // not one per column in lockstep — that was 3.7 of a block's 16 us), the 32 factors come back as lane broadcasts
-    T dj = T(1);
-#pragma unroll
-    for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
-    const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
-#pragma unroll
-    for (int c = 0; c < B; ++c) r[c] *= chol_bcast(rs, c);   // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
-    if (lane < bs) {
-#pragma unroll
-      for (int c = 0; c < B; ++c)
-        if (c <= lane && c < bs) { Ld[lane * LS + c] = r[c]; A[size_t(k0 + lane) * n + k0 + c] = r[c]; }
-      ys[n + 64 + lane] = rs;                          // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
-    }
-    if (bad && lane == 0) fail = 1;
+#ifdef TOA_CHOL_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long td0 = wall_clock64();
+#endif
+    using L3 = __attribute__((address_space(3))) T*;
+    chol_diag_block<T, LS>((L3)Ld, (L3)(ys + n + 64), (__attribute__((address_space(3))) int*)&fail, bs);
+#ifdef TOA_CHOL_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long td2 = wall_clock64();
+    tkc[5] += td0 - tsub; tkc[6] += td2 - td0; tsub = td2;
+#endif
   };
   bool have_diag = false;   // LOOK: the block was factored during the previous step's trailing update
   for (int k0 = 0; k0 < n; k0 += B) {
     const int bs = min(B, n - k0), k1 = k0 + bs;
+    TOA_CHOL_FRESH_LANE
     if (!have_diag) {
-      if (wave == 0) diag_block(k0, bs);
+      if (wave == 0) diag_block(k0, bs, false);
       __syncthreads();
     }
     CH_TICK(0)
@@ -1154,30 +1211,98 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
         if (lane < bs) ys[k0 + lane] = y;
       }
     }
-    // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update)
-    for (int i = k1 + tid; i < n; i += NT) {
-      T x[B];
+    // ---- the rows below: x L_kk^T = a, a thread per row; the result to the matrix (L) and to LDS (for the update).  Round 5:
+    //  * a thread per row read its 32 entries with 32 loads that touch 64 cache lines each and stored them the same way; now each
+    //    wave moves its 64 rows between the matrix and the panel in LDS with lane = column (two rows, four lines per instruction)
+    //  * the block's rows sit 16-byte aligned in LDS (stride 36): row c's entries come four (fp32) / two (fp64) per ds_read_b128 — the
+    //    phase was bound by the NUMBER of broadcast reads (496 per row and wave), not by their bytes; the right-looking order
+    //    (independent FMAs, strided reads of one entry each) measured 50 % slower for that reason
+    //  * every difference / product is in a register before the first store of a group: hipcc put an s_waitcnt vmcnt(0) in front
+    //    of each predicated store whose value was loaded — each store waiting for the previous one's acknowledgement
+    // (rows below exist only under a full block: bs == B here)
+    if (wave == NW - 1) {   // the factored block goes to the matrix from here, off wave 0's path (the substitutions read it there)
+      const int col = lane & 31;
 #pragma unroll
-      for (int c = 0; c < B; ++c) x[c] = c < bs ? A[size_t(i) * n + k0 + c] : T(0);
+      for (int q = 0; q < B / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        if (row < bs && col <= row) st_at(A, unsigned((k0 + row) * n + k0 + col), Ld[row * LS + col]);
+      }
+    }
+    for (int rb = k1 + 64 * wave; rb < n; rb += NT) {
+      {
+        T in[B];
+        const int col = lane & 31;
 #pragma unroll
-      for (int c = 0; c < B; ++c) {
-        asm volatile("" ::: "memory");   // (the block's entries are read where they are used: hoisted out of the row loop they are 528 registers)
-        if (c < bs) {
+        for (int q = 0; q < B; ++q) {
+          const int row = min(rb + 2 * q + (lane >> 5), n - 1);
+          in[q] = ld_at(A, unsigned(row * n + k0 + col));
+        }
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+          const int row = rb + 2 * q + (lane >> 5);
+          if (row < n) Lp[(row - k1) * LSP + col] = in[q];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      CH_SUB(8)
+      const int i = rb + lane;
+      if (i < n) {
+        T x[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) x[c] = Lp[(i - k1) * LSP + c];
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+          asm volatile("" ::: "memory");   // (the block's entries are read where they are used: hoisted out of the row loop they are 528 registers)
           T v = x[c];
 #pragma unroll
           for (int t = 0; t < c; ++t) v = fma(-x[t], Ld[c * LS + t], v);
           x[c] = v * ys[n + 64 + c];
         }
-      }
 #pragma unroll
-      for (int c = 0; c < B; ++c) {
-        if (c < bs) A[size_t(i) * n + k0 + c] = x[c];
-        Lp[size_t(i - k1) * LSP + c] = x[c];
+        for (int c = 0; c < B; ++c) Lp[(i - k1) * LSP + c] = x[c];
       }
+      __builtin_amdgcn_wave_barrier();
+      CH_SUB(9)
+      {
+        const int col = lane & 31;
+        T out[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) out[q] = Lp[(min(rb + 2 * q + (lane >> 5), n - 1) - k1) * LSP + col];
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+          const int row = rb + 2 * q + (lane >> 5);
+          if (row < n) st_at(A, unsigned(row * n + k0 + col), out[q]);
+        }
+      }
+      CH_SUB(10)
+    }
+    // the trailing block at k1: r rows, nt x nt tiles of 16 x 16, the lower triangle's ntile tiles numbered row-major.  A tile's four
+    // values per lane: element (out_row(lane, reg), lane & 15) of tile (ti, tj) = Ak[16 ti n + 16 tj + lane_off + reg * reg_step]
+    TOA_CHOL_FRESH_LANE
+    using Acc = typename Mfma<T>::Acc;
+    constexpr int U = sizeof(T) == 8 ? 2 : 4;          // tiles per trip (fp64, four: 211 -> 227 us in round 3, no better in round 5)
+    const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
+    const int l15 = lane & 15, kq = lane >> 4;
+    T* const Ak = A + size_t(k1) * n + k1;
+    const int lane_off = Mfma<T>::out_row(lane, 0) * n + l15;
+    const int reg_step = (Mfma<T>::out_row(0, 1) - Mfma<T>::out_row(0, 0)) * n;
+    auto tile_full = [&](const int ti, const int tj) __attribute__((always_inline)) { return ti != tj && 16 * ti + 16 <= r; };
+    const bool look = LOOK && k1 < n;   // there is a next diagonal block: tiles 0 .. 2 of the trailing triangle (3 rides along)
+    T look_old[4][4];                   // wave 0: their old values (final since the last barrier), asked for at the end of the panel phase
+    // (on their way across the barrier, the y update and the products; held across the whole panel phase they cost 32 registers
+    //  beside a row's 64 and the kernel spilled)
+    if (look && wave == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int gi = 16 * (u == 0 ? 0 : u == 3 ? 2 : 1) + Mfma<T>::out_row(lane, reg), gj = 16 * (u == 2 ? 1 : 0) + l15;
+          look_old[u][reg] = (gi < r && gj <= gi) ? ld_at(Ak, unsigned(gi * n + gj)) : T(0);
+        }
     }
     __syncthreads();
     CH_TICK(1)
-    // ---- trailing update A22 -= L21 L21^T on the matrix cores: 16 x 16 tiles of the lower triangle dealt to the four waves, both
+    // ---- trailing update A22 -= L21 L21^T on the matrix cores: 16 x 16 tiles of the lower triangle dealt to the waves, both
     // operands straight from the panel in LDS (row stride 36: conflict-free), eight v_mfma_*_16x16x4 per tile, then a
     // read-modify-write of the tile in the L2-resident matrix.  (A lane per column with the rows in batches of eight — VALU, one
     // dependent global round trip per batch — took 122 us of a 376 us n = 256 solve.)
@@ -1185,18 +1310,62 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
       if constexpr (LOOK) {   // y_i -= L_i,k . y_k for the rows below, from the panel in LDS (same order of FMAs as the separate pass)
         for (int i = k1 + tid; i < n; i += NT) {
           T sy = ys[i];
-          const T* Li = Lp + size_t(i - k1) * LSP;
+          const T* Li = Lp + (i - k1) * LSP;
 #pragma unroll
-          for (int c = 0; c < B; ++c) sy = fma(-Li[c], ys[k0 + (c < bs ? c : 0)], sy);
+          for (int c = 0; c < B; ++c) sy = fma(-Li[c], ys[k0 + c], sy);
           ys[i] = sy;
         }
       }
-      using Acc = typename Mfma<T>::Acc;
-      const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
-      const int l15 = lane & 15, kq = lane >> 4;
-      constexpr int U = sizeof(T) == 8 ? 2 : 4;
-      // U tiles per trip (t, t + step, ...): their old values are in flight under the MFMAs
-      auto trip = [&](const int t, const int step) __attribute__((always_inline)) {
+      // the products of N tiles: the tiles take turns on the matrix pipe, the operands of the next step on their way from LDS during
+      // the MFMAs of this one (round 5; tile after tile the 8 MFMAs of a tile were one dependent chain with an exposed LDS round
+      // trip per pair, and an fp64 16x16x4 occupies the pipe for 64 cycles on this part).  Each tile still sums q = 0 .. 7 in order.
+      auto products = [&](const auto& ti, const auto& tj, auto& acc) __attribute__((always_inline)) {
+        constexpr int N = int(sizeof(ti) / sizeof(ti[0]));
+#pragma unroll
+        for (int u = 0; u < N; ++u) acc[u] = Acc{0, 0, 0, 0};
+        const T* pa[N];
+        const T* pb[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+          pa[u] = Lp + (16 * ti[u] + l15) * LSP + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
+          pb[u] = Lp + (16 * tj[u] + l15) * LSP + kq;
+        }
+#pragma unroll
+        for (int q = 0; q < B / 4; ++q)
+#pragma unroll
+          for (int u = 0; u < N; ++u) acc[u] = Mfma<T>::fma(pa[u][4 * q], pb[u][4 * q], acc[u]);
+        // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
+        if constexpr (N == 4) asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+        else asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]));
+      };
+      auto store_res = [&](const int t, const int step, const int (&ti)[U], const int (&tj)[U], const T (&res)[U][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (t + u * step < ntile) {
+            T* dst = Ak + (16 * ti[u] * n + 16 * tj[u]);
+            if (tile_full(ti[u], tj[u])) {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) st_at(dst, unsigned(lane_off + reg * reg_step), res[u][reg]);
+            } else {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int gi = 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = 16 * tj[u] + l15;
+                if (gi < r && gj <= gi) st_at(dst, unsigned(lane_off + reg * reg_step), res[u][reg]);
+              }
+            }
+          }
+        }
+      };
+      // trips t, t + U step, ... of this wave.  What round 5 found in a trip (n = 384 fp64, 1.9 us per two tiles, 0.4 of them MFMAs):
+      //  * `A = old - acc` inside each predicated store: hipcc put an s_waitcnt vmcnt(0) in front of every store (a loaded register
+      //    first read after a branch join), each store waiting for the previous one's acknowledgement — every difference is in
+      //    a register before the first store now
+      //  * t -> (ti, tj) as a loop from zero, in VECTOR registers with the wave index = threadIdx >> 6 (0.7 us per trip): the wave
+      //    index is uniform by readfirstlane, the pair is carried from trip to trip
+      //  * per-lane masks and 64-bit index arithmetic per access: tiles off the diagonal that end inside the matrix go without
+      // (the trip's old values loaded one trip ahead, two register sets: built, measured, no change — dropped)
+      auto sweep = [&](int t, const int step) __attribute__((always_inline)) {
+        const int stride = U * step;
         int ti[U], tj[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {                    // t -> (ti, tj), ti >= tj, row-major over the lower triangle
@@ -1204,47 +1373,75 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
           while (rem > row) { rem -= row + 1; ++row; }
           ti[u] = row; tj[u] = rem;
         }
-        T old[U][4];
+        for (; t < ntile; t += stride) {
+          T old[U][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+          for (int u = 0; u < U; ++u) {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            old[u][reg] = (t + u * step < ntile && gi < n && gj <= gi) ? A[size_t(gi) * n + gj] : T(0);
+            for (int reg = 0; reg < 4; ++reg) old[u][reg] = T(0);
+            if (t + u * step < ntile) {
+              const T* src = Ak + (16 * ti[u] * n + 16 * tj[u]);
+              if (tile_full(ti[u], tj[u])) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) old[u][reg] = ld_at(src, unsigned(lane_off + reg * reg_step));
+              } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                  const int gi = 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = 16 * tj[u] + l15;
+                  if (gi < r && gj <= gi) old[u][reg] = ld_at(src, unsigned(lane_off + reg * reg_step));
+                }
+              }
+            }
           }
-        Acc acc[U];
+          Acc acc[U];
+          products(ti, tj, acc);
+          T res[U][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = Acc{0, 0, 0, 0};
+          for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const T* pa = Lp + size_t(16 * ti[u] + l15) * LSP + kq;   // (rows past the trailing block hold stale panel rows: their products are not stored)
-          const T* pb = Lp + size_t(16 * tj[u] + l15) * LSP + kq;
+            for (int reg = 0; reg < 4; ++reg) { res[u][reg] = old[u][reg] - acc[u][reg]; asm volatile("" : "+v"(res[u][reg])); }
+          store_res(t, step, ti, tj, res);
 #pragma unroll
-          for (int q = 0; q < B / 4; ++q) acc[u] = Mfma<T>::fma(pa[4 * q], pb[4 * q], acc[u]);
+          for (int u = 0; u < U; ++u) {                  // the same tiles of the next trip
+            tj[u] += stride;
+            while (tj[u] > ti[u]) { tj[u] -= ti[u] + 1; ++ti[u]; }
+          }
         }
-        if constexpr (U == 4) asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
-        else asm volatile("s_nop 9" : "+a"(acc[0]), "+a"(acc[1]));   // (hipcc's own wait states for the builtin are enough for the hardware; tools/isa_lint.py asks for the 16-pass margin)
+      };
+#ifdef TOA_CHOL_TIMING
+      const unsigned long long tw0 = wall_clock64();
+#endif
+      if (!look) {
+        sweep(wave, NW);
+      } else if (wave == 0) {
+        // look-ahead: the four tiles that hold the next diagonal block (their old values came in before the panel phase), the block
+        // staged in Ld — no store / fence / reload through the matrix — and factored at once; tile 3 = (2, 0) rides along
+        const int lti[4] = {0, 1, 1, 2}, ltj[4] = {0, 0, 1, 0};
+        Acc acc[4];
+        products(lti, ltj, acc);
+        T res[4][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) { res[u][reg] = look_old[u][reg] - acc[u][reg]; asm volatile("" : "+v"(res[u][reg])); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const int gi = k1 + 16 * ti[u] + Mfma<T>::out_row(lane, reg), gj = k1 + 16 * tj[u] + l15;
-            if (t + u * step < ntile && gi < n && gj <= gi) A[size_t(gi) * n + gj] = old[u][reg] - acc[u][reg];
+            const int gi = 16 * lti[u] + Mfma<T>::out_row(lane, reg), gj = 16 * ltj[u] + l15;
+            if (u < 3) { if (gi < r && gj <= gi) Ld[gi * LS + gj] = res[u][reg]; }
+            else if (gi < r) st_at(Ak, unsigned(gi * n + gj), res[u][reg]);
           }
-      };
-      const bool look = LOOK && k1 < n;   // there is a next diagonal block: tiles 0 .. 2 of the trailing triangle (3 rides along)
-      if (!look) {
-        for (int t = wave; t < ntile; t += U * NW) trip(t, NW);
-      } else if (wave == 0) {
-        for (int t = 0; t < 4; t += U) trip(t, 1);
-        // wave 0's own stores of those tiles, then its loads of the block: ordered through the workgroup's memory scope
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        diag_block(k1, min(B, n - k1));
+        __builtin_amdgcn_wave_barrier();
+        diag_block(k1, min(B, n - k1), true);
       } else {
-        for (int t = 4 + (wave - 1); t < ntile; t += U * (NW - 1)) trip(t, NW - 1);
+        sweep(4 + (wave - 1), NW - 1);
       }
       have_diag = look;
+#ifdef TOA_CHOL_TIMING
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (lane == 0) { wt[wave] += wall_clock64() - tw0; if (k0 == 0) wt0[wave] = wall_clock64() - tw0; }
+#endif
     }
     __syncthreads();
     CH_TICK(2)
@@ -1343,13 +1540,17 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   }
   CH_TICK(4)
 #ifdef TOA_CHOL_TIMING
-  if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01);
+  if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us | wave 0: tiles+loads %.1f chain %.1f scale+store %.1f | panel: in %.1f rows %.1f out %.1f\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01,
+                              tkc[5] * 0.01, tkc[6] * 0.01, tkc[7] * 0.01, tkc[8] * 0.01, tkc[9] * 0.01, tkc[10] * 0.01);
+  if (tid == 0 && p == 0) printf("chol n=%d: shader clock %.0f MHz over the kernel\n", n, double(clock64() - clk0) / (double(wall_clock64() - wall0) * 0.01));
+  if (tid == 0 && p == 0) printf("chol n=%d: update phase by wave, all steps: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f | step 0: %.1f %.1f %.1f %.1f\n", n, wt[0] * 0.01, wt[1] * 0.01, wt[2] * 0.01, wt[3] * 0.01, wt[4] * 0.01, wt[5] * 0.01, wt[6] * 0.01, wt[7] * 0.01,
+                              wt0[0] * 0.01, wt0[1] * 0.01, wt0[4] * 0.01, wt0[7] * 0.01);
 #endif
   for (int i = tid; i < n; i += NT) a.rhs[p * n + i] = ys[i];
   if (tid == 0) a.info[p] = 0;
 }
 template <typename T>
-inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 33 + size_t(n) * 36 + size_t(n) + 64 + 32) * sizeof(T) + 64; }
+inline size_t chol_solve_lds_bytes(int n) { return (size_t(32) * 36 + size_t(n) * 36 + size_t(n) + 64 + 32) * sizeof(T) + 64; }
 
 template <typename T>
 inline size_t ldlt_image_bytes(int n) { return ((size_t(n) * (n | 1) + 16) * sizeof(T) + 15) & ~size_t(15); }
@@ -2062,7 +2263,7 @@ int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, co
                     int32_t* ok) {
   const bool force_lib = h->tune.large_library_solver != 0;
   const size_t chol_lds = ((size_t(n) * (n | 1) + 16) * (dtype == TOA_F32 ? 4 : 8) + 15) & ~size_t(15);
-  const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
+  const size_t chol2_lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
   const bool own2 = n > 128 && P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds);   // the one-workgroup blocked Cholesky (fp32: n <= 1024, fp64: n <= 512)
   if (!force_lib && ((n <= 128 && chol_lds + 4096 <= size_t(h->max_lds)) || own2)) {  // the workgroup LDL^T (ldlt_wg.hpp) / blocked Cholesky; the library beyond
     if (dtype == TOA_F32)
@@ -2089,7 +2290,7 @@ int toa_large_solve_unchecked(toa_handle h, int dtype, int n, int64_t P, const v
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok) {
   {  // our own kernels are batch-independent by construction (one workgroup per matrix, fixed-order sums): one launch for all
     const bool force_lib = h->tune.large_library_solver != 0;
-    const size_t chol2_lds = (size_t(32) * 33 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
+    const size_t chol2_lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;
     if (!force_lib && (n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds)))) return toa_large_solve(h, dtype, n, P, H, g, scale, dx, ok);
   }
   toa::RocApi& api = toa::roc_api();
