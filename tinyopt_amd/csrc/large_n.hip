@@ -17,6 +17,7 @@
 
 #include "kernels.hpp"
 #include "ldlt_wg.hpp"
+#include "chol_diag.hpp"
 
 namespace toa {
 namespace {
@@ -1062,57 +1063,6 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
 template <typename T>
 __device__ __forceinline__ T chol_bcast(const T v, const int src) { return wave_bcast(v, src); }
 constexpr int kCholThreads = 512;
-// The diagonal block of large_chol_solve_kernel: ONE wavefront factors the 32 x 32 block whose lower triangle sits in LDS (row stride
-// LS), lane r = row r in registers, in place; 1 / L_jj to rs_out.  A function of its own (round 5): inlined twice into the kernel,
-// its 500 lane broadcasts and 64 row registers pushed the fp64 kernel to the 256-register limit with hipcc hoisting ~900 scalar and
-// ~70 vector values of the other phases into spill slots (and a scratch reload + s_waitcnt in front of the look-ahead loads).
-//   32 unrolled Cholesky columns: column j before its scaling, lane by lane, comes out of the register by v_readlane (lane index =
-//   compile-time constant; one LDS round trip per column until late round 4); one division per pivot (A_ij / d against the unscaled
-//   column); the scalings 1 / sqrt(d_j) once at the end, lane j takes the root of ITS pivot (one sqrt and one division per lane)
-#ifndef TOA_CHOL_DIAG_CALL
-#define TOA_CHOL_DIAG_CALL __forceinline__
-#endif
-// a uniform base pointer + a 32-bit byte offset per lane: hipcc addresses it as global_load v, v_off, s[base] — one register per
-// address instead of two, no 64-bit index arithmetic (the kernel holds 32 such addresses at a time where it moves a panel row block)
-template <typename T>
-__device__ __forceinline__ T ld_at(const T* base, const unsigned elem) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem * unsigned(sizeof(T))); }
-template <typename T>
-__device__ __forceinline__ void st_at(T* base, const unsigned elem, const T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem * unsigned(sizeof(T))) = v; }
-template <typename T, int LS>
-__device__ TOA_CHOL_DIAG_CALL void chol_diag_block(__attribute__((address_space(3))) T* Ld, __attribute__((address_space(3))) T* rs_out,
-                                             __attribute__((address_space(3))) int* fail, const int bs) {
-  constexpr int B = 32;
-  const int lane = threadIdx.x & 63;
-  T r[B];
-#pragma unroll
-  for (int c = 0; c < B; ++c) r[c] = (lane < bs && c <= lane && c < bs) ? Ld[lane * LS + c] : T(0);   // (columns past the diagonal are never read)
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < B; ++j) {
-    const T d = wave_bcast(r[j], j);                   // the pivot: entry (j, j) after the updates of columns < j
-    const bool live = j < bs;
-    const bool pos = d > T(0) && d <= NumLimits<T>::max();
-    if (live && !pos) bad = true;
-    const T dd = (live && pos) ? d : T(1);
-    const T t = r[j] * (T(1) / dd);                    // A_ij / d: with the unscaled A_cj this is L_ij L_cj
-#pragma unroll
-    for (int c = j + 1; c < B; ++c) r[c] = fma(-t, wave_bcast(r[j], c), r[c]);   // (lanes < c hold zeros there and are not stored)
-    __builtin_amdgcn_sched_barrier(0);                 // one column's broadcasts at a time
-  }
-  T dj = T(1);
-#pragma unroll
-  for (int c = 0; c < B; ++c) dj = c == lane ? r[c] : dj;
-  const T rs = (lane < bs && dj > T(0) && dj <= NumLimits<T>::max()) ? T(1) / sqrt(dj) : T(1);
-#pragma unroll
-  for (int c = 0; c < B; ++c) r[c] *= wave_bcast(rs, c);   // lane j, column j: d / sqrt(d) = l; lanes > j: L_ij
-  if (lane < bs) {
-#pragma unroll
-    for (int c = 0; c < B; ++c)
-      if (c <= lane && c < bs) Ld[lane * LS + c] = r[c];
-    rs_out[lane] = rs;                                 // 1 / L_jj: the panel rows multiply by these (32 divisions per row were 2.4 us of a panel's 11.6)
-  }
-  if (bad && lane == 0) *fail = 1;
-}
 // LOOK (round 4): look-ahead — in the trailing-update phase of block k, wave 0 updates the four tiles that hold the NEXT diagonal
 // block first and factors it at once, while the other seven waves update the rest; the next step then starts at its panel.  The
 // diagonal blocks were 0.17 of an n = 384 fp64 solve's 0.68 ms with seven of eight waves waiting; every tile and every pivot
@@ -1515,17 +1465,82 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     // look-ahead again: once block k is solved, wave 0 updates the 32 unknowns of the block ABOVE it and solves that block at
     // once, while the other waves update the unknowns further up — one barrier per block instead of two, and the serial
     // 32-step chain of a block runs beside the updates of the previous one.  Every unknown sees the same FMAs in the same order.
+    // Round 5: wave 0's two operand blocks (the diagonal block above and the 32 x 32 block between) are in LDS when it gets there —
+    // wave 1 fetches them one block ahead into the idle panel buffer (two parities) — instead of two dependent L2 round trips per
+    // block in front of the chain: 4.7 -> ~2 us per block.
     const int klast = ((n - 1) / B) * B;
+    auto stage_blocks = [&](const int k0, const int bs, const int par) __attribute__((always_inline)) {   // one wave: what takes wave 0 from block k0 to block k0 - B
+      const int kn = k0 - B, col = lane & 31;
+      T* sd = Lp + 2 * par * B * LSP;
+      T* sb = sd + B * LSP;
+      T v1[B / 2], v2[B / 2];
+#pragma unroll
+      for (int q = 0; q < B / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        v1[q] = row >= col ? ld_at(A, unsigned((kn + row) * n + kn + col)) : T(0);
+        v2[q] = row < bs ? ld_at(A, unsigned((k0 + row) * n + kn + col)) : T(0);
+      }
+#pragma unroll
+      for (int q = 0; q < B / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        sd[row * LSP + col] = v1[q];
+        sb[row * LSP + col] = v2[q];
+      }
+    };
+    // the chain of one block: xv = the right-hand side of unknown `lane` with every block below already taken off
+    auto solve_block = [&](const int kb, const int bsb, T xv, const T (&lcol)[B]) __attribute__((always_inline)) {
+      T ldiag = T(1);
+#pragma unroll
+      for (int c = 0; c < B; ++c) ldiag = (c == lane && c < bsb) ? lcol[c] : ldiag;
+      ldiag = T(1) / ldiag;
+#pragma unroll
+      for (int c = B - 1; c >= 0; --c) {
+        const T xc = chol_bcast(xv * ldiag, c);          // lane c: its unknown (for c >= bs: 0)
+        if (lane == c) xv = xc;
+        else if (lane < c) xv = fma(-lcol[c], xc, xv);   // L_c,lane: the entry of L^T this lane's equation holds for unknown c
+      }
+      if (lane < bsb) ys[kb + lane] = xv;
+    };
+    // the other waves' unknown j0 (first trip): its 32 entries of the NEXT block's rows are loaded one block ahead as well
+    const int j0 = tid - 64;
+    T lvN[B];
+    auto load_rows = [&](const int k0, const int bs, T (&lv)[B]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) lv[c] = (c < bs && j0 < k0 - B) ? ld_at(A, unsigned((k0 + c) * n + j0)) : T(0);   // (coalesced across lanes)
+    };
     if (wave == 0) back_block(klast, min(B, n - klast));
+    else {
+      if (wave == 1 && klast > 0) stage_blocks(klast, min(B, n - klast), 0);
+      load_rows(klast, min(B, n - klast), lvN);
+    }
     __syncthreads();
-    for (int k0 = klast; k0 > 0; k0 -= B) {
+    int par = 0;
+    for (int k0 = klast; k0 > 0; k0 -= B, par ^= 1) {
       const int bs = min(B, n - k0), kn = k0 - B;      // (every block above the last one is full)
       if (wave == 0) {
-        if (lane < B) back_update(kn + lane, k0, bs);
-        __builtin_amdgcn_wave_barrier();
-        back_block(kn, B);
+        const T* sd = Lp + 2 * par * B * LSP;
+        const T* sb = sd + B * LSP;
+        const int l31 = lane & 31;
+        T lcol[B], lv[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) { lcol[c] = (lane < B && c >= lane) ? sd[c * LSP + l31] : T(0); lv[c] = lane < B ? sb[c * LSP + l31] : T(0); }
+        T sx = lane < B ? ys[kn + lane] : T(0);
+#pragma unroll
+        for (int c = 0; c < B; ++c) sx = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], sx);
+        solve_block(kn, B, sx, lcol);
       } else {
-        for (int j = tid - 64; j < kn; j += NT - 64) back_update(j, k0, bs);
+        T lv[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) lv[c] = lvN[c];
+        if (wave == 1 && kn > 0) stage_blocks(kn, B, par ^ 1);
+        if (kn > 0) load_rows(kn, B, lvN);
+        if (j0 < kn) {
+          T sx = ys[j0];
+#pragma unroll
+          for (int c = 0; c < B; ++c) sx = fma(-lv[c], ys[k0 + (c < bs ? c : 0)], sx);
+          ys[j0] = sx;
+        }
+        for (int j = j0 + NT - 64; j < kn; j += NT - 64) back_update(j, k0, bs);
       }
       __syncthreads();
     }
