@@ -1268,6 +1268,24 @@ __global__ void __launch_bounds__(256) bl_psolve_kernel(const BlParams* __restri
   w[wk.q + 3 * j + 2] = r22 * y2;
 }
 
+// *p += v on an LDS word nobody else touches concurrently: ds_add_f32 / ds_add_f64 without return (IEEE add, as v_add would)
+template <typename T>
+__device__ __forceinline__ void bl_lds_add(T* p, const T v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// K consecutive elements of a 64-byte aligned observation record as 16-byte loads (round 5: bl_schur_kernel's B stage issued 42
+// eight-byte loads per thread for the 18 values of a record pair: 8.3 of a 23.5 us chunk)
+template <int K, typename T>
+__device__ __forceinline__ void bl_load_rec(const T* __restrict__ src, T (&out)[K]) {
+  constexpr int W = 16 / int(sizeof(T));
+  using V = T __attribute__((ext_vector_type(W)));
+  static_assert(K % W == 0, "whole 16-byte words");
+#pragma unroll
+  for (int q = 0; q < K / W; ++q) {
+    const V v = *reinterpret_cast<const V*>(src + W * q);
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[W * q + k] = v[k];
+  }
+}
+
 // Block row c of the reduced camera system.  Thread c' (< C, in tiles of 256) owns block (c, c'); the camera's observations
 // are walked in list order in chunks of 64 whose per-observation factors T_i = J_c,i^T (J_p,i V_j^-1) (6 x 3) are staged
 // in LDS by the first 64 threads.  For observation i of point j, camera c' contributes iff it sees j: a binary search of
@@ -1320,15 +1338,22 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
   const bool live = lane < 54;
   const int ad = live ? 9 * (tid >> 6) + lane / kFast : 0, a = ad / 6, d = ad % 6;   // component (a, d), list entries ent, ent + 6, ...
   T rva = T(0);   // lanes (a, d = 0, entry 0): row a of W V^-1 g_p
+#ifdef TOA_BL_TIMING
+  unsigned long long tq[6] = {0, 0, 0, 0, 0, 0}, tp = wall_clock64();
+#define BL_TICK(i) { __syncthreads(); const unsigned long long now_ = wall_clock64(); tq[i] += now_ - tp; tp = now_; }
+#else
+#define BL_TICK(i)
+#endif
   for (int cbase = 0; cbase <= c; cbase += kTile) {                  // camera tiles of the lower block triangle
     for (int e = tid; e < kTile * 36; e += 256) (&Srow[0][0])[e] = T(0);
+    BL_TICK(0)
     for (int kk = k0; kk < k1; kk += kS) {
       __syncthreads();
       if (tid < kS && kk + tid < k1) {
         const int i = iw[ix.cam_order + kk + tid];
         const int j = prm->obs_pt[size_t(p) * M + i];
-        jl[tid] = j;
         const int a0 = iw[ix.pt_start + j], a1 = iw[ix.pt_start + j + 1];
+        jl[tid] = j;
         l0[tid] = a0;
         ln[tid] = a1 - a0;
         gl[tid][0] = w[wk.gp + 3 * j]; gl[tid][1] = w[wk.gp + 3 * j + 1]; gl[tid][2] = w[wk.gp + 3 * j + 2];
@@ -1339,59 +1364,93 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
         // V^-1 = R^-T R^-1 with R^-1 lower: rows
         const T v00 = r00 * r00 + r10 * r10 + r20 * r20, v01 = r10 * r11 + r20 * r21, v02 = r20 * r22;
         const T v11 = r11 * r11 + r21 * r21, v12 = r21 * r22, v22 = r22 * r22;
+        T jpi[8], jci[12];
+        bl_load_rec<8>(w + wk.Jp + size_t(i) * 8, jpi);
+        bl_load_rec<12>(w + wk.Jc + size_t(i) * 16, jci);
         T A[2][3];   // J_p,i V^-1 (2 x 3)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const T p0 = w[wk.Jp + size_t(i) * 8 + (3 * q)], p1 = w[wk.Jp + size_t(i) * 8 + (3 * q + 1)], p2 = w[wk.Jp + size_t(i) * 8 + (3 * q + 2)];
+          const T p0 = jpi[3 * q], p1 = jpi[3 * q + 1], p2 = jpi[3 * q + 2];
           A[q][0] = p0 * v00 + p1 * v01 + p2 * v02;
           A[q][1] = p0 * v01 + p1 * v11 + p2 * v12;
           A[q][2] = p0 * v02 + p1 * v12 + p2 * v22;
         }
 #pragma unroll
         for (int dd = 0; dd < 6; ++dd) {
-          const T jc0 = w[wk.Jc + size_t(i) * 16 + (dd)], jc1 = w[wk.Jc + size_t(i) * 16 + (6 + dd)];
+          const T jc0 = jci[dd], jc1 = jci[6 + dd];
 #pragma unroll
           for (int b = 0; b < 3; ++b) Tl[tid][3 * dd + b] = jc0 * A[0][b] + jc1 * A[1][b];
         }
       }
       __syncthreads();
+      BL_TICK(1)
       const int cnt = min(kS, k1 - kk);
       if (tid < kS * kFast) {   // B_se for the first kFast observers of every staged point
         const int s_ = tid / kFast, e_ = tid % kFast;
         if (s_ < cnt && e_ < ln[s_]) {
           const int i2 = l0[s_] + e_;
+          T jp[8], jc[12];
+          bl_load_rec<8>(w + wk.Jp + size_t(i2) * 8, jp);
+          bl_load_rec<12>(w + wk.Jc + size_t(i2) * 16, jc);
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
-            const T p0 = w[wk.Jp + size_t(i2) * 8 + (b)], p1 = w[wk.Jp + size_t(i2) * 8 + (3 + b)];
+            const T p0 = jp[b], p1 = jp[3 + b];
 #pragma unroll
-            for (int dd = 0; dd < 6; ++dd) Bl[s_][e_][6 * b + dd] = p0 * w[wk.Jc + size_t(i2) * 16 + (dd)] + p1 * w[wk.Jc + size_t(i2) * 16 + (6 + dd)];
+            for (int dd = 0; dd < 6; ++dd) Bl[s_][e_][6 * b + dd] = p0 * jc[dd] + p1 * jc[6 + dd];
           }
         }
       }
       __syncthreads();
+      BL_TICK(2)
       if (live) {
-        for (int s_ = 0; s_ < cnt; ++s_) {
-          const int len = ln[s_];
-          const T t0 = Tl[s_][3 * a], t1 = Tl[s_][3 * a + 1], t2 = Tl[s_][3 * a + 2];
-          for (int e_ = ent; e_ < len; e_ += kFast) {
+        // round 5: the operands of observation s + 1 (list length, its first observer's camera and product, T_s) are on their way
+        // from LDS while observation s is added — the loop was one chain of ~4 dependent LDS round trips per observation (length ->
+        // camera -> product / row -> write: 880 cycles, 11.7 of a 23.5 us chunk); what stays serial is the read-modify-write of
+        // the row itself.  Same additions in the same order.
+        struct Op { int len, c2; T t0, t1, t2, b0, b1, b2; };
+        auto fetch = [&](const int s_) __attribute__((always_inline)) {
+          Op o;
+          o.len = ln[s_];
+          o.t0 = Tl[s_][3 * a]; o.t1 = Tl[s_][3 * a + 1]; o.t2 = Tl[s_][3 * a + 2];
+          o.c2 = int(cl[s_][ent]);                       // (ent < kFast <= kListCap; 32767 past the end of the list)
+          o.b0 = Bl[s_][ent][d]; o.b1 = Bl[s_][ent][6 + d]; o.b2 = Bl[s_][ent][12 + d];   // (unused when ent >= len)
+          return o;
+        };
+        T* const Sflat = &Srow[0][0];
+        auto add_obs = [&](const int s_, const Op& cur) __attribute__((always_inline)) {
+          const T t0 = cur.t0, t1 = cur.t1, t2 = cur.t2;
+          {
+            // (an LDS add without return instead of read - subtract - write: nothing of the row comes back into the loop.  A wave's LDS
+            //  operations execute in order and no two lanes of the workgroup share an address, so every sum still runs in order s.
+            //  Past the end of the point's list the staged camera is 32767 > c: no separate test of the list length.)
+            const int c2 = cur.c2;
+            if (!(c2 > c || c2 < cbase || c2 >= cbase + kTile)) bl_lds_add(Sflat + (unsigned(c2 - cbase) * 36u + unsigned(ad)), -(t0 * cur.b0 + t1 * cur.b1 + t2 * cur.b2));
+          }
+          for (int e_ = ent + kFast; e_ < cur.len; e_ += kFast) {   // a point seen by more cameras than the fast path stages
             int c2;
             if (e_ < kListCap) c2 = int(cl[s_][e_]); else c2 = oc[l0[s_] + e_];
             if (c2 > c || c2 < cbase || c2 >= cbase + kTile) continue;
-            T b0, b1, b2;
-            if (e_ < kFast) {
-              b0 = Bl[s_][e_][d]; b1 = Bl[s_][e_][6 + d]; b2 = Bl[s_][e_][12 + d];
-            } else {   // a point seen by more cameras than the fast path stages: its entry straight from the records
-              const int i2 = l0[s_] + e_;
-              const T jc0 = w[wk.Jc + size_t(i2) * 16 + (d)], jc1 = w[wk.Jc + size_t(i2) * 16 + (6 + d)];
-              b0 = w[wk.Jp + size_t(i2) * 8 + 0] * jc0 + w[wk.Jp + size_t(i2) * 8 + 3] * jc1;
-              b1 = w[wk.Jp + size_t(i2) * 8 + 1] * jc0 + w[wk.Jp + size_t(i2) * 8 + 4] * jc1;
-              b2 = w[wk.Jp + size_t(i2) * 8 + 2] * jc0 + w[wk.Jp + size_t(i2) * 8 + 5] * jc1;
-            }
-            Srow[c2 - cbase][ad] -= t0 * b0 + t1 * b1 + t2 * b2;
+            const int i2 = l0[s_] + e_;                  // its entry straight from the records
+            const T jc0 = w[wk.Jc + size_t(i2) * 16 + (d)], jc1 = w[wk.Jc + size_t(i2) * 16 + (6 + d)];
+            const T b0 = w[wk.Jp + size_t(i2) * 8 + 0] * jc0 + w[wk.Jp + size_t(i2) * 8 + 3] * jc1;
+            const T b1 = w[wk.Jp + size_t(i2) * 8 + 1] * jc0 + w[wk.Jp + size_t(i2) * 8 + 4] * jc1;
+            const T b2 = w[wk.Jp + size_t(i2) * 8 + 2] * jc0 + w[wk.Jp + size_t(i2) * 8 + 5] * jc1;
+            bl_lds_add(Sflat + (unsigned(c2 - cbase) * 36u + unsigned(ad)), -(t0 * b0 + t1 * b1 + t2 * b2));
           }
           if (cbase == 0 && ent == 0 && d == 0) rva -= t0 * gl[s_][0] + t1 * gl[s_][1] + t2 * gl[s_][2];
+        };
+        // two observations per trip, each one's operands fetched while the other is added (no register copies)
+        Op oa = fetch(0), ob;
+        int s_ = 0;
+        for (; s_ + 1 < cnt; s_ += 2) {
+          ob = fetch(s_ + 1);
+          add_obs(s_, oa);
+          if (s_ + 2 < cnt) oa = fetch(s_ + 2);
+          add_obs(s_ + 1, ob);
         }
+        if (s_ < cnt) add_obs(s_, oa);
       }
+      BL_TICK(3)
     }
     __syncthreads();
     if (split > 1) {   // the partial block row of this run, tile by tile
@@ -1415,6 +1474,10 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
     }
     __syncthreads();
   }
+  BL_TICK(4)
+#ifdef TOA_BL_TIMING
+  if (tid == 0 && p == 0 && (blockIdx.x == 5 || blockIdx.x == 250)) printf("bl_schur wg %d: %d obs: zero %.1f stage %.1f B %.1f accumulate %.1f epilogue %.1f us\n", int(blockIdx.x), k1 - k0, tq[0] * 0.01, tq[1] * 0.01, tq[2] * 0.01, tq[3] * 0.01, tq[4] * 0.01);
+#endif
   if (live && ent == 0 && d == 0) {
     if (split > 1) rpart[((size_t(p) * C + c) * split + part) * 6 + a] = rva;
     else rg[6 * c + a] = w[wk.gc + 6 * c + a] + rva;
@@ -1672,7 +1735,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const size_t b_work = al(size_t(P) * wk.total * sizeof(T)), b_iwork = al(size_t(P) * ix.total * sizeof(int)), b_ok = al(size_t(P) * sizeof(int32_t));
   const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
   // bl_schur split (see the kernel): a property of the scene's shape only
-  const int split = (C <= 128 && M / std::max(C, 1) >= 256) ? 4 : 1;   // (8: 5.02 ms at four scenes against 5.10, 10.43 against 10.28 at 32)
+  const int split = (C <= 128 && M / std::max(C, 1) >= 256) ? 3 : 1;   // (round 5, four scenes x 64 cameras, it/s: 2: 6759, 3: 7001, 4: 6730, 5: 6701, 6: 6865, 8: 6764; round 4: 8 against 4: 5.02 / 5.10 ms)   // (8: 5.02 ms at four scenes against 5.10, 10.43 against 10.28 at 32)
   const size_t b_sp = split > 1 ? al(size_t(P) * C * split * C * 36 * sizeof(T)) : 0, b_rp = split > 1 ? al(size_t(P) * C * split * 6 * sizeof(T)) : 0;
   const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v + b_sp + b_rp;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
