@@ -524,23 +524,47 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
     if (c < nv) xv[k] = *reinterpret_cast<const V*>(xs + c * VEC);
   }
   const int slot = blockIdx.x * 4 + wave;
-  for (int i0 = slot * RPW; i0 < m; i0 += gridDim.x * 4 * RPW) {
-    const int i = i0 + rg;
-    const bool live = i < m;
-    V av[KV];
-    T t = 0;
+  // Round 5: R of the wave's trips at a time.  A trip was: one 16-byte load per lane and vector, wait, dot, butterfly, and then the
+  // row's SCALAR work — sincos, residual, loss, scale — executed by all 64 lanes for the one or two rows of the trip: ~250 vector
+  // instructions per row, and the kernel ran at 1.8 TB/s bound by issue (23 % of the n = 256 pipeline).  Now the R trips' loads go
+  // out together, their butterflies interleave, the rows' totals are collected one per lane (lane u of a row group takes trip u's)
+  // so that the scalar work runs ONCE per R trips, and scale and residual come back to the row's lanes for J^T r.  Every row sees
+  // the arithmetic it saw before and a wave's rows enter J^T r in the same order.
+  constexpr int R = KV >= 5 ? 1 : (KV >= 3 ? 2 : (KV == 2 ? 4 : 8));
+  const int stride = gridDim.x * 4 * RPW, gbase = lane & ~(LPR - 1);
+  for (int ib = slot * RPW; ib < m; ib += R * stride) {
+    V av[R][KV];
+    T t[R];
 #pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      const int c = rl + k * LPR;
-      av[k] = V(0);
-      if (live && c < nv) av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A + size_t(i) * n) + c);
+    for (int u = 0; u < R; ++u) {
+      const int i = ib + u * stride + rg;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) t = fma(av[k][e], xv[k][e], t);
+      for (int k = 0; k < KV; ++k) {
+        const int c = rl + k * LPR;
+        av[u][k] = V(0);
+        if (i < m && c < nv) av[u][k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A + size_t(i) * n) + c);
+      }
     }
-    for (int off = 1; off < LPR; off <<= 1) t += __shfl_xor(t, off);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      t[u] = 0;
+#pragma unroll
+      for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t[u] = fma(av[u][k][e], xv[k][e], t[u]);
+    }
+    for (int off = 1; off < LPR; off <<= 1) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) t[u] += __shfl_xor(t[u], off);
+    }
+    T tt = 0;
+#pragma unroll
+    for (int u = 0; u < R; ++u) tt = rl == u ? t[u] : tt;
+    const int i = ib + rl * stride + rg;             // lane rl < R of a row group: the row of trip rl
+    const bool live = rl < R && i < m;
     T sn, cs;
-    sincos_t(t, &sn, &cs);
-    T ri = live ? t + T(0.1) * sn - bv[live ? i : 0] : T(0);
+    sincos_t(tt, &sn, &cs);
+    T ri = live ? tt + T(0.1) * sn - bv[live ? i : 0] : T(0);
     T sq = T(1);
     if (a.loss != TOA_LOSS_L2) {   // (wave-uniform)
       const T n2 = ri * ri;
@@ -548,22 +572,27 @@ __global__ void __launch_bounds__(256) large_rows_vec_kernel(const LargeArgs<T> 
       robust_norm(a.loss, n2, a.th2, l, sw);
       sq = r_sqrt(sw);
       ri *= sq;
-      if (live && rl == 0) {
+      if (live) {
         a.lossv[p * m + i] = l;
         if (n2 <= a.th2) atomicAdd(&a.ninl[p], 1);
       }
     }
-    if (live && rl == 0) rp[i] = ri;
+    if (live) rp[i] = ri;
     if (want_j) {
       const T sc = (T(1) + T(0.1) * cs) * sq;
+      if (a.own_gram && live) a.sc[p * m + i] = sc;
 #pragma unroll
-      for (int k = 0; k < KV; ++k) {
-        const int c = rl + k * LPR;
-        const V jv = av[k] * sc;
-        gacc[k] += jv * ri;
-        if (!a.own_gram && live && c < nv) __builtin_nontemporal_store(jv, reinterpret_cast<V*>(Jp + size_t(i) * n) + c);
+      for (int u = 0; u < R; ++u) {
+        const T sc_u = __shfl(sc, gbase | u), ri_u = __shfl(ri, gbase | u);
+        const int iu = ib + u * stride + rg;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+          const int c = rl + k * LPR;
+          const V jv = av[u][k] * sc_u;
+          gacc[k] += jv * ri_u;
+          if (!a.own_gram && iu < m && c < nv) __builtin_nontemporal_store(jv, reinterpret_cast<V*>(Jp + size_t(iu) * n) + c);
+        }
       }
-      if (a.own_gram && live && rl == 0) a.sc[p * m + i] = sc;
     }
   }
   if (want_j) {  // fold the row groups of the wave (fixed order), then one partial vector per wave
