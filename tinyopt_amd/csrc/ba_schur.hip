@@ -872,6 +872,7 @@ int toa_ba_launch_robust(toa_handle h, int dtype, BaParams& prm) {
 // Observations: sorted by (point, camera), each pair at most once.
 }  // namespace toa
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+int toa_large_solve_inplace(toa_handle h, int dtype, int n, int64_t P, void* H, const void* g, void* dx, int32_t* ok);
 int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 int toa_large_solve_unchecked(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
 namespace toa {
@@ -1844,7 +1845,9 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
       // rocSOLVER: ONE matrix per call — its batched Cholesky picks its blocking by batch size, and a scene solved alone must
       // give the bits of its row in a batch (tests/test_gpu_ba_lists.py); scenes of this size are few per call
       // (toa_large_solve_each: the calls go out over side streams, so the scenes' factorisations overlap)
-      rc_all = toa_large_solve_each(h, dtype, n, P, prm.Sall, prm.rhsall, 1.0, prm.dcall, ok);
+      // (round 5: the one-workgroup Cholesky runs IN PLACE on S — every pass rebuilds S — and writes step and verdict itself: no mask /
+      //  copy / finish launches around it; toa_large_solve_each where it does not apply)
+      rc_all = toa_large_solve_inplace(h, dtype, n, P, prm.Sall, prm.rhsall, prm.dcall, ok);
       if (rc_all != TOA_OK) break;
     }
     hipLaunchKernelGGL(bl_back_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok);

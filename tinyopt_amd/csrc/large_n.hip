@@ -391,6 +391,13 @@ struct LargeArgs {
   int* ninl;     // [P], zeroed by the pre kernel once read
   T *hdu, *g_m, *hdu_m, *xs_m;     // [P][n]: undamped diagonal of the current linearisation; memo: J^T r, diagonal, x
   double *lin_cost, *memo_cost;    // [P]: normalised cost of the current / parked linearisation
+  // the blocked Cholesky called DIRECTLY on a caller's matrices (toa_large_solve_inplace, round 5): factorised in place in `work`, the
+  // right-hand side read from `rhs`, the step -x (or 0 and ok = 0) written to ddx / dok by the kernel itself, matrix p skipped where
+  // dmask[p * dmask_stride] == 0 — the three launches around the factorisation (mask -> flags, copy + damping, finish) are gone
+  T* ddx = nullptr;
+  int32_t* dok = nullptr;
+  const int32_t* dmask = nullptr;
+  long long dmask_stride = 0;
   __device__ __forceinline__ bool on(const long long p) const { return active[p] != 0 && !(stepped && stepped[p] != 0); }
   __device__ __forceinline__ bool streams(const long long p) const { return on(p) && !(skip && skip[p] != 0); }   // takes part in the data pass
   __device__ __forceinline__ T* Hcur(const long long p) const {
@@ -1106,7 +1113,14 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   T* ys = Lp + size_t(a.n) * LSP;                  // [n]       right-hand side / solution (+ 64 scratch entries, + 32 reciprocals of the block's diagonal)
   __shared__ int fail;
   const size_t p = blockIdx.x;
-  if (!a.on(p) || !(a.built[p] & 1)) return;
+  const bool direct = a.ddx != nullptr;
+  if (direct) {
+    if (a.dmask && a.dmask[p * a.dmask_stride] == 0) {   // a masked-out matrix is not factorised: no step, no verdict
+      for (int i = threadIdx.x; i < a.n; i += NT) a.ddx[p * a.n + i] = T(0);
+      if (threadIdx.x == 0) a.dok[p] = 0;
+      return;
+    }
+  } else if (!a.on(p) || !(a.built[p] & 1)) return;
   const int n = a.n, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
   int tid = threadIdx.x, lane = tid & 63;   // (not const: see TOA_CHOL_FRESH_LANE)
   // hipcc hoists every per-lane invariant of the block loop's phases (LDS addresses, masks like c == lane, row offsets: hundreds of
@@ -1426,7 +1440,10 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     CH_TICK(2)
   }
   if (fail) {
-    if (tid == 0) a.info[p] = 1;
+    if (direct) {
+      for (int i = tid; i < n; i += NT) a.ddx[p * n + i] = T(0);
+      if (tid == 0) a.dok[p] = 0;
+    } else if (tid == 0) a.info[p] = 1;
     return;
   }
   // ---- L y = b (LOOK: done inside the factorisation loop)
@@ -1590,6 +1607,15 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   if (tid == 0 && p == 0) printf("chol n=%d: update phase by wave, all steps: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f | step 0: %.1f %.1f %.1f %.1f\n", n, wt[0] * 0.01, wt[1] * 0.01, wt[2] * 0.01, wt[3] * 0.01, wt[4] * 0.01, wt[5] * 0.01, wt[6] * 0.01, wt[7] * 0.01,
                               wt0[0] * 0.01, wt0[1] * 0.01, wt0[4] * 0.01, wt0[7] * 0.01);
 #endif
+  if (direct) {   // large_finish_kernel's part: a solution that is not finite is refused
+    for (int i = tid; i < n; i += NT)
+      if (!(fabs(ys[i]) <= NumLimits<T>::max())) fail = 1;   // (benign race: every writer stores 1)
+    __syncthreads();
+    const bool good = fail == 0;
+    for (int i = tid; i < n; i += NT) a.ddx[p * n + i] = good ? -ys[i] : T(0);
+    if (tid == 0) a.dok[p] = good ? 1 : 0;
+    return;
+  }
   for (int i = tid; i < n; i += NT) a.rhs[p * n + i] = ys[i];
   if (tid == 0) a.info[p] = 0;
 }
@@ -2302,6 +2328,36 @@ int large_solve_own_t(toa_handle h, int n, int64_t P, const T* H, const T* g, do
 
 }  // namespace
 }  // namespace toa
+
+int toa_large_solve_each(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx, int32_t* ok);
+// (H + 0) dx = -g for 128 < n with the matrices factorised IN PLACE (H is destroyed) and no launch but the factorisation's: for a
+// caller that rebuilds H before every call anyway (bundle adjustment with lists: the reduced camera system of a pass).  Falls back to
+// toa_large_solve_each (one library call per matrix: batch-independent bits) where the one-workgroup Cholesky does not apply.  h->solve_mask as there.
+int toa_large_solve_inplace(toa_handle h, int dtype, int n, int64_t P, void* H, const void* g, void* dx, int32_t* ok) {
+  const size_t lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * (dtype == TOA_F32 ? 4 : 8) + 64;   // chol_solve_lds_bytes
+  if (h->tune.large_library_solver != 0 || n <= 128 || P > 65535 || lds + 2048 > size_t(h->max_lds)) return toa_large_solve_each(h, dtype, n, P, H, g, 1.0, dx, ok);
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    toa::LargeArgs<T> a;
+    std::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.n = n;
+    a.P = P;
+    a.work = static_cast<T*>(H);
+    a.rhs = const_cast<T*>(static_cast<const T*>(g));
+    a.ddx = static_cast<T*>(dx);
+    a.dok = ok;
+    a.dmask = h->solve_mask;
+    a.dmask_stride = (long long)h->solve_mask_stride;
+    const size_t chol_lds = toa::chol_solve_lds_bytes<T>(n);
+    if (int rc = toa::ensure_lds_attr(h, (const void*)toa::large_chol_solve_kernel<T>, chol_lds)) return rc;
+    if (int rc = toa::ensure_lds_attr(h, (const void*)toa::large_chol_solve_kernel<T, false>, chol_lds)) return rc;
+    if (h->tune.large_chol_no_lookahead) hipLaunchKernelGGL((toa::large_chol_solve_kernel<T, false>), dim3(unsigned(P)), dim3(toa::kCholThreads), chol_lds, h->stream, a);
+    else hipLaunchKernelGGL(toa::large_chol_solve_kernel<T>, dim3(unsigned(P)), dim3(toa::kCholThreads), chol_lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  };
+  return dtype == TOA_F32 ? run(float()) : run(double());
+}
 
 int toa_large_solve(toa_handle h, int dtype, int n, int64_t P, const void* H, const void* g, double scale, void* dx,
                     int32_t* ok) {
