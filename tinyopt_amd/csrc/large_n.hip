@@ -1088,10 +1088,15 @@ __global__ void __launch_bounds__(256) large_ldlt_solve_kernel(const LargeArgs<T
 // substitution launches, syr2k, small GEMMs): 0.75 ms of a 1.5 ms pass at n = 256 and 65 % of a bundle-adjustment pass with 384
 // camera unknowns — latency, not flops (n^3 / 3 = 5.6 Mflop).  Here ONE workgroup factors its matrix in place (row-major lower
 // triangle of `work`, L2-resident) by panels of 32 columns and solves, in one launch for the whole batch:
-//   diagonal block   wave 0, a row per lane in registers: 32 unrolled Cholesky columns, pivots and column entries by broadcast
-//   panel below      a thread per row: x L_kk^T = a (32-step substitution against the block in LDS); the rows stay in LDS
-//   trailing update  a thread per COLUMN j (its panel row in registers), rows i >= j: A_ij -= L_i . L_j (coalesced across lanes)
-//   substitutions    the same panels: the block by wave 0 (lane r owns unknown r), the rest by a thread per row / column
+//   diagonal block   wave 0, a row per lane in registers (chol_diag.hpp): 32 unrolled Cholesky columns, pivots and column entries by
+//                    lane broadcast; LDS in, LDS out
+//   panel below      rows through LDS with lane = column, then a thread per row: x L_kk^T = a (32-step substitution against the block
+//                    in LDS); the rows stay in LDS for the update and go back to the matrix with lane = column
+//   trailing update  16 x 16 tiles of the lower triangle on the matrix cores, operands from the panel in LDS, read-modify-write of the
+//                    tile in the L2-resident matrix
+//   substitutions    forward inside the factorisation loop; backward block by block: wave 0 the chain of a block, the others the
+//                    unknowns above, operands one block ahead
+// (rounds 3-5: profiles/r03_ab_log.md section 6-7, r04 section 8a, r05 section 5 — the last one with the per-wave timers of -DTOA_CHOL_TIMING)
 // Cholesky without pivoting, as the library path: a pivot that is not positive (or not finite) fails the solve (info != 0).
 // Every sum has a fixed order: a matrix solved alone gives the bits of its row in a batch.
 // (round 4, late: v_readlane into scalar registers instead of ds_bpermute — the lane index is a compile-time constant at every call site
@@ -1121,12 +1126,12 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
       return;
     }
   } else if (!a.on(p) || !(a.built[p] & 1)) return;
-  const int n = a.n, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int n = a.n, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // (uniform for hipcc: tile indices, trip counts and the wave-0 branches live in scalar registers)
   int tid = threadIdx.x, lane = tid & 63;   // (not const: see TOA_CHOL_FRESH_LANE)
   // hipcc hoists every per-lane invariant of the block loop's phases (LDS addresses, masks like c == lane, row offsets: hundreds of
   // values) in front of the loop and then spills them — scratch reloads with an s_waitcnt in front of loads that should be in flight
   // together.  The lane index is re-declared opaque at the head of each phase: what depends on it is computed where it is used.
-#define TOA_CHOL_FRESH_LANE asm volatile("" : "+v"(lane), "+v"(tid));   // (uniform for hipcc: tile indices, trip counts and the wave-0 branches live in scalar registers)
+#define TOA_CHOL_FRESH_LANE asm volatile("" : "+v"(lane), "+v"(tid));
   T* A = a.work + p * size_t(n) * n;
   for (int i = tid; i < n; i += NT) ys[i] = a.rhs[p * n + i];
   if (tid == 0) fail = 0;
@@ -1601,8 +1606,8 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
   }
   CH_TICK(4)
 #ifdef TOA_CHOL_TIMING
-  if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us | wave 0: tiles+loads %.1f chain %.1f scale+store %.1f | panel: in %.1f rows %.1f out %.1f\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01,
-                              tkc[5] * 0.01, tkc[6] * 0.01, tkc[7] * 0.01, tkc[8] * 0.01, tkc[9] * 0.01, tkc[10] * 0.01);
+  if (tid == 0 && p == 0) printf("chol n=%d: diag %.1f us  panel %.1f us  update %.1f us  forward %.1f us  backward %.1f us | wave 0 (look-ahead): tiles + staging %.1f diagonal block %.1f | panel: in %.1f rows %.1f out %.1f\n", n, tkc[0] * 0.01, tkc[1] * 0.01, tkc[2] * 0.01, tkc[3] * 0.01, tkc[4] * 0.01,
+                              tkc[5] * 0.01, tkc[6] * 0.01, tkc[8] * 0.01, tkc[9] * 0.01, tkc[10] * 0.01);
   if (tid == 0 && p == 0) printf("chol n=%d: shader clock %.0f MHz over the kernel\n", n, double(clock64() - clk0) / (double(wall_clock64() - wall0) * 0.01));
   if (tid == 0 && p == 0) printf("chol n=%d: update phase by wave, all steps: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f | step 0: %.1f %.1f %.1f %.1f\n", n, wt[0] * 0.01, wt[1] * 0.01, wt[2] * 0.01, wt[3] * 0.01, wt[4] * 0.01, wt[5] * 0.01, wt[6] * 0.01, wt[7] * 0.01,
                               wt0[0] * 0.01, wt0[1] * 0.01, wt0[4] * 0.01, wt0[7] * 0.01);
