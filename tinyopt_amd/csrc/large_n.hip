@@ -835,16 +835,31 @@ __global__ void __launch_bounds__(TRI ? 768 : 1024) large_gram_kernel(const Larg
   auto run = [&](auto stage_c) __attribute__((always_inline)) {
     constexpr int STAGE = decltype(stage_c)::value;
     int cur = 0;
+#ifdef TOA_GRAM_TIMING
+    unsigned long long tg[3] = {0, 0, 0}, tgp = wall_clock64(); const unsigned long long tg0 = tgp; int nst = 0;
+#define GR_TICK(i) { const unsigned long long now_ = wall_clock64(); tg[i] += now_ - tgp; tgp = now_; }
+#else
+#define GR_TICK(i)
+#endif
     for (int r0 = row0; r0 < row1; r0 += K) {
       if (r0 + K < row1) {
         put(cur ? 0 : buf_bytes);
         fetch(r0 + 2 * K);
       }
+      GR_TICK(0)
       if constexpr (STAGE == 0) syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K);
       else if constexpr (TRI) syrk_stage_tri<T, STAGE == 2>(acc, syrk_lds, cur ? buf_bytes : 0, offA[0], offA[1], offA[2], K);
+#ifdef TOA_GRAM_TIMING
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); ++nst;
+#endif
+      GR_TICK(1)
       __syncthreads();
+      GR_TICK(2)
       cur ^= 1;
     }
+#ifdef TOA_GRAM_TIMING
+    if (lane == 0 && blockIdx.x == 1 && p == 3 && (wave == 0 || wave == 5 || wave == 11)) printf("gram wave %d: %d stages, %.1f us: put+fetch %.2f stage %.2f barrier %.2f us per stage\n", wave, nst, (wall_clock64() - tg0) * 0.01, tg[0] * 0.01 / nst, tg[1] * 0.01 / nst, tg[2] * 0.01 / nst);
+#endif
     // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
