@@ -1293,7 +1293,7 @@ __global__ void __launch_bounds__(kCholThreads) large_chol_solve_kernel(const La
     // values per lane: element (out_row(lane, reg), lane & 15) of tile (ti, tj) = Ak[16 ti n + 16 tj + lane_off + reg * reg_step]
     TOA_CHOL_FRESH_LANE
     using Acc = typename Mfma<T>::Acc;
-    constexpr int U = sizeof(T) == 8 ? 2 : 4;          // tiles per trip (fp64, four: 211 -> 227 us in round 3, no better in round 5)
+    constexpr int U = sizeof(T) == 8 ? 2 : 4;          // tiles per trip (fp64, four: 211 -> 227 us in round 3; 341.7 -> 352.0 us per call on the finished kernel of round 5)
     const int r = n - k1, nt = (r + 15) >> 4, ntile = nt * (nt + 1) / 2;
     const int l15 = lane & 15, kq = lane >> 4;
     T* const Ak = A + size_t(k1) * n + k1;
