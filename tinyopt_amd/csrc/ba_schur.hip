@@ -1298,7 +1298,7 @@ __global__ void __launch_bounds__(256) bl_schur_kernel(const BlParams* __restric
   // batch, so that a scene solved alone still gives the bits of its row in a batch) the observations of camera c are dealt to
   // `split` workgroups in contiguous runs; each leaves its partial block row (and partial right-hand side) in spart / rpart
   // and bl_schur_reduce_kernel sums them in run order and finishes the row.  Four scenes x 64 cameras are 256 workgroups of
-  // ~470 observations each — one per compute unit, 0.255 ms per pass; dealt four ways the chip is full.
+  // ~470 observations each — one per compute unit, 0.255 ms per pass; dealt three ways (round 5; four in round 4) 768 workgroups are one round of three per compute unit.
   // One workgroup per camera c forms block row c of S (lower block triangle, mirrored) and of the reduced right-hand side.
   // Per staged chunk of 32 of the camera's observations (point j each):
   //   T_s  = J_c,s^T (J_p,s V_j^-1)                 6 x 3   thread s
@@ -1736,7 +1736,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const size_t b_work = al(size_t(P) * wk.total * sizeof(T)), b_iwork = al(size_t(P) * ix.total * sizeof(int)), b_ok = al(size_t(P) * sizeof(int32_t));
   const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
   // bl_schur split (see the kernel): a property of the scene's shape only
-  const int split = (C <= 128 && M / std::max(C, 1) >= 256) ? 3 : 1;   // (round 5, four scenes x 64 cameras, it/s: 2: 6759, 3: 7001, 4: 6730, 5: 6701, 6: 6865, 8: 6764; round 4: 8 against 4: 5.02 / 5.10 ms)   // (8: 5.02 ms at four scenes against 5.10, 10.43 against 10.28 at 32)
+  const int split = (C <= 128 && M / std::max(C, 1) >= 256) ? 3 : 1;   // (round 5, four scenes x 64 cameras, it/s: 2: 6759, 3: 7001, 4: 6730, 5: 6701, 6: 6865, 8: 6764; round 4, 8 against 4: 5.02 / 5.10 ms at four scenes, 10.43 / 10.28 at 32)
   const size_t b_sp = split > 1 ? al(size_t(P) * C * split * C * 36 * sizeof(T)) : 0, b_rp = split > 1 ? al(size_t(P) * C * split * 6 * sizeof(T)) : 0;
   const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v + b_sp + b_rp;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
