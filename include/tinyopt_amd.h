@@ -431,8 +431,11 @@ int toa_ba_run(toa_handle h, int dtype, int num_cameras, int num_points, int64_t
  *      the one-workgroup blocked Cholesky up to 512 (85 cameras in fp64; 170 in fp32) and by rocSOLVER's potrf + potrs (opened
  *      with dlopen, one scene per call) beyond — up to 682 cameras.  A pipeline of small
  *      kernels per Build + Solve attempt (csrc/ba_schur.hip, "bl_*"); every sum has a fixed order.  The host enqueues two passes
- *      ahead and reads each pass's stop flag (a pinned ring) two passes late; the call returns when the solve is done and is
- *      not graph-capturable (refused with a message under capture).  With max_duration_ms > 0 the flag is read after every pass, which is where it is
+ *      ahead and reads each pass's stop flag (a pinned ring) two passes late; the call returns when the solve is done.  Under
+ *      stream capture (round 5) the whole pass budget of the options is recorded instead — (max_iters + 2) x (max_consec_failures + 1)
+ *      passes, at most 256, needs max_consec_failures > 0, use_ldlt, max_duration_ms == 0, workspaces from an earlier eager call of
+ *      the shape; scenes still running at the end of the budget end with kMaxIters — and the replay gives the bits of the eager
+ *      call (the graph LIFETIME rule above applies).  With max_duration_ms > 0 the flag is read after every pass, which is where it is
  *      honoured: > 0 ends every scene still running with kTimedOut once the launches' device time exceeds it
  *      (Options::max_duration_ms, optimizer.h:302-305).
  *        intr_dev:    [P][4] of T = f cx cy 0

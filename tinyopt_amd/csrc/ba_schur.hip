@@ -1723,10 +1723,15 @@ __global__ void __launch_bounds__(64) bl_force_stop_kernel(const BlParams* __res
 
 template <typename T>
 int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms) {
-  {   // a host loop over passes (stop flags come back through a pinned ring): refused under stream capture, never half-recorded
+  // Under stream capture (hipGraph; round 5) the host can look at no stop flag: the whole pass budget of the options is recorded — every
+  // kernel of a pass returns at once for the scenes that have finished, the solver takes its per-scene mask — and the scenes still
+  // running at the end of it are finalised as kMaxIters, as the eager loop does.  Like the n > 128 pipeline's captured form this needs
+  // a bounded budget (max_consec_failures > 0), every stage a kernel of this library (use_ldlt, the one-workgroup factorisations) and
+  // workspaces that exist (a first eager call of the shape makes them); max_duration_ms needs the host's clock and is refused.
+  bool capturing = false;
+  {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run cannot be captured into a hipGraph (its pass loop runs on the host)");
+    capturing = hipStreamIsCapturing(h->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   }
   const int C = prm.C, N = prm.N, M = prm.M, n = 6 * C;
   const long long P = prm.P;
@@ -1740,7 +1745,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const size_t b_sp = split > 1 ? al(size_t(P) * C * split * C * 36 * sizeof(T)) : 0, b_rp = split > 1 ? al(size_t(P) * C * split * 6 * sizeof(T)) : 0;
   const size_t need = b_work + b_iwork + b_ok + 256 + b_S + 2 * b_v + b_sp + b_rp;
   if (need > h->aux_bytes) {   // (h->scratch belongs to toa_large_solve, which this pipeline calls)
-    if (int rc = grow_sync(h, "bundle adjustment workspace")) return rc;
+    if (int rc = grow_sync(h, "bundle adjustment workspace")) return rc;   // (refused under capture with a message that says why)
     toa_release_workspace(h, h->aux);
     h->aux = nullptr;
     h->aux_bytes = 0;
@@ -1770,7 +1775,22 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   hipLaunchKernelGGL(bl_init_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
   HIP_TRY(hipGetLastError());
   // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
-  const long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
+  long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
+  if (capturing) {
+    constexpr long long kMaxCapturedPasses = 256;
+    const long long tries = prm.opt.max_consec_failures > 0 ? (long long)prm.opt.max_consec_failures + 1 : 256;
+    max_passes = (long long)(prm.opt.max_iters + 2) * tries;
+    const size_t chol2_lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * sizeof(T) + 64;
+    const bool own_solver = n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds));
+    if (max_duration_ms > 0 || !prm.opt.use_ldlt || h->tune.large_library_solver != 0 || !own_solver)
+      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: only solves whose every stage is a kernel of this library can be captured "
+                                         "(use_ldlt, the one-workgroup factorisation of the reduced camera system, no max_duration_ms)");
+    if (max_passes > kMaxCapturedPasses)
+      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: the pass budget of these options is " + std::to_string(max_passes) +
+                                         " passes (~" + std::to_string(max_passes * 12) + " graph nodes); at most " + std::to_string(kMaxCapturedPasses) +
+                                         " are recorded — set max_consec_failures > 0 (the retry bound per iteration) or lower max_iters");
+    h->shadow_retired = true;   // (a graph of this handle now exists: its workspaces are never freed under it, toa_release_workspace)
+  }
   // Round 4: the host no longer waits for a pass before it enqueues the next one.  Every pass leaves "is any scene still
   // running" in its own slot of a small ring; the slot is copied to pinned host memory behind the pass and the host looks at
   // pass k's answer only before it enqueues pass k + kAhead — the GPU always has the next pass queued (round 3: a
@@ -1794,16 +1814,18 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     HIP_TRY(hipEventCreate(&ev.t1));
     HIP_TRY(hipEventRecord(ev.t0, st));
   }
-  if (int rc = ensure_pass_ring(h)) return rc;
-  ev.done = h->pass_done;
-  ev.host_flags = h->pass_flags;
+  if (!capturing) {
+    if (int rc = ensure_pass_ring(h)) return rc;
+    ev.done = h->pass_done;
+    ev.host_flags = h->pass_flags;
+  }
   int* any_ring = prm.any_active;   // kRing ints (the block reserves 256 bytes)
   int rc_all = TOA_OK;
   bool finished = false;
   long long pass = 0;
   for (; pass < max_passes; ++pass) {
     const int slot = int(pass % kRing);
-    if (pass >= kAhead || timed) {   // the answer of pass - kAhead (timed form: of the previous pass)
+    if (!capturing && (pass >= kAhead || timed)) {   // the answer of pass - kAhead (timed form: of the previous pass)
       const long long look = timed ? pass - 1 : pass - kAhead;
       if (look >= 0) {
         HIP_TRY(hipEventSynchronize(ev.done[look % kRing]));
@@ -1855,10 +1877,17 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     hipLaunchKernelGGL(bl_update_kernel<T>, dim3(gX, unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_clear_action_kernel, dim3(unsigned((P + 63) / 64)), dim3(64), 0, st, dev);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&ev.host_flags[slot], any_slot, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(ev.done[slot], st));
+    if (!capturing) {
+      HIP_TRY(hipMemcpyAsync(&ev.host_flags[slot], any_slot, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(ev.done[slot], st));
+    }
   }
   if (rc_all != TOA_OK) return rc_all;
+  if (capturing) {   // whoever still runs when the recorded budget ends: kMaxIters (the kernel looks at the scenes' own flags)
+    hipLaunchKernelGGL(bl_force_stop_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
+    HIP_TRY(hipGetLastError());
+    return TOA_OK;
+  }
   if (!finished) {
     // the passes enqueued last have not been looked at yet; and a loop that ran out of passes must not hand back scenes that
     // are still running with whatever the caller's result arrays held: they end with kMaxIters, like
