@@ -483,7 +483,7 @@ def run_balists(args, ta, rank, world, local_rank):
                    "parallelism": f"scene-sharded x{world}, no data-path collective",
                    "iters_per_problem": iters_all / args.steps / (P * world), "ms_per_lm_iteration": elapsed / max(iters_all / (P * world), 1) * 1e3,
                    "final_reprojection_rms_px_max": rms, "device": info["name"], "num_cus": info["num_cus"]},
-        "roofline": {"bound": "latency", "kernel": "bl_* pipeline (12 launches per Build + Solve attempt, enqueued two passes ahead of the stop flag; one-workgroup blocked Cholesky of the 384 x 384 reduced camera system per scene, in place, one launch)",
+        "roofline": {"bound": "latency", "kernel": "bl_* pipeline (10 launches per Build + Solve attempt, enqueued two passes ahead of the stop flag; one-workgroup blocked Cholesky of the 384 x 384 reduced camera system per scene, in place, one launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bl,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_pass": bytes_per_pass, "passes_per_launch": passes_total / args.steps,
                      "note": "launch / latency-bound at this size (a few scenes, ~1 MB of observations each): the figure of merit is ms per LM "

@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(256) bl_obs_kernel(const BlParams* __restrict_
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restrict__ prm) {
+__device__ __forceinline__ void bl_point_body(const BlParams* __restrict__ prm, const int bx) {   // block bx of the scene's points
   const long long p = blockIdx.y;
   const int C = prm->C, N = prm->N, M = prm->M;
   const BlWork<T> wk(C, N, M);
@@ -1092,7 +1092,7 @@ __global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restric
   const int* iw = prm->iwork + size_t(p) * ix.total;
   if (!iw[ix.flags + 0]) return;
   const bool do_acc = iw[ix.flags + 1] != 0;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = bx * 256 + threadIdx.x;
   if (j >= N) return;
   T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
   const int i0 = iw[ix.pt_start + j], i1 = iw[ix.pt_start + j + 1];
@@ -1120,10 +1120,8 @@ __global__ void __launch_bounds__(256) bl_point_kernel(const BlParams* __restric
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) bl_cam_kernel(const BlParams* __restrict__ prm) {
-  __shared__ T red[4][32];
+__device__ __forceinline__ void bl_cam_body(const BlParams* __restrict__ prm, const int c, T (&red)[4][32]) {
   const long long p = blockIdx.y;
-  const int c = blockIdx.x;
   const int C = prm->C, N = prm->N, M = prm->M;
   const BlWork<T> wk(C, N, M);
   const BlIdx ix(C, N, M);
@@ -1161,6 +1159,15 @@ __global__ void __launch_bounds__(256) bl_cam_kernel(const BlParams* __restrict_
     if (b < 6) { w[wk.U + 36 * c + 6 * a + b] = s; w[wk.U + 36 * c + 6 * b + a] = s; if (a == b) w[wk.Ud + 6 * c + a] = s; }
     else if (a < 6) w[wk.gc + 6 * c + a] = s;
   }
+}
+
+// The points' 3 x 3 blocks and the cameras' 6 x 6 blocks read the observation records and nothing of each other: ONE launch (round 5;
+// two launches of 9 and 7 us, each mostly launch latency): blocks [0, gN) are bl_point_body's, blocks [gN, gN + C) a camera each.
+template <typename T>
+__global__ void __launch_bounds__(256) bl_point_cam_kernel(const BlParams* __restrict__ prm, const int gN) {
+  __shared__ T red[4][32];
+  if (int(blockIdx.x) < gN) bl_point_body<T>(prm, int(blockIdx.x));
+  else bl_cam_body<T>(prm, int(blockIdx.x) - gN, red);
 }
 
 // fixed-order sum of arr[0 .. count) by the 256 threads of a block
@@ -1576,7 +1583,10 @@ __global__ void __launch_bounds__(256) bl_step_kernel(const BlParams* __restrict
   const BlWork<T> wk(C, N, M);
   const BlIdx ix(C, N, M);
   int* fl = prm->iwork + size_t(p) * ix.total + ix.flags;
-  if (!fl[0]) return;
+  if (!fl[0]) {   // a finished scene: its last action (applied by the pass that finished it) must not be applied again — round 5: here instead of a launch of its own behind bl_update
+    if (threadIdx.x == 0) fl[2] = 0;
+    return;
+  }
   T* w = static_cast<T*>(prm->work) + size_t(p) * wk.total;
   LmState<T>& S = *bl_state<T>(prm, wk, p);
   const toa_options& opt = prm->opt;
@@ -1685,12 +1695,6 @@ __global__ void __launch_bounds__(256) bl_update_kernel(const BlParams* __restri
     if (action == 1) { const T d = w[wk.dp + i]; X[size_t(12) * C + i] += d; w[wk.ldp + i] = d; }
     else X[size_t(12) * C + i] -= w[wk.ldp + i];
   }
-}
-
-__global__ void bl_clear_action_kernel(const BlParams* __restrict__ prm) {
-  const BlIdx ix(prm->C, prm->N, prm->M);
-  const long long p = blockIdx.x * 64 + threadIdx.x;
-  if (p < prm->P) prm->iwork[size_t(p) * ix.total + ix.flags + 2] = 0;
 }
 
 // a scene that is still running when the host's pass budget is exhausted: finalised as kMaxIters (optimizer.h:320-321)
@@ -1843,8 +1847,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     int* const any_slot = any_ring + slot;
     HIP_TRY(hipMemsetAsync(any_slot, 0, sizeof(int), st));
     hipLaunchKernelGGL(bl_obs_kernel<T>, dim3(gM, unsigned(P)), dim3(256), 0, st, dev);
-    hipLaunchKernelGGL(bl_point_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
-    hipLaunchKernelGGL(bl_cam_kernel<T>, dim3(unsigned(C), unsigned(P)), dim3(256), 0, st, dev);
+    hipLaunchKernelGGL(bl_point_cam_kernel<T>, dim3(gN + unsigned(C), unsigned(P)), dim3(256), 0, st, dev, int(gN));
     hipLaunchKernelGGL(bl_build_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_psolve_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev);
     hipLaunchKernelGGL(bl_schur_kernel<T>, dim3(unsigned(C * split), unsigned(P)), dim3(256), 0, st, dev, split, spart, rpart);
@@ -1875,7 +1878,6 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
     hipLaunchKernelGGL(bl_back_kernel<T>, dim3(gN, unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok);
     hipLaunchKernelGGL(bl_step_kernel<T>, dim3(unsigned(P)), dim3(256), 0, st, dev, (const int32_t*)ok, timed_out, any_slot);
     hipLaunchKernelGGL(bl_update_kernel<T>, dim3(gX, unsigned(P)), dim3(256), 0, st, dev);
-    hipLaunchKernelGGL(bl_clear_action_kernel, dim3(unsigned((P + 63) / 64)), dim3(64), 0, st, dev);
     HIP_TRY(hipGetLastError());
     if (!capturing) {
       HIP_TRY(hipMemcpyAsync(&ev.host_flags[slot], any_slot, sizeof(int), hipMemcpyDeviceToHost, st));
