@@ -707,13 +707,17 @@ __device__ __forceinline__ void syrk_stage(float __attribute__((ext_vector_type(
 // with blocks x > y > z owns tiles (x,y), (x,z), (y,z) — three operands for three MFMAs; the four matched pairs a > b take (a,a), (b,b),
 // (a,b) — two operands.  Still three MFMAs per wave and step on every SIMD.  Which wave computes a tile never mattered to its bits.
 __device__ static constexpr unsigned kTriBlocks[12] = {0x420, 0x630, 0x750, 0x721, 0x531, 0x641, 0x652, 0x743, 0x010, 0x032, 0x054, 0x076};
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, typename Mid>
 __device__ __forceinline__ void syrk_stage_tri(float __attribute__((ext_vector_type(16))) (&acc)[3], const unsigned char* lds, const int base,
-                                               const int o0, const int o1, const int o2, const int K) {
+                                               const int o0, const int o1, const int o2, const int K, const int mid_at, Mid&& mid) {
+  // `mid` (the staging of the stage after next, round 5) runs in front of the k8 == mid_at group of this wave: the three waves of a SIMD
+  // take it at three different points of the stage, so that one wave's loads / scales / LDS writes fall under the others' MFMAs —
+  // with every wave staging at the head of the stage, in step behind the barrier, the matrix pipe idled a third of the time
   int p0 = base + o0, p1 = base + o1, p2 = base + o2;
   if constexpr (!PAIR) {
     T r0 = *reinterpret_cast<const T*>(lds + p0), r1 = *reinterpret_cast<const T*>(lds + p1), r2 = *reinterpret_cast<const T*>(lds + p2);
     for (int k8 = 0; k8 < K; k8 += 8) {
+      if (k8 == mid_at) mid();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {             // the next step's operands are in flight during this step's MFMAs (q == 3: see syrk_stage)
         const T n0 = *reinterpret_cast<const T*>(lds + p0 + (q + 1) * 256), n1 = *reinterpret_cast<const T*>(lds + p1 + (q + 1) * 256),
@@ -728,6 +732,7 @@ __device__ __forceinline__ void syrk_stage_tri(float __attribute__((ext_vector_t
   } else {
     T r0 = *reinterpret_cast<const T*>(lds + p0), r1 = *reinterpret_cast<const T*>(lds + p1);
     for (int k8 = 0; k8 < K; k8 += 8) {
+      if (k8 == mid_at) mid();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const T n0 = *reinterpret_cast<const T*>(lds + p0 + (q + 1) * 256), n1 = *reinterpret_cast<const T*>(lds + p1 + (q + 1) * 256);
@@ -841,14 +846,21 @@ __global__ void __launch_bounds__(TRI ? 768 : 1024) large_gram_kernel(const Larg
 #else
 #define GR_TICK(i)
 #endif
+    // (the waves w, w + 4, w + 8 share a SIMD: their staging goes in front of the 1st, 2nd, 3rd group of eight rows — TOA_GRAM_STAGGER 0: all at the head)
+#ifndef TOA_GRAM_STAGGER
+#define TOA_GRAM_STAGGER 1
+#endif
+    const int mid_at = (TRI && STAGE != 0 && TOA_GRAM_STAGGER && K >= 32) ? 8 * (wave >> 2) : 0;
     for (int r0 = row0; r0 < row1; r0 += K) {
-      if (r0 + K < row1) {
-        put(cur ? 0 : buf_bytes);
-        fetch(r0 + 2 * K);
-      }
+      auto staging = [&]() __attribute__((always_inline)) {
+        if (r0 + K < row1) {
+          put(cur ? 0 : buf_bytes);
+          fetch(r0 + 2 * K);
+        }
+      };
       GR_TICK(0)
-      if constexpr (STAGE == 0) syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K);
-      else if constexpr (TRI) syrk_stage_tri<T, STAGE == 2>(acc, syrk_lds, cur ? buf_bytes : 0, offA[0], offA[1], offA[2], K);
+      if constexpr (STAGE == 0) { staging(); syrk_stage<T, TPW, TPW>(acc, syrk_lds, cur ? buf_bytes : 0, offA, offB, K); }
+      else if constexpr (TRI) syrk_stage_tri<T, STAGE == 2>(acc, syrk_lds, cur ? buf_bytes : 0, offA[0], offA[1], offA[2], K, mid_at, staging);
 #ifdef TOA_GRAM_TIMING
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); ++nst;
 #endif
