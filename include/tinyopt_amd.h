@@ -500,6 +500,9 @@ typedef struct toa_jit_spec {
 int toa_model_compile_ex(toa_handle h, const toa_jit_spec* spec, const char* body, toa_jit_model* out, char* log_out, size_t log_cap);
 int toa_jit_set_cache_dir(const char* dir);
 int toa_jit_model_info(toa_jit_model m, int* from_cache, int* xdim);   /* from_cache: 1 = the code object came from the disk cache */
+/* What the run-time build of the fused kernel came out as: resident workgroups (of four wavefronts) per compute unit, its dynamic
+ * LDS per workgroup, vector registers (VGPR + AGPR) per lane and scratch bytes per lane (0 = nothing spilled).  Any pointer may be NULL. */
+int toa_jit_model_stats(toa_jit_model m, int* wg_per_cu, int* lds_bytes_per_wg, int* num_regs, int* scratch_bytes);
 int toa_model_destroy(toa_jit_model m);   /* waits for the model's last launch before the code is unloaded */
 int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
                    const toa_options* options, const toa_results* results, uint64_t* counters_dev);

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "toa_model_compile_ex": (C.c_int, [_P, C.POINTER(ToaJitSpec), C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "toa_jit_set_cache_dir": (C.c_int, [C.c_char_p]),
     "toa_jit_model_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "toa_jit_model_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "toa_model_destroy": (C.c_int, [_P]),
     "toa_jit_lm_run": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.POINTER(ToaOptions), C.POINTER(ToaResults), _P]),
     "toa_jit_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P, _P, _P]),

@@ -489,6 +489,13 @@ class JitResidual:
         check(self.ctx.lib.toa_jit_model_info(self._h, C.byref(fc), None))
         self.from_cache = bool(fc.value)
 
+    def stats(self) -> dict:
+        """What the run-time build of the fused kernel came out as: resident workgroups per compute unit, LDS per workgroup,
+        vector registers per lane, scratch bytes per lane (0 = nothing spilled)."""
+        v = [C.c_int(0) for _ in range(4)]
+        check(self.ctx.lib.toa_jit_model_stats(self._h, *[C.byref(t) for t in v]))
+        return dict(wg_per_cu=v[0].value, lds_bytes_per_wg=v[1].value, num_regs=v[2].value, scratch_bytes=v[3].value)
+
     @staticmethod
     def set_cache_dir(path: Optional[str], ctx: Optional["Context"] = None) -> None:
         """Where compiled code objects are kept (default: $XDG_CACHE_HOME/tinyopt_amd or ~/.cache/tinyopt_amd); "" = no cache."""

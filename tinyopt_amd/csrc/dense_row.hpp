@@ -827,11 +827,48 @@ struct DenseRowGram {
 
   // One step (4 residual rows, one per row group) handed in as operands instead of being loaded: w = this lane's NBM main
   // columns of W = [J | r], v = the thin columns (every lane of the row group holds the same values).  For the models
-  // that PRODUCE their rows (JetRowModel: forward-mode AD of a user functor) rather than stream them; the hot streaming
+  // that PRODUCE their rows (RowModel, row_model.hpp: a user's functor) rather than stream them; the hot streaming
   // loop above keeps its own hand-scheduled copy of this arithmetic.  last != 0: final step of the pass (see run_tail).
+  // TAIL: this may be the final step of the pass (then `last` != 0 waits the matrix pipe out, see run_tail).
+  template <bool TAIL = true>
   __device__ __forceinline__ void add_step(T (&w)[NBM], T (&v)[THIN ? THIN : 1], const int last) {
-    GramStep<T, NBM>::run_tail(acc, w, last);
-    if constexpr (THIN > 0) {
+    if constexpr (TAIL) GramStep<T, NBM>::run_tail(acc, w, last);
+    else GramStep<T, NBM>::run(acc, w);
+    if constexpr (sizeof(T) == 4 && THIN > 0) {   // the packed-FMA forms of apply_step (two products per v_pk_fma_f32)
+      using f2 = float __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int pb = 0; pb < NBM / 2; ++pb) {
+        const f2 wp = {w[2 * pb], w[2 * pb + 1]};
+#pragma unroll
+        for (int j = 0; j < THIN; ++j) {
+          f2 a = {accT[ti(2 * pb, j)], accT[ti(2 * pb + 1, j)]};
+          a += wp * f2{v[j], v[j]};
+          accT[ti(2 * pb, j)] = a[0];
+          accT[ti(2 * pb + 1, j)] = a[1];
+        }
+      }
+      if constexpr (NBM & 1) {
+#pragma unroll
+        for (int j = 0; j + 1 < THIN; j += 2) {
+          f2 a = {accT[ti(NBM - 1, j)], accT[ti(NBM - 1, j + 1)]};
+          a += f2{w[NBM - 1], w[NBM - 1]} * f2{v[j], v[j + 1]};
+          accT[ti(NBM - 1, j)] = a[0];
+          accT[ti(NBM - 1, j + 1)] = a[1];
+        }
+        if constexpr (THIN & 1) accT[ti(NBM - 1, THIN - 1)] += w[NBM - 1] * v[THIN - 1];
+      }
+#pragma unroll
+      for (int j2 = 0; j2 < THIN; ++j2) {
+#pragma unroll
+        for (int j = 0; j + 1 <= j2; j += 2) {
+          f2 a = {accTT[tt(j, j2)], accTT[tt(j + 1, j2)]};
+          a += f2{v[j], v[j + 1]} * f2{v[j2], v[j2]};
+          accTT[tt(j, j2)] = a[0];
+          accTT[tt(j + 1, j2)] = a[1];
+        }
+        if ((j2 & 1) == 0) accTT[tt(j2, j2)] += v[j2] * v[j2];
+      }
+    } else if constexpr (THIN > 0) {
 #pragma unroll
       for (int cb = 0; cb < NBM; ++cb)
 #pragma unroll

@@ -82,23 +82,23 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
 }
 #elif defined(TOA_INST_JETROW)
 // TOA_MODEL_DENSE_ROW_AD: the DenseRow residual written as r(x) only, differentiated on the device for WIDE parameter
-// blocks (JetRowModel): n = 12 (the C3 shape) and n = 50 (the C4 shape) are instantiated — a functor's parameter count is
+// blocks (RowModel over AdRowFunctor, row_model.hpp): n = 12 (the C3 shape) and n = 50 (the C4 shape) are instantiated — a functor's parameter count is
 // a compile-time constant, as in the reference's static-size Jets.
 int TOA_CAT(toa_inst_jetrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
-  if (n == 12) return launch_fused<JetRowModel<InstT, 1, 0, DenseRowAdFunctor<InstT, 12>>>(h, prm);
-  if (n == 50) return launch_fused<JetRowModel<InstT, 3, 3, DenseRowAdFunctor<InstT, 50>>>(h, prm);
+  if (n == 12) return launch_fused<RowModel<InstT, 1, 0, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 12>>>>(h, prm);
+  if (n == 50) return launch_fused<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, prm);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
 int TOA_CAT(toa_inst_jetrow_wide_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
   using E = EuclidManifold<InstT>;
-  if (n == 12) return launch_stepping<JetRowModel<InstT, 1, 0, DenseRowAdFunctor<InstT, 12>>, 16, E>(h, prm);
-  if (n == 50) return launch_stepping<JetRowModel<InstT, 3, 3, DenseRowAdFunctor<InstT, 50>>, 64, E>(h, prm);
+  if (n == 12) return launch_stepping<RowModel<InstT, 1, 0, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 12>>>, 16, E>(h, prm);
+  if (n == 50) return launch_stepping<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>, 64, E>(h, prm);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
 int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, int m, int64_t P, const void* data, const void* x,
                                                          int want_grad, void* g, void* H, double* cost, int32_t* nres) {
-  if (n == 12) return launch_accumulate<JetRowModel<InstT, 1, 0, DenseRowAdFunctor<InstT, 12>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
-  if (n == 50) return launch_accumulate<JetRowModel<InstT, 3, 3, DenseRowAdFunctor<InstT, 50>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (n == 12) return launch_accumulate<RowModel<InstT, 1, 0, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 12>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (n == 50) return launch_accumulate<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
 #elif defined(TOA_INST_SOLVE)

@@ -1254,127 +1254,19 @@ struct DenseRowAdFunctor {
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// Device AD for WIDE parameter blocks (13 <= kN <= 63; SURVEY §8f rank 1 "chunked Jets"; optimize_autodiff.h:91-166).
-// JetModel above keeps the (kN+1)(kN+2)/2 Gram of one item per lane in registers, which stops at kN = 12.  Here the
-// Jacobian row of an item is produced directly in the operand layout of DenseRowGram: the 16 lanes of a row group
-// evaluate the SAME residual, each on Jet<T, W> dual numbers seeded on the W = NBM + THIN - 1 columns that lane feeds to
-// the matrix cores (its NBM main columns + the thin columns every lane of the group carries) — the 16 chunks of the full
-// ceres::Jet<T, kN> evaluated side by side, r.v landing in MFMA operand order, no transposition, and the same Gram /
-// LDL^T / state machine as the hand-derived DenseRowModel from there on.  The parameters are handed to the functor
-// through SeededX: x[j] materialises parameter j as a Jet whose partials are 1 on the slot (if any) this lane owns for j.
-// One residual per item (kR == 1); cost-only passes evaluate the functor on plain T, one item per lane.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int W>
-struct SeededX {
-  const T* xs;   // the parameters (LDS)
-  int col[W];    // parameter index of each partial slot of this lane (-1: the slot is unused)
-  __device__ __forceinline__ Jet<T, W> operator[](int j) const {
-    Jet<T, W> r;
-    r.a = xs[j];
-#pragma unroll
-    for (int s = 0; s < W; ++s) r.v[s] = (col[s] == j) ? T(1) : T(0);   // optimize_autodiff.h:56-69 seeding, per chunk
-    return r;
-  }
-};
-
-template <typename T, int NBM, int THIN, typename F>
-struct JetRowModel {
-  using Scalar = T;
-  static constexpr int kXdim = 0;
-  static constexpr int kNmax = THIN > 0 ? 16 * NBM + THIN - 1 : 16 * NBM - 1;
-  static constexpr int kNpad = (kNmax + 7) & ~7;
-  static constexpr int kW = NBM + (THIN ? THIN - 1 : 0);
-  static_assert(F::kR >= 1 && F::kR <= 8, "residuals per item");
-  static_assert(F::kN <= kNmax, "functor has more parameters than this layout holds");
-  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
-  __device__ __forceinline__ void set_loss(int, double) {}
-  DenseRowGram<T, NBM, THIN> gram;
-  const T* data;
-  const T* d;
-  DenseRowLayout lay;
-  int m;           // residual ROWS of a problem: items x kR (an item's kR residuals are kR consecutive rows — optimize_autodiff.h:123-164
-                   // takes vector residuals of any width; round 5)
-  int row0, mrows; // the rows of the bound problem this model works on: all of them, or one chunk of the row-split form
-  __device__ __forceinline__ void init(int n, int m_, const void* dp) {
-    m = m_;
-    lay = DenseRowLayout::make(n, m_);
-    data = static_cast<const T*>(dp);
-    row0 = 0; mrows = m_;
-  }
-  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (F::kH + size_t(m / F::kR) * F::kD); row0 = 0; mrows = m; }
-  // row-split execution: rows [r0, r0 + rows) of problem p — r0 on an item boundary (a multiple of lcm(16, kR): jit.hip)
-  __device__ __forceinline__ void bind_chunk(long long p, int r0, int rows, int) { bind(p); row0 = r0; mrows = max(0, min(rows, m - r0)); }
-  __device__ __forceinline__ void accumulate(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    const int k = lane >> 4, c = lane & 15;
-    SeededX<T, kW> X;
-    X.xs = L.xs;
-#pragma unroll
-    for (int cb = 0; cb < NBM; ++cb) {
-      const int q = NBM * c + cb;
-      X.col[cb] = (q < lay.nmr && q < n) ? q : -1;
-    }
-#pragma unroll
-    for (int j = 0; j + 1 < THIN; ++j) X.col[NBM + j] = lay.nmr + j;
-    const bool isB = (THIN == 0) && ((c + 1) * NBM == lay.rsm);
-    gram.clear();
-    const T* items = d + F::kH;
-    const int steps = (mrows + 3) >> 2;
-    for (int s = 0; s < steps; ++s) {
-      const int row = 4 * s + k;
-      Jet<T, kW> rr[F::kR];
-      Jet<T, kW> r0;          // the row's residual: component (row mod kR) of its item's (the item is evaluated once per row)
-      if (row < mrows) {      // padding rows stay all-zero
-        const int grow = row0 + row, item = grow / F::kR, comp = grow - item * F::kR;
-        F::template eval<Jet<T, kW>>(X, d, items + size_t(item) * F::kD, rr);
-        r0 = rr[0];
-#pragma unroll
-        for (int q = 1; q < F::kR; ++q) if (comp == q) r0 = rr[q];
-      }
-      T w[NBM], v[THIN ? THIN : 1];
-#pragma unroll
-      for (int cb = 0; cb < NBM; ++cb) w[cb] = r0.v[cb];                              // J.row(i) = res[i].v (:127-148)
-      if constexpr (THIN == 0) {
-        if (isB) w[NBM - 1] = r0.a;
-      } else {
-#pragma unroll
-        for (int j = 0; j + 1 < THIN; ++j) v[j] = r0.v[NBM + j];
-        v[THIN - 1] = r0.a;
-      }
-      gram.add_step(w, v, __builtin_amdgcn_readfirstlane(int(s + 1 == steps)));
-    }
-    gram.finish_steps();
-    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
-    nres = m;
-  }
-  __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
-    T csum = 0;
-    const T* items = d + F::kH;
-    const int it0 = row0 / F::kR, nit = mrows / F::kR;
-    for (int i = lane; i < nit; i += 64) {
-      T r[F::kR];
-      F::template eval<T>(L.xs, d, items + size_t(it0 + i) * F::kD, r);   // the same functor on plain scalars (grad == nullptr)
-#pragma unroll
-      for (int q = 0; q < F::kR; ++q) csum += r[q] * r[q];
-    }
-    cost = wave_allreduce_sum(csum);
-    nres = m;
-  }
-  template <typename O>
-  __device__ __forceinline__ void write_sym(O* M, int LD, int n, int lane) const { gram.write_sym(M, LD, lay, n, lane); }
-  // memo of the last accepted linearisation (lm_device.hpp) — worth 25 x more here than on the analytic rows
-  static constexpr bool kMemo = true;
-  static constexpr size_t kMemoBytes = size_t(DenseRowGram<T, NBM, THIN>::kMemoElems) * sizeof(T);
-  __device__ __forceinline__ void memo_save(WaveLds<T>& L, int lane) const { gram.memo_save(reinterpret_cast<T*>(L.st->memo_slot), lane); }
-  __device__ __forceinline__ void memo_reextract(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
-    nres = m;
-  }
-  __device__ __forceinline__ void memo_restore(WaveLds<T>& L, int n, int lane, T& cost, int& nres) {
-    gram.memo_load(reinterpret_cast<const T*>(L.st->memo_slot), lane);
-    memo_reextract(L, n, lane, cost, nres);
-  }
-};
+template <typename F, typename = void>
+struct FunctorComputeBound { static constexpr bool value = false; };
+template <typename F>
+struct FunctorComputeBound<F, std::enable_if_t<F::kComputeBound>> { static constexpr bool value = true; };
+template <typename F, typename = void>
+struct FunctorIndexed { static constexpr bool value = false; };
+template <typename F>
+struct FunctorIndexed<F, std::enable_if_t<F::kIndexedOperands>> { static constexpr bool value = true; };
+// Row models for WIDE parameter blocks (13 <= kN <= 63): a row is a lane — the user's Jacobian rows, or chunked Jets, staged
+// through LDS into the matrix cores' operand layout (row_model.hpp; SURVEY §8f rank 1, optimize_autodiff.h:91-166).
+}  // namespace toa
+#include "row_model.hpp"
+namespace toa {
 
 // Per-problem LM state parked in HBM between launches: the stepping form (`Optimizer_::Step`, optimizer.h:331-539, one
 // loop pass per call) and the launch-per-iteration row-split path both resume the same state machine from it.
@@ -1438,6 +1330,25 @@ template <typename M, typename = void>
 struct ModelStageBytes { static constexpr size_t value = 0; };
 template <typename M>
 struct ModelStageBytes<M, std::enable_if_t<(M::kStageBytes > 0)>> { static constexpr size_t value = M::kStageBytes; };
+// A staged model's LDS stage begins at the wave's region and ends INSIDE its carve, over the part of it that is dead while a
+// pass runs (WaveLds::pass_dead_bytes): the carve starts stage_carve_off bytes into the region.  One rule for every kernel and
+// for the host's LDS sizing (lds_fit): a function of the stage size and n only.
+template <typename T>
+__host__ __device__ inline size_t stage_carve_off(size_t stage_bytes, int n) {
+  const size_t st = (stage_bytes + 15) & ~size_t(15), dead = WaveLds<T>::pass_dead_bytes(n);
+  return st > dead ? st - dead : 0;
+}
+// launch-per-iteration kernels: binds the model's stage, returns where the wave's carve starts
+template <typename Model>
+__device__ __forceinline__ char* model_bind_stage(Model& model, char* wave_base, int n) {
+  if constexpr (ModelStageBytes<Model>::value > 0) {
+    model.stage = reinterpret_cast<unsigned char*>(wave_base);
+    return wave_base + stage_carve_off<typename Model::Scalar>(ModelStageBytes<Model>::value, n);
+  } else {
+    (void)model; (void)n;
+    return wave_base;
+  }
+}
 template <typename M, typename = void>
 struct ModelWaves { static constexpr int value = 4; };
 template <typename M>
@@ -1451,7 +1362,10 @@ struct ModelCoop<M, std::enable_if_t<M::kCoop>> { static constexpr bool value = 
 // hipcc parks the destination registers of the in-flight asm loads in AGPRs right after issuing them — tools/isa_lint.py
 // caught exactly that when 5 waves/SIMD were requested for the fp64 n <= 15 kernel.)
 template <typename Model>
-__global__ void __launch_bounds__(64 * ModelWaves<Model>::value) lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
+#ifndef TOA_FUSED_ATTR
+#define TOA_FUSED_ATTR   // run-time builds may ask for an occupancy here (jit.hip: __attribute__((amdgpu_waves_per_eu(3, 3))))
+#endif
+__global__ void __launch_bounds__(64 * ModelWaves<Model>::value) TOA_FUSED_ATTR lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kW = ModelWaves<Model>::value;   // waves per workgroup: 4, or 12 in the team form
@@ -1607,11 +1521,11 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const void* data_, cons
   using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * lds_per_wave, n);
   const T* X = static_cast<const T*>(x_);
   Model model;
   model.init(n, m, data_);
   model.set_loss(loss, loss_th2);
+  WaveLds<T> L = WaveLds<T>::carve(model_bind_stage(model, smem + size_t(wave) * lds_per_wave, n), n);
   const int xd = Model::kXdim ? Model::kXdim : n;
   for (long long p = (long long)blockIdx.x * 4 + wave; p < P; p += (long long)gridDim.x * 4) {
     wave_sync();
@@ -1798,16 +1712,16 @@ __global__ void __launch_bounds__(256) wide_partial_kernel(const WideParams* __r
   const int sidx = int(unit % S);
   const WideState<T>* ws = static_cast<const WideState<T>*>(prm->state) + p;
   if (ws->st.stop != TOA_STOP_NONE || ws->st.iter >= ws->st.max_iters) return;  // this problem is finished
-  WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm->lds_per_wave, n);
+  Model model;
+  model.init(n, prm->m, prm->data);
+  model.set_loss(prm->loss, prm->loss_th2);
+  WaveLds<T> L = WaveLds<T>::carve(model_bind_stage(model, smem + size_t(wave) * prm->lds_per_wave, n), n);
   L.xs[lane] = ws->xs[lane];
   wave_sync();
   const bool do_acc = prm->opt.solver_type != 0 || ws->st.rebuild;
   const int m4 = (prm->m + 3) & ~3;
   const int row0 = sidx * prm->chunk_rows;
   const int rows = min(prm->chunk_rows, m4 - row0);
-  Model model;
-  model.init(n, prm->m, prm->data);
-  model.set_loss(prm->loss, prm->loss_th2);
   model.bind_chunk(p, row0, rows, n);
   const int stride = n * n + n + 2;
   T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
@@ -2096,6 +2010,7 @@ __global__ void __launch_bounds__(512) wide_team_kernel(const WideParams* __rest
   Model model;
   model.init(n, prm->m, prm->data);
   model.set_loss(prm->loss, prm->loss_th2);
+  static_assert(ModelStageBytes<Model>::value == 0, "the team form of the row-split kernels has no room for a model's LDS stage");
   model.bind_chunk(p, row0, rows, n);
   T* part = parts + size_t(wave) * stride;
 
@@ -2181,7 +2096,7 @@ __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* _
   const long long p = (long long)blockIdx.x / S;
   const int sidx = int((long long)blockIdx.x % S);
   const bool leader = sidx == 0;
-  WaveLds<T> L = WaveLds<T>::carve(smem, n);
+  WaveLds<T> L = WaveLds<T>::carve(smem + stage_carve_off<T>(ModelStageBytes<Model>::value, n), n);
   WideState<T>* ws = static_cast<WideState<T>*>(prm->state) + p;  // mailbox: x + flags published by the leader
   unsigned* arrive = prm->sync + 2 * p;
   unsigned* go = arrive + 1;
@@ -2194,6 +2109,7 @@ __global__ void __launch_bounds__(64) wide_persistent_kernel(const WideParams* _
   Model model;
   model.init(n, prm->m, prm->data);
   model.set_loss(prm->loss, prm->loss_th2);
+  (void)model_bind_stage(model, smem, n);
   model.bind_chunk(p, row0, rows, n);
   const int stride = n * n + n + 2;
   T* part = static_cast<T*>(prm->partials) + (size_t(p) * S + sidx) * stride;
@@ -2477,9 +2393,10 @@ inline int ensure_pass_ring(toa_handle h) {
 
 // waves per workgroup: 4 (256 threads) everywhere but the team form of the fused kernel; LDS per wave decides how many WGs fit per CU.
 template <typename T>
-inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg, int waves = 4) {
+inline int lds_fit(toa_handle h, int n, size_t* per_wave, size_t* per_wg, int waves = 4, size_t stage = 0) {
   size_t pw = WaveLds<T>::bytes(n);
   pw = (pw + 15) & ~size_t(15);
+  pw += stage_carve_off<T>(stage, n);   // a model's LDS stage (row_model.hpp) overlays the carve's pass-dead head: what sticks out in front
   *per_wave = pw;
   *per_wg = pw * waves;
   if (*per_wg > 160 * 1024) return toa_fail(TOA_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB per workgroup");
@@ -2519,7 +2436,7 @@ inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* 
   const long long cap = (long long)h->num_cus * 8;
   if (grid > cap) grid = cap;
   size_t pw, pwg;
-  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg, 4, ModelStageBytes<Model>::value)) return rc;
   using RModel = typename RobustOf<Model>::type;
   if (h->loss != TOA_LOSS_L2 && !std::is_same<RModel, Model>::value) {
     if (int rc = ensure_lds_attr(h, (const void*)accumulate_kernel<RModel>, pwg)) return rc;
@@ -2726,7 +2643,7 @@ inline int launch_stepping(toa_handle h, const FusedParams& fp) {
   const int n = fp.n, m = fp.m;
   const long long P = fp.P;
   size_t pw, pwg, o_part, o_hsum;
-  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg, 4, ModelStageBytes<Model>::value)) return rc;
   (void)stepping_state_bytes<T>(n, P, &o_part, &o_hsum);
   WideParams wp;
   std::memset(&wp, 0, sizeof(wp));
@@ -2790,7 +2707,7 @@ inline int launch_wide(toa_handle h, const FusedParams& fp, int splits_req) {
   chunk = (chunk + 15) & ~15;
   S = (m4 + chunk - 1) / chunk;
   size_t pw, pwg;
-  if (int rc = lds_fit<T>(h, n, &pw, &pwg)) return rc;
+  if (int rc = lds_fit<T>(h, n, &pw, &pwg, 4, ModelStageBytes<Model>::value)) return rc;
   const size_t stride = size_t(n) * n + n + 2;
   const size_t b_state = (size_t(P) * sizeof(WideState<T>) + 255) & ~size_t(255);
   const size_t b_part = (size_t(P) * S * stride * sizeof(T) + 255) & ~size_t(255);

@@ -149,8 +149,11 @@ def lint_object(obj):
         local = os.path.join(td, os.path.basename(obj))
         with open(obj, "rb") as f, open(local, "wb") as g:
             g.write(f.read())
-        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], cwd=td, check=True, capture_output=True)
-        cos = [p for p in glob.glob(local + ".*") if "amdgcn" in p]
+        if obj.endswith(".co"):   # a bare gfx950 code object (e.g. one taken out of the run-time compiler's cache, tools/jit_lint.py)
+            cos = [local]
+        else:
+            subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", local], cwd=td, check=True, capture_output=True)
+            cos = [p for p in glob.glob(local + ".*") if "amdgcn" in p]
         for co in cos:
             dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
             func = "?"
