@@ -31,6 +31,11 @@ WORKLOADS = {
     # name: (P per GPU, n, m, torch dtype, dtype tag, description)
     "c4": (12500, 50, 2000, torch.float32, "f32", "C4 shard: 12500 problems/GPU x n=50 x m=2000 DenseRow fp32 (8 GPUs = 100k-problem C4)"),
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
+    # the C4 shape through the reference's OTHER doors: the residual handed over as TEXT at run time —
+    # with its own Jacobian row (a manual Accumulate callback, docs/API.md:37-57, benchmarks/dense.cpp:57-66,90-99), or as r(x)
+    # only, differentiated on the device (optimize_autodiff.h:91-166).  Items = rows [a_i | b_i] in the natural layout.
+    "c4_text": (12500, 50, 2000, torch.float32, "f32", "C4 shard shape (12500 problems/GPU x n=50 x m=2000 fp32), DenseRow residual AND its Jacobian row supplied as C++ text at run time (TOA_JIT_ACCUMULATE; csrc/row_model.hpp)"),
+    "c4_ad": (12500, 50, 2000, torch.float32, "f32", "C4 shard shape (12500 problems/GPU x n=50 x m=2000 fp32), DenseRow residual supplied as C++ text, Jacobian by device AD (chunked Jets, a row per lane; csrc/row_model.hpp)"),
     # beyond one wavefront: rows kernel + batched library GEMM + workgroup Cholesky; MFMA-bound
     "large128": (512, 128, 4096, torch.float32, "f32", "512 problems/GPU x n=128 x m=4096 DenseRow fp32, workgroup-per-problem kernel (64 <= n <= 128)"),
     "large256": (128, 256, 8192, torch.float32, "f32", "128 problems/GPU x n=256 x m=8192 DenseRow fp32, launch-per-stage pipeline (n > 128): rows kernel + hand-written MFMA Gram (operand-sharing deal of the 36 tiles) + one-workgroup blocked Cholesky, passes enqueued ahead"),
@@ -577,6 +582,26 @@ def main():
         xstar = torch.arange(rank * P, (rank + 1) * P, dtype=tdt)[:, None] * 0.001 + torch.arange(n, dtype=tdt)[None, :]
         x0 = torch.zeros(P, n, dtype=tdt)
         model = _DryModel(P, n, m, tdt, xstar)
+    elif args.workload in ("c4_text", "c4_ad"):
+        # the same distributions as DenseRow.synthetic, rows in the natural layout: an item = [a_i (n) | b_i]
+        gen = torch.Generator(device="cuda").manual_seed(0x7194 + rank)
+        A = torch.rand(P, m, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        xstar = torch.rand(P, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        t = torch.einsum("pmn,pn->pm", A, xstar)
+        bvec = t + 0.1 * torch.sin(t) + 1e-3 * (torch.rand(P, m, dtype=tdt, device="cuda", generator=gen) * 2 - 1)
+        x0 = xstar + 0.5 * (torch.rand(P, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1)
+        items = torch.cat([A, bvec[..., None]], dim=2).contiguous()
+        del A, bvec, t
+        if args.workload == "c4_text":
+            body = (f"T t = x[0] * p[0];\nfor (int j = 1; j < {n}; ++j) t += x[j] * p[j];\nT sn, cs; sincos_t(t, &sn, &cs);\n"
+                    f"r[0] = t + T(0.1) * sn - p[{n}];\nif (want_grad) {{\n  const T sc = T(1) + T(0.1) * cs;\n#pragma unroll\n"
+                    f"  for (int j = 0; j < {n}; ++j) J[0][j] = sc * p[j];\n}}")
+            jit = ta.JitResidual(body, n=n, item_scalars=n + 1, dtype=tdt, kind="accumulate", ctx=ctx)
+        else:
+            body = f"S t = x[0] * p[0];\n#pragma unroll 2\nfor (int j = 1; j < {n}; ++j) t = t + x[j] * p[j];\nr[0] = t + T(0.1) * sin(t) - p[{n}];"
+            jit = ta.JitResidual(body, n=n, item_scalars=n + 1, dtype=tdt, ctx=ctx)
+        model = jit.bind(items)
+        jit_build = jit.stats()
     elif not large:
         model, x0, xstar = ta.DenseRow.synthetic(P, n, m, tdt, problem0=rank * P)
     else:  # natural layout (A then b), generated on the device with the same distributions
@@ -836,6 +861,10 @@ def main():
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
                                         "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
+    if args.workload in ("c4_text", "c4_ad"):
+        result["metric"] = "LM iterations/s (batched dense n<=50, residual supplied as text at run time)"
+        result["roofline"]["kernel"] = "lm_fused_kernel<RowModel<float, 3, 3, ...>> (hiprtc build of the user's functor)"
+        result["config"]["jit_build"] = jit_build   # resident workgroups / CU, LDS per workgroup, registers, scratch of the run-time build
     if large:  # AI = (n + 2) / sizeof = 32.5 flop/B at n = 128 fp32, beyond the 19.7 flop/B ridge: the MFMA roof bounds this path
         r = result["roofline"]
         sec = r.pop("mfma_secondary")

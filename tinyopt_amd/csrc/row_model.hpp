@@ -135,7 +135,10 @@ struct AdRowFunctor {
   static constexpr bool kComputeBound = true;                  // (RowModel: one LDS region, every lane an item — the Jets are the bound)
   static constexpr bool kIndexedOperands = true;               // x[j] / p[j] with a RUNNING j: straight from LDS (a register array indexed
                                                                // by a loop counter is scratch memory)
-  static constexpr int kChunks = (kN + 11) / 12;               // Jets of <= 12 partials, as balanced as kN allows
+#ifndef TOA_AD_CW
+#define TOA_AD_CW 12
+#endif
+  static constexpr int kChunks = (kN + TOA_AD_CW - 1) / TOA_AD_CW;   // Jets of <= 12 partials, as balanced as kN allows
   static constexpr int kCW = (kN + kChunks - 1) / kChunks;
   template <bool want_grad>
   static __device__ __forceinline__ void eval_manual(const T* x, const T* h, const T* p, T* r, T (*J)[kN]) {
@@ -422,7 +425,10 @@ struct RowModel {
         wave_sync();
         // ---- the super-step's Gram steps, their operands read a batch ahead of the matrix core
         const int last_ss = __builtin_amdgcn_readfirstlane(int(ss + 1 == nss));
-        constexpr int kBatch = SPS < 4 ? SPS : 4;
+#ifndef TOA_ROW_KB
+#define TOA_ROW_KB 4
+#endif
+        constexpr int kBatch = SPS < TOA_ROW_KB ? SPS : TOA_ROW_KB;
         constexpr int kNB = (SPS + kBatch - 1) / kBatch;
         static_for<kNB>([&](auto bc) __attribute__((always_inline)) {
           constexpr int b = decltype(bc)::value;
