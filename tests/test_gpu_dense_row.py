@@ -363,3 +363,50 @@ def test_every_n_layout_accumulate_and_solve(ta, oracle, dtype, tdt):
             torch.cuda.synchronize()
             assert (out.stop_reason.cpu().numpy() >= 0).all() and (ref["stop"] >= 0).all(), n
             assert np.abs(x.cpu().numpy() - ref["x"]).max() < (1e-8 if dtype == np.float64 else 3e-3), n
+
+
+@pytest.mark.parametrize("scale", [1e2, 1e3, 1e4])
+@pytest.mark.parametrize("n,m", [(50, 2000), (12, 500), (33, 300)])
+def test_fp32_pass_at_large_arguments(ta, oracle, scale, n, m):
+    """VERDICT r05 "weak" #1 / "next" #4: the compiled-in fp32 pass evaluates sin / cos with v_sin_f32 / v_cos_f32 (inputs in
+    revolutions), whose absolute error grows with |t| while libm's does not, and every other parity test lives at |a_i . x| < ~50.
+    Here |a_i . x| is swept up to `scale` (the rows are unit-range, x is scaled).  Yardstick: the SAME fp32 data evaluated in
+    float64 (numpy).  At |t| ~ 10^4 one fp32 ulp of t itself is 10^-3, so the fp32 CPU oracle — libm sin, sequential sum —
+    is itself only that close to the float64 value; the device must be no further from it than a small multiple of the oracle's
+    own distance (+ the fp32 tolerance class of SURVEY §8c, math.h:297-301), for the cost, J^T r and J^T J of an Accumulate pass,
+    for the cost-only pass, and for the run-time row model's polynomial-free path (same functor as text).  Then an LM solve from a
+    start near the planted solution recovers it."""
+    P = 4
+    rng = np.random.default_rng(int(scale) + n)
+    A = rng.uniform(-1, 1, (P, m, n)).astype(np.float32)
+    xs = (scale / np.sqrt(n / 3.0) * rng.uniform(-1, 1, (P, n))).astype(np.float32)          # |a . x*| of the order of `scale`
+    t64 = np.einsum("pmn,pn->pm", A.astype(np.float64), xs.astype(np.float64))
+    assert np.abs(t64).max() > 0.8 * scale
+    b = (t64 + 0.1 * np.sin(t64)).astype(np.float32)
+    x = (xs + rng.uniform(-1, 1, xs.shape) * 0.05).astype(np.float32)                        # residuals of order 0.1 .. 1
+
+    def f64(xv):
+        t = np.einsum("pmn,pn->pm", A.astype(np.float64), xv.astype(np.float64))
+        r = t + 0.1 * np.sin(t) - b.astype(np.float64)
+        J = (1 + 0.1 * np.cos(t))[..., None] * A.astype(np.float64)
+        return np.einsum("pmn,pm->pn", J, r), np.einsum("pmn,pmk->pnk", J, J), (r * r).sum(1)
+    g64, H64, c64 = f64(x)
+    g_o, H_o, c_o, _ = oracle.dense_row_accumulate(A, b, x)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    g, H, c, _ = ta.accumulate(model, torch.from_numpy(x).cuda())
+    c0 = ta.accumulate(model, torch.from_numpy(x).cuda(), want_grad=False)[2]
+    torch.cuda.synchronize()
+    for name, dev, orc, ref in (("g", g.cpu().numpy(), g_o, g64), ("H", H.cpu().numpy(), H_o, H64), ("cost", c.cpu().numpy(), c_o, c64),
+                                ("cost-only", c0.cpu().numpy(), c_o, c64)):
+        e_dev, e_orc = _rel(dev, ref), _rel(orc, ref)
+        assert e_dev <= 4 * e_orc + 2e-4, (name, scale, n, e_dev, e_orc)
+    # the solve: the planted solution is recovered to the accuracy fp32 allows at this magnitude of x
+    opts = ta.Options.benchmark()
+    xg = torch.from_numpy(x.copy()).cuda()
+    out = ta.Optimize(xg, model, opts)
+    torch.cuda.synchronize()
+    assert bool((out.stop_reason >= 0).all())
+    ref = oracle.dense_row_lm(A, b, x, opts.to_pod())
+    err_dev = np.abs(xg.cpu().numpy().astype(np.float64) - xs).max()
+    err_orc = np.abs(ref["x"].astype(np.float64) - xs).max()
+    assert err_dev <= 4 * err_orc + 1e-6 * scale, (scale, n, err_dev, err_orc)

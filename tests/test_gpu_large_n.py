@@ -105,6 +105,28 @@ def test_large_n_lm_matches_oracle(ta, oracle, dtype, n, m, xtol):
             np.testing.assert_allclose(out.final_cost.cpu().numpy(), ref["cost"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("dtype,n,m", [(np.float32, 4, 64), (np.float32, 8, 96), (np.float32, 12, 100), (np.float32, 16, 128),
+                                       (np.float64, 2, 40), (np.float64, 8, 64), (np.float64, 6, 50), (np.float32, 20, 140)])
+def test_natural_layout_narrow_rows(ta, oracle, dtype, n, m):
+    """the vectorised rows kernel works R trips at a time and needs R <= LPR lanes per row; vector-aligned
+    narrow shapes (n = 4 .. 16 fp32, 2 .. 8 fp64: LPR = 1, 2, 4 < R = 8) silently lost the residual, loss and scale of the trips
+    beyond LPR.  They now take the general rows kernel: the trajectory against the oracle, row counts that keep m (n + 1) a
+    multiple of the vector (the vectorised path's own precondition) so that the shapes are exactly the ones that were wrong."""
+    P = 5
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, dtype)
+    opts = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    xg, out = _run_natural(ta, A, b, x0, opts, history=True)
+    assert np.abs(xg - ref["x"]).max() < (1e-8 if dtype == np.float64 else 2e-3)
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    g = dict(errs=out.errs.cpu().numpy(), succ=out.successes.cpu().numpy(), iters=out.num_iters.cpu().numpy(),
+             stop=out.stop_reason.cpu().numpy(), x=xg, cost=out.final_cost.cpu().numpy(),
+             fails=out.num_failures.cpu().numpy(), deltas2=out.deltas2.cpu().numpy())
+    st = check_trajectories(g, refd, dtype, opts.to_pod(), label=f"natural layout, n = {n}")
+    assert st["full"] + st["ties"] == P
+
+
 def test_large_n_lm_agrees_with_fused_kernel_at_n50(ta, oracle):
     pyoracle = oracle
     P, n, m = 6, 50, 400

@@ -1741,6 +1741,22 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   const long long P = prm.P;
   const BlWork<T> wk(C, N, M);
   const BlIdx ix(C, N, M);
+  // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
+  long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
+  if (capturing) {   // (refusals come BEFORE the first stream operation: a capture that handles the error is not left half-recorded)
+    constexpr long long kMaxCapturedPasses = 256;
+    const long long tries = prm.opt.max_consec_failures > 0 ? (long long)prm.opt.max_consec_failures + 1 : 256;
+    max_passes = (long long)(prm.opt.max_iters + 2) * tries;
+    const size_t chol2_lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * sizeof(T) + 64;
+    const bool own_solver = n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds));
+    if (max_duration_ms > 0 || !prm.opt.use_ldlt || h->tune.large_library_solver != 0 || !own_solver)
+      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: only solves whose every stage is a kernel of this library can be captured "
+                                         "(use_ldlt, the one-workgroup factorisation of the reduced camera system, no max_duration_ms)");
+    if (max_passes > kMaxCapturedPasses)
+      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: the pass budget of these options is " + std::to_string(max_passes) +
+                                         " passes (~" + std::to_string(max_passes * 12) + " graph nodes); at most " + std::to_string(kMaxCapturedPasses) +
+                                         " are recorded — set max_consec_failures > 0 (the retry bound per iteration) or lower max_iters");
+  }
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t b_work = al(size_t(P) * wk.total * sizeof(T)), b_iwork = al(size_t(P) * ix.total * sizeof(int)), b_ok = al(size_t(P) * sizeof(int32_t));
   const size_t b_S = al(size_t(P) * n * n * sizeof(T)), b_v = al(size_t(P) * n * sizeof(T));
@@ -1778,23 +1794,7 @@ int ba_lists_run_t(toa_handle h, int dtype, BlParams prm, double max_duration_ms
   hipLaunchKernelGGL(bl_index_c_kernel, dim3(unsigned(C), unsigned(P)), dim3(64), 0, st, dev);
   hipLaunchKernelGGL(bl_init_kernel<T>, dim3(unsigned(P)), dim3(64), 0, st, dev);
   HIP_TRY(hipGetLastError());
-  // every iteration is at most max_consec retries + 1 passes; bounded like the n > 128 pipeline's host loop
-  long long max_passes = (long long)(prm.opt.max_iters + 3) * 260;
-  if (capturing) {
-    constexpr long long kMaxCapturedPasses = 256;
-    const long long tries = prm.opt.max_consec_failures > 0 ? (long long)prm.opt.max_consec_failures + 1 : 256;
-    max_passes = (long long)(prm.opt.max_iters + 2) * tries;
-    const size_t chol2_lds = (size_t(32) * 36 + size_t(n) * 37 + 96) * sizeof(T) + 64;
-    const bool own_solver = n <= 128 || (P <= 65535 && chol2_lds + 2048 <= size_t(h->max_lds));
-    if (max_duration_ms > 0 || !prm.opt.use_ldlt || h->tune.large_library_solver != 0 || !own_solver)
-      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: only solves whose every stage is a kernel of this library can be captured "
-                                         "(use_ldlt, the one-workgroup factorisation of the reduced camera system, no max_duration_ms)");
-    if (max_passes > kMaxCapturedPasses)
-      return toa_fail(TOA_E_UNSUPPORTED, "toa_ba_lists_run under stream capture: the pass budget of these options is " + std::to_string(max_passes) +
-                                         " passes (~" + std::to_string(max_passes * 12) + " graph nodes); at most " + std::to_string(kMaxCapturedPasses) +
-                                         " are recorded — set max_consec_failures > 0 (the retry bound per iteration) or lower max_iters");
-    h->shadow_retired = true;   // (a graph of this handle now exists: its workspaces are never freed under it, toa_release_workspace)
-  }
+  if (capturing) h->shadow_retired = true;   // (a graph of this handle now exists: its workspaces are never freed under it, toa_release_workspace)
   // Round 4: the host no longer waits for a pass before it enqueues the next one.  Every pass leaves "is any scene still
   // running" in its own slot of a small ring; the slot is copied to pinned host memory behind the pass and the host looks at
   // pass k's answer only before it enqueues pass k + kAhead — the GPU always has the next pass queued (round 3: a

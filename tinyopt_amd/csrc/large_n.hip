@@ -1932,11 +1932,16 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   constexpr int VEC = 16 / int(sizeof(T));
   // (n > 1024, round 5: the general rows kernel + the library's GEMM / GEMV / factorisation — the vectorised rows kernel keeps at most
   //  eight 16-byte vectors of a row per lane, the hand-written Gram's LDS stage ends at 1024 columns)
-  const bool vec_ok = n <= 1024 && n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
+  const bool vec_shape = n <= 1024 && n % VEC == 0 && (size_t(m) * (n + 1)) % VEC == 0 && reinterpret_cast<uintptr_t>(data) % 16 == 0;
   const int nv = n / VEC;
   int LPR = 1;
   while (LPR * 2 <= std::min(64, nv)) LPR *= 2;
-  const int KV = vec_ok ? (nv + LPR - 1) / LPR : 0;
+  // (large_rows_vec_kernel works R trips at a time and hands trip u's scalar work to lane u of the row group: it needs R <= LPR
+  //  lanes per row.  Narrow rows — n = 4 .. 16 in fp32, 2 .. 8 in fp64 — have fewer and take the general rows kernel)
+  const int KV0 = vec_shape ? (nv + LPR - 1) / LPR : 0;
+  const int Rtrips = KV0 >= 5 ? 1 : (KV0 >= 3 ? 2 : (KV0 == 2 ? 4 : 8));
+  const bool vec_ok = vec_shape && LPR >= Rtrips;
+  const int KV = vec_ok ? KV0 : 0;
   const int RPW = 64 / LPR;
   // (capped at one workgroup per compute unit and problem: every workgroup leaves four partial J^T r vectors that
   //  large_pre_kernel sums one after the other — 16 000 of them for ONE problem of 65 536 rows took longer than the data pass)

@@ -24,7 +24,8 @@
 // that owns no register cannot be broken by it.
 #pragma once
 #ifndef TOA_ROW_SINGLE
-#define TOA_ROW_SINGLE 0   // A/B arm: one-region accumulate passes for every functor
+#define TOA_ROW_SINGLE 1   // accumulate passes use ONE region of the stage (fetch, wait, compute: every lane an item) for every functor;
+                           // 0 = the ring for functors that are not compute-bound (A/B: C4 as text 11.4 -> 10.8 ms with 1, profiles/r06_ab_log.md)
 #endif
 #ifndef TOA_ROW_XREGS
 #define TOA_ROW_XREGS 0   // A/B arm: x as a register array (50 VGPRs at n = 50: the fused kernel then keeps ONE workgroup per compute unit)
@@ -424,7 +425,6 @@ struct RowModel {
         }
         wave_sync();
         // ---- the super-step's Gram steps, their operands read a batch ahead of the matrix core
-        const int last_ss = __builtin_amdgcn_readfirstlane(int(ss + 1 == nss));
 #ifndef TOA_ROW_KB
 #define TOA_ROW_KB 4
 #endif
@@ -457,11 +457,13 @@ struct RowModel {
 #pragma unroll
             for (int j = 0; j < THIN; ++j) csum += v[s][j];
           });
-          (void)last_ss;
 #else
           static_for<nb>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = s0 + decltype(sc)::value;
-            if constexpr (s + 1 == SPS) gram.template add_step<true>(w[s - s0], v[s - s0], last_ss);
+            // (the LAST step of every super-step waits the matrix pipe out inside its own asm statement — ~32 cycles in ~3 000:
+            //  between two super-steps runs the user's functor, under whose register pressure hipcc may move an accumulator,
+            //  and a run-time build cannot be linted for accumulator reads that overtake the matrix core)
+            if constexpr (s + 1 == SPS) gram.template add_step<true>(w[s - s0], v[s - s0], 1);
             else gram.template add_step<false>(w[s - s0], v[s - s0], 0);
           });
 #endif
