@@ -161,6 +161,52 @@ def test_round2_golden(oracle):
     assert np.allclose(rn["x"], g["nat_x"], rtol=1e-10, atol=1e-12) and np.abs(rn["x"] - xs).max() < 2e-2
 
 
+def test_round6_golden(oracle):
+    """tests/golden/round6.npz (make_golden.py --only-round6): the fixtures SURVEY §8(c) lists that were missing — GaussianPrior at
+    the reference table's sizes (the (g, H, cost) triple is recomputed HERE from the definition, benchmarks/dense.cpp:57-66, and the
+    oracle's LM must reproduce its frozen result and land on y), DenseRow C2 / C3 in fp32, SE3 exp / log / reprojection samples."""
+    from tinyopt_amd.api import Options
+    g = np.load(os.path.join(GOLD, "round6.npz"))
+    for n in (3, 6, 12, 33, 50):
+        y, sigma, x0 = g[f"gp{n}_y"], g[f"gp{n}_sigma"], g[f"gp{n}_x0"]
+        r = (x0 - y) / sigma
+        assert np.allclose(r / sigma, g[f"gp{n}_g"], rtol=1e-14) and np.allclose(1 / sigma ** 2, g[f"gp{n}_Hdiag"], rtol=1e-14)
+        assert np.allclose((r * r).sum(1), g[f"gp{n}_cost"], rtol=1e-14)
+        o = Options.benchmark()
+        o.hessian.save_last = True
+        lm = oracle.gaussian_prior_lm(y, sigma, x0, o.to_pod(), history=True)
+        assert np.array_equal(lm["stop"], g[f"gp{n}_stop"]) and np.array_equal(lm["iters"], g[f"gp{n}_iters"])
+        assert np.allclose(lm["x"], g[f"gp{n}_x"], rtol=1e-12, atol=1e-14) and np.abs(lm["x"] - y).max() < 1e-6   # the prior's mean
+        assert np.allclose(lm["errs"][:, 0], g[f"gp{n}_cost"], rtol=1e-12)          # the first iteration's error IS the triple's cost
+        for p in range(y.shape[0]):                                                   # final undamped H = diag(sigma^-2) (tests/cov.cpp:20-169)
+            assert np.allclose(np.diag(lm["H"][p]), 1 / sigma[p] ** 2, rtol=1e-9) and np.allclose(lm["H"][p], g[f"gp{n}_final_H"][p], rtol=1e-12, atol=1e-14)
+    for tag in ("c2f32_", "c3f32_"):
+        n, m, P = int(g[tag + "n"]), int(g[tag + "m"]), int(g[tag + "P"])
+        A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=0x71940917)
+        assert np.isclose(A.astype(np.float64).sum(), g[tag + "A_sum"], rtol=1e-12) and np.array_equal(x0, g[tag + "x0"])
+        gg, H, c, _ = oracle.dense_row_accumulate(A, b, x0)
+        assert np.array_equal(gg, g[tag + "g"]) and np.array_equal(H, g[tag + "H"]) and np.array_equal(c, g[tag + "cost"])
+        rl = oracle.dense_row_lm(A, b, x0, Options.benchmark().to_pod(), history=True)
+        assert np.array_equal(rl["stop"], g[tag + "stop"]) and np.array_equal(rl["iters"], g[tag + "iters"]) and np.array_equal(rl["x"], g[tag + "x"])
+        assert np.abs(rl["x"] - xs).max() < 2e-2
+    ident = np.tile(np.concatenate([np.eye(3).ravel(), np.zeros(3)]), (6, 1))
+    poses = oracle.se3_plus(ident, g["se3_delta"])
+    assert np.allclose(poses, g["se3_exp"], rtol=1e-13, atol=1e-15)
+    R = poses[:, :9].reshape(-1, 3, 3)
+    assert np.allclose(np.einsum("pij,pkj->pik", R, R), np.eye(3), atol=1e-13) and np.allclose(np.linalg.det(R), 1.0, atol=1e-13)
+    assert np.allclose(oracle.se3_log(poses), g["se3_log"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(g["se3_log"], g["se3_delta"], rtol=1e-9, atol=1e-12)         # log(exp(delta)) = delta: independent of the fixture
+    assert np.allclose(oracle.se3_log(g["se3_exp2"]), g["se3_log2"], rtol=1e-12, atol=1e-14)
+    gs, Hs, cs = oracle.se3_reproj_accumulate(g["rp_data"], g["rp_pose0"], 64)
+    assert np.allclose(gs, g["rp_g"], rtol=1e-12) and np.allclose(Hs, g["rp_H"], rtol=1e-12) and np.allclose(cs, g["rp_cost"], rtol=1e-12)
+    gp, Hp, cp = oracle.se3_prior_accumulate(g["pr_prior_inv"], g["pr_pose"])
+    assert np.allclose(gp, g["pr_g"], rtol=1e-12, atol=1e-14) and np.allclose(cp, g["pr_cost"], rtol=1e-12)
+    xi = oracle.se3_log(oracle.se3_compose(g["pr_prior_inv"], g["pr_pose"]))        # cost = || log(prior_inv * x) ||^2
+    assert np.allclose((xi * xi).sum(1), g["pr_cost"], rtol=1e-10)
+    gg, H, c, _ = oracle.dense_row_accumulate(g["rm_A"], g["rm_b"], g["rm_x0"])
+    assert np.allclose(gg, g["rm_g"], rtol=1e-13) and np.allclose(H, g["rm_H"], rtol=1e-13) and np.allclose(c, g["rm_cost"], rtol=1e-13)
+
+
 def test_oracle_follows_the_second_reading(oracle):
     """tests/golden/reference_traces.json: per-iteration traces of an INDEPENDENT Python restatement of the LM state
     machine (tests/golden/make_reference_traces.py, written from optimizer.h / lm.h / gn.h and SURVEY Appendix A, not from
