@@ -166,7 +166,7 @@ int toa_create(toa_handle* out, int device, void* stream);
 /* ---- ABI version.  4 (round 4): counters_dev arrays are [TOA_NUM_COUNTERS = 8] uint64 (they were [4] up to version 2 — a caller
  *      that still allocates 4 entries would be written out of bounds by the memo counter), toa_tuning / toa_jit_spec exist.
  *      The host mirrors (include/tinyopt_amd/tinyopt.hpp, tinyopt_amd/_capi.py) refuse a library whose version differs. */
-#define TOA_ABI_VERSION 5
+#define TOA_ABI_VERSION 6
 int toa_abi_version(void);
 
 /* ---- tuning (per handle).  The arms of the A/B logs (profiles/r0N_ab_log.md) and of the bit-identity tests, as typed state
@@ -397,6 +397,12 @@ int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* stat
 int toa_lm_stop(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data_dev, void* x_dev,
                 const toa_options* options, const toa_results* results, uint64_t* counters_dev, void* state_dev,
                 const int32_t* stop_request_dev);
+/* The rest of what the reference's per-iteration log line prints (optimizer.h:463-516, off-by-default Options::log; the adaptors
+ * form the line from this and toa_lm_step_info): after a step, per problem, the solver's damping lambda (SolverLM::stateAsString
+ * prints 1 / lambda, lm.h:150-154; 0 for Gauss-Newton), the residual count of the iteration's cost and its inlier residuals
+ * (Cost::NumInliers, cost.h:84).  Any pointer may be NULL. */
+int toa_lm_step_log(toa_handle h, int dtype, int n, int64_t P, const void* state_dev, double* lambda_dev, int32_t* num_residuals_dev,
+                    int32_t* num_inliers_dev);
 
 /* ---- row-split execution of the same solve, for FEW, HUGE problems (BASELINE configs C2 / C5: P = 1,
  *      m = 10^3 .. 5*10^4).  Same contract and results as toa_lm_run; the rows of each problem are split into

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdint>
 #include <functional>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <algorithm>
@@ -67,7 +68,22 @@ struct Options {  // include/tinyopt/optimizers/options.h:18-156 (numeric knobs)
   double max_duration_ms = 0;                                          // 0 = no limit -> kTimedOut
   std::function<bool(double, double, double)> stop_callback;           // (err, |dx|^2, |g|^2) -> kUserStopped
   std::function<bool(float, const std::vector<float>&, const std::vector<float>&)> stop_callback2;   // (err, dx, g)
-  bool has_host_controls() const { return max_duration_ms > 0 || stop_callback || stop_callback2; }
+  // The per-iteration log line of Optimizer_::Step (options.h:113-125, optimizer.h:463-516), through the same stepping form.  Off by
+  // default here (the reference logs by default; a batched solve would print one line per problem and iteration): the problems
+  // named in `problems` (empty = problem 0) are logged to `sink` (empty = std::cout, like TINYOPT_LOG: log.h:23).
+  // print_max_stdev / print_J_jet / print_failure are not mirrored.
+  struct Log {
+    bool enable = false;
+    std::string e = "\xCE\xB5\xC2\xB2";   // "ε²"
+    bool print_emoji = true;
+    bool print_x = false;
+    bool print_dx = false;
+    bool print_inliers = false;
+    bool print_t = true;
+    std::vector<int64_t> problems;
+    std::function<void(const std::string&)> sink;
+  } log;
+  bool has_host_controls() const { return max_duration_ms > 0 || stop_callback || stop_callback2 || log.enable; }
   struct LM {
     float damping_init = 1e-4f;
     std::array<float, 2> damping_range{{1e-9f, 1e9f}};
@@ -538,6 +554,16 @@ class Optimizer {
     if (dx) { dx->resize(size_t(P_) * n_); vdx.download(dx->data()); }
     if (g) { g->resize(size_t(P_) * n_); vg.download(g->data()); }
   }
+  // The rest of what the reference's log line prints (optimizer.h:463-516): damping, residual count, inlier residuals.
+  void StepLog(std::vector<double>& lambda, std::vector<int32_t>& nres, std::vector<int32_t>& ninl) const {
+    const Context& ctx = cost_->ctx();
+    DeviceBuffer<double> dl(ctx, P_);
+    DeviceBuffer<int32_t> dn(ctx, P_), di(ctx, P_);
+    check(toa_lm_step_log(ctx.get(), dtype_of<Scalar>(), n_, P_, state_.data(), dl.data(), dn.data(), di.data()));
+    check(toa_synchronize(ctx.get()));
+    lambda.resize(P_); nres.resize(P_); ninl.resize(P_);
+    dl.download(lambda.data()); dn.download(nres.data()); di.download(ninl.data());
+  }
   // Ends the still-running problems p with request[p] != 0 with that StopReason (kUserStopped, kTimedOut).
   void Stop(const std::vector<int32_t>& request) {
     if (int64_t(request.size()) != P_) throw std::invalid_argument("tinyopt_amd::Optimizer::Stop: one request per problem");
@@ -588,9 +614,66 @@ BatchOutput OptimizeWithHostControls(std::vector<Scalar>& x, const Cost& cost, c
   std::vector<Scalar> dxv, gv;
   std::vector<float> dxf(n), gf(n);
   double duration_ms = 0;
+  // the log line's running state (optimizer.h:428-446): the last accepted cost of every logged problem
+  std::vector<int64_t> logged;
+  if (options.log.enable) {
+    if (options.log.problems.empty()) logged.push_back(0);
+    for (int64_t q : options.log.problems) if (q >= 0 && q < P) logged.push_back(q);
+  }
+  const double big = double(std::numeric_limits<Scalar>::max()), eps = sizeof(Scalar) == 4 ? 1e-4 : double(1e-7f);   // math.h:297-301
+  std::vector<double> final_cost(logged.size(), big);
   for (int it = 0; it < int(options.max_iters) + 2; ++it) {
     const auto t0 = std::chrono::steady_clock::now();
+    std::vector<Scalar> x_before;   // (the line shows the x the iteration STARTED from: the reference forms it inside Step)
+    if (!logged.empty() && options.log.print_x) x_before = x;
     const int64_t active = opt.Step();
+    if (!logged.empty()) {   // optimizer.h:463-516: the same fields in the same order, one line per logged problem that made this iteration
+      std::vector<double> lam;
+      std::vector<int32_t> nres, ninl;
+      opt.StepInfo(err, dx2, g2, options.log.print_dx ? &dxv : nullptr, nullptr);
+      opt.StepLog(lam, nres, ninl);
+      const double took = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const std::vector<Scalar>& xnow = x_before;
+      for (size_t li = 0; li < logged.size(); ++li) {
+        const int64_t q = logged[li];
+        if (!running_before[q]) continue;
+        const double fc = final_cost[li], derr = err[q] - fc;
+        const bool good = derr < 0.0;
+        const double rel = (fc > eps && fc < big) ? (fc - err[q]) / fc : 0.0;
+        char buf[256];
+        std::string line;
+        if (options.log.print_emoji) line += (good || it == 0) ? (it == 0 ? "\xE2\x84\xB9\xEF\xB8\x8F" : "\xE2\x9C\x85") : "\xE2\x9D\x8C";
+        std::snprintf(buf, sizeof(buf), "#%d ", it);
+        line += buf;
+        if (options.log.print_x) {
+          const size_t xd = xnow.size() / size_t(P);
+          line += "x:[";
+          for (size_t j = 0; j < xd; ++j) { std::snprintf(buf, sizeof(buf), j ? " %.6g" : "%.6g", double(xnow[size_t(q) * xd + j])); line += buf; }
+          line += "] ";
+        }
+        std::snprintf(buf, sizeof(buf), "%s:%.4e n:%d d%s:%+.2e r%s:%+.1e |\xCE\xB4x|:%.2e ", options.log.e.c_str(), err[q], int(nres[q]),
+                      options.log.e.c_str(), it == 0 ? 0.0 : derr, options.log.e.c_str(), rel, std::sqrt(dx2[q]));
+        line += buf;
+        if (options.log.print_dx) {
+          line += "\xCE\xB4x:[";
+          for (int j = 0; j < n; ++j) { std::snprintf(buf, sizeof(buf), j ? " %.6g" : "%.6g", double(dxv[size_t(q) * n + j])); line += buf; }
+          line += "] ";
+        }
+        if (options.min_grad_norm2 > 0) { std::snprintf(buf, sizeof(buf), "|\xE2\x88\x87|:%.2e ", std::sqrt(g2[q])); line += buf; }
+        if (options.solver_type == Options::LevenbergMarquardt && lam[q] > 0) {   // SolverLM::stateAsString (lm.h:150-154)
+          std::snprintf(buf, sizeof(buf), "\xE2\x97\x8B:%.2e ", 1.0 / lam[q]);
+          line += buf;
+        }
+        if (options.log.print_inliers) {
+          std::snprintf(buf, sizeof(buf), "in:%.2f%% (%d) ", 100.0 * ninl[q] / std::max(1, int(nres[q])), int(ninl[q]));
+          line += buf;
+        }
+        if (options.log.print_t) { std::snprintf(buf, sizeof(buf), "\xCF\x84:%.2f ", duration_ms + took); line += buf; }
+        if (options.log.sink) options.log.sink(line);
+        else std::cout << line << std::endl;
+        if (good || it == 0) final_cost[li] = err[q];
+      }
+    }
     BatchOutput now = opt.output();
     std::vector<char> running(P);
     for (int64_t p = 0; p < P; ++p) running[p] = running_before[p] && now.stop_reason[p] == kNone;

@@ -119,6 +119,34 @@ static void sqrt2() {
   }
 }
 
+// The reference's per-iteration log line (optimizer.h:463-516, Options::log) through the stepping form, off by default: sqrt(2) from
+// x0 = 1 reproduces README.md:91-96 — |dx| = 5.00e-01, 8.33e-02, 2.45e-03 on iterations 0, 1, 2 — one line per iteration of the
+// logged problem, and a run without log.enable prints nothing and gives the same result.
+static void log_line() {
+  Context ctx(0);
+  Sqrt2<double> cost(ctx, 2);
+  std::vector<double> x{1.0, 3.2};
+  Options options;
+  options.max_iters = 20;
+  options.max_consec_failures = 0;
+  std::vector<std::string> lines;
+  options.log.enable = true;
+  options.log.print_x = true;
+  options.log.sink = [&](const std::string& l) { lines.push_back(l); };
+  const auto out = Optimize(x, cost, options);
+  REQUIRE(out.Succeeded(0) && out.Converged(0));
+  REQUIRE(int(lines.size()) == out.num_iters[0]);                       // problem 0 only, one line per iteration it made
+  REQUIRE(lines.size() >= 3 && lines[0].find("#0 x:[1] ") != std::string::npos && lines[0].find("5.00e-01") != std::string::npos);
+  REQUIRE(lines[1].find("#1 ") != std::string::npos && lines[1].find("8.33e-02") != std::string::npos);
+  REQUIRE(lines[2].find("#2 ") != std::string::npos && lines[2].find("2.4") != std::string::npos);
+  REQUIRE(lines[1].find("x:[1.49995") != std::string::npos);            // README.md:92: x after the first step
+  std::vector<double> x2{1.0, 3.2};
+  Options quiet = options;
+  quiet.log = Options::Log{};
+  const auto out2 = Optimize(x2, cost, quiet);
+  REQUIRE(out2.num_iters[0] == out.num_iters[0] && x2[0] == x[0] && x2[1] == x[1]);
+}
+
 // tests/circle.cpp:32-68 — 10 points on the circle (2, 7, r = 2), x0 = (0, 0, 1), damping_init = 10 -> (2, 7, 2) +- 1e-5
 static void circle() {
   const int n = 10;
@@ -499,6 +527,7 @@ int main() {
   stepping();
   single_problem_overload();
   stop_controls();
+  log_line();
   huber();
   sqrt2<double>();
   sqrt2<float>();

@@ -184,3 +184,43 @@ def test_callbacks_are_consulted_on_the_last_allowed_iteration(ta):
         assert all(e == float(np.float32(e)) for e in seen)
         want = ta.StopReason.kUserStopped if trip else ta.StopReason.kMaxIters
         assert int(out.stop_reason[0]) == int(want)
+
+
+def test_per_iteration_log_line(ta, oracle):
+    """The reference's per-iteration log line (optimizer.h:463-516; Options::log, options.h:113-125; VERDICT r05 "missing" #4) through the
+    stepping form, off by default.  sqrt(2) from x0 = 1 reproduces README.md:91-96 — x 1 -> 1.49995 -> 1.41667 -> 1.41422, |dx| 5.00e-01,
+    8.33e-02, 2.45e-03 — one line per iteration of every logged problem, each with the iteration's cost as the history records it,
+    the damping the solver holds after the step (1 / lambda, lm.h:150-154) and, on request, the inliers."""
+    lines = []
+    model = ta.Sqrt2(3, torch.float64)
+    x = torch.tensor([[1.0], [-0.3], [3.2]], dtype=torch.float64, device="cuda")
+    o = ta.Options()
+    o.max_iters, o.max_consec_failures = 20, 0            # tests/sqrt2.cpp:22-28
+    o.log.enable, o.log.print_x, o.log.sink = True, True, lines.append
+    out = ta.Optimize(x, model, o, history=True)
+    torch.cuda.synchronize()
+    assert len(lines) == int(out.num_iters[0])            # problem 0 only by default
+    assert lines[0].startswith("ℹ️#0 x:[1] ") and "|δx|:5.00e-01" in lines[0]
+    assert "#1 " in lines[1] and "x:[1.49995" in lines[1] and "|δx|:8.33e-02" in lines[1]
+    assert "#2 " in lines[2] and "x:[1.41667" in lines[2] and "|δx|:2.4" in lines[2]
+    errs = out.errs.cpu().numpy()
+    for it, line in enumerate(lines):
+        assert f"ε²:{errs[0, it]:.4e} n:1 " in line and "○:" in line and "τ:" in line
+    assert "○:1.00e+04" in lines[0]                   # 1 / damping_init: the first iteration changes nothing (iter == 0)
+    # every problem, without emoji / x / time, with the inliers of a loss
+    from test_gpu_robust_dense import _with_outliers
+    P, n, m = 3, 12, 203
+    A, b, x0, xs, _ = _with_outliers(oracle, P, n, m, np.float64)
+    lines2 = []
+    o2 = ta.Options()
+    o2.log.enable, o2.log.print_emoji, o2.log.print_t, o2.log.print_inliers, o2.log.problems, o2.log.sink = True, False, False, True, "all", lines2.append
+    md = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()).with_loss("huber", 0.05)
+    xg = torch.from_numpy(x0.copy()).cuda()
+    out2 = ta.Optimize(xg, md, o2, history=True)
+    torch.cuda.synchronize()
+    assert len(lines2) == int(out2.num_iters.sum()) and all(l.startswith("#") and f"n:{m} " in l and "in:" in l for l in lines2)
+    # off (the default): the same result, nothing printed
+    xq = torch.from_numpy(x0.copy()).cuda()
+    outq = ta.Optimize(xq, md, ta.Options(), history=True)
+    torch.cuda.synchronize()
+    assert torch.equal(outq.num_iters, out2.num_iters) and torch.equal(outq.stop_reason, out2.stop_reason) and float((xq - xg).abs().max()) < 1e-12

@@ -58,7 +58,7 @@ class ToaResults(C.Structure):
 
 
 # every symbol include/tinyopt_amd.h declares: name -> (restype, argtypes)
-ABI_VERSION = 5   # include/tinyopt_amd.h TOA_ABI_VERSION
+ABI_VERSION = 6   # include/tinyopt_amd.h TOA_ABI_VERSION
 
 
 class ToaTuning(C.Structure):   # include/tinyopt_amd.h toa_tuning
@@ -122,6 +122,7 @@ PROTOTYPES = {
     "toa_debug_timeline": (C.c_int, [_P, C.c_char_p]),
     "toa_model_compile_ex": (C.c_int, [_P, C.POINTER(ToaJitSpec), C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "toa_jit_set_cache_dir": (C.c_int, [C.c_char_p]),
+    "toa_lm_step_log": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "toa_jit_model_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "toa_jit_model_stats": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "toa_model_destroy": (C.c_int, [_P]),

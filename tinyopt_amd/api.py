@@ -62,11 +62,26 @@ class _LM:  # options.h:127-141
 
 
 @dataclass
+class _Log:  # options.h:113-125 — the per-iteration log line of Optimizer_::Step (optimizer.h:463-516)
+    enable: bool = False           # (the reference logs by default; a batched solve does not: one line per problem and iteration)
+    e: str = "\u03b5\u00b2"          # symbol of the error in the line
+    print_emoji: bool = True
+    print_x: bool = False
+    print_dx: bool = False
+    print_inliers: bool = False
+    print_t: bool = True
+    problems: Optional[object] = None   # which problems of the batch are logged: None = problem 0, an iterable of indices, or "all"
+    sink: Optional[object] = None       # callable(str); None = print (the reference's TINYOPT_LOG writes to std::cout, log.h:23)
+
+
+@dataclass
 class Options:
     """tinyopt::Options (options.h:18-156).  ``max_duration_ms``, ``stop_callback`` and ``stop_callback2`` are
     host-side controls: when any of them is set, ``Optimize`` runs the loop through the stepping form and evaluates
     them between iterations (optimizer.h:302-305, 529-534) — per problem: ``stop_callback(err, dx_norm2, grad_norm2)``
-    / ``stop_callback2(err, dx, g)`` with numpy vectors.  log.* is not mirrored."""
+    / ``stop_callback2(err, dx, g)`` with numpy vectors.  ``log.enable`` (off by default here) prints the reference's
+    per-iteration line for the chosen problems through the same stepping form (``log.print_max_stdev`` / ``print_J_jet`` /
+    ``print_failure`` are not mirrored)."""
     LevenbergMarquardt = 0
     GaussNewton = 1
     solver_type: int = 0
@@ -86,9 +101,10 @@ class Options:
     stop_callback: Optional[object] = None     # options.h:97-101  bool(err, |dx|^2, |g|^2)
     stop_callback2: Optional[object] = None    # options.h:102-106 bool(err, dx, g)
     lm: _LM = field(default_factory=_LM)
+    log: _Log = field(default_factory=_Log)
 
     def has_host_controls(self) -> bool:
-        return self.max_duration_ms > 0 or self.stop_callback is not None or self.stop_callback2 is not None
+        return self.max_duration_ms > 0 or self.stop_callback is not None or self.stop_callback2 is not None or self.log.enable
 
     @staticmethod
     def benchmark() -> "Options":
@@ -923,6 +939,17 @@ class Optimizer:
                                             g.data_ptr() if vectors else None))
         return err, dx2, g2, dx, g
 
+    def step_log(self):
+        """The rest of what the reference's log line prints (optimizer.h:463-516): per problem the damping lambda, the residual
+        count of the iteration's cost and its inlier residuals."""
+        x, P = self.x, self.x.shape[0]
+        lam = torch.zeros(P, dtype=torch.float64, device=x.device)
+        nres = torch.zeros(P, dtype=torch.int32, device=x.device)
+        ninl = torch.zeros(P, dtype=torch.int32, device=x.device)
+        check(self.ctx.lib.toa_lm_step_log(self.ctx.h, _dtype_code(x.dtype), self.cost.n, P, self._state.data_ptr(), lam.data_ptr(),
+                                           nres.data_ptr(), ninl.data_ptr()))
+        return lam, nres, ninl
+
     def stop(self, request: torch.Tensor) -> None:
         """End the still-running problems p with request[p] != 0 (int32, a StopReason such as kUserStopped / kTimedOut):
         their Output rows are finalised exactly as for a problem that stops by itself."""
@@ -951,9 +978,56 @@ def _optimize_with_host_controls(x, cost, options: Options, history: bool, ctx: 
     want_vec = options.stop_callback2 is not None
     duration_ms = 0.0
     running_before = torch.ones(P, dtype=torch.bool, device=x.device)
-    for _ in range(options.max_iters + 2):
+    lg = options.log
+    if lg.enable:   # the problems whose iterations are logged, and what the line needs from one iteration to the next
+        logged = [0] if lg.problems is None else (list(range(P)) if lg.problems == "all" else [int(q) for q in lg.problems])
+        logged = [q for q in logged if 0 <= q < P]
+        sink = lg.sink or print
+        eps = 1e-4 if x.dtype == torch.float32 else float(np.float32(1e-7))    # FloatEpsilon<Scalar> (math.h:297-301)
+        big = float(np.finfo(np.float32 if x.dtype == torch.float32 else np.float64).max)
+        final_cost = {q: big for q in logged}
+    for it in range(options.max_iters + 2):
         t0 = time.perf_counter()
+        x_before = x.clone() if (lg.enable and lg.print_x) else None   # (the line shows the x the iteration STARTED from: it is formed inside Step)
         active = opt.Step()
+        if lg.enable and logged:
+            # optimizer.h:463-516, one line per logged problem that made this iteration (the same fields in the same order)
+            err_t, dx2_t, g2_t, dxv_t, _ = opt.step_info(vectors=lg.print_dx)
+            lam_t, nres_t, ninl_t = opt.step_log()
+            torch.cuda.synchronize(x.device)
+            took = (time.perf_counter() - t0) * 1e3
+            rb = running_before.cpu().numpy()
+            for q in logged:
+                if not rb[q]:
+                    continue
+                err, dxn2, gn2 = float(err_t[q]), float(dx2_t[q]), float(g2_t[q])
+                fc = final_cost[q]
+                derr = err - fc
+                good = derr < 0.0                                                        # :428-429
+                rel = (fc - err) / fc if (fc > eps and fc < big) else 0.0                # :431-434
+                line = ""
+                if lg.print_emoji:
+                    line += ("\u2139\ufe0f" if it == 0 else "\u2705") if (good or it == 0) else "\u274c"
+                line += f"#{it} "
+                if lg.print_x:
+                    line += "x:[" + " ".join(f"{float(v):.6g}" for v in x_before[q].cpu()) + "] "
+                line += f"{lg.e}:{err:.4e} n:{int(nres_t[q])} d{lg.e}:{0.0 if it == 0 else derr:+.2e} r{lg.e}:{rel:+.1e} "
+                line += f"|\u03b4x|:{dxn2 ** 0.5:.2e} "
+                if lg.print_dx:
+                    line += "\u03b4x:[" + " ".join(f"{float(v):.6g}" for v in dxv_t[q].cpu()) + "] "
+                if options.min_grad_norm2 > 0:                                            # has_grad_norm2 (:413-415)
+                    line += f"|\u2207|:{gn2 ** 0.5:.2e} "
+                if options.solver_type == Options.LevenbergMarquardt and float(lam_t[q]) > 0:
+                    line += f"\u25cb:{1.0 / float(lam_t[q]):.2e} "                       # SolverLM::stateAsString (lm.h:150-154)
+                if lg.print_inliers:
+                    nr = max(int(nres_t[q]), 1)
+                    line += f"in:{100.0 * int(ninl_t[q]) / nr:.2f}% ({int(ninl_t[q])}) "
+                if lg.print_t:
+                    duration_so_far = duration_ms + took
+                    line += f"\u03c4:{duration_so_far:.2f} "
+                sink(line)
+                if good or it == 0:
+                    final_cost[q] = err                                                   # :441-446
         running = out.stop_reason == int(StopReason.kNone)
         running &= running_before          # a row reports kNone until its problem stops
         req = torch.zeros(P, dtype=torch.int32)

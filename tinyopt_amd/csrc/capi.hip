@@ -268,6 +268,7 @@ size_t toa_large_state_bytes(int dtype, int n, int64_t P);
 int toa_large_lm_step(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, void* x, const toa_options* options,
                       const toa_results* results, uint64_t* counters, int mode, void* state, int32_t* active_dev,
                       const int32_t* stop_request);
+int toa_large_step_log(toa_handle h, int dtype, int n, int64_t P, const void* state, double* lambda, int32_t* nres, int32_t* ninl);
 int toa_large_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state, double* err, double* dx2, double* g2,
                         void* dx_out, void* g_out);
 int toa_inst_solve(int dtag, int npad, toa_handle h, int n, int64_t P, const void* H, const void* g, double scale,
@@ -893,6 +894,27 @@ int toa_lm_step_info(toa_handle h, int dtype, int n, int64_t P, const void* stat
   else
     hipLaunchKernelGGL(toa::step_info_kernel<double>, dim3(grid), dim3(256), 0, h->stream, state_dev, (long long)P, n, err_dev,
                        dx_norm2_dev, grad_norm2_dev, (double*)dx_dev, (double*)g_dev);
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+int toa_lm_step_log(toa_handle h, int dtype, int n, int64_t P, const void* state_dev, double* lambda_dev, int32_t* num_residuals_dev,
+                    int32_t* num_inliers_dev) {
+  if (!h || !state_dev) return fail(TOA_E_ARG, "toa_lm_step_log: null argument");
+  if (n >= 64) {
+    if ((dtype != TOA_F32 && dtype != TOA_F64) || n > 4096 || P < 0 || P > 65535) return fail(TOA_E_ARG, "toa_lm_step_log: bad shape");
+    if (P == 0) return TOA_OK;
+    TOA_ON_DEVICE(h->device);
+    return toa_large_step_log(h, dtype, n, P, state_dev, lambda_dev, num_residuals_dev, num_inliers_dev);
+  }
+  if (int rc = check_shape(dtype, n, 1, P)) return rc;
+  if (P == 0) return TOA_OK;
+  TOA_ON_DEVICE(h->device);
+  const unsigned grid = unsigned((P + 255) / 256);
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::step_log_kernel<float>, dim3(grid), dim3(256), 0, h->stream, state_dev, (long long)P, lambda_dev, num_residuals_dev, num_inliers_dev);
+  else
+    hipLaunchKernelGGL(toa::step_log_kernel<double>, dim3(grid), dim3(256), 0, h->stream, state_dev, (long long)P, lambda_dev, num_residuals_dev, num_inliers_dev);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }

@@ -1956,6 +1956,17 @@ __global__ void __launch_bounds__(256) step_info_kernel(const void* state_, long
   if (g_out && lane < n) g_out[size_t(p) * n + lane] = g;
 }
 
+// toa_lm_step_log: what the per-iteration log line prints besides step_info's numbers (optimizer.h:463-516)
+template <typename T>
+__global__ void __launch_bounds__(256) step_log_kernel(const void* state_, long long P, double* lambda, int* nres, int* ninl) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const WideState<T>* ws = static_cast<const WideState<T>*>(state_) + p;
+  if (lambda) lambda[p] = double(ws->st.lambda);
+  if (nres) nres[p] = ws->st.cost_nres;
+  if (ninl) ninl[p] = ws->st.cost_ninl;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent form of the row-split solve: ONE launch for the whole solve instead of 1 + 2 x (max_iters + 1).
 // The multi-launch form is bound by the GPU's kernel-to-kernel dependency latency (~10 us per launch, the same

@@ -1912,6 +1912,18 @@ __global__ void __launch_bounds__(256) large_step_info_kernel(const char* __rest
   }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) large_step_log_kernel(const char* __restrict__ state, const long long P, const int n, double* __restrict__ lambda,
+                                                             int* __restrict__ nres, int* __restrict__ ninl) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const LargeStateLayout<T> lay(n, P);
+  const LmState<T>& S = reinterpret_cast<const LmState<T>*>(state + lay.st)[p];
+  if (lambda) lambda[p] = double(S.lambda);
+  if (nres) nres[p] = S.cost_nres;
+  if (ninl) ninl[p] = S.cost_ninl;
+}
+
 // mode 0: the whole solve.  1 / 2 / 3: toa_lm_begin / toa_lm_step / toa_lm_stop on `state` (LargeStateLayout).
 template <typename T>
 int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
@@ -2505,6 +2517,16 @@ int toa_large_step_info(toa_handle h, int dtype, int n, int64_t P, const void* s
   else
     hipLaunchKernelGGL(toa::large_step_info_kernel<double>, dim3(unsigned(P)), dim3(256), 0, h->stream, static_cast<const char*>(state),
                        (long long)P, n, err, dx2, g2, static_cast<double*>(dx_out), static_cast<double*>(g_out));
+  HIP_TRY(hipGetLastError());
+  return TOA_OK;
+}
+
+int toa_large_step_log(toa_handle h, int dtype, int n, int64_t P, const void* state, double* lambda, int32_t* nres, int32_t* ninl) {
+  const unsigned grid = unsigned((P + 255) / 256);
+  if (dtype == TOA_F32)
+    hipLaunchKernelGGL(toa::large_step_log_kernel<float>, dim3(grid), dim3(256), 0, h->stream, static_cast<const char*>(state), (long long)P, n, lambda, nres, ninl);
+  else
+    hipLaunchKernelGGL(toa::large_step_log_kernel<double>, dim3(grid), dim3(256), 0, h->stream, static_cast<const char*>(state), (long long)P, n, lambda, nres, ninl);
   HIP_TRY(hipGetLastError());
   return TOA_OK;
 }
