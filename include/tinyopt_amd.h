@@ -193,13 +193,7 @@ typedef struct toa_tuning {
   int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
   int32_t large_gram_plain_deal; /* 224 < n <= 256, own Gram: the tiles dealt round-robin to the waves instead of the operand-sharing deal (triangles of
                                     blocks; A/B and the bit-identity test: which wave computes a tile does not change its bits) */
-  int32_t team_on;               /* lm_fused_kernel, f32 n = 50 (the C4 layout): the TEAM form — a workgroup of twelve waves of which only
-                                    `team_owners` pull problems, the others take row chunks of theirs, so that <= 512 problems are in flight and
-                                    their rows stay in the 256 MiB Infinity Cache.  Same bits as the classic form; measured SLOWER (the serial
-                                    part of an LM iteration bounds a problem's chain: DESIGN §4k, profiles/r05_ab_log.md §1) — kept as an A/B arm */
-  int32_t team_owners;           /* team form: problems in flight per compute unit (0 = 2, i.e. 512 problems = 209 MB at C4; 1 .. 12) */
-  int32_t team_prio;             /* team form: 0 = owners at priority 3 / helpers at 1; 1 = everybody at the classic per-problem level */
-  int32_t reserved[12];
+  int32_t reserved[15];          /* (three of them were the team form of the fused kernel, round 5: removed in round 6, profiles/r06_pruned_arms.patch) */
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
 int toa_get_tuning(toa_handle h, toa_tuning* out);

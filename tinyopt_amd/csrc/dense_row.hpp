@@ -21,10 +21,9 @@
 // DPP rows); s = 1 + 0.1 cos t scales the lane's a-values into J in registers; the lane holding
 // b_i replaces it by r_i = t + 0.1 sin t - b_i.
 #pragma once
-// Register class of the Gram accumulators in the inline-asm MFMAs: AGPRs ("+a") — or VGPRs ("+v") in the translation units
-// of the TEAM form (-DTOA_ACC_VGPR): under a launch bound that leaves fewer than 256 registers per lane hipcc splits the
-// budget of a kernel whose inline asm names AGPRs HALF AND HALF between the two files (768 threads: 84 + 84) and parks the
-// destination registers of in-flight loads in the accumulator file (tools/isa_lint.py); with "+v" the whole budget is VGPRs.
+// Register class of the Gram accumulators in the inline-asm MFMAs: AGPRs ("+a").  (-DTOA_ACC_VGPR, "+v", served the team form of
+// round 5 and a three-waves-per-SIMD experiment of round 6 — profiles/r06_ab_log.md: under a launch bound below 256 registers
+// hipcc splits the budget of a kernel whose inline asm names AGPRs half and half between the two files.)
 #ifdef TOA_ACC_VGPR
 #define TOA_ACC "+v"
 #else

@@ -119,25 +119,8 @@ int TOA_CAT(toa_inst_inv_cov_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, in
     default: return launch_inv_cov<InstT, 64>(h, n, P, H, C, ok);
   }
 }
-#elif defined(TOA_INST_TEAM)
-// The TEAM form of the fused kernel (kernels.hpp DenseRowModel<.., TEAMW = 12>) for the C4 layout, f32 (3, 3).  Its own
-// translation unit, compiled with -DTOA_ACC_VGPR: the Gram accumulators of the inline-asm MFMAs are VGPRs here.  Under a
-// 768-thread launch bound a kernel whose asm names AGPRs gets its 168 registers split 84 + 84 between the two files, and
-// hipcc then parks the destination registers of in-flight loads in the accumulator file (tools/isa_lint.py: 170 hazards);
-// with "+v" the budget is one file and the kernel is the classic one's 160 registers (163).
-static_assert(TOA_INST_DT == 0 && TOA_INST_NBM == 3, "team form: f32, three main blocks");
-int toa_inst_team_fused_0_3(toa_handle h, const FusedParams& prm) {
-  return launch_fused<DenseRowModel<float, 3, 3, false, true, kTeamWaves>>(h, prm);
-}
 #else
-#if TOA_INST_DT == 0 && TOA_INST_NBM == 3
-int toa_inst_team_fused_0_3(toa_handle h, const FusedParams& prm);   // the TOA_INST_TEAM translation unit
-#endif
 int TOA_CAT(toa_inst_fused_, TOA_INST_DT, TOA_INST_NBM)(int thin, toa_handle h, const FusedParams& prm) {
-#if TOA_INST_DT == 0 && TOA_INST_NBM == 3
-  // toa_tuning::team_on: the team form (same bits, A/B arm — DESIGN §4k) where it exists and fits
-  if (thin == 3 && h->tune.team_on && prm.mode == 0 && team_fits<float>(h, prm.n, prm.m)) return toa_inst_team_fused_0_3(h, prm);
-#endif
   // the fused kernel runs the COOP variant of the model (ticketed row chunks: kernels.hpp CoopCtl) wherever one exists —
   // everywhere but the fp64 n <= 15 shapes, whose pass works in 64-row super-batches
   // ... and the three layouts where the variant costs a resident wave per SIMD (tools/kernel_regs.py against the plain

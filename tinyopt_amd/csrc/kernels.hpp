@@ -54,29 +54,21 @@ __device__ __forceinline__ void euclid_plus_eq(WaveLds<T>& L, const T* d, T sign
 // K chunks itself (steady state: nobody is idle) or its three siblings took some: results do not depend on timing, on the
 // batch size or on the position of a problem in the batch.  All of it lives in LDS at workgroup scope; no barrier (the
 // four waves run different problems at their own pace), no HBM traffic.
-struct CoopSlot {          // one per wave, written by the OWNER except ticket / eticket (everybody), turn (whoever folds), edone
+struct CoopSlot {          // one per wave, written by the OWNER except ticket (everybody) and turn (whoever folds)
   int p;                   // problem of the open pass
   int ticket;              // next chunk of the open ACCUMULATE pass to hand out; >= K: no open pass.  Evaluate-only passes never
                            // touch it, so whatever ticket a helper draws — however long ago it looked at the counter — belongs
                            // to an accumulate pass of this slot, and the acquire half of the fetch-add shows it that pass's
                            // problem and x
   int turn;                // next chunk whose partial may be folded; == K: the pass is complete
-  int eticket;             // TEAM form only: the same counter for the open EVALUATE-only pass (its own word for the reason above:
-                           // a ticket drawn from it names a chunk of an evaluate-only pass, whenever it is drawn); classic form:
-                           // stays closed, the owner walks the chunks of an evaluate-only pass alone
-  int edone;               // TEAM form: chunks of the open evaluate-only pass whose partial cost sits in the owner's L.tmp[chunk]
-  int pad_[3];
+  int pad_[5];
 };
-constexpr int kCoopMaxWaves = 12;
-#ifndef TOA_TEAM_WAVES
-#define TOA_TEAM_WAVES 12
-#endif
-constexpr int kTeamWaves = TOA_TEAM_WAVES;   // waves per workgroup of the team form
+constexpr int kCoopMaxWaves = 4;
 struct CoopCtl {
   CoopSlot slot[kCoopMaxWaves];
   int active[kCoopMaxWaves];   // wave w still has (or may still get) problems of its own
 };
-constexpr int kCoopCtlBytes = 512;
+constexpr int kCoopCtlBytes = 512;   // (the size the round-3 .. 5 layouts reserved: LDS geometry, and with it every measured number, unchanged)
 static_assert(sizeof(CoopCtl) <= kCoopCtlBytes, "control block");
 
 // ROBUST = true: the variant whose passes apply the handle's M-estimator (toa_set_loss) to every residual.  It exists only in
@@ -85,21 +77,13 @@ static_assert(sizeof(CoopCtl) <= kCoopCtlBytes, "control block");
 // COOP = true: the variant whose passes are ALWAYS the ticketed chunk form (coop_K >= 1; one chunk = the classic pass, bit
 // for bit) — instantiated by the fused kernel only.  A compile-time property, not a run-time branch: two MFMA loops over
 // the same accumulators in one kernel made hipcc keep two AGPR sets (156 -> 196 registers at n = 50: 3 -> 2 waves / SIMD).
-// TEAMW != 4 (12): the TEAM form of the fused kernel (toa_tuning::team_on) — a workgroup of TEAMW waves of which
-// only the first `coop_NO` pull problems (owners); the others are helpers from the first cycle on (ghost problems, as in the
-// tail of the classic form) and evaluate-only passes are ticketed as well.  With 2 owners on each of 256 compute units 512
-// problems are in flight instead of 3 072: their rows (209 MB at C4) stay in the 256 MiB Infinity Cache between two passes.
-// Which wave computes a chunk never changes its bits: the team form and the classic form of a shape give the same bits
-// (tests/test_gpu_team.py).  Built, measured, and NOT the default: the part of an LM iteration that only the owner can do
-// (fold, LDL^T, step test) bounds a problem's chain at ~45 us per iteration, two chains per compute unit leave the SIMDs
-// short of work, and with enough chains to fill them the rows no longer fit the cache (profiles/r05_ab_log.md §1).
-template <typename T, int NBM, int THIN, bool ROBUST = false, bool COOP = false, int TEAMW = 4>
+// (A TEAM form of this kernel — twelve-wave workgroups of which two pull problems, so that the rows of the problems in flight stay in
+// the 256 MiB Infinity Cache — was built in round 5, bit-identical, measured slower (9.28 vs 7.3 ms at C4) and removed from the
+// library in round 6: profiles/r05_ab_log.md §1, profiles/r06_pruned_arms.patch.)
+template <typename T, int NBM, int THIN, bool ROBUST = false, bool COOP = false>
 struct DenseRowModel {
   using Scalar = T;
-  static constexpr int kWaves = TEAMW;            // waves per workgroup of the fused kernel
-  static constexpr bool kTeam = TEAMW != 4;
-  static_assert(TEAMW == 4 || (COOP && !ROBUST), "the team form is a cooperative form");
-  static_assert(TEAMW <= kCoopMaxWaves, "control block");
+  static constexpr int kWaves = 4;                // waves per workgroup of the fused kernel
   static constexpr int kXdim = 0;  // parameters per problem as stored in x; 0 = n (Euclidean)
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* d, T sign, int, int lane) const { euclid_plus_eq(L, d, sign, lane); }
   // register-LDL^T width: the largest n this (NBM, THIN) layout serves, rounded to the 8-column chunk (n = 50: 56, not 64)
@@ -125,15 +109,12 @@ struct DenseRowModel {
   static constexpr int kCoopPeriod = DenseRowGram<T, NBM, THIN>::kSuper16 ? 16 : 8;   // steps per super-batch / per turn of the load ring (kDepth * U)
   static_assert(!(COOP && ROBUST), "no cooperative form of the robust passes");
   int coop_K, coop_cs, coop_lds_per_wave, coop_tot_off, cur_p, helping, help_o, help_c;
-  int coop_NO;     // owners per workgroup (classic form: every wave, 4)
-  int help_kind;   // team form: the ticket coop_find drew names a chunk of an accumulate (0) / evaluate-only (1) pass
   __device__ __forceinline__ void init(int n, int m_, const void* d) {
     m = m_;
     lay = DenseRowLayout::make(n, m_);
     data = static_cast<const T*>(d);
     loss = TOA_LOSS_L2; th2 = T(0); rows_real = m_; ninl = -1;
     coop_K = 0; coop_cs = 0; coop_lds_per_wave = 0; coop_tot_off = 0; cur_p = 0; helping = 0; help_o = 0; help_c = 0;
-    coop_NO = 4; help_kind = 0;
     stage = nullptr;
   }
   // the workgroup's control block sits behind the kWaves carves
@@ -172,63 +153,17 @@ struct DenseRowModel {
   // The shape of the loop is what hipcc's register allocation tolerated (A/B log, profiles/r03_ab_log.md): do-while, the
   // scalars that cross the pass re-derived behind optimisation barriers, the total read back through in-out asm operands.
   __device__ __forceinline__ T coop_eval(WaveLds<T>& L, const int n, const int lane) {
-    // Evaluate-only pass: the same chunks, summed in the same order.  Classic form: by the owner alone — no ticket, no slot.
+    // Evaluate-only pass: the same chunks, summed in the same order, by the owner alone — no ticket, no slot.
     // (A helper that looked at this slot's counter during the previous accumulate pass and draws its ticket only now must
     // never land in a pass of a different kind — ADVICE r03: the accumulate counter stays closed across evaluate-only passes.)
-    // Team form: ticketed through the slot's SECOND counter (eticket), owner and helpers in this one loop; every chunk's
-    // partial cost goes to the owner's L.tmp[chunk] and the owner adds them up in chunk order — the classic form's sum.
+    (void)L;
     const int st = lay.m4 >> 2;
     T tot = T(0);
-    if constexpr (!kTeam) {
-      for (int c = 0; c < coop_K; ++c) {
-        reg_fence();
-        const T part = gram.template pass_chunk<false>(prob, lay, n, L.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
-        reg_fence();
-        tot = c == 0 ? part : tot + part;
-      }
-    } else {
-      extern __shared__ __attribute__((aligned(16))) char smem[];
-      const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-      const bool help = helping != 0;
-      int c, o;
-      if (!help) {
-        o = w;
-        CoopSlot& S = coop_ctl()->slot[w];
-        if (lane == 0) {
-          S.p = cur_p;
-          S.edone = 0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&S.eticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // chunk 0 is the owner's
-        c = 0;
-      } else {
-        o = __builtin_amdgcn_readfirstlane(help_o);
-        c = __builtin_amdgcn_readfirstlane(help_c);
-      }
-      do {
-        const WaveLds<T> Lo = WaveLds<T>::carve(smem + size_t(o) * coop_lds_per_wave, n);
-        CoopSlot& S = coop_ctl()->slot[o];
-        const T* pr = help ? data + size_t(__builtin_amdgcn_readfirstlane(S.p)) * lay.elems_per_problem() : prob;
-        reg_fence();
-        const T part = gram.template pass_chunk<false>(pr, lay, n, Lo.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
-        reg_fence();
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (lane == 0) Lo.tmp[c] = part;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) {
-          __hip_atomic_fetch_add(&S.edone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          c = __hip_atomic_fetch_add(&S.eticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        c = __builtin_amdgcn_readfirstlane(c);
-      } while (c < coop_K);
-      if (!help) {
-        CoopSlot& S = coop_ctl()->slot[w];
-        for (int spin = 0; __hip_atomic_load(&S.edone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K; ++spin) {
-          __builtin_amdgcn_s_sleep(2);
-          if (spin > (1 << 24)) asm volatile("s_trap 2");
-        }
-        for (int q = 0; q < coop_K; ++q) tot = q == 0 ? L.tmp[0] : tot + L.tmp[q];
-      }
+    for (int c = 0; c < coop_K; ++c) {
+      reg_fence();
+      const T part = gram.template pass_chunk<false>(prob, lay, n, L.xs, lane, c * coop_cs, min(st, (c + 1) * coop_cs));
+      reg_fence();
+      tot = c == 0 ? part : tot + part;
     }
     return tot;
   }
@@ -297,7 +232,6 @@ struct DenseRowModel {
   }
   // A wave whose queue is dry looks for a sibling's open ACCUMULATE pass and takes a ticket of it (only accumulate passes
   // ever open the counter: a ticket drawn late still names a chunk of an accumulate pass).  false: no sibling is active any more.
-  // Team form: the helpers (and owners whose queue is dry) look at the OWNERS' slots only, and at both counters.
   __device__ __forceinline__ bool coop_find(const int lane) {
     const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     CoopCtl* ctl = coop_ctl();
@@ -306,13 +240,10 @@ struct DenseRowModel {
       help_o = w;
       if (lane == 0) __hip_atomic_store(&ctl->active[w], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    const int no = kTeam ? coop_NO : 4;
     for (int spins = 0;;) {
       bool any = false;
-      for (int t = 1; t <= (kTeam ? no : 3); ++t) {
-        int q;
-        if constexpr (kTeam) { q = help_o + t; while (q >= no) q -= no; }
-        else q = (help_o + t) & 3;
+      for (int t = 1; t <= 3; ++t) {
+        const int q = (help_o + t) & 3;
         if (q == w) continue;
         if (__hip_atomic_load(&ctl->active[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
         any = true;
@@ -323,26 +254,12 @@ struct DenseRowModel {
           if (cc < coop_K) {
             help_o = __builtin_amdgcn_readfirstlane(q);
             help_c = cc;
-            help_kind = 0;
             return true;
-          }
-        }
-        if constexpr (kTeam) {
-          if (__hip_atomic_load(&ctl->slot[q].eticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < coop_K) {
-            int cc = 0;
-            if (lane == 0) cc = __hip_atomic_fetch_add(&ctl->slot[q].eticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cc = __builtin_amdgcn_readfirstlane(cc);
-            if (cc < coop_K) {
-              help_o = __builtin_amdgcn_readfirstlane(q);
-              help_c = cc;
-              help_kind = 1;
-              return true;
-            }
           }
         }
       }
       if (!any) return false;
-      __builtin_amdgcn_s_sleep(kTeam ? 2 : 8);
+      __builtin_amdgcn_s_sleep(8);
       if (++spins > (1 << 24)) asm volatile("s_trap 2");   // (a sibling that never finishes: trap rather than hang)
     }
   }
@@ -394,7 +311,7 @@ struct DenseRowModel {
 // The model whose data passes honour toa_set_loss, for the kernels that only run passes (Model itself where the family
 // has no separate variant: the Jet models branch at run time, the others have no M-estimator).
 template <typename M> struct RobustOf { using type = M; };
-template <typename T, int NBM, int THIN, bool COOP, int TEAMW> struct RobustOf<DenseRowModel<T, NBM, THIN, false, COOP, TEAMW>> { using type = DenseRowModel<T, NBM, THIN, true, false>; };
+template <typename T, int NBM, int THIN, bool COOP> struct RobustOf<DenseRowModel<T, NBM, THIN, false, COOP>> { using type = DenseRowModel<T, NBM, THIN, true, false>; };
 
 // Gaussian prior  r = (x - y) / sigma,  m = n — the residual of the reference's published dense
 // benchmark, with the semantics of its manual Accumulate callback (benchmarks/dense.cpp:57-66, 90-99;
@@ -1322,8 +1239,7 @@ struct FusedParams {
   int memo_lds_off;              // != 0: the memo slot is in LDS instead, at this byte offset of the wave's carve (small Grams)
   int coop_K;                    // cooperative passes (CoopCtl): chunks per pass, 0 = off
   int coop_cs;                   // steps (of 4 rows) per chunk, a multiple of the load ring's period
-  int team_owners;               // team form (ModelWaves != 4): waves of a workgroup that pull problems (the rest only help)
-  int team_prio;                 // team form: toa_tuning::team_prio
+  int reserved_[2];              // (the team form's two fields, round 5: the block's layout is unchanged)
 };
 
 template <typename M, typename = void>
@@ -1368,14 +1284,12 @@ template <typename Model>
 __global__ void __launch_bounds__(64 * ModelWaves<Model>::value) TOA_FUSED_ATTR lm_fused_kernel(const FusedParams* __restrict__ prm_g) {
   using T = typename Model::Scalar;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kW = ModelWaves<Model>::value;   // waves per workgroup: 4, or 12 in the team form
-  constexpr bool kTeam = kW != 4;
+  constexpr int kW = ModelWaves<Model>::value;   // waves per workgroup
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n = prm_g->n;
-  // owners: the waves that pull problems.  Classic form: all four.  Team form: the first team_owners of the workgroup.
-  const int NO = kTeam ? __builtin_amdgcn_readfirstlane(prm_g->team_owners) : 4;
-  const bool owner = !kTeam || __builtin_amdgcn_readfirstlane(wave) < NO;
+  constexpr int NO = kW;                         // every wave of a workgroup pulls problems
+  constexpr bool owner = true;
   WaveLds<T> L = WaveLds<T>::carve(smem + size_t(wave) * prm_g->lds_per_wave + prm_g->carve_off, n);
   // private per-wave copies of the option / result PODs (no inter-wave synchronisation anywhere)
   {
@@ -1405,13 +1319,10 @@ __global__ void __launch_bounds__(64 * ModelWaves<Model>::value) TOA_FUSED_ATTR 
   int* queue = prm_g->queue;
   if constexpr (ModelCoop<Model>::value) {   // the workgroup's control block: every wave marks itself as an owner, no pass open
     model.coop_init(prm_g->coop_K, prm_g->coop_cs, prm_g->lds_per_wave, prm_g->coop_tot_off);
-    model.coop_NO = NO;
     CoopCtl* ctl = reinterpret_cast<CoopCtl*>(smem + size_t(kW) * prm_g->lds_per_wave);
     if (lane == 0) {
       ctl->slot[wave].ticket = prm_g->coop_K;
       ctl->slot[wave].turn = prm_g->coop_K;
-      ctl->slot[wave].eticket = prm_g->coop_K;
-      ctl->slot[wave].edone = prm_g->coop_K;
       ctl->active[wave] = owner ? 1 : 0;
     }
     __syncthreads();   // the only workgroup barrier of the kernel: nobody scans the slots before they exist
@@ -1459,12 +1370,7 @@ __global__ void __launch_bounds__(64 * ModelWaves<Model>::value) TOA_FUSED_ATTR 
     // the issue slots: a wave drops one level per problem it has finished.  (Measured and rejected, profiles/r02_ab_log.md:
     // no priorities; a level that follows the lag behind the average wave; re-queueing unfinished problems iteration by
     // iteration through HBM during the drain.)
-    if (kTeam && prm_g->team_prio == 0) {
-      // Team form: an owner's LDL^T, step test and bookkeeping are the serial part of its problem's chain — every other wave
-      // of the compute unit can only work on a chunk that some owner has opened — so the owners outrank the helpers.
-      if (owner && !ghost) __builtin_amdgcn_s_setprio(3);
-      else __builtin_amdgcn_s_setprio(1);
-    } else {
+    {
       const int lag = 1 - solved;
       if (lag >= 1) __builtin_amdgcn_s_setprio(3);
       else if (lag == 0) __builtin_amdgcn_s_setprio(2);
@@ -1472,14 +1378,6 @@ __global__ void __launch_bounds__(64 * ModelWaves<Model>::value) TOA_FUSED_ATTR 
       else __builtin_amdgcn_s_setprio(0);
     }
     ++solved;
-    if constexpr (kTeam) {
-      // a ticket of an evaluate-only pass: its chunk(s) are worked off right here (DenseRowModel::coop_eval — the helper's
-      // side of the owner's loop), no ghost problem needed
-      if (ghost && model.help_kind) {
-        (void)model.coop_eval(L, n, lane);
-        continue;
-      }
-    }
     if (ghost) p = 0;
     model.bind(p);
     wave_sync();
@@ -2431,14 +2329,6 @@ inline void coop_chunking(toa_handle h, int n, int m, int* K_out, int* cs_out) {
   *cs_out = cs;
   *K_out = (steps_total + cs - 1) / cs;
 }
-// Can this shape run in the team form (kTeamWaves carves + the control block in one workgroup, cooperative passes on)?
-template <typename T>
-inline bool team_fits(toa_handle h, int n, int m) {
-  if (h->tune.coop_off || m < 1024) return false;
-  const size_t pw = (WaveLds<T>::bytes(n) + 15) & ~size_t(15);
-  return pw * kTeamWaves + kCoopCtlBytes <= 160 * 1024;
-}
-
 template <typename Model>
 inline int launch_accumulate(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad,
                              void* g, void* H, double* cost, int32_t* nres) {
@@ -2466,14 +2356,10 @@ template <typename Model>
 inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
   using T = typename Model::Scalar;
   constexpr int kW = ModelWaves<Model>::value;
-  constexpr bool kTeam = kW != 4;
+  constexpr int NO = kW;   // (every wave of a workgroup pulls problems)
   FusedParams prm = prm_in;
   size_t pw, pwg;
   if (int rc = lds_fit<T>(h, prm.n, &pw, &pwg, kW)) return rc;
-  // team form: owners per workgroup = problems in flight per compute unit (one workgroup of twelve waves per CU)
-  const int NO = kTeam ? std::max(1, std::min(kW, h->tune.team_owners > 0 ? h->tune.team_owners : (kW >= 12 ? 2 : 1))) : 4;
-  prm.team_owners = NO;
-  prm.team_prio = h->tune.team_prio;
   prm.lds_per_wave = (int)pw;
   prm.queue = h->queue;
   // [0] pop counter, [16] waves that have left: zeroed when the handle is created and by the last wave of every launch
@@ -2530,7 +2416,7 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
       // a small Gram is parked in LDS when that costs no resident workgroup (C3: parking in HBM after every accepted step
       // measured 1.5 % of the launch for a workload that never rejects a step)
       const size_t mb = (Model::kMemoBytes + 15) & ~size_t(15);
-      if (!kTeam && mb <= 4096 && (pw + mb) * 4 <= 160 * 1024) {
+      if (mb <= 4096 && (pw + mb) * 4 <= 160 * 1024) {
         int w2 = 0;
         if (int rc = occupancy((pw + mb) * 4, &w2)) return rc;
         if (w2 == wg_per_cu) {
@@ -2570,7 +2456,6 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
         }
       }
     }
-    if (kTeam && !(coop_on && room)) return toa_fail(TOA_E_UNSUPPORTED, "team form of the fused kernel: this shape has no cooperative passes");
     if (coop_on && prm.m >= (super16 ? 256 : 1024) && room) {
       // chunks per pass: ~1024 rows each (256 for the super-batch form).  Same box, C4 (m = 2000), three interleaved rounds
       // (profiles/r03_ab_log.md): K = 2: 12.83 M it/s, K = 3: 12.69, K = 4: 12.71, K = 8: 12.41, off: 12.52 — every chunk pays

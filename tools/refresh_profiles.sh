@@ -19,8 +19,6 @@ python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large
 python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu --tuning memo_off=1 > $O/bench_large128_memo0.json 2>/dev/null
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning memo_off=1 > $O/bench_large256_memo0.json 2>/dev/null
 python bench.py --workload c4 --no-cpu --tuning coop_chunks=6 > $O/bench_c4_k6.json 2>/dev/null
-python bench.py --workload c4 --no-cpu --tuning team_on=1,coop_chunks=6 > $O/bench_c4_team2_k6.json 2>/dev/null
-python bench.py --workload c4 --no-cpu --tuning team_on=1,coop_chunks=6,team_owners=4 > $O/bench_c4_team4_k6.json 2>/dev/null
 tools/ubench/llc_probe 20 > $O/llc_probe.txt 2>&1
 python bench.py --workload c4 --no-cpu --tuning coop_off=1 > $O/bench_c4_coop0.json 2> $O/bench_c4_coop0.err
 python bench.py --workload c4 --no-cpu --tuning memo_off=1,coop_off=1 > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
