@@ -31,7 +31,7 @@ def counters(dirpath, kernel_substr):
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(glob.glob(os.path.join(SRC, "stats", "runc", "*_kernel_stats.csv"))[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
-    for wl in ("c3", "c2", "c5", "large128", "large256", "ba", "balists"):
+    for wl in ("c3", "c2", "c5", "large128", "large256", "ba", "balists", "c4_text", "c4_ad"):
         hits = glob.glob(os.path.join(SRC, f"stats_{wl}", "runc", "*_kernel_stats.csv"))
         if hits:
             shutil.copy(hits[0], os.path.join(DST, f"{tag}_kernel_stats_{wl}.csv"))
@@ -55,7 +55,7 @@ def main():
                        "bench_line_kernel_ms_avg_hip_events": line["roofline"].get("kernel_ms_avg"),
                        "ratio_rocprof_over_hip_events": (sum(warm) / len(warm)) / line["roofline"]["kernel_ms_avg"] if line["roofline"].get("kernel_ms_avg") else None,
                        "bench_line_value": line["value"], "bench_line_frac": line["roofline"]["frac"]}, f, indent=1)
-    for txt in ("ad_ratio", "large_n_bench", "k3_crossover", "probe_phases", "coop_sweep", "llc_probe", "pytest_gpu"):
+    for txt in ("row_model_bench", "ad_ratio", "large_n_bench", "k3_crossover", "probe_phases", "coop_sweep", "llc_probe", "pytest_gpu"):
         if os.path.exists(os.path.join(SRC, txt + ".txt")):
             shutil.copy(os.path.join(SRC, txt + ".txt"), os.path.join(DST, f"{tag}_{txt}.txt"))
     if os.path.isdir(os.path.join(SRC, "pmc_large128")):   # counters of the n = 128 workgroup-per-problem kernel
@@ -72,7 +72,7 @@ def main():
                  "bench_under_rocprof_c2", "bench_under_rocprof_c5", "bench_under_rocprof_large128", "bench_large128", "bench_ba", "bench_under_rocprof_ba",
                  "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0",
                  "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane", "bench_large256_two_lanes", "bench_large256_plain_deal",
-                 "bench_large128_memo0", "bench_large256_memo0", "bench_c4_k6", "bench_c4_team2_k6", "bench_c4_team4_k6"):
+                 "bench_large128_memo0", "bench_large256_memo0", "bench_c4_k6", "bench_c4_text", "bench_c4_ad", "bench_under_rocprof_c4_text", "bench_under_rocprof_c4_ad"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:
@@ -108,6 +108,33 @@ def main():
     for name in (f"{tag}_pmc.json", "pmc_latest.json"):
         with open(os.path.join(DST, name), "w") as f:
             json.dump(out, f, indent=1)
+    # ---- the C4 shape as text (row models): the run-time build's fused kernel, FETCH_SIZE calibrated on its own cost-only seam
+    if os.path.isdir(os.path.join(SRC, "pmc_fused_c4_text")) and os.path.exists(os.path.join(DST, f"{tag}_bench_c4_text.json")):
+        bt = json.loads(open(os.path.join(DST, f"{tag}_bench_c4_text.json")).read())
+        ft = {}
+        for d in sorted(glob.glob(os.path.join(SRC, "pmc_fused_c4_text", "*"))):
+            try:
+                c, durs = counters(d, kern)
+            except IndexError:
+                continue
+            ft.update(c)
+            ft.setdefault("_kernel_ms", {})[os.path.basename(d)] = durs
+        evt, _ = counters(os.path.join(SRC, "pmc_eval_c4_text", "FETCH_SIZE"), "accumulate_kernel")
+        Pt, bppt = bt["config"]["problems_per_gpu"], bt["roofline"]["algorithmic_bytes_per_pass"]
+        calt = float(Pt) * bppt / (evt["FETCH_SIZE"] * 1024.0)
+        hbmt = ft["FETCH_SIZE"] * 1024.0 * calt + ft["WRITE_SIZE"] * 1024.0
+        algt = bt["roofline"]["passes_per_launch"] * bppt
+        outt = {"round": tag, "workload": "c4_text", "problems": Pt, "kernel": "lm_fused_kernel<RowModel<float, 3, 3, UserFunctor<float>>> (hiprtc build)",
+                "FETCH_SIZE_KB_per_launch": ft["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": ft["WRITE_SIZE"],
+                "fetch_calibration": {"kernel": "accumulate_kernel<RowModel<...>> want_grad=0 (LDS-DMA: reads every item byte exactly once)",
+                                      "known_bytes": float(Pt) * bppt, "FETCH_SIZE_KB": evt["FETCH_SIZE"], "bytes_per_reported_byte": calt},
+                "hbm_bytes_per_launch": hbmt, "algorithmic_bytes_per_launch": algt, "traffic_over_algorithmic": hbmt / algt,
+                "sq_counters_per_launch": {k: v for k, v in ft.items() if k.startswith("SQ_") or k.startswith("GRBM")},
+                "kernel_ms_under_pmc": ft["_kernel_ms"]}
+        for name in (f"{tag}_pmc_c4_text.json", "pmc_latest_c4_text.json"):
+            with open(os.path.join(DST, name), "w") as f:
+                json.dump(outt, f, indent=1)
+        print("c4_text", {k: outt[k] for k in ("hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")})
     lf = globals().get("_large128")
     if lf and os.path.exists(os.path.join(DST, f"{tag}_bench_large128.json")):
         bl = json.loads(open(os.path.join(DST, f"{tag}_bench_large128.json")).read())

@@ -7,7 +7,8 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O   # NOTE: also delete the LOCAL gpurun_out/refresh before calling gpurun (results are merged, not mirrored)
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
-for wl in c4 c3 c2 c5 c1 ba balists; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+for wl in c4 c3 c2 c5 c1 ba balists c4_text c4_ad; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+python tools/row_model_bench.py 12500 > $O/row_model_bench.txt 2>&1
 python bench.py --workload large128 --steps 5 --warmup 2 > $O/bench_large128.json 2> $O/bench_large128.err
 python bench.py --workload large256 --steps 5 --warmup 2 > $O/bench_large256.json 2> $O/bench_large256.err
 python bench.py --workload large256 --steps 5 --warmup 2 --no-cpu --tuning large_library_solver=1 > $O/bench_large256_rocsolver.json 2>/dev/null
@@ -29,13 +30,19 @@ python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1
 bash tools/coop_sweep.sh > $O/coop_sweep.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
-for wl in c3 c2 c5 large128 large256 ba balists; do
+for wl in c3 c2 c5 large128 large256 ba balists c4_text c4_ad; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python $R/bench.py --workload $wl --steps 20 --warmup 3 --no-cpu > $O/bench_under_rocprof_$wl.json 2> $O/stats_$wl.err
 done
 for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA"; do
   tag=$(echo $C | tr " " "_" | cut -c1-48)
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_fused/$tag -- python $R/tools/prof_phase.py fused > /dev/null 2>&1
 done
+# the C4 shape as text (row models, round 6): traffic and issue mix of the run-time build's fused kernel, calibrated on ITS cost-only seam
+for C in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_MFMA"; do
+  tag=$(echo $C | tr " " "_" | cut -c1-48)
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_fused_c4_text/$tag -- python $R/tools/prof_phase.py fused c4_text > /dev/null 2>&1
+done
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_eval_c4_text/FETCH_SIZE -- python $R/tools/prof_phase.py eval c4_text > /dev/null 2>&1
 # FETCH_SIZE calibration on the evaluate seam (reads every packed byte exactly once)
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_eval/FETCH_SIZE -- python $R/tools/prof_phase.py eval > /dev/null 2>&1
 # the same for the C3 launch (fp64, n = 12)
