@@ -199,3 +199,38 @@ def test_headline_shape_as_text_follows_the_compiled_in_model(ta, oracle):
     st = check_trajectories(gpu_dict(out, x), ref, np.float32, opts.to_pod(), label="C4 as text")
     assert st["full"] + st["ties"] == P
     assert np.abs(x.cpu().numpy() - ref["x"]).max() < 2e-3
+
+
+@pytest.mark.parametrize("n", [16, 32, 48])
+@pytest.mark.parametrize("kind", ["accumulate", "residual"])
+def test_row_models_in_the_row_split_and_stepping_forms_at_block_boundaries(ta, oracle, n, kind):
+    """a run-time row model with P * 4 <= #CUs and >= 512 rows is routed to the row-split form by toa_jit_lm_run
+    itself; at n = 16, 32, 48 the step kernels' register LDL^T is exactly as wide as the parameter block (npad = n), narrower than
+    the compiled-in families' width.  One huge problem per shape: the automatic route, explicit chunk counts and the stepping form
+    against the oracle's trajectory, and the one-wavefront form (toa_tuning::wide_no_autosplit) on the same data."""
+    P, m = 1, 1600
+    A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float64, seed=910 + n)
+    body = manual_body(n, fast_sincos=False) if kind == "accumulate" else ad_body(n)
+    model = ta.JitResidual(body, n=n, item_scalars=n + 1, dtype=torch.float64, kind=kind).bind(_items(A, b))
+    opts = ta.Options.benchmark()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+    for splits in (None, 1, 5, 64):
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, opts, history=True) if splits is None else ta.Optimize(x, model, opts, history=True, splits=splits)
+        torch.cuda.synchronize()
+        st = check_trajectories(gpu_dict(out, x), ref, np.float64, opts.to_pod(), label=f"row model n = {n}, splits = {splits}")
+        assert st["full"] + st["ties"] == P
+    with ta.api.default_context().tuning(wide_no_autosplit=1):
+        x1 = torch.from_numpy(x0.copy()).cuda()
+        o1 = ta.Optimize(x1, model, opts, history=True)
+        torch.cuda.synchronize()
+    st = check_trajectories(gpu_dict(o1, x1), ref, np.float64, opts.to_pod(), label=f"row model n = {n}, one wavefront")
+    assert st["full"] + st["ties"] == P
+    xs_ = torch.from_numpy(x0.copy()).cuda()
+    opt = ta.Optimizer(xs_, model, opts, history=True)
+    for _ in range(opts.max_iters + 3):
+        if opt.Step() == 0:
+            break
+    torch.cuda.synchronize()
+    st = check_trajectories(gpu_dict(opt.out, xs_), ref, np.float64, opts.to_pod(), label=f"row model n = {n}, stepping")
+    assert st["full"] + st["ties"] == P
