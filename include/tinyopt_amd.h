@@ -465,9 +465,13 @@ typedef struct toa_jit_model_s* toa_jit_model;
 int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per_item, int scalars_per_item, int header_scalars,
                       const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
 /*      Round 4 — the general form.
- *        num_params up to 63: beyond 12 the model is JetRowModel (chunked Jets evaluated in matrix-core operand order, the path
- *          of TOA_MODEL_DENSE_ROW_AD): a Euclidean residual functor, no M-estimator; residuals_per_item up to 8 (an item's
- *          residuals are consecutive rows; round 5), scalars_per_item up to 512; the row-split and the stepping forms take it too.
+ *        num_params up to 63: beyond 12 the model is RowModel (csrc/row_model.hpp, round 6; the path of TOA_MODEL_DENSE_ROW_AD):
+ *          an item is evaluated by ONE lane — TOA_JIT_RESIDUAL bodies on Jets, twelve parameters at a time; TOA_JIT_ACCUMULATE
+ *          bodies on plain T with the Jacobian rows they fill — and its rows [J | r] are staged through LDS into the operand
+ *          layout of the matrix-core Gram.  A Euclidean functor (manifolds stop at 12 tangent dimensions); the handle's
+ *          M-estimator (toa_set_loss) applies per item; residuals_per_item up to 8 (an item's residuals are consecutive rows),
+ *          scalars_per_item up to 512 (as many as the LDS stage holds with num_params: the build is refused with a message
+ *          otherwise); the row-split and the stepping forms take it too.
  *        manifold = TOA_MANIFOLD_SE3: x is ONE pose stored as R (row-major 9) + t (3) = 12 scalars, num_params = 6 (its tangent
  *          in Sophus order upsilon, omega); the body reads the pose through x[0..11] — Jets over the right perturbation
  *          x * exp(delta) at delta = 0 (optimize_autodiff.h:48-77, 3rdparty/traits/sophus.h:13-27) — and may call
@@ -481,6 +485,7 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
  *          plus(x, Jets seeded on d at d = 0) (optimize_autodiff.h:48-77); the residual body reads x[0 .. x_scalars).
  *        kind = TOA_JIT_ACCUMULATE: a manual Accumulate callback (docs/API.md:37-57, tests/optimize_easy.cpp:35-79) — the body
  *          fills r[q] and, `if (want_grad)`, the Jacobian rows J[q][a] itself (plain T, no AD); x[j], h[k], p[k] as before.
+ *          Any num_params up to 63 (round 6; benchmarks/dense.cpp:57-66,90-99 is such a callback at n = 50: bench.py --workload c4_text).
  *        A compiled model is cached on disk (code object keyed by the generated source, the library's headers, the hiprtc
  *          version and the device architecture): toa_jit_set_cache_dir(dir), default $XDG_CACHE_HOME/tinyopt_amd or
  *          $HOME/.cache/tinyopt_amd; "" = off, NULL = the default again.  The library's headers are embedded in it: no source tree is needed at run time. */
@@ -513,10 +518,14 @@ int toa_jit_accumulate(toa_handle h, toa_jit_model model, int num_items, int64_t
  *      toa_lm_run_split.  The items of each problem are cut into `splits` chunks (0 = chosen automatically), a wavefront per
  *      chunk, partials folded in fixed order; ONE persistent launch when P * splits <= the device's compute units, one launch
  *      pair per iteration otherwise.  Its kernels are a second code object, compiled (or loaded from the cache) at the first
- *      such call.  toa_jit_lm_run takes this route by itself when P * 4 <= #CUs and m >= 512 (toa_tuning::wide_no_autosplit). */
+ *      such call.  toa_jit_lm_run takes this route by itself when P * 4 <= #CUs and m >= 512 (toa_tuning::wide_no_autosplit) —
+ *      since round 5 also for models beyond 12 parameters.  Consequences for a caller: the first such call pays that second
+ *      build, and it is refused with TOA_E_UNSUPPORTED (nothing recorded) when that first call happens under stream capture:
+ *      run the shape once un-captured beforehand, or set wide_no_autosplit to keep the one-wavefront form; the chunked sum
+ *      order differs from the one-wavefront form's, so results across the crossover agree to round-off, not bit for bit. */
 int toa_jit_lm_run_split(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,
                          const toa_options* options, const toa_results* results, uint64_t* counters_dev, int splits);
-/*      The stepping form of a run-time model (num_params <= 12): the contracts of toa_lm_begin / toa_lm_step / toa_lm_stop with
+/*      The stepping form of a run-time model (any num_params): the contracts of toa_lm_begin / toa_lm_step / toa_lm_stop with
  *      state_dev = toa_lm_state_bytes(dtype, num_params, P) bytes; toa_lm_step_info reads that block as for the built-in
  *      families.  This is what lets Options::stop_callback / stop_callback2 / max_duration_ms (options.h:96-106) work for a
  *      residual that arrived as text: both host mirrors run their callback loop over it. */

@@ -2,7 +2,7 @@
 """ISA lint for the inline-asm MFMAs: hipcc's hazard recognizer does not look inside asm statements, so an
 accumulator copy it inserts (v_accvgpr_read / v_accvgpr_mov / any non-MFMA reader of an AGPR) could overtake
 the matrix core.  This scans the gfx950 code objects of the built translation units and fails if such a
-reader follows an MFMA that wrote the same AGPR (or, in the VGPR-accumulator translation units of the team form, any
+reader follows an MFMA that wrote the same AGPR (or, in the VGPR-accumulator translation units (-DTOA_ACC_VGPR: ba_schur), any
 instruction that touches a VGPR an MFMA wrote) with fewer than MIN_WAIT wait states in between
 (every instruction = 1, `s_nop N` = N + 1, a later MFMA = its passes - 1; straight-line approximation, conservative).
 
