@@ -1,4 +1,4 @@
-"""Cooperative passes (csrc/kernels.hpp CoopCtl / DenseRowModel::coop_pass): in the fused kernel a data pass of a problem with
+"""Cooperative passes (csrc/models_dense.hpp CoopCtl / DenseRowModel::coop_pass): in the fused kernel a data pass of a problem with
 m >= 1024 rows is K ticketed row chunks, each accumulated from zero and folded into the owner's LDS total in TICKET ORDER; a
 wave whose work queue is dry takes tickets of its workgroup siblings' passes.  What must hold:
   * whoever computes the chunks, the bits are the same: run-to-run, for any batch size, for any position in the batch —
