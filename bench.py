@@ -889,6 +889,38 @@ def main():
                                                 "passes_per_launch": r["passes_per_launch"],
                                                 "measured_read_ceiling_GBps": r["measured_read_ceiling_GBps"],
                                                 "llc_read_ceiling_GBps": r["llc_read_ceiling_GBps"]}}
+    if args.workload == "large128" and gpu and world == 1:
+        # 512 problems = 256 CUs x 2 resident workgroups: every slot holds exactly ONE problem, so the launch lasts as long as the CU
+        # with the two longest ones (iterations per problem: mean 7.3, max 10-11).  The kernel's own rate shows on a batch that keeps
+        # the slots refilled — the same generator at four times the problems, after the timed region (profiles/r06_ab_log.md §4):
+        itp = out.num_iters.to(torch.float64)
+        result["roofline"]["one_problem_per_slot"] = {"iterations_per_problem_mean": float(itp.mean()), "iterations_per_problem_max": float(itp.max()),
+                                                      "mean_over_max": float(itp.mean() / itp.max())}
+        del model, x, x0, out
+        torch.cuda.empty_cache()
+        Pb = 4 * P
+        gen = torch.Generator(device="cuda").manual_seed(0x7194 + 977)
+        A = torch.rand(Pb, m, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        xs_b = torch.rand(Pb, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
+        tb = torch.einsum("pmn,pn->pm", A, xs_b)
+        bb = tb + 0.1 * torch.sin(tb) + 1e-3 * (torch.rand(Pb, m, dtype=tdt, device="cuda", generator=gen) * 2 - 1)
+        x0b = xs_b + 0.5 * (torch.rand(Pb, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1) / (n / 50) ** 0.5
+        mb = ta.DenseRowNatural(A, bb)
+        del A, bb, tb
+        xb = x0b.clone()
+        ob = optimize(xb, mb, opts)
+        sync()
+        tms, accp = [], 0
+        for _ in range(4):
+            xb.copy_(x0b)
+            e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
+            e0.record(); optimize(xb, mb, opts, out=ob); e1.record(); sync()
+            tms.append(e0.elapsed_time(e1)); accp = int(ob.counters[0])
+        tb_s = sum(tms[1:]) / len(tms[1:]) * 1e-3
+        result["roofline"]["balanced_batch"] = {"problems": Pb, "kernel_ms_avg": tb_s * 1e3, "accumulate_passes_per_launch": accp,
+                                                "lm_iterations_per_s": float(ob.num_iters.sum()) / tb_s,
+                                                "frac": accp * result["roofline"]["flop_per_accumulate_pass"] / tb_s / 1e12 / result["roofline"]["peak"]}
+        del mb, xb, x0b, ob
     if not args.no_cpu and world == 1:  # the CPU baseline leg runs on rank 0 at N = 1 only
         np_dtype = np.float32 if tdt == torch.float32 else np.float64
         est = 4e-4 * (n * n * m) / (50 * 50 * 2000) * 8  # rough seconds per problem (8 iterations)

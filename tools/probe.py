@@ -19,8 +19,14 @@ def timeit(fn, reps=5):
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
-    n, m, dt = (50, 2000, torch.float32) if wl == "c4" else (12, 500, torch.float64)
-    for P in ((12288, 12500) if wl == "c4" else (8192, 10000)):
+    if wl == "shape":   # probe.py shape n m f32|f64 P [P ...]
+        n, m, dt = int(sys.argv[2]), int(sys.argv[3]), (torch.float64 if sys.argv[4] == "f64" else torch.float32)
+        Ps = tuple(int(v) for v in sys.argv[5:])
+        wl = f"n={n} m={m} {sys.argv[4]}"
+    else:
+        n, m, dt = (50, 2000, torch.float32) if wl == "c4" else (12, 500, torch.float64)
+        Ps = (12288, 12500) if wl == "c4" else (8192, 10000)
+    for P in Ps:
         model, x0, xs = ta.DenseRow.synthetic(P, n, m, dt)
         bpp = model.algorithmic_bytes_per_pass
         t_acc = timeit(lambda: ta.accumulate(model, x0, True))
