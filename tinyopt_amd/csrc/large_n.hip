@@ -1045,6 +1045,54 @@ __global__ void __launch_bounds__(256) large_pre_kernel(const LargeArgs<T> a) {
     a.built[p] = (built ? 1 : 0) | (assigned ? 2 : 0);   // bit 0: Build succeeded; bit 1: H = Hnew is due (large_stage_kernel)
   }
 }
+// ---- the K1 / K2 seam beyond 128 unknowns (toa_accumulate on the natural layout; SolverGN::Accumulate / Evaluate, gn.h:97-113, any
+// Dims): ONE data pass of the pipeline — the rows kernel, the Gram (ours or the library's) — and this kernel instead of Build: the cost
+// summed in large_pre_kernel's order, J^T r from the rows kernel's partials in slot order, H copied out.  want_grad == 0: the cost only
+// (the rows kernels skip the Jacobian side when the state says "no rebuild").
+template <typename T>
+struct LargeSeamOut {
+  T* g;           // [P][n]    (want_grad)
+  T* H;           // [P][n][n] (want_grad)
+  double* cost;   // [P] raw: sum of r_i^2, or of the losses l_i with toa_set_loss
+  int32_t* nres;  // [P] optional
+  int want_grad;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) large_seam_prep_kernel(const LargeArgs<T> a, const int want_grad) {
+  const long long p = blockIdx.x * 256ll + threadIdx.x;
+  if (p < a.P) a.st[p].rebuild = want_grad ? 1 : 0;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) large_seam_out_kernel(const LargeArgs<T> a, const LargeSeamOut<T> o) {
+  __shared__ double red[256];
+  const long long p = blockIdx.x;
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  const T* v = (a.loss != TOA_LOSS_L2 ? a.lossv : a.r) + size_t(p) * m;
+  const bool sq = a.loss == TOA_LOSS_L2;
+  double c = 0;
+  for (int i = tid; i < m; i += 256) { const T r = v[i]; c += sq ? double(r * r) : double(r); }   // (large_pre_kernel's order of additions)
+  c = block_sum<T>(c, red);
+  if (tid == 0) {
+    o.cost[p] = double(T(c));
+    if (o.nres) o.nres[p] = m;
+  }
+  if (!o.want_grad) return;
+  for (int i = tid; i < n; i += 256) {
+    T gi;
+    if (a.gslots > 0) {
+      gi = 0;
+      const T* gq = a.gpart + size_t(p) * a.gslots * n + i;
+      for (int sl = 0; sl < a.gslots; ++sl) gi += gq[size_t(sl) * n];
+    } else {
+      gi = a.gnew[p * n + i];
+    }
+    o.g[p * n + i] = gi;
+  }
+  const T* Hn = a.Hnew + size_t(p) * n * n;
+  T* Ho = o.H + size_t(p) * n * n;
+  for (size_t e = tid; e < size_t(n) * n; e += 256) Ho[e] = Hn[e];
+}
+
 // The two n x n copies of Build — H = the fresh accumulation (gn.h:77-81), work = H with the damped diagonal (lm.h:108-117)
 // — spread over (row slices, problems) instead of riding in large_pre_kernel's one workgroup per problem (128 workgroups on
 // 256 CUs: 0.2 ms of a 2 ms pass at n = 256).  16-byte accesses when a row is a multiple of four elements.
@@ -1928,7 +1976,7 @@ __global__ void __launch_bounds__(256) large_step_log_kernel(const char* __restr
 template <typename T>
 int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, const toa_options& opt,
                    const toa_results& res, uint64_t* counters, int mode = 0, void* state = nullptr,
-                   int32_t* active_dev = nullptr, const int32_t* stop_request = nullptr) {
+                   int32_t* active_dev = nullptr, const int32_t* stop_request = nullptr, const LargeSeamOut<T>* seam_out = nullptr) {
   const size_t nn = size_t(n) * n;
   auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
   const unsigned max_tries = opt.max_consec_failures > 0 ? (opt.max_consec_failures > 1 ? opt.max_consec_failures : 1) : 255;
@@ -1936,7 +1984,8 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const size_t b_st = al(size_t(P) * sizeof(LmState<T>)), b_i = al(size_t(P) * sizeof(int));
   const size_t b_vec = al(size_t(P) * n * sizeof(T)), b_mat = al(size_t(P) * nn * sizeof(T));
   const size_t b_J = al(size_t(P) * m * n * sizeof(T)), b_r = al(size_t(P) * m * sizeof(T));
-  const bool stepping = mode != 0;
+  const bool seam = mode == 4;              // toa_accumulate: one data pass, no Build (seam_out says where the results go)
+  const bool stepping = mode != 0 && !seam;
   const LargeStateLayout<T> lay(n, P);
   const long long step_passes = (long long)max_tries + 2;   // one iteration: a pass + its retries (optimizer.h:370-390)
   const size_t b_sum = stepping ? al(size_t(4) * sizeof(int) * size_t(step_passes + 1)) : al(size_t(2) * sizeof(int) * size_t(max_passes + 1) * toa_context::kLanes);
@@ -1990,7 +2039,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   const size_t b_piv = lu ? al(size_t(P) * n * sizeof(int)) : 0;
   // what outlives a pass (LargeStateLayout) sits in the caller's state block in the stepping form, in the scratch otherwise
   // memo of linearisations (LargeArgs::skip ...): the whole-solve form only — the stepping form's state block has one H slot
-  const bool memo_on = !stepping && !h->tune.memo_off;
+  const bool memo_on = !stepping && !seam && !h->tune.memo_off;
   const size_t b_dbl = al(size_t(P) * sizeof(double));
   const size_t b_memo = memo_on ? 5 * b_i + 4 * b_vec + 2 * b_dbl + 2 * b_mat : 0;
   const bool robust = h->loss != TOA_LOSS_L2;
@@ -2056,7 +2105,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
   }
   // rocBLAS / rocSOLVER are opened (dlopen, a handle: a cold load of their code objects, minutes in a bare process) only
   // when a stage of THIS solve is theirs — fp32 with aligned rows up to n = 1024 never touches them
-  const bool needs_lib = !(own_gram && (own_chol || own_chol2));
+  const bool needs_lib = seam ? !own_gram : !(own_gram && (own_chol || own_chol2));
   static RocApi no_api;
   RocApi& api = needs_lib ? roc_api() : no_api;
   if (needs_lib) {
@@ -2068,7 +2117,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     HIP_TRY(hipGetLastError());
     return TOA_OK;
   }
-  if (mode <= 1) {   // the whole solve, or toa_lm_begin: construct the state (no data pass)
+  if (mode <= 1 || seam) {   // the whole solve, or toa_lm_begin: construct the state (no data pass)
     HIP_TRY(hipMemsetAsync(a.ldx, 0, b_vec, st));
     HIP_TRY(hipMemsetAsync(a.dx, 0, b_vec, st));
     HIP_TRY(hipMemsetAsync(a.g, 0, b_vec, st));
@@ -2076,6 +2125,7 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     hipLaunchKernelGGL(large_init_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (mode == 1) return TOA_OK;
+    if (seam) hipLaunchKernelGGL(large_seam_prep_kernel<T>, dim3(unsigned((P + 255) / 256)), dim3(256), 0, st, a, seam_out->want_grad);
   }
   HIP_TRY(hipMemsetAsync(a.summary, 0, b_sum, st));
   if (stepping) HIP_TRY(hipMemsetAsync(a.stepped, 0, b_i, st));
@@ -2153,6 +2203,11 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
       }
       if (rc != 0) return toa_fail(TOA_E_HIP, "rocBLAS gemm/gemv returned status " + std::to_string(rc));
     }
+    if (seam) {
+      hipLaunchKernelGGL(large_seam_out_kernel<T>, dim3(unsigned(Pl)), dim3(256), 0, ls, la, *seam_out);
+      HIP_TRY(hipGetLastError());
+      return TOA_OK;
+    }
     hipLaunchKernelGGL(large_pre_kernel<T>, dim3(unsigned(Pl)), dim3(256), 0, ls, la);
     hipLaunchKernelGGL(large_stage_kernel<T>, dim3(unsigned((n + stage_rows - 1) / stage_rows), unsigned(Pl)), dim3(256), 0, ls, la, stage_rows);
     int rc = 0;
@@ -2184,6 +2239,10 @@ int large_lm_run_t(toa_handle h, int n, int m, int64_t P, const T* data, T* x, c
     return TOA_OK;
   };
 
+  if (seam) {
+    int want_j = seam_out->want_grad ? int(P) : 0;
+    return enqueue_pass(a, st, P, a.summary, want_j);
+  }
   // Under stream capture (hipGraph) the host can look at nothing: where every stage is ours the whole pass budget is recorded —
   // max_passes passes, each kernel of which returns at once for the problems that have finished — and the graph replays the
   // solve with no host in the loop (one lane: a captured fork / join would only add edges).  A typical solve needs a fifth of
@@ -2507,6 +2566,35 @@ int toa_large_lm_step(toa_handle h, int dtype, int n, int m, int64_t P, const vo
                                       counters, mode, state, active_dev, stop_request);
   return toa::large_lm_run_t<double>(h, n, m, P, static_cast<const double*>(data), static_cast<double*>(x), *options, *results,
                                      counters, mode, state, active_dev, stop_request);
+}
+
+// toa_accumulate for the natural layout where the one-launch kernel of large_fused.hip does not reach: n > 128, or an M-estimator
+// (one data pass of the pipeline; batches beyond grid.y = 65 535 problems slice by slice like toa_large_lm_run)
+int toa_large_accumulate_pipeline(toa_handle h, int dtype, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
+                                  void* H, double* cost, int32_t* nres) {
+  toa_options opt;
+  toa_options_default(&opt);
+  toa_results res{};
+  constexpr int64_t kSlice = 65535;
+  const size_t es = dtype == TOA_F32 ? 4 : 8;
+  for (int64_t p0 = 0; p0 < P; p0 += kSlice) {
+    const int64_t Ps = std::min<int64_t>(kSlice, P - p0);
+    const char* d = static_cast<const char*>(data) + size_t(p0) * size_t(m) * (size_t(n) + 1) * es;
+    char* xs = const_cast<char*>(static_cast<const char*>(x)) + size_t(p0) * size_t(n) * es;
+    char* gs = g ? static_cast<char*>(g) + size_t(p0) * size_t(n) * es : nullptr;
+    char* Hs = H ? static_cast<char*>(H) + size_t(p0) * size_t(n) * size_t(n) * es : nullptr;
+    int32_t* nr = nres ? nres + p0 : nullptr;
+    int rc;
+    if (dtype == TOA_F32) {
+      const toa::LargeSeamOut<float> o{reinterpret_cast<float*>(gs), reinterpret_cast<float*>(Hs), cost + p0, nr, want_grad};
+      rc = toa::large_lm_run_t<float>(h, n, m, Ps, reinterpret_cast<const float*>(d), reinterpret_cast<float*>(xs), opt, res, nullptr, 4, nullptr, nullptr, nullptr, &o);
+    } else {
+      const toa::LargeSeamOut<double> o{reinterpret_cast<double*>(gs), reinterpret_cast<double*>(Hs), cost + p0, nr, want_grad};
+      rc = toa::large_lm_run_t<double>(h, n, m, Ps, reinterpret_cast<const double*>(d), reinterpret_cast<double*>(xs), opt, res, nullptr, 4, nullptr, nullptr, nullptr, &o);
+    }
+    if (rc != TOA_OK) return rc;
+  }
+  return TOA_OK;
 }
 
 int toa_large_step_info(toa_handle h, int dtype, int n, int64_t P, const void* state, double* err, double* dx2, double* g2,

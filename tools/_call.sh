@@ -1,6 +1,4 @@
 set -x
-python -m pytest tests/test_gpu_jit.py tests/test_gpu_row_models.py tests/test_gpu_coop.py -x -q 2>&1 | tail -3
-python tools/lf_balance.py 2>&1 | grep -v amdgpu.ids
-python tools/probe.py shape 6 1000 f64 71428 2>&1 | grep -v amdgpu.ids
-python tools/probe.py shape 6 1000 f32 142857 2>&1 | grep -v amdgpu.ids
-python tools/probe.py shape 12 500 f64 76923 2>&1 | grep -v amdgpu.ids
+python -m pytest tests/test_gpu_large_n.py -x -q -k "seam or narrow or loss" 2>&1 | tail -8
+python bench.py --workload large128 --steps 5 --warmup 2 --no-cpu 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r.get('one_problem_per_slot'), r.get('balanced_batch'))"
