@@ -470,7 +470,8 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
  *        num_params up to 63: beyond 12 the model is RowModel (csrc/row_model.hpp, round 6; the path of TOA_MODEL_DENSE_ROW_AD):
  *          an item is evaluated by ONE lane — TOA_JIT_RESIDUAL bodies on Jets, twelve parameters at a time; TOA_JIT_ACCUMULATE
  *          bodies on plain T with the Jacobian rows they fill — and its rows [J | r] are staged through LDS into the operand
- *          layout of the matrix-core Gram.  A Euclidean functor (manifolds stop at 12 tangent dimensions); the handle's
+ *          layout of the matrix-core Gram.  Euclidean parameters or TOA_MANIFOLD_USER (round 6: up to 64 stored scalars; an AD body is then differentiated through
+ *          x (+) d, whose Jets are formed once per pass, a TOA_JIT_ACCUMULATE body fills J over the TANGENT); the handle's
  *          M-estimator (toa_set_loss) applies per item; residuals_per_item up to 8 (an item's residuals are consecutive rows),
  *          scalars_per_item up to 512 (as many as the LDS stage holds with num_params: the build is refused with a message
  *          otherwise); the row-split and the stepping forms take it too.
@@ -480,7 +481,7 @@ int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per
  *          se3_log<S, T>(R, t, xi); the update is pose <- pose * exp(delta).  tests/sophus.cpp:26-44 `Optimize(pose, lambda)`.
  *        manifold = TOA_MANIFOLD_USER (round 5): the caller's own parameter container — the reference's extension point
  *          traits::params_trait<T> (traits.h:103-359; 3rdparty/traits/lieplusplus.h) as text.  x is stored as x_scalars scalars
- *          per problem, num_params (<= 12) is the dimension of its tangent, and plus_body is the body of
+ *          per problem, num_params is the dimension of its tangent, and plus_body is the body of
  *              template <class S> void plus(const T* x, const S* d, S* xp)        xp[0 .. x_scalars) = x (+) d
  *          written once over the scalar type S like the residual.  The update is x <- plus(x, +-delta) on plain T (PlusEq,
  *          traits.h:184-190; the roll-back is plus(x, -last_delta), optimizer.h:283-287), the derivative is taken through
@@ -500,7 +501,7 @@ typedef struct toa_jit_spec {
   int32_t dtype, num_params, residuals_per_item, scalars_per_item, header_scalars;
   int32_t manifold;   /* TOA_MANIFOLD_* */
   int32_t kind;       /* TOA_JIT_* */
-  int32_t x_scalars;  /* TOA_MANIFOLD_USER: scalars of x as STORED ([P][x_scalars]; 1 .. 32); num_params = the tangent's dimension */
+  int32_t x_scalars;  /* TOA_MANIFOLD_USER: scalars of x as STORED ([P][x_scalars]; 1 .. 32, beyond 12 parameters 1 .. 64); num_params = the tangent's dimension */
   const char* plus_body;   /* TOA_MANIFOLD_USER: the body of `template <class S> void plus(const T* x, const S* d, S* xp)`: xp = x (+) d */
   int32_t reserved[6];
 } toa_jit_spec;

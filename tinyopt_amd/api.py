@@ -482,7 +482,8 @@ class JitResidual:
         """Round 5 — ``manifold="user"``: the caller's own parameter container (the reference's traits::params_trait<T>, traits.h:103-359).
         x is stored as ``x_scalars`` scalars per problem ([P, x_scalars]), ``n`` is the dimension of its tangent and ``plus_body``
         is the body of ``template <class S> void plus(const T* x, const S* d, S* xp)``: xp = x (+) d, written over the scalar type
-        like the residual — the update and the roll-back run it on plain T, the differentiation on Jets seeded on d at d = 0."""
+        like the residual — the update and the roll-back run it on plain T, the differentiation on Jets seeded on d at d = 0.
+        Round 6: at every n (beyond 12 parameters: up to 64 stored scalars; ``kind="accumulate"`` bodies fill J over the tangent)."""
         from ._capi import ToaJitSpec
         self.ctx = ctx or default_context()
         self.n, self.kR, self.kD, self.kH, self.dtype = int(n), int(residuals_per_item), int(item_scalars), int(header_scalars), dtype

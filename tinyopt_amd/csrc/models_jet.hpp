@@ -63,6 +63,20 @@ template <typename T, typename F>
 struct UserManifoldOf {
   static constexpr int kXdim = FunctorX<F>::value;
   static __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) {
+    if constexpr (kXdim > 32 || F::kN > 12) {
+      // wide containers (row models, round 6): x, +-delta and x (+) delta as REGISTER arrays of one lane would be ~190 registers —
+      // the factorisation workspace is dead by now (the step has been solved for; n >= 13: n (n | 1) >= 169 scalars), so delta
+      // goes to M[0 .. kN), x (+) delta to M[64 ..), and the user's text indexes LDS
+      T* dd = L.M;
+      T* xn = L.M + 64;
+      if (lane < F::kN) dd[lane] = sign * dv[lane];
+      wave_sync();
+      if (lane == 0) F::template plus<T>(static_cast<const T*>(L.xs), static_cast<const T*>(dd), xn);
+      wave_sync();
+      if (lane < kXdim) L.xs[lane] = xn[lane];
+      wave_sync();
+      return;
+    }
     T xo[kXdim], dd[F::kN], xn[kXdim];
 #pragma unroll
     for (int i = 0; i < kXdim; ++i) xo[i] = L.xs[i];

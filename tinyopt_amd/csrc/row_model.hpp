@@ -48,6 +48,7 @@ struct RowStageGeom {
   int ps;      // item stride in the raw image, elements (>= kD)
   int rsp;     // row stride of the [J | r] image, elements (>= the packed row)
   int bytes;   // the wave's LDS stage
+  int table_off;   // where the model's own `extra` bytes begin, behind the regions (AdRowFunctor on a manifold: the Jets of x (+) d)
   // Both images are read and written a ROW (an item) PER LANE: a stride of 16 bytes x an odd number makes every 16-byte access of
   // sixteen consecutive lanes hit sixteen different bank quads (ds_read_b128 / ds_write_b128 without conflicts) and keeps every
   // row 16-byte aligned.
@@ -74,7 +75,7 @@ struct RowStageGeom {
 #define TOA_ROW_WAVES 2
 #endif
   static __host__ __device__ constexpr RowStageGeom make(int sz, int n, int kR, int kD, bool compute_bound, int nbuf = TOA_ROW_NBUF,
-                                                        int waves = TOA_ROW_WAVES) {
+                                                        int waves = TOA_ROW_WAVES, int extra = 0) {
     const int rem = n & 15;
     const bool thin = n >= 16 && rem + 1 <= 4;
     const int nbm = thin ? (n >> 4) : (n + 16) / 16;
@@ -83,7 +84,7 @@ struct RowStageGeom {
     g.rsp = stride16(rs, sz);
     g.ps = kD > 0 ? stride16(kD, sz) : 0;
     const int itmax = 64 / kR;           // rows of a super-step <= 64
-    const int bud = budget(sz, waves);
+    const int bud = budget(sz, waves) - extra;
     g.nbuf = nbuf;
     int it = itmax;                      // the largest multiple of 4 (one Gram step = four rows) whose ring fits; else 2, 1
     if (it >= 4) it &= ~3;
@@ -99,6 +100,8 @@ struct RowStageGeom {
       if (region(it, g.ps, g.rsp, kR, sz) > g.bytes) g.bytes = region(it, g.ps, g.rsp, kR, sz);
     }
     g.bytes = (g.bytes + 15) & ~15;
+    g.table_off = g.bytes;
+    g.bytes += (extra + 15) & ~15;
     return g;
   }
 };
@@ -129,9 +132,29 @@ struct ChunkSeededX {
     return r;
   }
 };
-template <typename T, typename F>
+// Seeds of the tangent for one chunk, d = 0: d[a] as a Jet (optimize_autodiff.h:48-77) — c0 is a run-time value here (the chunk is
+// the LANE that builds the table below; once per pass)
+template <typename T, int CW>
+struct ChunkSeededD {
+  int c0;
+  __device__ __forceinline__ Jet<T, CW> operator[](int a) const {
+    Jet<T, CW> r;
+    r.a = T(0);
+#pragma unroll
+    for (int s = 0; s < CW; ++s) r.v[s] = (a == c0 + s) ? T(1) : T(0);
+    return r;
+  }
+};
+// MANIFOLD == 2 (TOA_MANIFOLD_USER; round 6): the parameters live in the user's container of F::kX stored scalars and the
+// derivative is taken through x (+) d at d = 0.  x (+) d does not depend on the item, so its Jets — per chunk, kX of them — are
+// formed ONCE per accumulate pass (lane c builds chunk c, straight into LDS) and every lane's functor reads them from that table
+// (the same address in every lane: a broadcast read).  Cost-only passes evaluate F on the stored scalars themselves.
+template <typename T, typename F, int MANIFOLD = 0>
 struct AdRowFunctor {
   static constexpr int kN = F::kN, kR = F::kR, kD = F::kD, kH = F::kH;
+  static constexpr int kX = MANIFOLD == 2 ? FunctorX<F>::value : F::kN;   // stored scalars of x
+  template <class S, class XA_, class DA_, class XP_>
+  static __device__ __forceinline__ void plus(const XA_& x, const DA_& d, XP_&& xp) { F::template plus<S>(x, d, xp); }
   static constexpr bool kManual = true;
   static constexpr bool kComputeBound = true;                  // (RowModel: one LDS region, every lane an item — the Jets are the bound)
   static constexpr bool kIndexedOperands = true;               // x[j] / p[j] with a RUNNING j: straight from LDS (a register array indexed
@@ -141,6 +164,36 @@ struct AdRowFunctor {
 #endif
   static constexpr int kChunks = (kN + TOA_AD_CW - 1) / TOA_AD_CW;   // Jets of <= 12 partials, as balanced as kN allows
   static constexpr int kCW = (kN + kChunks - 1) / kChunks;
+  static constexpr bool kTable = MANIFOLD == 2;
+  static constexpr int kTableBytes = kTable ? ((kChunks * kX * (kCW + 1) * int(sizeof(T)) + 15) & ~15) : 0;
+  using TabJet = Jet<T, kCW>;
+  static __device__ __forceinline__ void build_table(const T* xs, TabJet* tab, const int lane) {
+    if (lane < kChunks) {
+      const ChunkSeededD<T, kCW> D{lane * kCW};
+      F::template plus<TabJet>(xs, D, tab + lane * kX);
+    }
+    wave_sync();
+  }
+  template <bool want_grad>
+  static __device__ __forceinline__ void eval_manual_tab(const T* x, const TabJet* tab, const T* h, const T* p, T* r, T (*J)[kN]) {
+    if constexpr (!want_grad) {
+      F::template eval<T>(x, h, p, r);
+    } else {
+      static_for<kChunks>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c0 = decltype(cc)::value * kCW;
+        const TabJet* X = tab + decltype(cc)::value * kX;
+        TabJet rr[kR];
+        F::template eval<TabJet>(X, h, p, rr);
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+          if constexpr (c0 == 0) r[q] = rr[q].a;
+#pragma unroll
+          for (int s = 0; s < kCW; ++s)
+            if (c0 + s < kN) J[q][c0 + s] = rr[q].v[s];
+        }
+      });
+    }
+  }
   template <bool want_grad>
   static __device__ __forceinline__ void eval_manual(const T* x, const T* h, const T* p, T* r, T (*J)[kN]) {
     if constexpr (!want_grad) {
@@ -163,10 +216,20 @@ struct AdRowFunctor {
   }
 };
 
-template <typename T, int NBM, int THIN, typename F>
+template <typename F, typename = void>
+struct FunctorTable { static constexpr int bytes = 0; };
+template <typename F>
+struct FunctorTable<F, std::enable_if_t<F::kTable>> { static constexpr int bytes = F::kTableBytes; };
+
+// MANIFOLD: 0 = Euclidean, 2 = the user's container (TOA_MANIFOLD_USER: F::kX stored scalars, F::plus; round 6).  A functor with
+// its own Jacobian fills J over the TANGENT (kN columns) from the stored scalars; an AD functor goes through AdRowFunctor's table.
+template <typename T, int NBM, int THIN, typename F, int MANIFOLD = 0>
 struct RowModel {
   using Scalar = T;
-  static constexpr int kXdim = 0;
+  static_assert(MANIFOLD == 0 || MANIFOLD == 2, "row models: Euclidean parameters or a user manifold");
+  static constexpr int kXdim = MANIFOLD == 2 ? FunctorX<F>::value : 0;
+  static_assert(kXdim <= 64, "stored scalars of x: one per lane");
+  static constexpr int kTableBytes = FunctorTable<F>::bytes;
   static constexpr int kN = F::kN, kR = F::kR, kD = F::kD;
   static constexpr int kNmax = THIN > 0 ? 16 * NBM + THIN - 1 : 16 * NBM - 1;
   static constexpr int kNpad = (kNmax + 7) & ~7;
@@ -177,16 +240,20 @@ struct RowModel {
   static constexpr int kNmr = THIN ? 16 * NBM : kN;
   static constexpr int kRsm = THIN ? 16 * NBM : NBM * ((kN + NBM) / NBM);
   static constexpr int kRs = kRsm + THIN;
-  static constexpr RowStageGeom kGeom = RowStageGeom::make(int(sizeof(T)), kN, kR, kD, FunctorComputeBound<F>::value || TOA_ROW_SINGLE);
+  static constexpr RowStageGeom kGeom = RowStageGeom::make(int(sizeof(T)), kN, kR, kD, FunctorComputeBound<F>::value || TOA_ROW_SINGLE, TOA_ROW_NBUF, TOA_ROW_WAVES, kTableBytes);
+  static_assert(kGeom.items2 >= 1 && (kTableBytes == 0 || kGeom.items1 >= 4), "the Jets of x (+) d leave no room for the items in the wave's LDS stage");
   static constexpr int PS = kGeom.ps, RSP = kGeom.rsp;
   static constexpr size_t kStageBytes = size_t(kGeom.bytes);
   static_assert(RSP >= kRs, "geometry");
   // x and the item as REGISTER arrays when they are small (the functor's loops over them unroll: no LDS traffic in its
   // arithmetic); straight from LDS otherwise, and for functors that index them with a running index
-  static constexpr bool kXRegs = TOA_ROW_XREGS && !FunctorIndexed<F>::value && kN * int(sizeof(T)) <= 256;
+  static constexpr bool kXRegs = TOA_ROW_XREGS && MANIFOLD == 0 && !FunctorIndexed<F>::value && kN * int(sizeof(T)) <= 256;
   static constexpr bool kPRegs = !FunctorIndexed<F>::value && kD * int(sizeof(T)) <= 256;
 
-  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int, int lane) const { euclid_plus_eq(L, dv, sign, lane); }
+  __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
+    if constexpr (MANIFOLD == 2) UserManifoldOf<T, F>::plus_eq(L, dv, sign, n, lane);
+    else euclid_plus_eq(L, dv, sign, lane);
+  }
   DenseRowGram<T, NBM, THIN> gram;
   const T* data;
   const T* d;            // the bound problem: [kH header scalars | items x kD]
@@ -331,6 +398,7 @@ struct RowModel {
       for (int j = 0; j < kN; ++j) xl[j] = xs[j];
     }
     const T* const xp = kXRegs ? xl : xs;
+    if constexpr (kTableBytes > 0 && WANT_H) F::build_table(xs, reinterpret_cast<typename F::TabJet*>(stg + kGeom.table_off), lane);
     if constexpr (NBUF >= 2) {   // prologue: the first NBUF - 1 super-steps start towards their regions
       static_for<NBUF - 1>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
@@ -384,8 +452,13 @@ struct RowModel {
           }
         }
 #else
-        if constexpr (WANT_H) F::template eval_manual<true>(xp, d, p, rv, Jv);
-        else F::template eval_manual<false>(xp, d, p, rv, static_cast<T(*)[kN]>(nullptr));
+        if constexpr (kTableBytes > 0) {
+          if constexpr (WANT_H) F::template eval_manual_tab<true>(xp, reinterpret_cast<const typename F::TabJet*>(stg + kGeom.table_off), d, p, rv, Jv);
+          else F::template eval_manual_tab<false>(xp, nullptr, d, p, rv, static_cast<T(*)[kN]>(nullptr));
+        } else {
+          if constexpr (WANT_H) F::template eval_manual<true>(xp, d, p, rv, Jv);
+          else F::template eval_manual<false>(xp, d, p, rv, static_cast<T(*)[kN]>(nullptr));
+        }
 #endif
 #pragma unroll
         for (int q = 0; q < kR; ++q) n2 += rv[q] * rv[q];
