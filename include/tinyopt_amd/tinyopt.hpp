@@ -325,7 +325,8 @@ class JitResidual {
   //   it through x[0..11] and may call se3_log<S, T>(R, t, xi)  (tests/sophus.cpp:26-44 `Optimize(pose, lambda)`);
   // kind: TOA_JIT_RESIDUAL (differentiated on the device), or TOA_JIT_ACCUMULATE — a manual Accumulate callback: the body fills
   //   r[q] and, inside `if (want_grad)`, its own Jacobian rows J[q][a]  (docs/API.md:37-57);
-  // n up to 63 (beyond 12: Euclidean residual functors, up to 8 residuals per item).  Compiled code objects are cached on disk (toa_jit_set_cache_dir).
+  // n up to 63, up to 8 residuals per item (beyond 12 parameters a row is a lane on the matrix-core Gram: both kinds, M-estimators, user manifolds —
+  //   round 6).  Compiled code objects are cached on disk (toa_jit_set_cache_dir).
   // manifold = TOA_MANIFOLD_USER (round 5): the caller's own parameter container — tinyopt's traits::params_trait<T> (traits.h:103-359) as text:
   //   x_scalars = the container as stored, n = the dimension of its tangent, plus_body = the body of
   //   `template <class S> void plus(const T* x, const S* d, S* xp)`, xp = x (+) d (PlusEq on plain T; differentiated through Jets seeded on d).
