@@ -459,7 +459,8 @@ int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, i
  *      scalars as T,  r[q]  the item's residuals; every function of ceres::Jet (jet.h:557-1400: sin, exp, pow, atan2, ...)
  *      is in scope.  toa_model_compile builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> with hiprtc
  *      (opened with dlopen on first use; ~2-3 s, once) and loads the code object: no rebuild of the library.
- *        num_params <= 12: the register Gram of JetModel (13 .. 63: see toa_model_compile_ex below); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
+ *        num_params <= 63 (1 .. 3 and TOA_MANIFOLD_SE3: JetModel, an item per lane and the Gram in registers; from 4 parameters on: RowModel,
+ *        see toa_model_compile_ex below — the border is a measured one, profiles/r06_ab_log.md section 7); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
  *        m = num_items * residuals_per_item residuals per problem.  log_out (optional): the compiler's diagnostics.
  *        toa_jit_lm_run / toa_jit_accumulate: the contracts of toa_lm_run / toa_accumulate.  The handle's M-estimator
  *        (toa_set_loss) applies to each item's squared residual norm, as for TOA_MODEL_CIRCLE_FIT. */
@@ -467,7 +468,9 @@ typedef struct toa_jit_model_s* toa_jit_model;
 int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per_item, int scalars_per_item, int header_scalars,
                       const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
 /*      Round 4 — the general form.
- *        num_params up to 63: beyond 12 the model is RowModel (csrc/row_model.hpp, round 6; the path of TOA_MODEL_DENSE_ROW_AD):
+ *        num_params up to 63: from 4 parameters on (TOA_MANIFOLD_SE3 excepted) the model is RowModel (csrc/row_model.hpp, round 6; the path of
+ *          TOA_MODEL_DENSE_ROW_AD; the row-split / stepping kernels of a model with up to 12 parameters stay on JetModel, whose one-launch
+ *          persistent form serves few, huge problems):
  *          an item is evaluated by ONE lane — TOA_JIT_RESIDUAL bodies on Jets, twelve parameters at a time; TOA_JIT_ACCUMULATE
  *          bodies on plain T with the Jacobian rows they fill — and its rows [J | r] are staged through LDS into the operand
  *          layout of the matrix-core Gram.  Euclidean parameters or TOA_MANIFOLD_USER (round 6: up to 64 stored scalars; an AD body is then differentiated through

@@ -23,6 +23,15 @@ def timeit(fn, reps=5):
     return min(ts)
 
 
+def narrow_bodies(n):
+    """n <= 12 (JetModel: x and the Jets are REGISTER arrays of the lane): loops over x[j] have to unroll completely — a running
+    index into a register array is scratch memory (144 / 272 B per lane and 1.5-3 x the time with the row models' bodies)."""
+    man = (f"T t = x[0] * p[0];\n#pragma unroll\nfor (int j = 1; j < {n}; ++j) t += x[j] * p[j];\nT sn, cs; sincos_t(t, &sn, &cs);\n"
+           f"r[0] = t + T(0.1) * sn - p[{n}];\nif (want_grad) {{\n  const T sc = T(1) + T(0.1) * cs;\n#pragma unroll\n  for (int j = 0; j < {n}; ++j) J[0][j] = sc * p[j];\n}}")
+    ad = f"S t = x[0] * p[0];\n#pragma unroll\nfor (int j = 1; j < {n}; ++j) t = t + x[j] * p[j];\nr[0] = t + T(0.1) * sin(t) - p[{n}];"
+    return man, ad
+
+
 def main():
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -35,9 +44,10 @@ def main():
     b = t + 0.1 * torch.sin(t)
     x0 = xs + 0.3 * (torch.rand(P, n, dtype=dt, device="cuda", generator=gen) * 2 - 1)
     items = torch.cat([A, b[..., None]], dim=2).contiguous()
+    mb, ab = narrow_bodies(n) if n <= 12 else (manual_body(n), ad_body(n))
     models = [("compiled-in", ta.DenseRow.from_arrays(A, b)),
-              ("text+J", ta.JitResidual(manual_body(n), n=n, item_scalars=n + 1, dtype=dt, kind="accumulate").bind(items)),
-              ("text AD", ta.JitResidual(ad_body(n), n=n, item_scalars=n + 1, dtype=dt).bind(items))]
+              ("text+J", ta.JitResidual(mb, n=n, item_scalars=n + 1, dtype=dt, kind="accumulate").bind(items)),
+              ("text AD", ta.JitResidual(ab, n=n, item_scalars=n + 1, dtype=dt).bind(items))]
     if n in (12, 50):
         models.append(("built-in AD", ta.DenseRowAD(A, b)))
     only = os.environ.get("ROWBENCH_ONLY")
