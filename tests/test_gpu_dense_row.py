@@ -410,3 +410,37 @@ def test_fp32_pass_at_large_arguments(ta, oracle, scale, n, m):
     err_dev = np.abs(xg.cpu().numpy().astype(np.float64) - xs).max()
     err_orc = np.abs(ref["x"].astype(np.float64) - xs).max()
     assert err_dev <= 4 * err_orc + 1e-6 * scale, (scale, n, err_dev, err_orc)
+
+
+@pytest.mark.parametrize("n", [4, 5, 6, 7, 8, 9, 10, 11])
+def test_narrow_fp32_blocks_take_the_row_per_lane_route(ta, oracle, n):
+    """Round 6: TOA_MODEL_DENSE_ROW in fp32 with 4 <= n <= 11 runs a row per lane through the LDS stage (RowModel over the packed
+    rows) instead of sixteen lanes per row.  Whole trajectories against the oracle on ragged row counts (the packed layout pads rows
+    to a multiple of four: the route must not count them), the seam against the oracle, and both against the old route
+    (toa_tuning::narrow_mfma_pass) — same iterations, same end points to fp32 round-off."""
+    P = 70
+    for m in (4 * n + 2, 333, 1000):
+        A, b, x0, xs = oracle.synth_dense_row(P, n, m, np.float32, seed=300 + n + m)
+        opts = ta.Options.benchmark()
+        ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True)
+        model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        x = torch.from_numpy(x0.copy()).cuda()
+        out = ta.Optimize(x, model, opts, history=True)
+        torch.cuda.synchronize()
+        st = check_trajectories(gpu_dict(out, x), ref, np.float32, opts.to_pod(), label=f"narrow route n = {n}, m = {m}")
+        assert st["full"] + st["ties"] == P, st
+        assert int(out.counters[0]) + int(out.counters[4]) > 0
+        g_ref, H_ref, c_ref, _ = oracle.dense_row_accumulate(A, b, x0)
+        g, H, c, nres = ta.accumulate(model, torch.from_numpy(x0).cuda())
+        assert np.abs(g.cpu().numpy() - g_ref).max() <= 3e-5 * np.abs(g_ref).max()
+        assert np.abs(H.cpu().numpy() - H_ref).max() <= 3e-5 * np.abs(H_ref).max()
+        assert np.allclose(c.cpu().numpy(), c_ref, rtol=3e-5) and (nres.cpu().numpy() == m).all()
+        with ta.api.default_context().tuning(narrow_mfma_pass=1):
+            x2 = torch.from_numpy(x0.copy()).cuda()
+            out2 = ta.Optimize(x2, model, opts, history=True)
+            g2, H2, c2, _ = ta.accumulate(model, torch.from_numpy(x0).cuda())
+            torch.cuda.synchronize()
+        st2 = check_trajectories(gpu_dict(out2, x2), ref, np.float32, opts.to_pod(), label=f"sixteen lanes per row n = {n}, m = {m}")
+        assert st2["full"] + st2["ties"] == P, st2
+        assert float((x - x2).abs().max()) < 2e-3
+        assert np.abs((H - H2).cpu().numpy()).max() <= 3e-5 * np.abs(H_ref).max()

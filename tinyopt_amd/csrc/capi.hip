@@ -201,6 +201,8 @@ int toa_inst_wide_1_2(int thin, toa_handle h, const toa::FusedParams& prm, int s
 int toa_inst_wide_1_3(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 
+int toa_inst_narrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_narrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_jetrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_jetrow_fused_1_0(int n, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_jetrow_wide_0_0(int n, toa_handle h, const toa::FusedParams& prm);
@@ -688,6 +690,8 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
   if (model != TOA_MODEL_DENSE_ROW)
     return toa_inst_misc_accumulate(dtag, model, 16 * ((n + 15) / 16), h, n, m, P, data, x, want_grad, g, H, cost, nres);
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
+  if (dtag == 0 && n >= 4 && n <= 11 && h->loss == TOA_LOSS_L2 && !h->tune.narrow_mfma_pass)
+    return toa_inst_narrow_accumulate_0_0(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_inst_accumulate(dtag, lay_.nbm, lay_.thin, h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 
@@ -832,6 +836,8 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   }
   if (model == TOA_MODEL_DENSE_ROW_AD) return dtag == 0 ? toa_inst_jetrow_fused_0_0(n, h, prm) : toa_inst_jetrow_fused_1_0(n, h, prm);
   if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtag, model, 16 * ((n + 15) / 16), h, prm);
+  // narrow fp32 blocks: a row per lane (RowModel) instead of sixteen lanes per row (toa_tuning::narrow_mfma_pass: the old route)
+  if (dtag == 0 && n >= 4 && n <= 11 && !h->tune.narrow_mfma_pass) return toa_inst_narrow_fused_0_0(n, h, prm);
   return toa_inst_fused(dtag, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");
 }

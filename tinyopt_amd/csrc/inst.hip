@@ -101,6 +101,28 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
   if (n == 50) return launch_accumulate<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
+#if TOA_INST_DT == 0
+// TOA_MODEL_DENSE_ROW, fp32, 4 <= n <= 11 (round 6): a row per lane through the LDS stage (RowModel over DenseRowPackedFunctor) instead
+// of sixteen lanes per row — 5-30 % faster whole solves, the cost-only pass twice as fast (profiles/r06_ab_log.md section 7).
+#define TOA_NARROW_CASES(CALL) \
+  switch (n) {                 \
+    case 4: CALL(4); case 5: CALL(5); case 6: CALL(6); case 7: CALL(7); case 8: CALL(8); case 9: CALL(9); case 10: CALL(10); case 11: CALL(11); \
+    default: break;            \
+  }
+int toa_inst_narrow_fused_0_0(int n, toa_handle h, const FusedParams& prm) {
+#define TOA_NF(N) return launch_fused<RowModel<InstT, 1, 0, DenseRowPackedFunctor<InstT, N>>>(h, prm)
+  TOA_NARROW_CASES(TOA_NF)
+#undef TOA_NF
+  return toa_fail(TOA_E_ARG, "narrow DenseRow route: 4 <= n <= 11");
+}
+int toa_inst_narrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H,
+                                   double* cost, int32_t* nres) {
+#define TOA_NA(N) return launch_accumulate<RowModel<InstT, 1, 0, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
+  TOA_NARROW_CASES(TOA_NA)
+#undef TOA_NA
+  return toa_fail(TOA_E_ARG, "narrow DenseRow route: 4 <= n <= 11");
+}
+#endif
 #elif defined(TOA_INST_SOLVE)
 int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g,
                                              double scale, void* dx, int32_t* ok) {

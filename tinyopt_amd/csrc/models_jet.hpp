@@ -269,6 +269,34 @@ struct DenseRowAdFunctor {
   }
 };
 
+// The DenseRow residual WITH its Jacobian row, an item = one packed row [a_i | b_i] of the n <= 15 layouts (DenseRowLayout: no block
+// padding there, row stride n + 1): what RowModel runs for narrow fp32 blocks of TOA_MODEL_DENSE_ROW (round 6 — a row per lane
+// instead of sixteen lanes per row, whose pass costs ~26 vector instructions per four rows whatever their length).
+template <typename T, int NN>
+struct DenseRowPackedFunctor {
+  static constexpr int kN = NN, kR = 1, kD = NN + 1, kH = 0;
+  static constexpr bool kManual = true;
+  static constexpr bool kPackedRows = true;   // the problem stride is the packed layout's (rows padded to a multiple of four)
+  template <bool want_grad>
+  static __device__ __forceinline__ void eval_manual(const T* x, const T*, const T* p, T* r, T (*J)[kN]) {
+    T t = x[0] * p[0];
+#pragma unroll
+    for (int j = 1; j < NN; ++j) t = fma(x[j], p[j], t);
+    T sn, cs;
+    sincos_t(t, &sn, &cs);
+    r[0] = (t + T(0.1) * sn) - p[NN];
+    if constexpr (want_grad) {
+      const T sc = T(1) + T(0.1) * cs;
+#pragma unroll
+      for (int j = 0; j < NN; ++j) J[0][j] = sc * p[j];
+    }
+  }
+};
+template <typename F, typename = void>
+struct FunctorPackedRows { static constexpr bool value = false; };
+template <typename F>
+struct FunctorPackedRows<F, std::enable_if_t<F::kPackedRows>> { static constexpr bool value = true; };
+
 template <typename F, typename = void>
 struct FunctorComputeBound { static constexpr bool value = false; };
 template <typename F>

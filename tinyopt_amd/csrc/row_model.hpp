@@ -273,7 +273,11 @@ struct RowModel {
     stage = nullptr;
   }
   __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
-  __device__ __forceinline__ void bind(long long p) { d = data + size_t(p) * (F::kH + size_t(m / kR) * kD); it0 = 0; it1 = m / kR; }
+  __device__ __forceinline__ void bind(long long p) {
+    const size_t stride = FunctorPackedRows<F>::value ? lay.elems_per_problem() : F::kH + size_t(m / kR) * kD;
+    d = data + size_t(p) * stride;
+    it0 = 0; it1 = m / kR;
+  }
   // row-split execution: rows [r0, r0 + rows) of problem p — r0 on an item boundary (a multiple of lcm(16, kR): jit.hip)
   __device__ __forceinline__ void bind_chunk(long long p, int r0, int rows, int) {
     bind(p);
