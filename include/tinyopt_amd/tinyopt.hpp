@@ -356,6 +356,14 @@ class JitResidual {
   int item_scalars() const { return kD_; }
   int header_scalars() const { return kH_; }
   int xdim() const { return xdim_; }   // stored scalars of x per problem (12 for an SE3 pose)
+  // What the run-time build came out as (toa_jit_model_stats): resident workgroups per compute unit, LDS per workgroup, vector
+  // registers per lane, scratch bytes per lane — a body heavy enough to spill or to drop to one workgroup shows up here.
+  struct BuildStats { int wg_per_cu = 0, lds_bytes_per_wg = 0, num_regs = 0, scratch_bytes = 0; };
+  BuildStats stats() const {
+    BuildStats s;
+    check(toa_jit_model_stats(h_, &s.wg_per_cu, &s.lds_bytes_per_wg, &s.num_regs, &s.scratch_bytes));
+    return s;
+  }
 
  private:
   const Context* ctx_;

@@ -193,6 +193,8 @@ static void circle_jit() {
   CircleFit<double> builtin(ctx, 1, n, obs.data());
   const auto outb = Optimize(xb, builtin, options);
   REQUIRE(out.num_iters[0] == outb.num_iters[0] && x[0] == xb[0] && x[1] == xb[1] && x[2] == xb[2]);
+  const auto built = fit.stats();   // what the run-time build came out as (toa_jit_model_stats)
+  REQUIRE(built.wg_per_cu >= 1 && built.num_regs > 0 && built.lds_bytes_per_wg > 0 && built.scratch_bytes >= 0);
   // Options::stop_callback on a residual that arrived as text (the stepping form of the run-time model): stop after 3 iterations
   std::vector<double> xc{0, 0, 1};
   Options oc = options;

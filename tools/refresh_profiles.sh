@@ -25,6 +25,8 @@ python bench.py --workload c4 --no-cpu --tuning coop_off=1 > $O/bench_c4_coop0.j
 python bench.py --workload c4 --no-cpu --tuning memo_off=1,coop_off=1 > $O/bench_c4_memo0_coop0.json 2> $O/bench_c4_memo0_coop0.err
 python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
+python tools/throughput_map.py > $O/throughput_map.txt 2>&1
+python tools/lf_balance.py > $O/lf_balance.txt 2>&1
 python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1
 (python tools/probe.py c4; python tools/probe.py c3) > $O/probe_phases.txt 2>&1
 bash tools/coop_sweep.sh > $O/coop_sweep.txt 2>/dev/null
