@@ -69,7 +69,7 @@ def eigen_probe():
     return f"present at {os.path.dirname(os.path.dirname(hits[0]))} but unused: the reference's sources do not travel with the repo; baseline is the restatement"
 
 
-def cpu_baseline(n, m, np_dtype, pod, budget_problems):
+def cpu_baseline(n, m, np_dtype, pod, budget_problems, loss=None, th=0.0):
     """Oracle (CPU restatement of the reference algorithm) timed on this host, single thread, on a
     bounded sample of the same workload.  kind = "port" (the real reference needs Eigen; not buildable)."""
     from oracle import pyoracle
@@ -82,10 +82,10 @@ def cpu_baseline(n, m, np_dtype, pod, budget_problems):
         lib = pyoracle.load()
         build = "g++ -O3 -march=x86-64-v3"
     A, b, x0, _ = pyoracle.synth_dense_row(budget_problems, n, m, np_dtype)
-    r1 = pyoracle.dense_row_lm(A, b, x0, pod, nthreads=1, lib=lib)
+    r1 = pyoracle.dense_row_lm(A, b, x0, pod, nthreads=1, lib=lib, loss=loss, th2=th * th)
     it1 = int(r1["iters"].sum())
     ncores = os.cpu_count() or 1
-    rall = pyoracle.dense_row_lm(A, b, x0, pod, nthreads=ncores, lib=lib)
+    rall = pyoracle.dense_row_lm(A, b, x0, pod, nthreads=ncores, lib=lib) if loss is None else r1   # (the oracle's loss hook is single-threaded)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -523,6 +523,8 @@ def main():
     ap.add_argument("--problems", type=int, default=0, help="override problems per GPU (debug; invalidates the metric)")
     ap.add_argument("--cpu-problems", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
+    ap.add_argument("--loss", default="", help="an M-estimator on every residual of a packed DenseRow workload (c4, c3), e.g. huber:0.5 — "
+                                               "losses::Huber(n2, th2, true) inside the cost functor (robust_norms.h:20-26); recorded in the line")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1 plumbing check WITHOUT a GPU: gloo + CPU tensors and a stand-in for the solve go through the very same barriers, "
                          "reductions, result gather, watchdog and JSON assembly as a real run (tests/test_cpu_dist.py runs it at N = 2 and 8, "
@@ -604,6 +606,8 @@ def main():
         jit_build = jit.stats()
     elif not large:
         model, x0, xstar = ta.DenseRow.synthetic(P, n, m, tdt, problem0=rank * P)
+        if args.loss:
+            model = model.with_loss(args.loss.split(":")[0], float(args.loss.split(":")[1]))
     else:  # natural layout (A then b), generated on the device with the same distributions
         gen = torch.Generator(device="cuda").manual_seed(0x7194 + rank)
         A = torch.rand(P, m, n, dtype=tdt, device="cuda", generator=gen) * 2 - 1
@@ -861,6 +865,10 @@ def main():
                                         "frac": mfma_tflops / mfma_peak, "issued_flop_per_accumulate_pass": mfma_flop_per_pass,
                                         "accumulate_passes_per_launch": acc_passes_total / args.steps}},
     }
+    if args.loss:
+        result["metric"] = "LM iterations/s (batched dense n<=50, an M-estimator on every residual)"
+        result["config"]["loss"] = args.loss
+        result["config"]["tuning"] = args.tuning
     if args.workload in ("c4_text", "c4_ad"):
         result["metric"] = "LM iterations/s (batched dense n<=50, residual supplied as text at run time)"
         result["roofline"]["kernel"] = "lm_fused_kernel<RowModel<float, 3, 3, ...>> (hiprtc build of the user's functor)"
@@ -925,7 +933,7 @@ def main():
         np_dtype = np.float32 if tdt == torch.float32 else np.float64
         est = 4e-4 * (n * n * m) / (50 * 50 * 2000) * 8  # rough seconds per problem (8 iterations)
         sample = args.cpu_problems or int(max(16, min(P, 15.0 / max(est, 1e-6))))
-        base, r1 = cpu_baseline(n, m, np_dtype, pod, sample)
+        base, r1 = cpu_baseline(n, m, np_dtype, pod, sample, *((args.loss.split(":")[0], float(args.loss.split(":")[1])) if args.loss else ()))
         base["iters_per_problem"] = float(r1["iters"].mean())   # next to config.iters_per_problem of the device
         result["cpu_baseline"] = base
         result["config"]["speedup_vs_cpu_1thread"] = result["value"] / base["value"]

@@ -193,8 +193,10 @@ typedef struct toa_tuning {
   int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
   int32_t large_gram_plain_deal; /* 224 < n <= 256, own Gram: the tiles dealt round-robin to the waves instead of the operand-sharing deal (triangles of
                                     blocks; A/B and the bit-identity test: which wave computes a tile does not change its bits) */
-  int32_t narrow_mfma_pass;      /* TOA_MODEL_DENSE_ROW, fp32, 4 <= n <= 11: 1 = the sixteen-lanes-per-row pass of rounds 1-5 instead of the row-per-lane
-                                    route through the LDS stage (round 6, profiles/r06_ab_log.md section 7; A/B) */
+  int32_t narrow_mfma_pass;      /* TOA_MODEL_DENSE_ROW: 1 = the routes of rounds 1-5 — sixteen lanes per row for fp32 at 4 <= n <= 11, the
+                                    launch-per-iteration form for batches with an M-estimator — instead of the row-per-lane route through the LDS stage
+                                    (round 6: fp32 4 <= n <= 11 always; with toa_set_loss also n = 12, 50 and fp64 n = 6, 12, 50;
+                                    profiles/r06_ab_log.md sections 7-8; A/B) */
   int32_t reserved[14];          /* (three of them were the team form of the fused kernel, round 5: removed in round 6, profiles/r06_pruned_arms.patch) */
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);

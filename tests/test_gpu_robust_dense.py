@@ -169,3 +169,36 @@ def test_sticky_handle_loss_is_refused_not_ignored(ta):
     # the Python mirror sets the handle's loss from the model before every launch, so the same model solves fine through it
     out2 = ta.Optimize(x, prior, opts)
     assert bool((out2.stop_reason >= 0).all())
+
+
+@pytest.mark.parametrize("kind", ["huber", "cauchy"])
+@pytest.mark.parametrize("dtype,n,m", [(np.float32, 50, 402), (np.float64, 50, 130), (np.float64, 12, 203), (np.float32, 12, 100), (np.float64, 6, 150),
+                                       (np.float32, 8, 120), (np.float32, 5, 63)])
+def test_a_batch_with_a_loss_runs_inside_the_fused_kernel(ta, oracle, kind, dtype, n, m):
+    """Round 6: a BATCH of DenseRow problems with an M-estimator on the handle runs the loss inside the fused kernel wherever a
+    row-per-lane instance exists (fp32 4 <= n <= 11, n = 12, 50; fp64 n = 6, 12, 50) instead of the launch-per-iteration form.  Whole
+    trajectories, StopReasons, iterations and the inlier ratio against the oracle; the old route (toa_tuning::narrow_mfma_pass) lands on
+    the same points."""
+    P = 300      # (a batch: P * 4 > #CUs — few, huge problems keep the row-split form)
+    A, b, x0, xs, mask = _with_outliers(oracle, P, n, m, dtype, frac=0.08)
+    x0 = (xs + 0.05 * np.random.default_rng(3).uniform(-1, 1, xs.shape)).astype(dtype)
+    th = 0.05
+    opts = ta.Options()
+    ref = oracle.dense_row_lm(A, b, x0, opts.to_pod(), history=True, loss=kind, th2=th * th)
+    model = ta.DenseRow.from_arrays(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda()).with_loss(kind, th)
+    x = torch.from_numpy(x0.copy()).cuda()
+    out = ta.Optimize(x, model, opts, history=True)
+    torch.cuda.synchronize()
+    refd = dict(errs=ref["errs"], succ=ref["succ"], iters=ref["iters"], stop=ref["stop"], x=ref["x"], cost=ref["cost"],
+                fails=ref["fails"], deltas2=ref["deltas2"])
+    st = check_trajectories(gpu_dict(out, x), refd, dtype, opts.to_pod(), label=f"fused + {kind} {n}x{m}")
+    assert st["full"] + st["ties"] == P, st
+    inl = out.final_inlier_ratio.cpu().numpy()
+    assert np.abs(inl - ref["inlier_ratio"]).max() <= (2.0 / m if dtype == np.float64 else 6.0 / m)
+    assert int(out.counters[3]) == P     # every problem went through the fused kernel's queue
+    with ta.api.default_context().tuning(narrow_mfma_pass=1):
+        x2 = torch.from_numpy(x0.copy()).cuda()
+        out2 = ta.Optimize(x2, model, opts, history=True)
+        torch.cuda.synchronize()
+    assert float((x - x2).abs().max()) < (1e-8 if dtype == np.float64 else 3e-3)
+    assert np.abs(out2.final_inlier_ratio.cpu().numpy() - inl).max() <= (2.0 / m if dtype == np.float64 else 6.0 / m)

@@ -202,6 +202,13 @@ int toa_inst_wide_1_3(int thin, toa_handle h, const toa::FusedParams& prm, int s
 int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int splits);
 
 int toa_inst_narrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
+int toa_inst_narrow_fused_1_0(int n, toa_handle h, const toa::FusedParams& prm);
+// the instances of inst.hip's row-per-lane route of TOA_MODEL_DENSE_ROW (RowModel over the packed rows)
+static bool dense_row_lane_route(int dtag, int n, bool robust) {
+  if (dtag == 0 && n >= 4 && n <= 11) return true;           // narrow fp32 blocks, with or without an M-estimator
+  if (!robust) return false;
+  return n == 12 || n == 50 || (dtag == 1 && n == 6);         // the BASELINE shapes with an M-estimator on the handle
+}
 int toa_inst_narrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
 int toa_inst_jetrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_jetrow_fused_1_0(int n, toa_handle h, const toa::FusedParams& prm);
@@ -829,7 +836,13 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   }
   // DenseRow with an M-estimator on the handle: the robust data pass lives in the launch-per-iteration form (kernels.hpp
   // RobustOf): chunked automatically for a few huge problems, one chunk per problem for a batch
-  if (model == TOA_MODEL_DENSE_ROW && h->loss != TOA_LOSS_L2 && splits < 0) splits = (P * 4 <= h->num_cus && m >= 512) ? 0 : 1;
+  // (round 6: where a row-per-lane instance exists — inst.hip — a BATCH runs the loss inside the fused kernel instead)
+  if (model == TOA_MODEL_DENSE_ROW && h->loss != TOA_LOSS_L2 && splits < 0) {
+    const bool few = P * 4 <= h->num_cus && m >= 512;
+    if (!few && !h->tune.narrow_mfma_pass && dense_row_lane_route(dtag, n, true))
+      return dtag == 0 ? toa_inst_narrow_fused_0_0(n, h, prm) : toa_inst_narrow_fused_1_0(n, h, prm);
+    splits = few ? 0 : 1;
+  }
   if (splits >= 0) {
     if (!splittable) return fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
     return toa_inst_wide(dtag, model, lay_.nbm, lay_.thin, h, prm, splits);
@@ -837,7 +850,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (model == TOA_MODEL_DENSE_ROW_AD) return dtag == 0 ? toa_inst_jetrow_fused_0_0(n, h, prm) : toa_inst_jetrow_fused_1_0(n, h, prm);
   if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtag, model, 16 * ((n + 15) / 16), h, prm);
   // narrow fp32 blocks: a row per lane (RowModel) instead of sixteen lanes per row (toa_tuning::narrow_mfma_pass: the old route)
-  if (dtag == 0 && n >= 4 && n <= 11 && !h->tune.narrow_mfma_pass) return toa_inst_narrow_fused_0_0(n, h, prm);
+  if (!h->tune.narrow_mfma_pass && dense_row_lane_route(dtag, n, false)) return toa_inst_narrow_fused_0_0(n, h, prm);
   return toa_inst_fused(dtag, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");
 }

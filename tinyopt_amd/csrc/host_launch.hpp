@@ -310,7 +310,9 @@ inline int launch_fused(toa_handle h, const FusedParams& prm_in) {
     // One parked linearisation per resident wave (the Gram registers of the last accepted point: ~10 KB at n = 50, 2 KB at
     // n = 12 fp64): the re-accumulation that follows a rejected step reads it back instead of streaming the problem's rows
     // again.  toa_tuning::memo_off switches it off (A/B, and the test that the results do not depend on it).
-    memo_on = !h->tune.memo_off;
+    // (not with an M-estimator in the fused kernel — row models: the cost of a robust linearisation is the sum of the losses, which the
+    //  parked Gram does not carry)
+    memo_on = !h->tune.memo_off && prm.loss == TOA_LOSS_L2;
     if (memo_on) {
       // a small Gram is parked in LDS when that costs no resident workgroup (C3: parking in HBM after every accepted step
       // measured 1.5 % of the launch for a workload that never rejects a step)

@@ -101,26 +101,38 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
   if (n == 50) return launch_accumulate<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
+// TOA_MODEL_DENSE_ROW on the row-per-lane route (round 6; RowModel over DenseRowPackedFunctor: the packed rows of these layouts ARE items
+// [a_i | b_i]).  fp32, 4 <= n <= 11: every solve — 5-30 % faster than sixteen lanes per row, the cost-only pass twice as fast
+// (profiles/r06_ab_log.md section 7).  With an M-estimator on the handle (toa_set_loss) also the BASELINE shapes n = 12 and n = 50 (fp64:
+// n = 6, 12, 50): the loss then runs INSIDE the fused kernel instead of the launch-per-iteration form (C4 shape + Huber: 18.1 -> 10.7 ms,
+// n = 12 x 500 x 40 000 problems: 6.5 -> 1.9 ms; section 8).  A functor's parameter count is a compile-time constant, as for TOA_MODEL_DENSE_ROW_AD.
 #if TOA_INST_DT == 0
-// TOA_MODEL_DENSE_ROW, fp32, 4 <= n <= 11 (round 6): a row per lane through the LDS stage (RowModel over DenseRowPackedFunctor) instead
-// of sixteen lanes per row — 5-30 % faster whole solves, the cost-only pass twice as fast (profiles/r06_ab_log.md section 7).
 #define TOA_NARROW_CASES(CALL) \
   switch (n) {                 \
-    case 4: CALL(4); case 5: CALL(5); case 6: CALL(6); case 7: CALL(7); case 8: CALL(8); case 9: CALL(9); case 10: CALL(10); case 11: CALL(11); \
+    case 4: CALL(1, 0, 4); case 5: CALL(1, 0, 5); case 6: CALL(1, 0, 6); case 7: CALL(1, 0, 7); case 8: CALL(1, 0, 8); case 9: CALL(1, 0, 9); \
+    case 10: CALL(1, 0, 10); case 11: CALL(1, 0, 11); case 12: CALL(1, 0, 12); case 50: CALL(3, 3, 50); \
     default: break;            \
   }
-int toa_inst_narrow_fused_0_0(int n, toa_handle h, const FusedParams& prm) {
-#define TOA_NF(N) return launch_fused<RowModel<InstT, 1, 0, DenseRowPackedFunctor<InstT, N>>>(h, prm)
+#else
+#define TOA_NARROW_CASES(CALL) \
+  switch (n) {                 \
+    case 6: CALL(1, 0, 6); case 12: CALL(1, 0, 12); case 50: CALL(3, 3, 50); \
+    default: break;            \
+  }
+#endif
+int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
+#define TOA_NF(NB, TH, N) return launch_fused<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, prm)
   TOA_NARROW_CASES(TOA_NF)
 #undef TOA_NF
-  return toa_fail(TOA_E_ARG, "narrow DenseRow route: 4 <= n <= 11");
+  return toa_fail(TOA_E_ARG, "DenseRow row-per-lane route: no instance for this n");
 }
+#if TOA_INST_DT == 0
 int toa_inst_narrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H,
                                    double* cost, int32_t* nres) {
-#define TOA_NA(N) return launch_accumulate<RowModel<InstT, 1, 0, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
+#define TOA_NA(NB, TH, N) return launch_accumulate<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
   TOA_NARROW_CASES(TOA_NA)
 #undef TOA_NA
-  return toa_fail(TOA_E_ARG, "narrow DenseRow route: 4 <= n <= 11");
+  return toa_fail(TOA_E_ARG, "DenseRow row-per-lane route: no instance for this n");
 }
 #endif
 #elif defined(TOA_INST_SOLVE)
