@@ -897,7 +897,7 @@ def main():
                                                 "passes_per_launch": r["passes_per_launch"],
                                                 "measured_read_ceiling_GBps": r["measured_read_ceiling_GBps"],
                                                 "llc_read_ceiling_GBps": r["llc_read_ceiling_GBps"]}}
-    if args.workload == "large128" and gpu and world == 1:
+    if args.workload == "large128" and gpu and world == 1 and not args.no_cpu:   # (--no-cpu = a profiling run: only the launches of the timed workload)
         # 512 problems = 256 CUs x 2 resident workgroups: every slot holds exactly ONE problem, so the launch lasts as long as the CU
         # with the two longest ones (iterations per problem: mean 7.3, max 10-11).  The kernel's own rate shows on a batch that keeps
         # the slots refilled — the same generator at four times the problems, after the timed region (profiles/r06_ab_log.md §4):
