@@ -69,6 +69,9 @@ def main():
         base = base or ms
         cn = [int(v) for v in out.counters[:5].cpu()]
         st = f"   build: {model.res.stats()}" if hasattr(model, "res") else ""
+        if os.environ.get("ROWBENCH_SHORT"):
+            print(f"{name:12s} P={P} n={n} m={m} {str(dt)[6:]}: solve {ms:8.3f} ms  {its / ms * 1e3 / 1e6:7.3f} M it/s  acc {acc:7.3f} ms  cost-only {ev:7.3f} ms{st}", flush=True)
+            continue
         gbs = P * m * (n + 1) * A.element_size() / (acc * 1e-3) / 1e9
         print(f"{name:12s} P={P} n={n} m={m} {str(dt)[6:]}: solve {ms:8.3f} ms  {its / ms * 1e3 / 1e6:7.3f} M it/s  ({ms / base:5.2f}x compiled-in)   "
               f"accumulate seam {acc:7.3f} ms = {gbs:6.0f} GB/s, cost-only {ev:7.3f} ms   err {float((x - xs).abs().max()):.2e}   passes per iteration: {cn[0] / its:.3f} streamed + {cn[1] / its:.3f} cost-only, {cn[4] / its:.3f} from the memo{st}", flush=True)
