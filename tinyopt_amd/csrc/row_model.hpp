@@ -152,7 +152,8 @@ struct ChunkSeededD {
 template <typename T, typename F, int MANIFOLD = 0>
 struct AdRowFunctor {
   static constexpr int kN = F::kN, kR = F::kR, kD = F::kD, kH = F::kH;
-  static constexpr int kX = MANIFOLD == 2 ? FunctorX<F>::value : F::kN;   // stored scalars of x
+  static_assert(MANIFOLD != 1 || F::kN == 6, "TOA_MANIFOLD_SE3: one pose, six tangent dimensions");
+  static constexpr int kX = MANIFOLD == 1 ? 12 : (MANIFOLD == 2 ? FunctorX<F>::value : F::kN);   // stored scalars of x
   template <class S, class XA_, class DA_, class XP_>
   static __device__ __forceinline__ void plus(const XA_& x, const DA_& d, XP_&& xp) { F::template plus<S>(x, d, xp); }
   static constexpr bool kManual = true;
@@ -164,13 +165,25 @@ struct AdRowFunctor {
 #endif
   static constexpr int kChunks = (kN + TOA_AD_CW - 1) / TOA_AD_CW;   // Jets of <= 12 partials, as balanced as kN allows
   static constexpr int kCW = (kN + kChunks - 1) / kChunks;
-  static constexpr bool kTable = MANIFOLD == 2;
+  static constexpr bool kTable = MANIFOLD != 0;
   static constexpr int kTableBytes = kTable ? ((kChunks * kX * (kCW + 1) * int(sizeof(T)) + 15) & ~15) : 0;
   using TabJet = Jet<T, kCW>;
   static __device__ __forceinline__ void build_table(const T* xs, TabJet* tab, const int lane) {
-    if (lane < kChunks) {
-      const ChunkSeededD<T, kCW> D{lane * kCW};
-      F::template plus<TabJet>(xs, D, tab + lane * kX);
+    if constexpr (MANIFOLD == 1) {   // ONE SE3 pose (R row-major, t): the right perturbation pose * exp(d) at d = 0 (optimize_autodiff.h:48-55, 73-77)
+      if (lane == 0) {
+        T xr[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xr[i] = xs[i];
+        TabJet xj[12];
+        se3_seed_pose<T>(xr, xj);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) tab[i] = xj[i];
+      }
+    } else {
+      if (lane < kChunks) {
+        const ChunkSeededD<T, kCW> D{lane * kCW};
+        F::template plus<TabJet>(xs, D, tab + lane * kX);
+      }
     }
     wave_sync();
   }
@@ -221,13 +234,15 @@ struct FunctorTable { static constexpr int bytes = 0; };
 template <typename F>
 struct FunctorTable<F, std::enable_if_t<F::kTable>> { static constexpr int bytes = F::kTableBytes; };
 
-// MANIFOLD: 0 = Euclidean, 2 = the user's container (TOA_MANIFOLD_USER: F::kX stored scalars, F::plus; round 6).  A functor with
+// MANIFOLD: 0 = Euclidean, 1 = ONE SE3 pose (12 stored scalars, six tangent dimensions), 2 = the user's container (TOA_MANIFOLD_USER:
+// F::kX stored scalars, F::plus; round 6).  A functor with
 // its own Jacobian fills J over the TANGENT (kN columns) from the stored scalars; an AD functor goes through AdRowFunctor's table.
 template <typename T, int NBM, int THIN, typename F, int MANIFOLD = 0>
 struct RowModel {
   using Scalar = T;
-  static_assert(MANIFOLD == 0 || MANIFOLD == 2, "row models: Euclidean parameters or a user manifold");
-  static constexpr int kXdim = MANIFOLD == 2 ? FunctorX<F>::value : 0;
+  static_assert(MANIFOLD >= 0 && MANIFOLD <= 2, "TOA_MANIFOLD_*");
+  static_assert(MANIFOLD != 1 || F::kN == 6, "TOA_MANIFOLD_SE3: one pose, six tangent dimensions");
+  static constexpr int kXdim = MANIFOLD == 1 ? 12 : (MANIFOLD == 2 ? FunctorX<F>::value : 0);
   static_assert(kXdim <= 64, "stored scalars of x: one per lane");
   static constexpr int kTableBytes = FunctorTable<F>::bytes;
   static constexpr int kN = F::kN, kR = F::kR, kD = F::kD;
@@ -251,7 +266,8 @@ struct RowModel {
   static constexpr bool kPRegs = !FunctorIndexed<F>::value && kD * int(sizeof(T)) <= 256;
 
   __device__ __forceinline__ void plus_eq(WaveLds<T>& L, const T* dv, T sign, int n, int lane) const {
-    if constexpr (MANIFOLD == 2) UserManifoldOf<T, F>::plus_eq(L, dv, sign, n, lane);
+    if constexpr (MANIFOLD == 1) Se3Manifold<T>::plus_eq(L, dv, sign, n, lane);
+    else if constexpr (MANIFOLD == 2) UserManifoldOf<T, F>::plus_eq(L, dv, sign, n, lane);
     else euclid_plus_eq(L, dv, sign, lane);
   }
   DenseRowGram<T, NBM, THIN> gram;
