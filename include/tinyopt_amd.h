@@ -193,10 +193,10 @@ typedef struct toa_tuning {
   int32_t large_chol_no_lookahead; /* n > 128: the one-workgroup Cholesky without its look-ahead (A/B and the bit-identity test) */
   int32_t large_gram_plain_deal; /* 224 < n <= 256, own Gram: the tiles dealt round-robin to the waves instead of the operand-sharing deal (triangles of
                                     blocks; A/B and the bit-identity test: which wave computes a tile does not change its bits) */
-  int32_t narrow_mfma_pass;      /* TOA_MODEL_DENSE_ROW: 1 = the routes of rounds 1-5 — sixteen lanes per row for fp32 at 4 <= n <= 11, the
-                                    launch-per-iteration form for batches with an M-estimator — instead of the row-per-lane route through the LDS stage
-                                    (round 6: fp32 4 <= n <= 11 always; with toa_set_loss also n = 12, 50 and fp64 n = 6, 12, 50;
-                                    profiles/r06_ab_log.md sections 7-8; A/B) */
+  int32_t narrow_mfma_pass;      /* TOA_MODEL_DENSE_ROW: 1 = the routes of rounds 1-5 — sixteen lanes per row for narrow blocks, the
+                                    launch-per-iteration form for batches with an M-estimator — instead of the narrow routes of round 6 (an item per
+                                    lane with the Gram in registers: fp32 n <= 10, fp64 n <= 5; a row per lane through the LDS stage: fp32 n = 11; with
+                                    toa_set_loss also n = 12, 50 and fp64 n = 6, 12, 50; profiles/r06_ab_log.md sections 7, 8, 11; A/B) */
   int32_t reserved[14];          /* (three of them were the team form of the fused kernel, round 5: removed in round 6, profiles/r06_pruned_arms.patch) */
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
@@ -463,8 +463,9 @@ int toa_ba_lists_run(toa_handle h, int dtype, int num_cameras, int num_points, i
  *      scalars as T,  r[q]  the item's residuals; every function of ceres::Jet (jet.h:557-1400: sin, exp, pow, atan2, ...)
  *      is in scope.  toa_model_compile builds lm_fused_kernel / accumulate_kernel for JetModel<T, that functor> with hiprtc
  *      (opened with dlopen on first use; ~2-3 s, once) and loads the code object: no rebuild of the library.
- *        num_params <= 63 (1 .. 3 and TOA_MANIFOLD_SE3: JetModel, an item per lane and the Gram in registers; from 4 parameters on: RowModel,
- *        see toa_model_compile_ex below — the border is a measured one, profiles/r06_ab_log.md section 7); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
+ *        num_params <= 63 (narrow blocks — up to 10 parameters in fp32, 5 in fp64 —, items of several residuals up to 12 parameters and
+ *        TOA_MANIFOLD_SE3: JetModel, an item per lane and the Gram in registers; beyond: RowModel, see toa_model_compile_ex below — the border
+ *        is a measured one, profiles/r06_ab_log.md section 11); data_dev: [P][header_scalars + num_items * scalars_per_item]; x_dev: [P][num_params];
  *        m = num_items * residuals_per_item residuals per problem.  log_out (optional): the compiler's diagnostics.
  *        toa_jit_lm_run / toa_jit_accumulate: the contracts of toa_lm_run / toa_accumulate.  The handle's M-estimator
  *        (toa_set_loss) applies to each item's squared residual norm, as for TOA_MODEL_CIRCLE_FIT. */
@@ -472,7 +473,7 @@ typedef struct toa_jit_model_s* toa_jit_model;
 int toa_model_compile(toa_handle h, int dtype, int num_params, int residuals_per_item, int scalars_per_item, int header_scalars,
                       const char* residual_body, toa_jit_model* out, char* log_out, size_t log_cap);
 /*      Round 4 — the general form.
- *        num_params up to 63: from 4 parameters on (TOA_MANIFOLD_SE3 excepted) the model is RowModel (csrc/row_model.hpp, round 6; the path of
+ *        num_params up to 63: beyond the narrow blocks named above the model is RowModel (csrc/row_model.hpp, round 6; the path of
  *          TOA_MODEL_DENSE_ROW_AD; the row-split / stepping kernels of a model with up to 12 parameters stay on JetModel, whose one-launch
  *          persistent form serves few, huge problems):
  *          an item is evaluated by ONE lane — TOA_JIT_RESIDUAL bodies on Jets, twelve parameters at a time; TOA_JIT_ACCUMULATE

@@ -173,10 +173,10 @@ def test_sticky_handle_loss_is_refused_not_ignored(ta):
 
 @pytest.mark.parametrize("kind", ["huber", "cauchy"])
 @pytest.mark.parametrize("dtype,n,m", [(np.float32, 50, 402), (np.float64, 50, 130), (np.float64, 12, 203), (np.float32, 12, 100), (np.float64, 6, 150),
-                                       (np.float32, 8, 120), (np.float32, 5, 63)])
+                                       (np.float32, 8, 120), (np.float32, 5, 63), (np.float32, 11, 90), (np.float64, 4, 70), (np.float64, 2, 41)])
 def test_a_batch_with_a_loss_runs_inside_the_fused_kernel(ta, oracle, kind, dtype, n, m):
     """Round 6: a BATCH of DenseRow problems with an M-estimator on the handle runs the loss inside the fused kernel wherever a
-    row-per-lane instance exists (fp32 4 <= n <= 11, n = 12, 50; fp64 n = 6, 12, 50) instead of the launch-per-iteration form.  Whole
+    narrow-route instance exists (fp32 n <= 12, n = 50; fp64 n <= 6, n = 12, 50) instead of the launch-per-iteration form.  Whole
     trajectories, StopReasons, iterations and the inlier ratio against the oracle; the old route (toa_tuning::narrow_mfma_pass) lands on
     the same points."""
     P = 300      # (a batch: P * 4 > #CUs — few, huge problems keep the row-split form)

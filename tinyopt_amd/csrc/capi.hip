@@ -203,9 +203,10 @@ int toa_inst_wide_1_4(int thin, toa_handle h, const toa::FusedParams& prm, int s
 
 int toa_inst_narrow_fused_0_0(int n, toa_handle h, const toa::FusedParams& prm);
 int toa_inst_narrow_fused_1_0(int n, toa_handle h, const toa::FusedParams& prm);
-// the instances of inst.hip's row-per-lane route of TOA_MODEL_DENSE_ROW (RowModel over the packed rows)
+int toa_inst_narrow_accumulate_1_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H, double* cost, int32_t* nres);
+// the instances of inst.hip's narrow routes of TOA_MODEL_DENSE_ROW (JetModel / RowModel over the packed rows)
 static bool dense_row_lane_route(int dtag, int n, bool robust) {
-  if (dtag == 0 && n >= 4 && n <= 11) return true;           // narrow fp32 blocks, with or without an M-estimator
+  if (n >= 1 && n <= (dtag == 0 ? 11 : 5)) return true;      // narrow blocks, with or without an M-estimator
   if (!robust) return false;
   return n == 12 || n == 50 || (dtag == 1 && n == 6);         // the BASELINE shapes with an M-estimator on the handle
 }
@@ -697,8 +698,9 @@ int toa_accumulate(toa_handle h, int model, int dtype, int n, int m, int64_t P, 
   if (model != TOA_MODEL_DENSE_ROW)
     return toa_inst_misc_accumulate(dtag, model, 16 * ((n + 15) / 16), h, n, m, P, data, x, want_grad, g, H, cost, nres);
   const DenseRowLayout lay_ = DenseRowLayout::make(n, m);
-  if (dtag == 0 && n >= 4 && n <= 11 && h->loss == TOA_LOSS_L2 && !h->tune.narrow_mfma_pass)
-    return toa_inst_narrow_accumulate_0_0(h, n, m, P, data, x, want_grad, g, H, cost, nres);
+  if (h->loss == TOA_LOSS_L2 && !h->tune.narrow_mfma_pass && dense_row_lane_route(dtag, n, false))
+    return dtag == 0 ? toa_inst_narrow_accumulate_0_0(h, n, m, P, data, x, want_grad, g, H, cost, nres)
+                     : toa_inst_narrow_accumulate_1_0(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_inst_accumulate(dtag, lay_.nbm, lay_.thin, h, n, m, P, data, x, want_grad, g, H, cost, nres);
 }
 
@@ -850,7 +852,7 @@ static int lm_run_impl(toa_handle h, int model, int dtype, int n, int m, int64_t
   if (model == TOA_MODEL_DENSE_ROW_AD) return dtag == 0 ? toa_inst_jetrow_fused_0_0(n, h, prm) : toa_inst_jetrow_fused_1_0(n, h, prm);
   if (model != TOA_MODEL_DENSE_ROW) return toa_inst_misc_fused(dtag, model, 16 * ((n + 15) / 16), h, prm);
   // narrow fp32 blocks: a row per lane (RowModel) instead of sixteen lanes per row (toa_tuning::narrow_mfma_pass: the old route)
-  if (!h->tune.narrow_mfma_pass && dense_row_lane_route(dtag, n, false)) return toa_inst_narrow_fused_0_0(n, h, prm);
+  if (!h->tune.narrow_mfma_pass && dense_row_lane_route(dtag, n, false)) return dtag == 0 ? toa_inst_narrow_fused_0_0(n, h, prm) : toa_inst_narrow_fused_1_0(n, h, prm);
   return toa_inst_fused(dtag, lay_.nbm, lay_.thin, h, prm);
   return fail(TOA_E_ARG, "toa_lm_run: bad block count");
 }

@@ -101,40 +101,44 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
   if (n == 50) return launch_accumulate<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
-// TOA_MODEL_DENSE_ROW on the row-per-lane route (round 6; RowModel over DenseRowPackedFunctor: the packed rows of these layouts ARE items
-// [a_i | b_i]).  fp32, 4 <= n <= 11: every solve — 5-30 % faster than sixteen lanes per row, the cost-only pass twice as fast
-// (profiles/r06_ab_log.md section 7).  With an M-estimator on the handle (toa_set_loss) also the BASELINE shapes n = 12 and n = 50 (fp64:
-// n = 6, 12, 50): the loss then runs INSIDE the fused kernel instead of the launch-per-iteration form (C4 shape + Huber: 18.1 -> 10.7 ms,
-// n = 12 x 500 x 40 000 problems: 6.5 -> 1.9 ms; section 8).  A functor's parameter count is a compile-time constant, as for TOA_MODEL_DENSE_ROW_AD.
+// TOA_MODEL_DENSE_ROW on the narrow routes (round 6; the packed rows of the n <= 15 layouts — and of the thin layouts — ARE items [a_i | b_i]):
+//   JetModel over DenseRowPackedFunctor   an item per lane, the (n + 1)(n + 2) / 2 Gram in registers: fp32 n <= 10, fp64 n <= 5
+//   RowModel over DenseRowPackedFunctor   a row per lane staged into the MFMA Gram: fp32 n = 11; with an M-estimator on the handle
+//                                         (toa_set_loss) also the BASELINE shapes n = 12, 50 (fp64: n = 6, 12, 50) — the loss then runs
+//                                         INSIDE the fused kernel instead of the launch-per-iteration form
+// against sixteen lanes per row: fp32 n = 6 x 1000: 3.07 -> 1.46 ms per 2 GB of rows, fp64 n = 4: 3.30 -> 2.02 (profiles/r06_ab_log.md
+// sections 7, 8, 11).  A functor's parameter count is a compile-time constant, as for TOA_MODEL_DENSE_ROW_AD.
 #if TOA_INST_DT == 0
-#define TOA_NARROW_CASES(CALL) \
-  switch (n) {                 \
-    case 4: CALL(1, 0, 4); case 5: CALL(1, 0, 5); case 6: CALL(1, 0, 6); case 7: CALL(1, 0, 7); case 8: CALL(1, 0, 8); case 9: CALL(1, 0, 9); \
-    case 10: CALL(1, 0, 10); case 11: CALL(1, 0, 11); case 12: CALL(1, 0, 12); case 50: CALL(3, 3, 50); \
-    default: break;            \
+#define TOA_NARROW_CASES(JET, ROW) \
+  switch (n) {                     \
+    case 1: JET(1); case 2: JET(2); case 3: JET(3); case 4: JET(4); case 5: JET(5); case 6: JET(6); case 7: JET(7); case 8: JET(8); case 9: JET(9); \
+    case 10: JET(10); case 11: ROW(1, 0, 11); case 12: ROW(1, 0, 12); case 50: ROW(3, 3, 50); \
+    default: break;                \
   }
 #else
-#define TOA_NARROW_CASES(CALL) \
-  switch (n) {                 \
-    case 6: CALL(1, 0, 6); case 12: CALL(1, 0, 12); case 50: CALL(3, 3, 50); \
-    default: break;            \
+#define TOA_NARROW_CASES(JET, ROW) \
+  switch (n) {                     \
+    case 1: JET(1); case 2: JET(2); case 3: JET(3); case 4: JET(4); case 5: JET(5); case 6: ROW(1, 0, 6); case 12: ROW(1, 0, 12); case 50: ROW(3, 3, 50); \
+    default: break;                \
   }
 #endif
 int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
+#define TOA_NJ(N) return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, prm)
 #define TOA_NF(NB, TH, N) return launch_fused<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, prm)
-  TOA_NARROW_CASES(TOA_NF)
+  TOA_NARROW_CASES(TOA_NJ, TOA_NF)
+#undef TOA_NJ
 #undef TOA_NF
-  return toa_fail(TOA_E_ARG, "DenseRow row-per-lane route: no instance for this n");
+  return toa_fail(TOA_E_ARG, "DenseRow narrow route: no instance for this n");
 }
-#if TOA_INST_DT == 0
-int toa_inst_narrow_accumulate_0_0(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g, void* H,
-                                   double* cost, int32_t* nres) {
+int TOA_CAT(toa_inst_narrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
+                                                         void* H, double* cost, int32_t* nres) {
+#define TOA_NJ(N) return launch_accumulate<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
 #define TOA_NA(NB, TH, N) return launch_accumulate<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
-  TOA_NARROW_CASES(TOA_NA)
+  TOA_NARROW_CASES(TOA_NJ, TOA_NA)
+#undef TOA_NJ
 #undef TOA_NA
-  return toa_fail(TOA_E_ARG, "DenseRow row-per-lane route: no instance for this n");
+  return toa_fail(TOA_E_ARG, "DenseRow narrow route: no instance for this n");
 }
-#endif
 #elif defined(TOA_INST_SOLVE)
 int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g,
                                              double scale, void* dx, int32_t* ok) {

@@ -92,6 +92,12 @@ struct UserManifoldOf {
   }
 };
 
+// kPackedRows: the items are the packed rows of a TOA_MODEL_DENSE_ROW problem (n <= 15: [m4][n + 1], rows padded to a multiple of four)
+template <typename F, typename = void>
+struct FunctorPackedRows { static constexpr bool value = false; };
+template <typename F>
+struct FunctorPackedRows<F, std::enable_if_t<F::kPackedRows>> { static constexpr bool value = true; };
+
 template <typename T, typename F, int MANIFOLD = 0>
 struct JetModel {
   using Scalar = T;
@@ -117,7 +123,8 @@ struct JetModel {
   }
   __device__ __forceinline__ void set_loss(int kind, double t2) { loss = kind; th2 = T(t2); }
   __device__ __forceinline__ void bind(long long p) {
-    d = data + size_t(p) * (F::kH + size_t(items) * F::kD);
+    const size_t stride = FunctorPackedRows<F>::value ? size_t((items + 3) & ~3) * F::kD : F::kH + size_t(items) * F::kD;
+    d = data + size_t(p) * stride;
     it0 = 0; it1 = items;
   }
   // rows [row0, row0 + rows) of the problem = whole items (the launchers cut chunks at multiples of kR rows): the row-split form
@@ -270,8 +277,9 @@ struct DenseRowAdFunctor {
 };
 
 // The DenseRow residual WITH its Jacobian row, an item = one packed row [a_i | b_i] of the n <= 15 layouts (DenseRowLayout: no block
-// padding there, row stride n + 1): what RowModel runs for narrow fp32 blocks of TOA_MODEL_DENSE_ROW (round 6 — a row per lane
-// instead of sixteen lanes per row, whose pass costs ~26 vector instructions per four rows whatever their length).
+// padding there, row stride n + 1): what JetModel (the Gram in registers, n <= 10 in fp32, n <= 5 in fp64) and RowModel (a row per lane
+// staged into the MFMA Gram) run for narrow blocks of TOA_MODEL_DENSE_ROW (round 6) instead of sixteen lanes per row, whose pass costs
+// ~26 vector instructions per four rows whatever their length.
 template <typename T, int NN>
 struct DenseRowPackedFunctor {
   static constexpr int kN = NN, kR = 1, kD = NN + 1, kH = 0;
@@ -292,10 +300,6 @@ struct DenseRowPackedFunctor {
     }
   }
 };
-template <typename F, typename = void>
-struct FunctorPackedRows { static constexpr bool value = false; };
-template <typename F>
-struct FunctorPackedRows<F, std::enable_if_t<F::kPackedRows>> { static constexpr bool value = true; };
 
 template <typename F, typename = void>
 struct FunctorComputeBound { static constexpr bool value = false; };

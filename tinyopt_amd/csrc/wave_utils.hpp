@@ -149,33 +149,40 @@ __device__ __forceinline__ double dpp_row_xor4(double v) {
 // wave-wide sums; on return EVERY lane l holds the complete total of p[l & 31].  A butterfly over the lane bits (quad swaps,
 // row rotations, two cross-row shuffles): ~230 instructions for fp64 where 32 separate all-reduces cost ~800, and a
 // fixed order of additions (deterministic).
-template <typename T>
-__device__ __forceinline__ T wave_transposed_reduce32(const T (&p)[32], const int lane) {
+// (`get(std::integral_constant<int, i>)` = this lane's partial of sum i: every index is a compile-time constant by construction — the
+//  run-time compiler kept a 32-element operand ARRAY of the round-3 form in scratch memory, 144 / 272 B per lane, in every JetModel build)
+template <typename T, typename Get>
+__device__ __forceinline__ T wave_transposed_reduce32_of(Get&& get, const int lane) {
   const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0, b4 = (lane & 16) != 0;
   T r1[16], r2[8], r3[4], r4[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const T keep = b0 ? p[2 * i + 1] : p[2 * i], send = b0 ? p[2 * i] : p[2 * i + 1];
+  static_for<16>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const T pa = get(std::integral_constant<int, 2 * i>{}), pb = get(std::integral_constant<int, 2 * i + 1>{});
+    const T keep = b0 ? pb : pa, send = b0 ? pa : pb;
     r1[i] = keep + dpp_quad<kQuadSwap1>(send);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  });
+  static_for<8>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const T keep = b1 ? r1[2 * i + 1] : r1[2 * i], send = b1 ? r1[2 * i] : r1[2 * i + 1];
     r2[i] = keep + dpp_quad<kQuadSwap2>(send);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  });
+  static_for<4>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const T keep = b2 ? r2[2 * i + 1] : r2[2 * i], send = b2 ? r2[2 * i] : r2[2 * i + 1];
     r3[i] = keep + dpp_row_xor4(send);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  });
+  static_for<2>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
     const T keep = b3 ? r3[2 * i + 1] : r3[2 * i], send = b3 ? r3[2 * i] : r3[2 * i + 1];
     r4[i] = keep + dpp_row_ror<8>(send);
-  }
+  });
   const T keep = b4 ? r4[1] : r4[0], send = b4 ? r4[0] : r4[1];
   const T r5 = keep + __shfl_xor(send, 16, 64);
   return r5 + __shfl_xor(r5, 32, 64);
+}
+template <typename T>
+__device__ __forceinline__ T wave_transposed_reduce32(const T (&p)[32], const int lane) {
+  return wave_transposed_reduce32_of<T>([&](auto ic) __attribute__((always_inline)) { return p[decltype(ic)::value]; }, lane);
 }
 
 // All-reduce N independent per-lane partial sums: on return every lane holds every total.  N >= 12: transposed reductions of
@@ -187,16 +194,18 @@ __device__ __forceinline__ void wave_allreduce_many(T (&G)[N], const int lane) {
 #pragma unroll
     for (int i = 0; i < N; ++i) G[i] = wave_allreduce_sum(G[i]);
   } else {
-#pragma unroll
-    for (int c0 = 0; c0 < N; c0 += 32) {
-      T p[32];
-#pragma unroll
-      for (int i = 0; i < 32; ++i) p[i] = (c0 + i < N) ? G[(c0 + i < N) ? c0 + i : 0] : T(0);
-      const T r = wave_transposed_reduce32(p, lane);
-#pragma unroll
-      for (int i = 0; i < 32; ++i)
-        if (c0 + i < N) G[c0 + i] = wave_bcast(r, i);
-    }
+    static_for<(N + 31) / 32>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c0 = decltype(cc)::value * 32;
+      const T r = wave_transposed_reduce32_of<T>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (c0 + i < N) return G[c0 + i];
+        else return T(0);
+      }, lane);
+      static_for<32>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (c0 + i < N) G[c0 + i] = wave_bcast(r, i);
+      });
+    });
   }
 }
 
