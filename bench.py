@@ -31,6 +31,10 @@ WORKLOADS = {
     # name: (P per GPU, n, m, torch dtype, dtype tag, description)
     "c4": (12500, 50, 2000, torch.float32, "f32", "C4 shard: 12500 problems/GPU x n=50 x m=2000 DenseRow fp32 (8 GPUs = 100k-problem C4)"),
     "c3": (10000, 12, 500, torch.float64, "f64", "C3: 10000 problems/GPU x n=12 x m=500 DenseRow fp64"),
+    # a BATCH of C2-sized problems (C2 itself is ONE problem, latency-bound: SINGLE below) — what a GPU is for at this size; the narrow routes of
+    # round 6 (an item per lane, the Gram in registers: csrc/models_jet.hpp JetModel over the packed rows)
+    "c2_batch_f32": (131072, 6, 1000, torch.float32, "f32", "131072 problems/GPU x n=6 x m=1000 DenseRow fp32 (the C2 shape, batched)"),
+    "c2_batch": (65536, 6, 1000, torch.float64, "f64", "65536 problems/GPU x n=6 x m=1000 DenseRow fp64 (the C2 shape, batched)"),
     # the C4 shape through the reference's OTHER doors: the residual handed over as TEXT at run time —
     # with its own Jacobian row (a manual Accumulate callback, docs/API.md:37-57, benchmarks/dense.cpp:57-66,90-99), or as r(x)
     # only, differentiated on the device (optimize_autodiff.h:91-166).  Items = rows [a_i | b_i] in the natural layout.

@@ -73,7 +73,7 @@ def main():
                  "bench_balists", "bench_under_rocprof_balists", "bench_large256", "bench_under_rocprof_large256", "bench_c4_coop0", "bench_c4_memo0_coop0",
                  "bench_large256_rocsolver", "bench_balists_rocsolver", "bench_large128_rowsplit", "bench_large256_one_lane", "bench_large256_two_lanes", "bench_large256_plain_deal",
                  "bench_large128_memo0", "bench_large256_memo0", "bench_c4_k6", "bench_c4_text", "bench_c4_ad", "bench_under_rocprof_c4_text", "bench_under_rocprof_c4_ad",
-                 "bench_c4_huber", "bench_c4_huber_old_route", "bench_c3_huber", "bench_c3_huber_old_route"):
+                 "bench_c4_huber", "bench_c4_huber_old_route", "bench_c3_huber", "bench_c3_huber_old_route", "bench_c2_batch_f32", "bench_c2_batch"):
         if not os.path.exists(os.path.join(SRC, name + ".json")):
             continue
         with open(os.path.join(SRC, name + ".json")) as f:

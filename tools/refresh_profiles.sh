@@ -7,7 +7,7 @@ O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O   # NOTE: also delete the LOCAL gpurun_out/refresh before calling gpurun (results are merged, not mirrored)
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
-for wl in c4 c3 c2 c5 c1 ba balists c4_text c4_ad; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+for wl in c4 c3 c2 c5 c1 ba balists c4_text c4_ad c2_batch_f32 c2_batch; do python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python tools/row_model_bench.py 12500 > $O/row_model_bench.txt 2>&1
 python bench.py --workload c4 --loss huber:0.5 > $O/bench_c4_huber.json 2> $O/bench_c4_huber.err
 python bench.py --workload c4 --loss huber:0.5 --no-cpu --tuning narrow_mfma_pass=1 > $O/bench_c4_huber_old_route.json 2>/dev/null
