@@ -412,7 +412,7 @@ def test_fp32_pass_at_large_arguments(ta, oracle, scale, n, m):
     assert err_dev <= 4 * err_orc + 1e-6 * scale, (scale, n, err_dev, err_orc)
 
 
-@pytest.mark.parametrize("dtype,n", [(np.float32, n) for n in range(1, 12)] + [(np.float64, n) for n in range(1, 6)])
+@pytest.mark.parametrize("dtype,n", [(np.float32, n) for n in range(1, 12)] + [(np.float64, n) for n in range(1, 7)])
 def test_narrow_blocks_take_the_item_per_lane_routes(ta, oracle, dtype, n):
     """Round 6: narrow blocks of TOA_MODEL_DENSE_ROW run an item per lane — the Gram in registers (JetModel over the packed rows: fp32
     n <= 10, fp64 n <= 5) or staged into the MFMA Gram (RowModel, fp32 n = 11) — instead of sixteen lanes per row.  Whole trajectories

@@ -207,6 +207,7 @@ int toa_inst_narrow_accumulate_1_0(toa_handle h, int n, int m, int64_t P, const 
 // the instances of inst.hip's narrow routes of TOA_MODEL_DENSE_ROW (JetModel / RowModel over the packed rows)
 static bool dense_row_lane_route(int dtag, int n, bool robust) {
   if (n >= 1 && n <= (dtag == 0 ? 11 : 5)) return true;      // narrow blocks, with or without an M-estimator
+  if (dtag == 1 && n == 6) return true;                      // (fp64 n = 6: JetModel without the estimator branch for L2, RowModel with a loss)
   if (!robust) return false;
   return n == 12 || n == 50 || (dtag == 1 && n == 6);         // the BASELINE shapes with an M-estimator on the handle
 }

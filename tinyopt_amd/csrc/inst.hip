@@ -116,14 +116,25 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
     default: break;                \
   }
 #else
+// fp64: the estimators' exp / log / atan2 in double precision cost JetModel its occupancy (n = 6: 268 registers = one wave per SIMD), so plain L2
+// solves run the variant without that branch (167 registers: three waves per SIMD) — n <= 6 —, solves with an M-estimator the full one
 #define TOA_NARROW_CASES(JET, ROW) \
   switch (n) {                     \
-    case 1: JET(1); case 2: JET(2); case 3: JET(3); case 4: JET(4); case 5: JET(5); case 6: ROW(1, 0, 6); case 12: ROW(1, 0, 12); case 50: ROW(3, 3, 50); \
+    case 1: JET(1); case 2: JET(2); case 3: JET(3); case 4: JET(4); case 5: JET(5); case 6: if (!robust) { JET(6); } else { ROW(1, 0, 6); } \
+    case 12: ROW(1, 0, 12); case 50: ROW(3, 3, 50); \
     default: break;                \
   }
 #endif
 int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
+  const bool robust = prm.loss != TOA_LOSS_L2;
+  (void)robust;
+#if TOA_INST_DT == 0
 #define TOA_NJ(N) return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, prm)
+#else
+#define TOA_NJ(N) \
+  { if (robust) return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, prm); \
+    return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>, 0, false>>(h, prm); }
+#endif
 #define TOA_NF(NB, TH, N) return launch_fused<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, prm)
   TOA_NARROW_CASES(TOA_NJ, TOA_NF)
 #undef TOA_NJ
@@ -132,6 +143,8 @@ int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const F
 }
 int TOA_CAT(toa_inst_narrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, int m, int64_t P, const void* data, const void* x, int want_grad, void* g,
                                                          void* H, double* cost, int32_t* nres) {
+  const bool robust = false;   // (the seam takes this route for plain L2 only: capi.hip)
+  (void)robust;
 #define TOA_NJ(N) return launch_accumulate<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
 #define TOA_NA(NB, TH, N) return launch_accumulate<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres)
   TOA_NARROW_CASES(TOA_NJ, TOA_NA)

@@ -98,7 +98,10 @@ struct FunctorPackedRows { static constexpr bool value = false; };
 template <typename F>
 struct FunctorPackedRows<F, std::enable_if_t<F::kPackedRows>> { static constexpr bool value = true; };
 
-template <typename T, typename F, int MANIFOLD = 0>
+// ROBUST = false: a variant WITHOUT the M-estimator branch of the passes (toa_set_loss is ignored: the launchers pick it for plain L2
+// solves only).  The estimators' fp64 exp / log / atan2 cost the fused kernel its occupancy for everybody: fp64 n = 6 with the branch
+// 268 registers = one wave per SIMD, without 167 = three (profiles/r06_ab_log.md section 12).
+template <typename T, typename F, int MANIFOLD = 0, bool ROBUST = true>
 struct JetModel {
   using Scalar = T;
   static constexpr int kNpad = 16;
@@ -150,7 +153,7 @@ struct JetModel {
     }
     T csum = 0;
     T inl = 0;
-    const bool robust = loss != TOA_LOSS_L2;   // wave-uniform
+    const bool robust = ROBUST && loss != TOA_LOSS_L2;   // wave-uniform
     const T* itemsp = d + F::kH;
     for (int i = it0 + lane; i < it1; i += 64) {
       const T* item = itemsp + size_t(i) * F::kD;
