@@ -517,7 +517,11 @@ int toa_model_compile_ex(toa_handle h, const toa_jit_spec* spec, const char* bod
 int toa_jit_set_cache_dir(const char* dir);
 int toa_jit_model_info(toa_jit_model m, int* from_cache, int* xdim);   /* from_cache: 1 = the code object came from the disk cache */
 /* What the run-time build of the fused kernel came out as: resident workgroups (of four wavefronts) per compute unit, its dynamic
- * LDS per workgroup, vector registers (VGPR + AGPR) per lane and scratch bytes per lane (0 = nothing spilled).  Any pointer may be NULL. */
+ * LDS per workgroup, vector registers (VGPR + AGPR) per lane and scratch bytes per lane (0 = nothing spilled).  Any pointer may be NULL.
+ * A model has TWO builds (round 6): the one toa_model_compile makes and this call describes is WITHOUT the M-estimator branch of the passes
+ * — the estimators' exp / log / atan2, in double precision above all, cost every kernel that merely contains them its occupancy —; the one
+ * with it is made the first time the model runs on a handle that has a loss set (toa_set_loss): 2-3 s once, then from the disk cache, and
+ * refused (TOA_E_UNSUPPORTED, nothing recorded) if that first time is under stream capture. */
 int toa_jit_model_stats(toa_jit_model m, int* wg_per_cu, int* lds_bytes_per_wg, int* num_regs, int* scratch_bytes);
 int toa_model_destroy(toa_jit_model m);   /* waits for the model's last launch before the code is unloaded */
 int toa_jit_lm_run(toa_handle h, toa_jit_model model, int num_items, int64_t P, const void* data_dev, void* x_dev,

@@ -237,7 +237,8 @@ struct FunctorTable<F, std::enable_if_t<F::kTable>> { static constexpr int bytes
 // MANIFOLD: 0 = Euclidean, 1 = ONE SE3 pose (12 stored scalars, six tangent dimensions), 2 = the user's container (TOA_MANIFOLD_USER:
 // F::kX stored scalars, F::plus; round 6).  A functor with
 // its own Jacobian fills J over the TANGENT (kN columns) from the stored scalars; an AD functor goes through AdRowFunctor's table.
-template <typename T, int NBM, int THIN, typename F, int MANIFOLD = 0>
+// ROBUST = false: without the M-estimator branch of the passes (see JetModel; the launchers pick it for plain L2 solves only).
+template <typename T, int NBM, int THIN, typename F, int MANIFOLD = 0, bool ROBUST = true>
 struct RowModel {
   using Scalar = T;
   static_assert(MANIFOLD >= 0 && MANIFOLD <= 2, "TOA_MANIFOLD_*");
@@ -402,7 +403,7 @@ struct RowModel {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));   // keep the per-lane addresses out of LICM's reach (see DenseRowGram::extract_g_diag_cost)
     const int k = lane >> 4, c = lane & 15;
-    const bool robust = loss != TOA_LOSS_L2;   // wave-uniform
+    const bool robust = ROBUST && loss != TOA_LOSS_L2;   // wave-uniform
     const int nit = it1 - it0;
     const int nss = (nit + IT - 1) / IT;
     const T* const items = d + F::kH + size_t(it0) * kD;
@@ -583,7 +584,7 @@ struct RowModel {
     if constexpr (kGeom.items1 > 0) cl = pass<true, kGeom.items1, 1>(L.xs, lane);
     else cl = pass<true, kGeom.items2, kGeom.nbuf>(L.xs, lane);
     cost = gram.extract_g_diag_cost(L.g, L.hd, lay, n, lane, L.tmp);
-    if (loss != TOA_LOSS_L2) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
+    if (ROBUST && loss != TOA_LOSS_L2) cost = cl;   // sum of the robust losses, not the Gram's r^T r (which is scaled by s)
     nres = m;
   }
   __device__ __forceinline__ void evaluate(WaveLds<T>& L, int, int lane, T& cost, int& nres) {
