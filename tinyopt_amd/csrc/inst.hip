@@ -85,8 +85,9 @@ int TOA_CAT(toa_inst_misc_accumulate_, TOA_INST_DT, 0)(int model, int npad, toa_
 // blocks (RowModel over AdRowFunctor, row_model.hpp): n = 12 (the C3 shape) and n = 50 (the C4 shape) are instantiated — a functor's parameter count is
 // a compile-time constant, as in the reference's static-size Jets.
 int TOA_CAT(toa_inst_jetrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
-  if (n == 12) return launch_fused<RowModel<InstT, 1, 0, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 12>>>>(h, prm);
-  if (n == 50) return launch_fused<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, prm);
+  // (toa_set_loss is refused for this family — capi.hip check_loss_supported — so its fused kernel is the variant without the M-estimator branch)
+  if (n == 12) return launch_fused<RowModel<InstT, 1, 0, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 12>>, 0, false>>(h, prm);
+  if (n == 50) return launch_fused<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>, 0, false>>(h, prm);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
 int TOA_CAT(toa_inst_jetrow_wide_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
