@@ -177,3 +177,45 @@ def test_capture_of_an_unbounded_retry_budget_is_refused_with_the_numbers(ta):
             with torch.cuda.graph(g, stream=s):
                 ta.Optimize(x, mdl, opts, out=out)
     torch.cuda.synchronize()
+
+
+def test_a_run_time_models_second_build_is_refused_under_capture_and_fine_after_a_warm_call(ta):
+    """Round 6: a run-time model is built twice — without the M-estimator branch at toa_model_compile, with it the first time it runs on
+    a handle that has a loss set.  That second build cannot happen inside a stream capture (TOA_E_UNSUPPORTED, nothing recorded, the
+    capture left valid); after one un-captured call the same solve captures and replays."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        P, items, n = 512, 200, 6
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        A = torch.rand(P, items, n, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+        xs = torch.rand(P, n, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+        t = torch.einsum("pmn,pn->pm", A, xs)
+        data = torch.cat([A, (t + 0.1 * torch.sin(t))[..., None]], 2).contiguous()
+        x0 = xs + 0.2
+        body = "S t = x[0] * p[0];\n" + "".join(f"t = t + x[{j}] * p[{j}];\n" for j in range(1, n)) + f"r[0] = t + T(0.1) * sin(t) - p[{n}];"
+        jit = ta.JitResidual(body + "  // capture test: a text of its own, so that no other test has built its variants", n=n, item_scalars=n + 1, dtype=torch.float64)
+        opts = ta.Options.benchmark()
+        plain = jit.bind(data)
+        robust = plain.with_loss("huber", 0.5)
+        x = x0.clone()
+        out = ta.Optimize(x, plain, opts)                 # the plain build runs (and warms the context of this stream)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(Exception, match="cannot happen while the stream is being captured"):
+            with torch.cuda.graph(g, stream=s):
+                ta.Optimize(x, robust, opts, out=out)     # would need the second build
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        x_ref = x0.clone()
+        ref = ta.Optimize(x_ref, robust, opts)            # un-captured: builds the variant with the branch
+        s.synchronize()
+        x.copy_(x0)
+        out = ta.Optimize(x, robust, opts)
+        s.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=s):
+            ta.Optimize(x, robust, opts, out=out)
+        x.copy_(x0)
+        g2.replay()
+        s.synchronize()
+        assert torch.equal(x, x_ref) and torch.equal(out.num_iters, ref.num_iters)
