@@ -102,6 +102,7 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
   if (n == 50) return launch_accumulate<RowModel<InstT, 3, 3, AdRowFunctor<InstT, DenseRowAdFunctor<InstT, 50>>>>(h, n, m, P, data, x, want_grad, g, H, cost, nres);
   return toa_fail(TOA_E_UNSUPPORTED, "TOA_MODEL_DENSE_ROW_AD is instantiated for n = 12 and n = 50");
 }
+#elif defined(TOA_INST_NARROW)
 // TOA_MODEL_DENSE_ROW on the narrow routes (round 6; the packed rows of the n <= 15 layouts — and of the thin layouts — ARE items [a_i | b_i]):
 //   JetModel over DenseRowPackedFunctor   an item per lane, the (n + 1)(n + 2) / 2 Gram in registers: fp32 n <= 10, fp64 n <= 5
 //   RowModel over DenseRowPackedFunctor   a row per lane staged into the MFMA Gram: fp32 n = 11; with an M-estimator on the handle
@@ -126,7 +127,11 @@ int TOA_CAT(toa_inst_jetrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
     default: break;                \
   }
 #endif
-int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
+// (two translation units per dtype — -DTOA_NARROW_PART=0: the JetModel fused kernels, 1: the RowModel ones, the seam and the dispatch — so that
+//  neither is the long pole of the build)
+int TOA_CAT(toa_inst_narrow_jet_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm);
+#if TOA_NARROW_PART == 0
+int TOA_CAT(toa_inst_narrow_jet_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
   const bool robust = prm.loss != TOA_LOSS_L2;
   (void)robust;
 #if TOA_INST_DT == 0
@@ -136,6 +141,17 @@ int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const F
   { if (robust) return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>>>(h, prm); \
     return launch_fused<JetModel<InstT, DenseRowPackedFunctor<InstT, N>, 0, false>>(h, prm); }
 #endif
+#define TOA_NONE(NB, TH, N) break
+  TOA_NARROW_CASES(TOA_NJ, TOA_NONE)
+#undef TOA_NJ
+#undef TOA_NONE
+  return toa_fail(TOA_E_ARG, "DenseRow narrow route: no JetModel instance for this n");
+}
+#else
+int TOA_CAT(toa_inst_narrow_fused_, TOA_INST_DT, 0)(int n, toa_handle h, const FusedParams& prm) {
+  const bool robust = prm.loss != TOA_LOSS_L2;
+  (void)robust;
+#define TOA_NJ(N) return TOA_CAT(toa_inst_narrow_jet_fused_, TOA_INST_DT, 0)(n, h, prm)
 #define TOA_NF(NB, TH, N) return launch_fused<RowModel<InstT, NB, TH, DenseRowPackedFunctor<InstT, N>>>(h, prm)
   TOA_NARROW_CASES(TOA_NJ, TOA_NF)
 #undef TOA_NJ
@@ -153,6 +169,7 @@ int TOA_CAT(toa_inst_narrow_accumulate_, TOA_INST_DT, 0)(toa_handle h, int n, in
 #undef TOA_NA
   return toa_fail(TOA_E_ARG, "DenseRow narrow route: no instance for this n");
 }
+#endif   // TOA_NARROW_PART
 #elif defined(TOA_INST_SOLVE)
 int TOA_CAT(toa_inst_solve_, TOA_INST_DT, 0)(int npad, toa_handle h, int n, int64_t P, const void* H, const void* g,
                                              double scale, void* dx, int32_t* ok) {
