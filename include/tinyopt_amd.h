@@ -197,7 +197,11 @@ typedef struct toa_tuning {
                                     launch-per-iteration form for batches with an M-estimator — instead of the narrow routes of round 6 (an item per
                                     lane with the Gram in registers: fp32 n <= 10, fp64 n <= 5; a row per lane through the LDS stage: fp32 n = 11; with
                                     toa_set_loss also n = 12, 50 and fp64 n = 6, 12, 50; profiles/r06_ab_log.md sections 7, 8, 11; A/B) */
-  int32_t reserved[14];          /* (three of them were the team form of the fused kernel, round 5: removed in round 6, profiles/r06_pruned_arms.patch) */
+  int32_t se3_reproj_header_l2;  /* TOA_MODEL_SE3_REPROJ: 1 = the caller guarantees that no problem's data header names a loss (header[3] == 0 everywhere):
+                                    the kernels WITHOUT the M-estimator branch run (fp64: 308 -> 216 registers, one -> two waves per SIMD; round 6,
+                                    profiles/r06_ab_log.md section 12).  A header that names one anyway is then IGNORED.  Both host mirrors set it
+                                    for models constructed without a loss. */
+  int32_t reserved[13];          /* (three of them were the team form of the fused kernel, round 5: removed in round 6, profiles/r06_pruned_arms.patch) */
 } toa_tuning;
 int toa_set_tuning(toa_handle h, const toa_tuning* t);
 int toa_get_tuning(toa_handle h, toa_tuning* out);

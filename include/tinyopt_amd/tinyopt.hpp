@@ -205,9 +205,18 @@ struct LossTag {
   int loss_kind = TOA_LOSS_L2;
   double loss_th2 = 0;
   void set_loss(int kind, double th) { loss_kind = kind; loss_th2 = th * th; }
+  bool se3_header_l2 = false;   // SE3Reproj: no problem's data header names a loss -> the kernels without the M-estimator branch (toa_tuning)
 };
 template <typename Cost>
-inline void apply_loss(const Cost& cost) { check(toa_set_loss(cost.ctx().get(), cost.loss_kind, cost.loss_th2)); }
+inline void apply_loss(const Cost& cost) {
+  check(toa_set_loss(cost.ctx().get(), cost.loss_kind, cost.loss_th2));
+  toa_tuning t;
+  check(toa_get_tuning(cost.ctx().get(), &t));
+  if ((t.se3_reproj_header_l2 != 0) != cost.se3_header_l2) {   // (the field follows the model: a second host call only when it changes)
+    t.se3_reproj_header_l2 = cost.se3_header_l2 ? 1 : 0;
+    check(toa_set_tuning(cost.ctx().get(), &t));
+  }
+}
 
 // Device cost model: r_i(x) = a_i.x + 0.1 sin(a_i.x) - b_i for P problems.  Takes the place of the
 // residual functor in Optimize(x, cost) (e.g. benchmarks/dense.cpp:56,71-74).
@@ -308,7 +317,11 @@ struct DenseRowNatural : PlainModel<Scalar, TOA_MODEL_DENSE_ROW_NATURAL> {
 template <typename Scalar>
 struct SE3Reproj : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ> {
   SE3Reproj(const Context& ctx, int64_t P, int npts, const Scalar* data)
-      : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ>(ctx, P, 6, 2 * npts, 12, data, size_t(P) * (8 + 5 * size_t(npts))) {}
+      : PlainModel<Scalar, TOA_MODEL_SE3_REPROJ>(ctx, P, 6, 2 * npts, 12, data, size_t(P) * (8 + 5 * size_t(npts))) {
+    bool any = false;   // (a header that names a loss keeps the kernels with the M-estimator branch)
+    for (int64_t p = 0; p < P && !any; ++p) any = data[size_t(p) * (8 + 5 * size_t(npts)) + 3] != Scalar(0);
+    this->se3_header_l2 = !any;
+  }
 };
 
 // A residual supplied as C++ source text at RUN time (toa_model_compile: hiprtc + hipModuleLoad, no rebuild of the library) —

@@ -186,6 +186,37 @@ def test_se3_reproj_lm(ta, oracle, dtype, tdt, npts):
         assert np.abs(xg - ref["x"]).max() < 5e-4
 
 
+@pytest.mark.parametrize("dtype,tdt,npts,P", [(np.float64, torch.float64, 300, 700), (np.float32, torch.float32, 300, 700), (np.float64, torch.float64, 25000, 1)])
+def test_se3_reproj_without_a_header_loss_runs_the_kernels_without_the_estimator_branch(ta, oracle, dtype, tdt, npts, P):
+    """Round 6: a model whose data headers name no loss runs the kernels WITHOUT the M-estimator branch (toa_tuning::se3_reproj_header_l2, set by
+    the host mirrors from the model: fp64 308 -> 216 registers).  Same arithmetic on the L2 path: the results are the bits of the full kernels — a
+    batch (fused kernel) and BASELINE C5's single problem (row-split form) —; a model WITH a loss keeps the full kernels."""
+    data, p0, _ = oracle.synth_se3_reproj(P, npts, dtype, seed=9)
+    d = torch.from_numpy(data).cuda()
+    model = ta.SE3Reproj(d, npts)
+    assert model.header_l2
+    o = ta.Options()
+    ctx = ta.api.default_context()
+    x = torch.from_numpy(p0.copy()).cuda()
+    out = ta.Optimize(x, model, o, history=True)
+    torch.cuda.synchronize()
+    assert ctx.get_tuning()["se3_reproj_header_l2"] == 1
+    model.header_l2 = False                       # the same bytes through the kernels with the branch
+    x2 = torch.from_numpy(p0.copy()).cuda()
+    out2 = ta.Optimize(x2, model, o, history=True)
+    torch.cuda.synchronize()
+    assert ctx.get_tuning()["se3_reproj_header_l2"] == 0
+    assert torch.equal(x, x2) and torch.equal(out.num_iters, out2.num_iters) and torch.equal(out.errs, out2.errs) and torch.equal(out.final_cost, out2.final_cost)
+    robust = ta.SE3Reproj(d, npts, loss="huber", th=3.0)
+    assert not robust.header_l2
+    x3 = torch.from_numpy(p0.copy()).cuda()
+    out3 = ta.Optimize(x3, robust, o)
+    torch.cuda.synchronize()
+    assert ctx.get_tuning()["se3_reproj_header_l2"] == 0 and bool((out3.stop_reason > 0).all())
+    byhand = d.clone(); byhand[:, 3] = 2.0; byhand[:, 4] = 9.0     # a header filled in by the caller is seen at construction
+    assert not ta.SE3Reproj(byhand, npts).header_l2
+
+
 @pytest.mark.parametrize("dtype,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
 def test_inv_cov_and_output_covariance(ta, oracle, dtype, tdt):
     """tinyopt::InvCov (math.h:41-57) + Output::Covariance (output.h:80-94), pinned like tests/cov.cpp:20-47:

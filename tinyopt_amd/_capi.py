@@ -64,7 +64,7 @@ ABI_VERSION = 6   # include/tinyopt_amd.h TOA_ABI_VERSION
 class ToaTuning(C.Structure):   # include/tinyopt_amd.h toa_tuning
     _fields_ = [(k, C.c_int32) for k in ("memo_off", "coop_off", "coop_chunks", "max_workgroups", "wide_no_autosplit", "wide_multilaunch",
                                          "wide_no_team", "wide_team_max_per_cu", "wide_graph", "large_row_split", "large_pipeline",
-                                         "large_library_gram", "large_library_solver", "fail_workspace_alloc", "large_one_lane", "large_chol_no_lookahead", "large_gram_plain_deal", "narrow_mfma_pass")] + [("reserved", C.c_int32 * 14)]
+                                         "large_library_gram", "large_library_solver", "fail_workspace_alloc", "large_one_lane", "large_chol_no_lookahead", "large_gram_plain_deal", "narrow_mfma_pass", "se3_reproj_header_l2")] + [("reserved", C.c_int32 * 13)]
 
 
 class ToaJitSpec(C.Structure):   # include/tinyopt_amd.h toa_jit_spec

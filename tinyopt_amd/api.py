@@ -195,6 +195,7 @@ class Context:
                 raise ValueError(f"unknown tuning field {k!r}")
             setattr(t, k, int(v))
         check(self.lib.toa_set_tuning(self.h, C.byref(t) if kw else None))
+        self._se3_l2 = int(kw.get("se3_reproj_header_l2", 0))   # (what _apply_loss last left in that field: it only calls when it changes)
 
     def get_tuning(self) -> dict:
         t = _capi.ToaTuning()
@@ -275,6 +276,11 @@ class _LossMixin:
 
 def _apply_loss(ctx: "Context", cost) -> None:
     """The handle carries the cost functor's M-estimator (toa_set_loss): set it from the model before every launch."""
+    # SE3Reproj carries its loss in the data header: a model without one runs the kernels without the M-estimator branch (toa_tuning::
+    # se3_reproj_header_l2; fp64: 308 -> 216 registers) — the field follows the model, a host call only when it changes
+    want = 1 if getattr(cost, "header_l2", False) else 0
+    if getattr(ctx, "_se3_l2", 0) != want:
+        ctx.set_tuning(**{**ctx.get_tuning(), "se3_reproj_header_l2": want})
     kind = getattr(cost, "loss", None)
     if kind is None:
         check(ctx.lib.toa_set_loss(ctx.h, 0, 0.0))
@@ -379,6 +385,8 @@ class SE3Reproj:
                 self.packed = self.packed.clone()
             self.packed[:, 3] = float(LOSS_KINDS[loss])
             self.packed[:, 4] = float(th) * float(th)
+        # (one read-back at construction: a header the caller filled in by hand may name a loss too)
+        self.header_l2 = loss is None and not bool((self.packed[:, 3] != 0).any())
 
     @property
     def algorithmic_bytes_per_pass(self) -> int:

@@ -15,7 +15,8 @@ using InstT = double;
 int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handle h, const FusedParams& prm) {
   if (model == TOA_MODEL_SQRT2) return launch_fused<Sqrt2Model<InstT>>(h, prm);
   if (model == TOA_MODEL_TESTFN) return launch_fused<TestFnModel<InstT>>(h, prm);
-  if (model == TOA_MODEL_SE3_REPROJ) return launch_fused<Se3ReprojModel<InstT>>(h, prm);
+  if (model == TOA_MODEL_SE3_REPROJ)
+    return h->tune.se3_reproj_header_l2 ? launch_fused<Se3ReprojModel<InstT, false>>(h, prm) : launch_fused<Se3ReprojModel<InstT>>(h, prm);
   if (model == TOA_MODEL_SE3_PRIOR) return launch_fused<Se3PriorModel<InstT>>(h, prm);
   if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
   if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
@@ -35,7 +36,9 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
   }
 }
 int TOA_CAT(toa_inst_misc_wide_, TOA_INST_DT, 0)(int model, toa_handle h, const FusedParams& prm, int splits) {
-  if (model == TOA_MODEL_SE3_REPROJ) return launch_wide<Se3ReprojModel<InstT>, 16, Se3Manifold<InstT>>(h, prm, splits);
+  if (model == TOA_MODEL_SE3_REPROJ)
+    return h->tune.se3_reproj_header_l2 ? launch_wide<Se3ReprojModel<InstT, false>, 16, Se3Manifold<InstT>>(h, prm, splits)
+                                        : launch_wide<Se3ReprojModel<InstT>, 16, Se3Manifold<InstT>>(h, prm, splits);
   if (prm.mode == 0) return toa_fail(TOA_E_UNSUPPORTED, "row-split execution is available for DenseRow and SE3Reproj");
   // stepping form: every model, one chunk per problem
   using E = EuclidManifold<InstT>;

@@ -193,7 +193,10 @@ struct Se3PriorModel {
 // pose <- pose * exp(delta) (3rdparty/traits/sophus.h:24-26).  Thread-per-residual evaluation: lane l handles
 // points l, l+64, ...; the 7x7 upper Gram of [J | r] (28 values) is accumulated in registers and folded across
 // the wave once per pass.  Data per problem: [f cx cy 0 0 0 0 0 | x y z u v ...] (coalesced 5-scalar records).
-template <typename T>
+// HEADER_LOSS = false: the variant for callers who guarantee that no problem's header names a loss (toa_tuning::se3_reproj_header_l2; both host
+// mirrors set it for models constructed without one): without the estimators' exp / log / atan2 the fp64 fused kernel is 216 registers
+// instead of 308 — two waves per SIMD instead of one (profiles/r06_ab_log.md section 12).
+template <typename T, bool HEADER_LOSS = true>
 struct Se3ReprojModel {
   using Scalar = T;
   __device__ __forceinline__ void set_loss(int, double) {}  // this family carries its loss in the data header
@@ -224,7 +227,7 @@ struct Se3ReprojModel {
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = L.xs[9 + i];
     const T f = d[0], cx = d[1], cy = d[2];
-    const int loss = int(d[3]);  // TOA_LOSS_*; 0 = plain squared L2 (wave-uniform)
+    const int loss = HEADER_LOSS ? int(d[3]) : 0;  // TOA_LOSS_*; 0 = plain squared L2 (wave-uniform)
     const T th2 = d[4];
     if (WANT_H) {
 #pragma unroll
