@@ -18,8 +18,12 @@ int TOA_CAT(toa_inst_misc_fused_, TOA_INST_DT, 0)(int model, int npad, toa_handl
   if (model == TOA_MODEL_SE3_REPROJ)
     return h->tune.se3_reproj_header_l2 ? launch_fused<Se3ReprojModel<InstT, false>>(h, prm) : launch_fused<Se3ReprojModel<InstT>>(h, prm);
   if (model == TOA_MODEL_SE3_PRIOR) return launch_fused<Se3PriorModel<InstT>>(h, prm);
-  if (model == TOA_MODEL_CIRCLE_FIT) return launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm);
-  if (model == TOA_MODEL_DENSE_ROW_AD6) return launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm);
+  // (plain L2 solves: the variant without the M-estimator branch — models_jet.hpp JetModel ROBUST)
+  const bool robust = prm.loss != TOA_LOSS_L2;
+  if (model == TOA_MODEL_CIRCLE_FIT)
+    return robust ? launch_fused<JetModel<InstT, CircleFitFunctor<InstT>>>(h, prm) : launch_fused<JetModel<InstT, CircleFitFunctor<InstT>, 0, false>>(h, prm);
+  if (model == TOA_MODEL_DENSE_ROW_AD6)
+    return robust ? launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>>>(h, prm) : launch_fused<JetModel<InstT, DenseRowAdFunctor<InstT, 6>, 0, false>>(h, prm);
   if (model == TOA_MODEL_MAHA_PRIOR) {
     switch (npad) {
       case 16: return launch_fused<MahaPriorModel<InstT, 16>>(h, prm);
