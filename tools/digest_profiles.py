@@ -55,7 +55,7 @@ def main():
                        "bench_line_kernel_ms_avg_hip_events": line["roofline"].get("kernel_ms_avg"),
                        "ratio_rocprof_over_hip_events": (sum(warm) / len(warm)) / line["roofline"]["kernel_ms_avg"] if line["roofline"].get("kernel_ms_avg") else None,
                        "bench_line_value": line["value"], "bench_line_frac": line["roofline"]["frac"]}, f, indent=1)
-    for txt in ("row_model_bench", "ad_ratio", "large_n_bench", "throughput_map", "lf_balance", "k3_crossover", "probe_phases", "coop_sweep", "llc_probe", "pytest_gpu"):
+    for txt in ("row_model_bench", "ad_ratio", "large_n_bench", "throughput_map", "lf_balance", "se3_probe", "robust_probe", "k3_crossover", "probe_phases", "coop_sweep", "llc_probe", "pytest_gpu"):
         if os.path.exists(os.path.join(SRC, txt + ".txt")):
             shutil.copy(os.path.join(SRC, txt + ".txt"), os.path.join(DST, f"{tag}_{txt}.txt"))
     if os.path.isdir(os.path.join(SRC, "pmc_large128")):   # counters of the n = 128 workgroup-per-problem kernel

@@ -31,6 +31,8 @@ python tools/ad_ratio.py > $O/ad_ratio.txt 2>&1
 python tools/large_n_bench.py > $O/large_n_bench.txt 2>&1
 python tools/throughput_map.py > $O/throughput_map.txt 2>&1
 python tools/lf_balance.py > $O/lf_balance.txt 2>&1
+(python tools/se3_batch_probe.py 20000 400 f64; python tools/se3_batch_probe.py 40000 400 f32; python tools/jit_c5.py) > $O/se3_probe.txt 2>&1
+(python tools/robust_probe.py; python tools/robust_probe.py 40000 12 500) > $O/robust_probe.txt 2>&1
 python tools/k3_crossover.py > $O/k3_crossover.txt 2>&1
 (python tools/probe.py c4; python tools/probe.py c3) > $O/probe_phases.txt 2>&1
 bash tools/coop_sweep.sh > $O/coop_sweep.txt 2>/dev/null
